@@ -1,0 +1,1302 @@
+// =====================================================================================
+// lama_oracle.hpp -- CPU restatement of the iris_lama (LaMa v1.3.1) particle-filter
+// scan-matching path.  TEST INFRASTRUCTURE ONLY.
+//
+//   * This file is the parity CHECKER.  Only tests/, __graft_entry__.smoke() and
+//     bench.py's `cpu_baseline` leg may build, link, load or call it.  Nothing under
+//     iris_lama_amd/ (the product) includes or links anything from oracle/.
+//   * PARITY UNPINNED: the reference ships no tests / golden vectors / fixtures
+//      and cannot be compiled in this image because Eigen3 is absent
+//     (SURVEY.md F4).  The restatement below follows the cited reference lines
+//     statement by statement and is pinned only against the source-derived known
+//     answers of SURVEY.md Appendix A.9 (tests/test_oracle_kat.py) and against
+//     brute-force self-consistency checks.
+//   * Third-party arithmetic the reference uses on this path and that is absent here:
+//     Eigen3 (>=3.3, CMakeLists.txt:15; CI used Ubuntu 20.04 libeigen3-dev = 3.3.7).
+//     Its published algorithms are restated where used (AngleAxis/Quaternion ->
+//     rotation matrix, Affine composition, pivoted LDLT and its solve).  Summation
+//     order inside Eigen's dynamic-size products (J^T r, J^T J over 1080 rows) is
+//     implementation-defined (packet width / unrolling); this file sums sequentially.
+//     Expected oracle-vs-reference differences: ~1e-13 relative in g/A, none in
+//     integer map contents for identical poses.
+//   * libstdc++ pieces used by the reference are used here directly, so they behave
+//     identically: std::mt19937, std::normal_distribution, std::uniform_real_distribution
+//     (src/random.cpp:38-73) and std::priority_queue tie order
+//     (include/lama/sdm/dynamic_distance_map.h:90-98).
+//
+// All `file:line` citations are relative to /root/reference.
+// Plain C++14, no dependencies.
+// =====================================================================================
+#pragma once
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <random>
+#include <thread>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace orc {
+
+// -------------------------------------------------------------------------------------
+// small PODs
+// -------------------------------------------------------------------------------------
+struct V3d { double x, y, z; };
+struct V3u { uint32_t x, y, z; };
+struct V3l { int64_t x, y, z; };
+
+inline bool operator==(const V3u& a, const V3u& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// -------------------------------------------------------------------------------------
+// SE2 = unit complex (c,s) + translation.  include/lama/sophus/so2.hpp, se2.hpp,
+// src/pose2d.cpp.  
+// -------------------------------------------------------------------------------------
+struct SE2 {
+    double c = 1.0, s = 0.0;   // unit complex (so2.hpp:474 default = identity)
+    double tx = 0.0, ty = 0.0; // se2.hpp:611 default translation zero
+};
+
+// so2.hpp:205-214  normalize(); throws SophusException on (near) zero -- we abort.
+inline void so2_normalize(double& c, double& s)
+{
+    double length = std::sqrt(c * c + s * s);
+    if (length < 1e-10) { std::abort(); }          // sophus.hpp:37-39 epsilon
+    c /= length;
+    s /= length;
+}
+
+// so2.hpp:322-324 exp(theta) = SO2Group(cos, sin) ; ctor so2.hpp:506-509 normalizes
+inline void so2_exp(double theta, double& c, double& s)
+{
+    c = std::cos(theta);
+    s = std::sin(theta);
+    so2_normalize(c, s);
+}
+
+// se2.hpp:648-651  SE2Group(theta, translation) -> so2_(theta) (so2.hpp:537-539)
+inline SE2 se2_from_xyr(double x, double y, double theta)
+{
+    SE2 r;
+    so2_exp(theta, r.c, r.s);
+    r.tx = x; r.ty = y;
+    return r;
+}
+
+// so2.hpp:401-404 log() = atan2(imag, real) ; src/pose2d.cpp:118-121 rotation()
+inline double se2_rotation(const SE2& a) { return std::atan2(a.s, a.c); }
+
+// se2.hpp:262-265 operator*= : fastMultiply (se2.hpp:154-157, so2.hpp:168-176) then
+// normalize (se2.hpp:189-191).  operator* (se2.hpp:233-237) copies then *=.
+inline SE2 se2_mul(const SE2& a, const SE2& b)
+{
+    SE2 r = a;
+    // translation() += so2()*(other.translation())      so2.hpp:262-266
+    r.tx += a.c * b.tx - a.s * b.ty;
+    r.ty += a.s * b.tx + a.c * b.ty;
+    // complex multiplication                              so2.hpp:168-176
+    double lhs_real = a.c, lhs_imag = a.s;
+    r.c = lhs_real * b.c - lhs_imag * b.s;
+    r.s = lhs_real * b.s + lhs_imag * b.c;
+    so2_normalize(r.c, r.s);
+    return r;
+}
+
+// se2.hpp:163-167 inverse(): invR = SO2(real,-imag) [2-arg ctor normalizes];
+// translation = invR * (t * -1)
+inline SE2 se2_inverse(const SE2& a)
+{
+    SE2 r;
+    r.c = a.c; r.s = -a.s;
+    so2_normalize(r.c, r.s);
+    double mx = a.tx * -1.0, my = a.ty * -1.0;
+    r.tx = r.c * mx - r.s * my;
+    r.ty = r.s * mx + r.c * my;
+    return r;
+}
+
+// se2.hpp:389-411 exp([vx,vy,theta])
+inline SE2 se2_exp(double vx, double vy, double theta)
+{
+    SE2 r;
+    so2_exp(theta, r.c, r.s);
+    double sin_theta_by_theta, one_minus_cos_theta_by_theta;
+    if (std::abs(theta) < 1e-10) {
+        double theta_sq = theta * theta;
+        sin_theta_by_theta = 1. - (1. / 6.) * theta_sq;
+        one_minus_cos_theta_by_theta = 0.5 * theta - (1. / 24.) * theta * theta_sq;
+    } else {
+        sin_theta_by_theta = r.s / theta;
+        one_minus_cos_theta_by_theta = (1. - r.c) / theta;
+    }
+    r.tx = sin_theta_by_theta * vx - one_minus_cos_theta_by_theta * vy;
+    r.ty = one_minus_cos_theta_by_theta * vx + sin_theta_by_theta * vy;
+    return r;
+}
+
+// src/pose2d.cpp:76-96 : a + b = a*b ; a - b = a^-1 * b
+inline SE2 pose_plus(const SE2& a, const SE2& b) { return se2_mul(a, b); }
+inline SE2 pose_minus(const SE2& a, const SE2& b) { return se2_mul(se2_inverse(a), b); }
+
+// -------------------------------------------------------------------------------------
+// Eigen::Affine3d restated (linear 3x3 + translation).
+// -------------------------------------------------------------------------------------
+struct Affine3 {
+    double R[3][3];
+    double t[3];
+};
+
+// Eigen QuaternionBase::toRotationMatrix (published algorithm, Eigen 3.3 Quaternion.h)
+inline void quat_to_matrix(const double q[4] /*w,x,y,z*/, double R[3][3])
+{
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    R[0][0] = 1.0 - (tyy + tzz); R[0][1] = txy - twz;         R[0][2] = txz + twy;
+    R[1][0] = txy + twz;         R[1][1] = 1.0 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy;         R[2][1] = tyz + twx;         R[2][2] = 1.0 - (txx + tyy);
+}
+
+// Eigen AngleAxis::toRotationMatrix for axis = UnitZ (published algorithm, AngleAxis.h)
+inline void angle_axis_z(double angle, double R[3][3])
+{
+    const double ax[3] = {0.0, 0.0, 1.0};
+    const double sn = std::sin(angle), c = std::cos(angle);
+    const double sin_axis[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+    const double cos1_axis[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+    double tmp;
+    tmp = cos1_axis[0] * ax[1]; R[0][1] = tmp - sin_axis[2]; R[1][0] = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * ax[2]; R[0][2] = tmp + sin_axis[1]; R[2][0] = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * ax[2]; R[1][2] = tmp - sin_axis[0]; R[2][1] = tmp + sin_axis[0];
+    R[0][0] = cos1_axis[0] * ax[0] + c;
+    R[1][1] = cos1_axis[1] * ax[1] + c;
+    R[2][2] = cos1_axis[2] * ax[2] + c;
+}
+
+// Translation3d(t) * rotation  -> linear = R, translation = t
+inline Affine3 affine_from(const double t[3], const double R[3][3])
+{
+    Affine3 a;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) a.R[i][j] = R[i][j]; a.t[i] = t[i]; }
+    return a;
+}
+
+// Affine * Affine: linear = A.R*B.R ; translation = A.R*B.t + A.t  (sums in index order)
+inline Affine3 affine_mul(const Affine3& A, const Affine3& B)
+{
+    Affine3 r;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j)
+            r.R[i][j] = (A.R[i][0] * B.R[0][j] + A.R[i][1] * B.R[1][j]) + A.R[i][2] * B.R[2][j];
+        r.t[i] = ((A.R[i][0] * B.t[0] + A.R[i][1] * B.t[1]) + A.R[i][2] * B.t[2]) + A.t[i];
+    }
+    return r;
+}
+
+// Affine * point = linear*p + translation
+inline V3d affine_apply(const Affine3& A, const V3d& p)
+{
+    V3d r;
+    r.x = ((A.R[0][0] * p.x + A.R[0][1] * p.y) + A.R[0][2] * p.z) + A.t[0];
+    r.y = ((A.R[1][0] * p.x + A.R[1][1] * p.y) + A.R[1][2] * p.z) + A.t[1];
+    r.z = ((A.R[2][0] * p.x + A.R[2][1] * p.y) + A.R[2][2] * p.z) + A.t[2];
+    return r;
+}
+
+// include/lama/types.h:111-120 PointCloudXYZ
+struct Scan {
+    std::vector<V3d> points;
+    double sensor_origin[3] = {0, 0, 0};
+    double sensor_orientation[4] = {1, 0, 0, 0}; // w,x,y,z
+};
+
+// moving_tf = Translation3d(sensor_origin_) * sensor_orientation_
+// (src/match_surface_2d.cpp:49, src/pf_slam2d.cpp:397,444)
+inline Affine3 moving_tf(const Scan& s)
+{
+    double R[3][3];
+    quat_to_matrix(s.sensor_orientation, R);
+    return affine_from(s.sensor_origin, R);
+}
+
+// fixed_tf = Translation3d(x,y,0) * AngleAxisd(rotation, UnitZ)
+// (src/match_surface_2d.cpp:51-54, src/pf_slam2d.cpp:399-402,445)
+inline Affine3 fixed_tf(const SE2& pose)
+{
+    double R[3][3];
+    angle_axis_z(se2_rotation(pose), R);
+    const double t[3] = {pose.tx, pose.ty, 0.0};
+    return affine_from(t, R);
+}
+
+// -------------------------------------------------------------------------------------
+// Container  (include/lama/sdm/container.h:47-123,167-183; src/sdm/container.cpp:39-95)
+// 2-D only: SIZE = 1 << (2*log2dim).
+// -------------------------------------------------------------------------------------
+struct Container {
+    uint32_t element_size = 0;
+    uint32_t SIZE = 0;
+    uint32_t WORD_COUNT = 0;
+    std::vector<uint8_t> data;   // calloc'd: zero-initialised (container.cpp:78)
+    std::vector<uint64_t> mask;  // calloc'd (container.cpp:82)
+
+    Container(uint32_t log2dim, uint32_t elem)
+        : element_size(elem), SIZE(1u << (2 * log2dim)), WORD_COUNT(std::max(uint32_t(SIZE >> 6), uint32_t(1))),
+          data(size_t(SIZE) * elem, 0), mask(WORD_COUNT, 0) {}
+
+    bool is_on(uint32_t i) const { return 0 != (mask[i >> 6] & (uint64_t(1) << (i & 63))); }
+    void set_on(uint32_t i) { mask[i >> 6] |= (uint64_t(1) << (i & 63)); }
+
+    // container.h:102-106  non-const get sets the mask bit
+    uint8_t* get(uint32_t idx)
+    {
+        if (!is_on(idx)) set_on(idx);
+        return data.data() + size_t(idx) * element_size;
+    }
+    // container.h:119-123  const get returns nullptr when the bit is off
+    const uint8_t* get(uint32_t idx) const
+    {
+        if (!is_on(idx)) return nullptr;
+        return data.data() + size_t(idx) * element_size;
+    }
+};
+
+// per-(particle,scan) instrumentation used for the roofline model
+struct TouchSets {
+    bool enabled = false;
+    std::unordered_set<uint64_t> s_match, s_occ, s_bf;
+    void clear() { s_match.clear(); s_occ.clear(); s_bf.clear(); }
+};
+
+// -------------------------------------------------------------------------------------
+// Map  (include/lama/sdm/map.h:60-189 ; src/sdm/map.cpp:42-107,198-227,371-455)
+// LRU/compression/IO are out of scope (default use_compression=false, pf_slam2d.h:178).
+// -------------------------------------------------------------------------------------
+class Map {
+public:
+    static const uint64_t UNIVERSAL_CONSTANT = 2642244; // map.h:68
+
+    double resolution;
+    double scale;
+    size_t cell_memory_size;
+    uint32_t patch_length;
+    uint32_t patch_volume;
+    int log2dim;
+    double off; // translation of tf_ on every axis: (UNIVERSAL_CONSTANT>>1)*patch_length  map.cpp:55-58
+
+    // map.h:109 ; value = shared (copy-on-write) container, include/lama/cow_ptr.h
+    std::unordered_map<uint64_t, std::shared_ptr<Container>> patches;
+
+    // optional: which patch ids non-const get() touched (brushfire / raycast footprint)
+    std::unordered_set<uint64_t>* touch_rw = nullptr;
+    // optional: which (existing) patch ids const get() touched (match footprint)
+    mutable std::unordered_set<uint64_t>* touch_ro = nullptr;
+
+    Map(double res, size_t cell_size, uint32_t patch_size)
+        : resolution(res), scale(1.0 / res), cell_memory_size(cell_size),
+          patch_length(1u << ((int)std::log2((double)patch_size))),
+          patch_volume(patch_length * patch_length)
+    {
+        log2dim = (int)std::log2((double)patch_length);
+        off = double(UNIVERSAL_CONSTANT >> 1) * double(patch_length);
+    }
+
+    // map.cpp:72-107 copy: patches share containers (COW)
+    Map(const Map& o)
+        : resolution(o.resolution), scale(o.scale), cell_memory_size(o.cell_memory_size),
+          patch_length(o.patch_length), patch_volume(o.patch_volume), log2dim(o.log2dim), off(o.off),
+          patches(o.patches)
+    {}
+    virtual ~Map() {}
+
+    // tf_ * v with tf_ = Translation(off) * Scaling(scale)  (map.cpp:58)
+    // (the off-diagonal zeros of the Scaling only ever add +-0.0)
+    inline double tfc(double v) const { return scale * v + off; }
+
+    // map.h:125-126
+    inline V3u w2m(const V3d& p) const
+    {
+        V3u r;
+        r.x = (uint32_t)(tfc(p.x) + 0.5);
+        r.y = (uint32_t)(tfc(p.y) + 0.5);
+        r.z = (uint32_t)(tfc(p.z) + 0.5);
+        return r;
+    }
+    // map.h:137-138
+    inline V3d w2m_nocast(const V3d& p) const { return V3d{tfc(p.x), tfc(p.y), tfc(p.z)}; }
+
+    // map.h:153-161 (2-D branch)
+    inline uint64_t m2p(const V3u& c) const
+    {
+        return uint64_t(c.x >> log2dim) * UNIVERSAL_CONSTANT + uint64_t(c.y >> log2dim);
+    }
+    // map.h:182-189 (2-D: MASK3D = 0)
+    inline uint32_t m2c(const V3u& c) const
+    {
+        const uint32_t m = ((1u << log2dim) - 1);
+        return (c.x & m) | ((c.y & m) << log2dim);
+    }
+    // map.h:166-177 (2-D)
+    inline V3u p2m(uint64_t idx) const
+    {
+        return V3u{uint32_t((idx / UNIVERSAL_CONSTANT) << log2dim), uint32_t((idx % UNIVERSAL_CONSTANT) << log2dim), 0};
+    }
+
+    // map.cpp:371-412 (non-compressed branch) + COWPtr::operator-> detach (cow_ptr.h:86-114)
+    uint8_t* get(const V3u& c)
+    {
+        uint64_t idx = m2p(c);
+        if (prev_idx_ != idx || prev_patch_ == nullptr) {
+            auto it = patches.find(idx);
+            if (it == patches.end())
+                it = patches.insert(std::make_pair(idx, std::make_shared<Container>(log2dim, (uint32_t)cell_memory_size))).first;
+            prev_idx_ = idx;
+            prev_patch_ = &(it->second);
+            if (touch_rw) touch_rw->insert(idx);
+        }
+        if (prev_patch_->use_count() > 1)           // detach(): deep copy a shared patch
+            *prev_patch_ = std::make_shared<Container>(**prev_patch_);
+        return (*prev_patch_)->get(m2c(c));
+    }
+
+    // map.cpp:414-455 (non-compressed branch)
+    const uint8_t* get(const V3u& c) const
+    {
+        uint64_t idx = m2p(c);
+        if (prev_idx_ != idx) {
+            auto it = patches.find(idx);
+            if (it == patches.end()) {
+                prev_idx_ = idx;
+                prev_patch_ = nullptr;
+                return nullptr;
+            }
+            prev_idx_ = idx;
+            prev_patch_ = const_cast<std::shared_ptr<Container>*>(&(it->second));
+            if (touch_ro) touch_ro->insert(idx);
+        } else if (prev_patch_ == nullptr) {
+            return nullptr;
+        }
+        return static_cast<const Container*>(prev_patch_->get())->get(m2c(c));
+    }
+
+    // map.cpp:198-227  integer Bresenham, both end points excluded
+    template <class F>
+    void computeRay(const V3u& from, const V3u& to, F&& callback)
+    {
+        if (from == to) return;
+        int64_t error[3] = {0, 0, 0};
+        int64_t coord[3] = {(int64_t)from.x, (int64_t)from.y, (int64_t)from.z};
+        int64_t delta[3] = {(int64_t)to.x - coord[0], (int64_t)to.y - coord[1], (int64_t)to.z - coord[2]};
+        int64_t step[3];
+        for (int j = 0; j < 3; ++j) step[j] = (delta[j] < 0) ? -1 : 1;
+        for (int j = 0; j < 3; ++j) delta[j] = std::llabs(delta[j]);
+        int n = (int)std::max(delta[0], std::max(delta[1], delta[2]));
+        for (int i = 0; i < n - 1; ++i) {
+            for (int j = 0; j < 3; ++j) error[j] += delta[j];
+            for (int j = 0; j < 3; ++j) {
+                if ((error[j] << 1) < n) continue;
+                coord[j] += step[j];
+                error[j] -= n;
+            }
+            callback(V3u{(uint32_t)coord[0], (uint32_t)coord[1], (uint32_t)coord[2]});
+        }
+    }
+
+    // map.cpp:115-125
+    size_t memory() const
+    {
+        double total = 0.0;
+        for (auto& kv : patches) {
+            total += sizeof(uint64_t) + 16 /*sizeof(COWPtr<Container>)*/ + sizeof(void*);
+            total += (double)(kv.second->data.size()) / (double)kv.second.use_count();
+        }
+        return (size_t)total;
+    }
+
+    void reset_cache() const { prev_idx_ = uint64_t(-1); prev_patch_ = nullptr; }
+
+private:
+    mutable uint64_t prev_idx_ = uint64_t(-1);                    // map.h:374
+    mutable std::shared_ptr<Container>* prev_patch_ = nullptr;    // map.h:375 (guarded by prev_idx_)
+};
+
+// -------------------------------------------------------------------------------------
+// FrequencyOccupancyMap  (include/lama/sdm/frequency_occupancy_map.h:43-46,
+//                         src/sdm/frequency_occupancy_map.cpp:38-91)
+// -------------------------------------------------------------------------------------
+struct frequency { uint16_t occupied; uint16_t visited; };
+static_assert(sizeof(frequency) == 4, "frequency must be 4 bytes (SURVEY A.9-2)");
+
+class FrequencyOccupancyMap : public Map {
+public:
+    FrequencyOccupancyMap(double res, uint32_t patch_size = 32) : Map(res, sizeof(frequency), patch_size) {}
+    FrequencyOccupancyMap(const FrequencyOccupancyMap& o) : Map(o) {}
+
+    static double prob(const frequency& f)             // :38-45
+    {
+        if (f.visited == 0) return 0.25;
+        return ((double)f.occupied) / ((double)f.visited);
+    }
+    bool setFree(const V3u& c)                          // :65-74
+    {
+        frequency* cell = (frequency*)get(c);
+        bool free = prob(*cell) < 0.25;
+        cell->visited++;
+        if (free) return false;
+        return prob(*cell) < 0.25;
+    }
+    bool setOccupied(const V3u& c)                      // :81-91
+    {
+        frequency* cell = (frequency*)get(c);
+        bool occupied = prob(*cell) > 0.25;
+        cell->occupied++;
+        cell->visited++;
+        if (occupied) return false;
+        return prob(*cell) > 0.25;
+    }
+    bool isFree(const V3u& c) const                     // :119-125
+    {
+        const frequency* cell = (const frequency*)get(c);
+        if (cell == 0) return false;
+        return prob(*cell) < 0.25;
+    }
+    bool isOccupied(const V3u& c) const                 // :132-138
+    {
+        const frequency* cell = (const frequency*)get(c);
+        if (cell == 0) return false;
+        return prob(*cell) > 0.25;
+    }
+    double getProbability(const V3u& c) const           // :166-172
+    {
+        const frequency* cell = (const frequency*)get(c);
+        if (cell == 0) return 0.25;
+        return prob(*cell);
+    }
+};
+
+// -------------------------------------------------------------------------------------
+// DynamicDistanceMap  (include/lama/sdm/dynamic_distance_map.h:48-105,
+//                      src/sdm/dynamic_distance_map.cpp:36-330)
+// -------------------------------------------------------------------------------------
+#pragma pack(push, 1)
+struct distance_t {            // dynamic_distance_map.h:48-53 (Vector3s = 3 x int16)
+    int16_t obstacle[3];
+    uint16_t sqdist;
+    bool valid_obstacle;
+    bool is_queued;
+};
+#pragma pack(pop)
+static_assert(sizeof(distance_t) == 10, "distance_t must be 10 bytes (SURVEY A.9-2)");
+
+struct BrushfireStats {
+    uint64_t raise_pops = 0, lower_pops = 0, lower_fired = 0, pushes = 0, max_queue = 0, tie_overwrites = 0;
+};
+
+class DynamicDistanceMap : public Map {
+public:
+    DynamicDistanceMap(double res, uint32_t patch_size = 32)       // :36-47
+        : Map(res, sizeof(distance_t), patch_size), max_sqdist_(100) {}
+    DynamicDistanceMap(const DynamicDistanceMap& o)                // :49-61 (queues NOT copied)
+        : Map(o), max_sqdist_(o.max_sqdist_) {}
+
+    uint32_t max_sqdist() const { return max_sqdist_; }
+
+    void setMaxDistance(double distance)                           // :149-153
+    {
+        max_sqdist_ = (uint32_t)std::ceil(distance * scale);
+        max_sqdist_ *= max_sqdist_;
+    }
+    double maxDistance() const { return std::sqrt((double)max_sqdist_) * resolution; } // :155-158
+
+    double distance(const V3u& c) const                            // :140-147
+    {
+        const distance_t* cell = (const distance_t*)get(c);
+        if (cell == 0 || !cell->valid_obstacle)
+            return std::sqrt((double)max_sqdist_) * resolution;
+        return std::sqrt((double)cell->sqdist) * resolution;
+    }
+
+    // :66-138, 2-D branch :77-93
+    double distance(const V3d& coordinates, V3d* gradient) const
+    {
+        V3d m = w2m_nocast(coordinates);
+        V3u d{(uint32_t)m.x, (uint32_t)m.y, (uint32_t)m.z};
+        double mu0 = m.x - (double)d.x, mu1 = m.y - (double)d.y;
+        double muinv0 = 1.0 - mu0, muinv1 = 1.0 - mu1;
+
+        double v0 = distance(d);
+        double v1 = distance(V3u{d.x + 1, d.y, d.z});
+        double v2 = distance(V3u{d.x, d.y + 1, d.z});
+        double v3 = distance(V3u{d.x + 1, d.y + 1, d.z});
+
+        double dist = v0 * muinv0 * muinv1 + v1 * muinv1 * mu0 + v2 * muinv0 * mu1 + v3 * mu0 * mu1;
+        if (gradient) {
+            gradient->x = -((v0 - v1) * muinv1 + (v2 - v3) * mu1) * scale;
+            gradient->y = -((v0 - v2) * muinv0 + (v1 - v3) * mu0) * scale;
+            gradient->z = 0;
+        }
+        return dist;
+    }
+
+    void addObstacle(const V3u& location)                          // :212-226
+    {
+        distance_t* cell = (distance_t*)get(location);
+        if (cell->valid_obstacle && cell->sqdist == 0) return;
+        cell->sqdist = 0;
+        cell->obstacle[0] = cell->obstacle[1] = cell->obstacle[2] = 0;
+        cell->valid_obstacle = true;
+        cell->is_queued = true;
+        lower_.push({0, location});
+        ++stats.pushes;
+    }
+    void removeObstacle(const V3u& location)                       // :228-242
+    {
+        distance_t* cell = (distance_t*)get(location);
+        if (!(cell->valid_obstacle && cell->sqdist == 0)) return;
+        cell->sqdist = 0;
+        cell->obstacle[0] = cell->obstacle[1] = cell->obstacle[2] = 0;
+        cell->valid_obstacle = false;
+        cell->is_queued = true;
+        raise_.push({0, location});
+        ++stats.pushes;
+    }
+
+    uint32_t update()                                              // :160-197
+    {
+        uint32_t processed = 0;
+        while (!raise_.empty()) {
+            stats.max_queue = std::max<uint64_t>(stats.max_queue, raise_.size() + lower_.size());
+            V3u location = raise_.top().second; raise_.pop();
+            distance_t* current = (distance_t*)get(location);
+            ++processed; ++stats.raise_pops;
+            raise(location, current);
+        }
+        while (!lower_.empty()) {
+            stats.max_queue = std::max<uint64_t>(stats.max_queue, lower_.size());
+            V3u location = lower_.top().second; lower_.pop();
+            distance_t* current = (distance_t*)get(location);
+            ++processed; ++stats.lower_pops;
+            if (current->valid_obstacle) {
+                V3u obs = offs(location, current->obstacle);
+                const distance_t* obstacle = (distance_t*)get(obs);
+                current = (distance_t*)get(location);   // (re-fetch: no semantic effect)
+                if (obstacle->sqdist == 0)                         // :191 (valid_obstacle NOT tested)
+                    lower(location, current);
+            }
+        }
+        return processed;
+    }
+
+    BrushfireStats stats;
+
+private:
+    typedef std::pair<int, V3u> queue_pair_t;                      // .h:90
+    struct compare_prio {                                          // .h:92-95
+        bool operator()(const queue_pair_t& l, const queue_pair_t& r) const { return l.first > r.first; }
+    };
+    typedef std::priority_queue<queue_pair_t, std::vector<queue_pair_t>, compare_prio> queue_t; // .h:97-98
+
+    static V3u offs(const V3u& loc, const int16_t o[3])
+    {
+        return V3u{(uint32_t)((int64_t)loc.x + o[0]), (uint32_t)((int64_t)loc.y + o[1]), (uint32_t)((int64_t)loc.z + o[2])};
+    }
+
+    // deltas: dynamic_distance_map.cpp:40-43 (first 4 used in 2-D)
+    static void delta(int i, int64_t d[3])
+    {
+        static const int64_t D[4][3] = {{1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, -1, 0}};
+        d[0] = D[i][0]; d[1] = D[i][1]; d[2] = D[i][2];
+    }
+
+    void raise(const V3u& location, distance_t* current)           // :244-279
+    {
+        for (int i = 0; i < 4; ++i) {
+            int64_t d[3]; delta(i, d);
+            V3u newloc{(uint32_t)((int64_t)location.x + d[0]), (uint32_t)((int64_t)location.y + d[1]), (uint32_t)((int64_t)location.z + d[2])};
+            distance_t* neighbor = (distance_t*)get(newloc);
+            if (neighbor->is_queued || !neighbor->valid_obstacle) continue;
+
+            V3u obs = offs(newloc, neighbor->obstacle);
+            const distance_t* obstacle = (distance_t*)get(obs);
+            neighbor = (distance_t*)get(newloc);
+            if (!obstacle->valid_obstacle) {
+                raise_.push({neighbor->sqdist, newloc});
+                ++stats.pushes;
+                neighbor->sqdist = 0;
+                neighbor->obstacle[0] = neighbor->obstacle[1] = neighbor->obstacle[2] = 0;
+                neighbor->valid_obstacle = false;
+                neighbor->is_queued = true;
+            } else if (!neighbor->is_queued) {
+                lower_.push({neighbor->sqdist, newloc});
+                ++stats.pushes;
+                neighbor->is_queued = true;
+            }
+        }
+        current = (distance_t*)get(location);
+        current->is_queued = false;
+    }
+
+    void lower(const V3u& location, distance_t* current)           // :281-330
+    {
+        if (!current->is_queued) return;
+        ++stats.lower_fired;
+        const int16_t cobs[3] = {current->obstacle[0], current->obstacle[1], current->obstacle[2]};
+        for (int i = 0; i < 4; ++i) {
+            int64_t d[3]; delta(i, d);
+            // only update away from the obstacle                    :296
+            if (d[0] * cobs[0] > 0 || d[1] * cobs[1] > 0 || d[2] * cobs[2] > 0) continue;
+
+            int64_t newloc[3] = {(int64_t)location.x + d[0], (int64_t)location.y + d[1], (int64_t)location.z + d[2]};
+            V3u nl{(uint32_t)newloc[0], (uint32_t)newloc[1], (uint32_t)newloc[2]};
+            distance_t* neighbor = (distance_t*)get(nl);
+
+            int64_t obs[3] = {(int64_t)location.x + cobs[0], (int64_t)location.y + cobs[1], (int64_t)location.z + cobs[2]};
+            int64_t dist[3] = {newloc[0] - obs[0], newloc[1] - obs[1], newloc[2] - obs[2]};
+            uint32_t new_sqdist = (uint32_t)(dist[0] * dist[0] + dist[1] * dist[1] + dist[2] * dist[2]);
+            uint32_t cmp_sqdist = neighbor->valid_obstacle ? neighbor->sqdist : max_sqdist_;
+
+            bool overwrite = (new_sqdist < cmp_sqdist);
+            if (!overwrite && new_sqdist == neighbor->sqdist) {     // :311-317
+                V3u nobs = offs(nl, neighbor->obstacle);
+                const distance_t* obstacle = (distance_t*)get(nobs);
+                neighbor = (distance_t*)get(nl);
+                if (!neighbor->valid_obstacle || !(obstacle->valid_obstacle && obstacle->sqdist == 0)) {
+                    overwrite = true;
+                    ++stats.tie_overwrites;
+                }
+            }
+            if (overwrite) {                                        // :319-326
+                lower_.push({(int)new_sqdist, nl});
+                ++stats.pushes;
+                neighbor->sqdist = (uint16_t)new_sqdist;
+                neighbor->valid_obstacle = true;
+                neighbor->obstacle[0] = (int16_t)(obs[0] - newloc[0]);
+                neighbor->obstacle[1] = (int16_t)(obs[1] - newloc[1]);
+                neighbor->obstacle[2] = (int16_t)(obs[2] - newloc[2]);
+                neighbor->is_queued = true;
+            }
+        }
+        current = (distance_t*)get(location);
+        current->is_queued = false;
+    }
+
+    queue_t lower_;
+    queue_t raise_;
+    uint32_t max_sqdist_;
+};
+
+// -------------------------------------------------------------------------------------
+// nlls: CauchyWeight, GaussNewton, Solver  (src/nlls/*.cpp)
+// -------------------------------------------------------------------------------------
+struct CauchyWeight {                                              // robust_cost.cpp:66-73
+    double c_;
+    explicit CauchyWeight(double param) : c_(1.0 / (param * param)) {}
+    double value(double x) const { return (1.0 / (1.0 + x * x * c_)); }
+};
+
+// Eigen 3.3 LDLT<Matrix3d,Lower> (ldlt_inplace<Lower>::unblocked + LDLT::_solve_impl),
+// used by gauss_newton.cpp:66 `A.selfadjointView<Lower>().ldlt().solve(-g)`.
+inline void ldlt3_solve(const double Ain[3][3] /*lower used*/, const double b[3], double x[3])
+{
+    double m[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m[i][j] = (j <= i) ? Ain[i][j] : Ain[j][i];
+    int tr[3];
+    double temp[3];
+    const int size = 3;
+    bool zero_matrix = false;
+    for (int k = 0; k < size; ++k) {
+        // largest |diagonal| in the remaining corner (first maximum)
+        int big = k; double best = std::fabs(m[k][k]);
+        for (int i = k + 1; i < size; ++i) if (std::fabs(m[i][i]) > best) { best = std::fabs(m[i][i]); big = i; }
+        tr[k] = big;
+        if (k != big) {
+            int s = size - big - 1;
+            for (int j = 0; j < k; ++j) std::swap(m[k][j], m[big][j]);
+            for (int i = 0; i < s; ++i) std::swap(m[size - s + i][k], m[size - s + i][big]);
+            std::swap(m[k][k], m[big][big]);
+            for (int i = k + 1; i < big; ++i) { double tmp = m[i][k]; m[i][k] = m[big][i]; m[big][i] = tmp; }
+        }
+        int rs = size - k - 1;
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+            double acc = 0.0;
+            for (int j = 0; j < k; ++j) acc = (j == 0) ? m[k][0] * temp[0] : acc + m[k][j] * temp[j];
+            m[k][k] -= acc;
+            for (int i = 0; i < rs; ++i) {
+                double a2 = 0.0;
+                for (int j = 0; j < k; ++j) a2 = (j == 0) ? m[k + 1 + i][0] * temp[0] : a2 + m[k + 1 + i][j] * temp[j];
+                m[k + 1 + i][k] -= a2;
+            }
+        }
+        double realAkk = m[k][k];
+        bool pivot_is_valid = (std::fabs(realAkk) > 0.0);
+        if (k == 0 && !pivot_is_valid) { for (int j = 0; j < size; ++j) tr[j] = j; zero_matrix = true; break; }
+        if (rs > 0 && pivot_is_valid) for (int i = 0; i < rs; ++i) m[k + 1 + i][k] /= realAkk;
+    }
+    (void)zero_matrix;
+    // solve: dst = P b
+    double d[3] = {b[0], b[1], b[2]};
+    for (int k = 0; k < size; ++k) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+    // L^-1 (unit lower, forward substitution)
+    for (int i = 1; i < size; ++i) {
+        double acc = 0.0;
+        for (int j = 0; j < i; ++j) acc = (j == 0) ? m[i][0] * d[0] : acc + m[i][j] * d[j];
+        d[i] -= acc;
+    }
+    // pseudo-inverse of D; tolerance = 1/highest()
+    const double tol = 1.0 / 1.7976931348623157e308;
+    for (int i = 0; i < size; ++i) { if (std::fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0; }
+    // L^-T (unit upper, backward substitution)
+    for (int i = size - 2; i >= 0; --i) {
+        double acc = 0.0; bool first = true;
+        for (int j = i + 1; j < size; ++j) { acc = first ? m[j][i] * d[j] : acc + m[j][i] * d[j]; first = false; }
+        d[i] -= acc;
+    }
+    // P^T
+    for (int k = size - 1; k >= 0; --k) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+    x[0] = d[0]; x[1] = d[1]; x[2] = d[2];
+}
+
+struct SolveStats { uint32_t iterations = 0; uint32_t evals = 0; };
+
+// MatchSurface2D (src/match_surface_2d.cpp:35-122) as a plain struct
+struct MatchSurface2D {
+    const DynamicDistanceMap* surface_;
+    const Scan* scan_;
+    SE2 state_;
+
+    MatchSurface2D(const DynamicDistanceMap* s, const Scan* scan, const SE2& est) : surface_(s), scan_(scan), state_(est) {}
+
+    // :42-90.  J is row-major N x 3 here (values identical to the reference's col-major matrix)
+    void eval(std::vector<double>& residuals, std::vector<double>* J) const
+    {
+        Affine3 mtf = moving_tf(*scan_);
+        Affine3 ftf = fixed_tf(state_);          // AngleAxisd(state_.so2().log(), UnitZ)
+        Affine3 tf = affine_mul(ftf, mtf);
+        const size_t n = scan_->points.size();
+        residuals.resize(n);
+        if (J) J->resize(n * 3);
+        V3d grad;
+        for (size_t i = 0; i < n; ++i) {
+            V3d hit = affine_apply(tf, scan_->points[i]);
+            hit.z = 0.0;
+            residuals[i] = surface_->distance(hit, &grad);
+            if (J) {
+                (*J)[3 * i + 0] = grad.x;
+                (*J)[3 * i + 1] = grad.y;
+                (*J)[3 * i + 2] = grad.y * hit.x - grad.x * hit.y;
+            }
+        }
+    }
+    // :118-122
+    void update(const double h[3]) { state_ = se2_mul(se2_exp(h[0], h[1], h[2]), state_); }
+};
+
+// GaussNewton (src/nlls/gauss_newton.cpp:38-91) + Solver::solve (src/nlls/solver.cpp:53-107)
+// with robust cost = CauchyWeight.  Returns number of iterations (applied + reverted steps).
+inline SolveStats solve_gn(MatchSurface2D& problem, uint32_t max_iterations, const CauchyWeight& robust)
+{
+    const double eps1 = 1e-4, eps2 = 1e-4;             // gauss_newton.cpp:38-42
+    SolveStats st;
+    std::vector<double> r, ur, J;
+    double h[3] = {0, 0, 0};
+    bool stop_ = false;                                 // reset() :49-52
+    double chi2_ = 0.0;
+    bool valid = true;
+    uint32_t iter = 0;
+    while (!stop_ && iter < max_iterations) {           // solver.cpp:67
+        if (valid) {
+            problem.eval(r, &J); ++st.evals;            // :71
+            const size_t rows = r.size();
+            for (size_t i = 0; i < rows; ++i) {         // :74-79
+                double w = std::sqrt(robust.value(r[i]));
+                r[i] *= w;
+                J[3 * i + 0] *= w; J[3 * i + 1] *= w; J[3 * i + 2] *= w;
+            }
+        }
+        // strategy->step(r, J)                          gauss_newton.cpp:53-73
+        {
+            const size_t rows = r.size();
+            double g[3] = {0, 0, 0};
+            for (size_t i = 0; i < rows; ++i) { g[0] += J[3 * i] * r[i]; g[1] += J[3 * i + 1] * r[i]; g[2] += J[3 * i + 2] * r[i]; }
+            chi2_ = 0.0;
+            for (size_t i = 0; i < rows; ++i) chi2_ += r[i] * r[i];
+            double max_abs_g = std::max(std::fabs(g[0]), std::max(std::fabs(g[1]), std::fabs(g[2])));
+            if (max_abs_g < eps1) {
+                stop_ = true;
+                h[0] = h[1] = h[2] = 0.0;
+            } else {
+                double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                for (size_t i = 0; i < rows; ++i)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) A[a][b] += J[3 * i + a] * J[3 * i + b];
+                double mg[3] = {-g[0], -g[1], -g[2]};
+                ldlt3_solve(A, mg, h);
+                double max_abs_h = std::max(std::fabs(h[0]), std::max(std::fabs(h[1]), std::fabs(h[2])));
+                if (max_abs_h < eps2) stop_ = true;
+            }
+        }
+        if (stop_) break;                               // solver.cpp:84-86 (h NOT applied)
+
+        problem.update(h);                              // :89
+        problem.eval(ur, nullptr); ++st.evals;          // :90
+        double ur2 = 0.0;
+        for (size_t i = 0; i < ur.size(); ++i) {        // :92-96
+            double w = std::sqrt(robust.value(ur[i]));
+            ur[i] *= w;
+        }
+        for (size_t i = 0; i < ur.size(); ++i) ur2 += ur[i] * ur[i];
+        // strategy->valid(ur)                           gauss_newton.cpp:75-86
+        {
+            double dF = chi2_ - ur2;
+            if (dF > 0) valid = true;
+            else { stop_ = true; valid = false; }
+        }
+        if (!valid) {                                   // solver.cpp:99-102
+            double mh[3] = {-h[0], -h[1], -h[2]};
+            problem.update(mh);
+        }
+        ++iter;
+    }
+    st.iterations = iter;
+    return st;
+}
+
+// -------------------------------------------------------------------------------------
+// ThreadPool -- same dispatch MODEL as src/thread_pool.cpp:52-114 (one task per particle per
+// region, wait() barrier); plain mutex queue instead of moodycamel (vendor lib, not restated).
+// -------------------------------------------------------------------------------------
+class ThreadPool {
+public:
+    void init(size_t size)
+    {
+        if (size == 0) size = std::thread::hardware_concurrency();
+        for (size_t i = 0; i < size; ++i)
+            workers.emplace_back([this] {
+                for (;;) {
+                    std::function<void()> task;
+                    {
+                        std::unique_lock<std::mutex> lock(m);
+                        cv.wait(lock, [this] { return stop || !tasks.empty(); });
+                        if (stop && tasks.empty()) return;
+                        task = std::move(tasks.front());
+                        tasks.pop_front();
+                    }
+                    task();
+                    {
+                        std::unique_lock<std::mutex> lock(m);
+                        if (--pending == 0) done.notify_all();
+                    }
+                }
+            });
+    }
+    ~ThreadPool()
+    {
+        { std::unique_lock<std::mutex> lock(m); stop = true; }
+        cv.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    void enqueue(std::function<void()>&& f)
+    {
+        { std::unique_lock<std::mutex> lock(m); ++pending; tasks.emplace_back(std::move(f)); }
+        cv.notify_one();
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        done.wait(lock, [this] { return pending == 0; });
+    }
+    size_t size() const { return workers.size(); }
+private:
+    std::vector<std::thread> workers;
+    std::deque<std::function<void()>> tasks;
+    std::mutex m;
+    std::condition_variable cv, done;
+    size_t pending = 0;
+    bool stop = false;
+};
+
+// -------------------------------------------------------------------------------------
+// PFSlam2D  (include/lama/pf_slam2d.h, src/pf_slam2d.cpp)
+// -------------------------------------------------------------------------------------
+struct PFOptions {                                     // pf_slam2d.h:132-185
+    uint32_t particles = 30;
+    double srr = 0.1, str = 0.2, stt = 0.1, srt = 0.2;
+    double meas_sigma = 0.05, meas_sigma_gain = 3;
+    double trans_thresh = 0.5, rot_thresh = 0.5;
+    double l2_max = 0.5;
+    double truncated_ray = 0.0, truncated_range = 0.0;
+    double resolution = 0.05;
+    uint32_t patch_size = 32;
+    uint32_t max_iter = 100;
+    int32_t threads = -1;
+    uint32_t seed = 0;
+};
+
+struct ParticleCounters {   // per particle, last update() (instrumentation; not in the reference)
+    uint32_t iterations = 0, evals = 0;
+    uint64_t ray_cells = 0, occ_events = 0, bf_processed = 0;
+    uint32_t n_match = 0, n_occ = 0, n_bf = 0, n_match_or_bf = 0;
+};
+
+struct Particle {                                      // pf_slam2d.h:67-86
+    double weight = 0, normalized_weight = 0, weight_sum = 0;
+    SE2 pose;
+    std::vector<SE2> poses;
+    std::shared_ptr<DynamicDistanceMap> dm;
+    std::shared_ptr<FrequencyOccupancyMap> occ;
+    ParticleCounters ctr;
+    std::unordered_set<uint64_t> match_touch;   // instrumentation only
+};
+
+struct UpdateTimes { double total = 0, solving = 0, normalizing = 0, resampling = 0, mapping = 0; bool resampled = false; };
+
+class PFSlam2D {
+public:
+    explicit PFSlam2D(const PFOptions& o) : options_(o), gen_(o.seed)   // pf_slam2d.cpp:105-137
+    {
+        truncated_ray_ = o.truncated_ray;
+        truncated_range_ = o.truncated_range;
+        if (options_.threads <= 1) thread_pool_ = nullptr;              // :123-128
+        else { thread_pool_.reset(new ThreadPool); thread_pool_->init(options_.threads); }
+        // seed == 0 -> random_device in the reference (:131-134); tests always pass a seed
+        gen_.seed(options_.seed);
+    }
+
+    void setPrior(const SE2& prior) { pose_ = prior; }                  // :146-149
+
+    bool count_touches = false;  // enable roofline instrumentation (slower)
+
+    // src/pf_slam2d.cpp:178-312
+    bool update(const Scan& surface, const SE2& odometry, double timestamp)
+    {
+        using clk = std::chrono::steady_clock;
+        auto t0 = clk::now();
+        last_times = UpdateTimes();
+        current_surface_ = &surface;
+
+        if (!has_first_scan) {                                          // :185-228
+            odom_ = odometry;
+            timestamps_.push_back(timestamp);
+            const uint32_t P = options_.particles;
+            particles_[0].assign(P, Particle());
+            current_particle_set_ = 0;
+            Particle& p0 = particles_[0][0];
+            p0.poses.push_back(pose_);
+            p0.pose = pose_;
+            p0.weight = 0.0; p0.weight_sum = 0.0;
+            p0.dm = std::make_shared<DynamicDistanceMap>(options_.resolution, options_.patch_size);
+            p0.dm->setMaxDistance(options_.l2_max);
+            p0.occ = std::make_shared<FrequencyOccupancyMap>(options_.resolution, options_.patch_size);
+            updateParticleMaps(&p0);
+            for (uint32_t i = 1; i < P; ++i) {
+                Particle& p = particles_[0][i];
+                p.poses.push_back(pose_);
+                p.pose = pose_;
+                p.weight = 0.0; p.weight_sum = 0.0;
+                p.dm = std::make_shared<DynamicDistanceMap>(*p0.dm);
+                p.occ = std::make_shared<FrequencyOccupancyMap>(*p0.occ);
+            }
+            has_first_scan = true;
+            last_times.total = last_times.mapping = sec(t0);
+            return true;
+        }
+
+        // 1. predict from odometry                                      :231-236
+        SE2 odelta = pose_minus(odom_, odometry);
+        odom_ = odometry;
+        const uint32_t P = options_.particles;
+        auto& cur = particles_[current_particle_set_];
+        for (uint32_t i = 0; i < P; ++i) drawFromMotion(odelta, cur[i].pose);
+
+        acc_trans_ += std::sqrt(odelta.tx * odelta.tx + odelta.ty * odelta.ty);   // :239
+        acc_rot_ += std::fabs(se2_rotation(odelta));                               // :240
+        if (acc_trans_ <= options_.trans_thresh && acc_rot_ <= options_.rot_thresh) return false;
+        acc_trans_ = 0; acc_rot_ = 0;
+
+        // 2. scan matching                                               :252-269
+        auto t1 = clk::now();
+        if (thread_pool_) {
+            for (uint32_t i = 0; i < P; ++i) thread_pool_->enqueue([this, i]() { scanMatch(&particles_[current_particle_set_][i]); });
+            thread_pool_->wait();
+        } else {
+            for (uint32_t i = 0; i < P; ++i) scanMatch(&cur[i]);
+        }
+        last_times.solving = sec(t1);
+
+        // 3. normalize                                                   :271-277
+        auto t2 = clk::now();
+        normalize();
+        last_times.normalizing = sec(t2);
+
+        // 4. resample                                                    :279-287
+        if (neff_ < (options_.particles * 0.5)) {
+            auto t3 = clk::now();
+            resample();
+            last_times.resampling = sec(t3);
+            last_times.resampled = true;
+            ++num_resamples;
+        }
+
+        // 5. update maps                                                 :289-302
+        auto t4 = clk::now();
+        auto& cur2 = particles_[current_particle_set_];
+        if (thread_pool_) {
+            for (uint32_t i = 0; i < P; ++i) thread_pool_->enqueue([this, i]() { updateParticleMaps(&particles_[current_particle_set_][i]); });
+            thread_pool_->wait();
+        } else {
+            for (uint32_t i = 0; i < P; ++i) updateParticleMaps(&cur2[i]);
+        }
+        last_times.mapping = sec(t4);
+        last_times.total = sec(t0);
+        return true;
+    }
+
+    size_t getBestParticleIdx() const                                   // :314-330
+    {
+        const auto& cur = particles_[current_particle_set_];
+        size_t best_idx = 0;
+        double best_ws = cur[0].weight_sum;
+        for (uint32_t i = 1; i < options_.particles; ++i)
+            if (best_ws < cur[i].weight_sum) { best_ws = cur[i].weight_sum; best_idx = i; }
+        return best_idx;
+    }
+    SE2 getPose() const { return particles_[current_particle_set_][getBestParticleIdx()].pose; }
+    double getNeff() const { return neff_; }
+    std::vector<Particle>& particles() { return particles_[current_particle_set_]; }
+    const PFOptions& options() const { return options_; }
+    bool hasFirstScan() const { return has_first_scan; }
+
+    // ---- stage-wise entry points for teacher-forced parity tests (same code as update()) ----
+    void stage_set_scan(const Scan& s) { current_surface_ = &s; }
+    void stage_scan_match_all() { for (auto& p : particles()) scanMatch(&p); }
+    void stage_update_maps_all() { for (auto& p : particles()) updateParticleMaps(&p); }
+    void stage_normalize() { normalize(); }
+    void stage_resample_with(const std::vector<int32_t>& idx) { resample_apply(idx); }
+    std::vector<int32_t> stage_resample_indices(double u) { return resample_indices(u); }
+
+    // src/pf_slam2d.cpp:365-391
+    void drawFromMotion(const SE2& delta, SE2& pose)
+    {
+        double sigma, x, y, yaw;
+        double sxy = 0.3 * options_.stt;
+        const double dx = delta.tx, dy = delta.ty, drot = se2_rotation(delta);
+        sigma = options_.stt * std::fabs(dx) + options_.str * std::fabs(drot) + sxy * std::fabs(dy);
+        x = dx + normal(sigma);
+        sigma = options_.stt * std::fabs(dy) + options_.str * std::fabs(drot) + sxy * std::fabs(dx);
+        y = dy + normal(sigma);
+        sigma = options_.srr * std::fabs(drot) + options_.srt * std::sqrt(dx * dx + dy * dy);
+        yaw = drot + normal(sigma);
+        yaw = std::fmod(yaw, 2 * M_PI);
+        if (yaw > M_PI) yaw -= 2 * M_PI;
+        pose = se2_mul(pose, se2_from_xyr(x, y, yaw));                  // pose += Pose2D(x,y,yaw)
+    }
+
+    // src/pf_slam2d.cpp:393-414
+    double calculateLikelihood(const Particle& particle) const
+    {
+        const Scan& surface = *current_surface_;
+        Affine3 tf = affine_mul(fixed_tf(particle.pose), moving_tf(surface));
+        double likelihood = 0;
+        for (size_t i = 0; i < surface.points.size(); ++i) {
+            V3d hit = affine_apply(tf, surface.points[i]);
+            double dist = particle.dm->distance(hit, nullptr);
+            likelihood += -(dist * dist) / options_.meas_sigma;
+        }
+        return likelihood;
+    }
+
+    // src/pf_slam2d.cpp:416-437
+    void scanMatch(Particle* particle)
+    {
+        std::unordered_set<uint64_t> touched;
+        if (count_touches) { particle->dm->reset_cache(); particle->dm->touch_ro = &touched; }
+        MatchSurface2D ms(particle->dm.get(), current_surface_, particle->pose);
+        CauchyWeight cauchy(0.15);
+        SolveStats st = solve_gn(ms, options_.max_iter, cauchy);
+        particle->pose = ms.state_;
+        particle->poses.push_back(particle->pose);
+        double l = calculateLikelihood(*particle);
+        particle->weight_sum += l;
+        particle->weight += l;
+        particle->ctr.iterations = st.iterations;
+        particle->ctr.evals = st.evals + 1;
+        if (count_touches) {
+            particle->dm->touch_ro = nullptr;
+            particle->ctr.n_match = (uint32_t)touched.size();
+            particle->match_touch = std::move(touched);
+        }
+    }
+
+    // src/pf_slam2d.cpp:439-509
+    void updateParticleMaps(Particle* particle)
+    {
+        const Scan& surface = *current_surface_;
+        std::unordered_set<uint64_t> t_occ, t_bf;
+        if (count_touches) {
+            particle->occ->reset_cache(); particle->dm->reset_cache();
+            particle->occ->touch_rw = &t_occ; particle->dm->touch_rw = &t_bf;
+        }
+        Affine3 mtf = moving_tf(surface);
+        Affine3 ftf = fixed_tf(particle->pose);
+        Affine3 tf = affine_mul(ftf, mtf);
+        V3d wso{tf.t[0], tf.t[1], tf.t[2]};
+        uint64_t ray_cells = 0, events = 0;
+        const size_t num_points = surface.points.size();
+        for (size_t i = 0; i < num_points; ++i) {
+            V3d start = wso;
+            V3d hit = affine_apply(tf, surface.points[i]);
+            V3d AB{0, 0, 0};
+            double ray_length = 1.0;
+            bool mark_hit = true;
+            if (truncated_range_ > 0.0) {                               // :467-479
+                AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
+                ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
+                if (truncated_range_ < ray_length) {
+                    hit = V3d{start.x + AB.x / ray_length * truncated_range_, start.y + AB.y / ray_length * truncated_range_, start.z + AB.z / ray_length * truncated_range_};
+                    mark_hit = false;
+                }
+            }
+            if (mark_hit && (truncated_ray_ > 0.0)) {                   // :481-491
+                if (truncated_range_ == 0.0) {
+                    AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
+                    ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
+                }
+                if (truncated_ray_ < ray_length)
+                    start = V3d{hit.x - AB.x / ray_length * truncated_ray_, hit.y - AB.y / ray_length * truncated_ray_, hit.z - AB.z / ray_length * truncated_ray_};
+            }
+            V3u mhit = particle->occ->w2m(hit);                         // :493
+            if (mark_hit) {
+                bool changed = particle->occ->setOccupied(mhit);
+                if (changed) { particle->dm->addObstacle(mhit); ++events; }
+            }
+            particle->occ->computeRay(particle->occ->w2m(start), mhit, [&](const V3u& coord) {
+                ++ray_cells;
+                bool changed = particle->occ->setFree(coord);
+                if (changed) { particle->dm->removeObstacle(coord); ++events; }
+            });
+        }
+        uint32_t processed = particle->dm->update();                    // :508
+        particle->ctr.ray_cells = ray_cells;
+        particle->ctr.occ_events = events;
+        particle->ctr.bf_processed = processed;
+        if (count_touches) {
+            particle->occ->touch_rw = nullptr; particle->dm->touch_rw = nullptr;
+            particle->ctr.n_occ = (uint32_t)t_occ.size();
+            particle->ctr.n_bf = (uint32_t)t_bf.size();
+            std::unordered_set<uint64_t> u = t_bf;
+            u.insert(particle->match_touch.begin(), particle->match_touch.end());
+            particle->ctr.n_match_or_bf = (uint32_t)u.size();
+        }
+    }
+
+    // src/pf_slam2d.cpp:511-535
+    void normalize()
+    {
+        auto& cur = particles_[current_particle_set_];
+        double gain = 1.0 / (options_.meas_sigma_gain * options_.particles);
+        double max_l = cur[0].weight;
+        const uint32_t P = options_.particles;
+        for (uint32_t i = 1; i < P; ++i) if (max_l < cur[i].weight) max_l = cur[i].weight;
+        double sum = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            cur[i].normalized_weight = std::exp(gain * (cur[i].weight - max_l));
+            sum += cur[i].normalized_weight;
+        }
+        neff_ = 0;
+        for (uint32_t i = 0; i < P; ++i) {
+            cur[i].normalized_weight /= sum;
+            neff_ += cur[i].normalized_weight * cur[i].normalized_weight;
+        }
+        neff_ = 1.0 / neff_;
+    }
+
+    // src/pf_slam2d.cpp:537-556 (index generation)
+    std::vector<int32_t> resample_indices(double u01)
+    {
+        auto& cur = particles_[current_particle_set_];
+        const uint32_t P = options_.particles;
+        std::vector<int32_t> sample_idx(P);                             // zero-initialised (:540)
+        double interval = 1.0 / (double)P;
+        double target = interval * u01;
+        double cw = 0.0;
+        uint32_t n = 0;
+        for (size_t i = 0; i < P; ++i) {
+            cw += cur[i].normalized_weight;
+            while (cw > target) {
+                if (n >= P) break;   // the reference would write out of bounds here; cannot occur for sum(nw)~1
+                sample_idx[n++] = (int32_t)i;
+                target += interval;
+            }
+        }
+        return sample_idx;
+    }
+
+    // src/pf_slam2d.cpp:558-574 (particle-set construction)
+    void resample_apply(const std::vector<int32_t>& sample_idx)
+    {
+        const uint32_t P = options_.particles;
+        uint8_t ps = 1 - current_particle_set_;
+        particles_[ps].assign(P, Particle());
+        auto& cur = particles_[current_particle_set_];
+        for (size_t i = 0; i < P; ++i) {
+            uint32_t idx = (uint32_t)sample_idx[i];
+            particles_[ps][i] = cur[idx];
+            particles_[ps][i].weight = 0.0;
+            particles_[ps][i].weight_sum = cur[idx].weight_sum;
+            particles_[ps][i].dm = std::make_shared<DynamicDistanceMap>(*cur[idx].dm);
+            particles_[ps][i].occ = std::make_shared<FrequencyOccupancyMap>(*cur[idx].occ);
+        }
+        cur.clear();
+        current_particle_set_ = ps;
+        last_sample_idx = sample_idx;
+    }
+
+    void resample()
+    {
+        double u = std::uniform_real_distribution<double>(0.0, 1.0)(gen_);   // random.cpp:51-55
+        resample_apply(resample_indices(u));
+    }
+
+    double normal(double stddev)                                        // random.cpp:69-73
+    {
+        std::normal_distribution<double> distribution(0.0, stddev);
+        return distribution(gen_);
+    }
+
+    UpdateTimes last_times;
+    uint32_t num_resamples = 0;
+    std::vector<int32_t> last_sample_idx;
+
+private:
+    static double sec(std::chrono::steady_clock::time_point t0)
+    { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+    PFOptions options_;
+    std::mt19937 gen_;                                                  // random.cpp:38-39 (process-global there)
+    std::vector<Particle> particles_[2];
+    uint8_t current_particle_set_ = 0;
+    SE2 odom_, pose_;
+    double acc_trans_ = 0, acc_rot_ = 0;
+    bool has_first_scan = false;
+    double truncated_ray_ = 0, truncated_range_ = 0;
+    double neff_ = 0;
+    std::deque<double> timestamps_;
+    const Scan* current_surface_ = nullptr;
+    std::unique_ptr<ThreadPool> thread_pool_;
+};
+
+} // namespace orc
