@@ -1,0 +1,326 @@
+"""ctypes view of the CPU oracle (oracle/_build/liblama_oracle.so).  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_LIB = os.path.join(ROOT, "oracle", "_build", "liblama_oracle.so")
+
+DIST_T = np.dtype([("obstacle", "<i2", (3,)), ("sqdist", "<u2"), ("valid", "u1"), ("queued", "u1")])
+FREQ_T = np.dtype([("occupied", "<u2"), ("visited", "<u2")])
+assert DIST_T.itemsize == 10 and FREQ_T.itemsize == 4
+
+
+class PFOptions(C.Structure):
+    _fields_ = [("particles", C.c_uint32), ("srr", C.c_double), ("str", C.c_double), ("stt", C.c_double),
+                ("srt", C.c_double), ("meas_sigma", C.c_double), ("meas_sigma_gain", C.c_double),
+                ("trans_thresh", C.c_double), ("rot_thresh", C.c_double), ("l2_max", C.c_double),
+                ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
+                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("threads", C.c_int32), ("seed", C.c_uint32)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(_LIB)
+        vp, d, u32, i32, u64 = C.c_void_p, C.c_double, C.c_uint32, C.c_int, C.c_uint64
+        sig = {
+            "orc_se2_from_xyr": (None, [d, d, d, vp]), "orc_se2_rotation": (d, [vp]), "orc_cauchy": (d, [d, d]),
+            "orc_m2p": (u64, [d, u32, vp]), "orc_m2c": (u32, [d, u32, vp]), "orc_w2m": (None, [d, u32, vp, vp]),
+            "orc_compute_ray": (i32, [vp, vp, vp, i32]),
+            "orc_dm_new": (vp, [d, u32, d]), "orc_dm_clone": (vp, [vp]), "orc_dm_free": (None, [vp]),
+            "orc_dm_max_sqdist": (u32, [vp]),
+            "orc_dm_add_obstacle": (None, [vp, u32, u32, u32]), "orc_dm_remove_obstacle": (None, [vp, u32, u32, u32]),
+            "orc_dm_update": (u32, [vp]), "orc_dm_distance_cell": (d, [vp, u32, u32, u32]),
+            "orc_dm_distance": (d, [vp, vp, vp]), "orc_dm_patch_ids": (i32, [vp, vp, i32]),
+            "orc_dm_patch_read": (i32, [vp, u64, vp, vp]), "orc_dm_stats": (None, [vp, vp]),
+            "orc_occ_new": (vp, [d, u32]), "orc_occ_clone": (vp, [vp]), "orc_occ_free": (None, [vp]),
+            "orc_occ_set_free": (i32, [vp, u32, u32, u32]), "orc_occ_set_occupied": (i32, [vp, u32, u32, u32]),
+            "orc_occ_probability": (d, [vp, u32, u32, u32]), "orc_occ_patch_ids": (i32, [vp, vp, i32]),
+            "orc_occ_patch_read": (i32, [vp, u64, vp, vp]),
+            "orc_eval": (None, [vp, vp, i32, vp, vp, vp, vp, vp]),
+            "orc_solve": (i32, [vp, vp, i32, vp, vp, vp, u32, vp]),
+            "orc_loglik": (d, [vp, vp, i32, vp, vp, vp, d]),
+            "orc_pf_new": (vp, [vp]), "orc_pf_free": (None, [vp]), "orc_pf_set_prior": (None, [vp, vp]),
+            "orc_pf_count_touches": (None, [vp, i32]),
+            "orc_pf_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "orc_pf_times": (None, [vp, vp, vp]),
+            "orc_pf_num_resamples": (u32, [vp]), "orc_pf_neff": (d, [vp]), "orc_pf_best": (i32, [vp]),
+            "orc_pf_get_poses": (None, [vp, vp]), "orc_pf_set_poses": (None, [vp, vp]),
+            "orc_pf_get_weights": (None, [vp, vp, vp, vp]), "orc_pf_set_weights": (None, [vp, vp, vp]),
+            "orc_pf_particle_dm": (vp, [vp, i32]), "orc_pf_particle_occ": (vp, [vp, i32]),
+            "orc_pf_counters": (None, [vp, i32, vp]), "orc_pf_last_sample_idx": (i32, [vp, vp, i32]),
+            "orc_pf_stage_set_scan": (None, [vp, vp, i32, vp, vp]), "orc_pf_stage_scan_match": (None, [vp]),
+            "orc_pf_stage_update_maps": (None, [vp]), "orc_pf_stage_normalize": (d, [vp]),
+            "orc_pf_stage_resample_indices": (None, [vp, d, vp]), "orc_pf_stage_resample_with": (None, [vp, vp, i32]),
+            "orc_pf_draw_from_motion": (None, [vp, vp, vp]),
+            "orc_scan_tf": (None, [vp, vp, vp, vp]), "orc_ldlt3_solve": (None, [vp, vp, vp]),
+            "orc_se2_exp": (None, [vp, vp]), "orc_se2_mul": (None, [vp, vp, vp]), "orc_se2_inverse": (None, [vp, vp]),
+            "orc_pose_minus": (None, [vp, vp, vp]),
+        }
+        for name, (res, args) in sig.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+IDENT_Q = np.array([1.0, 0, 0, 0])
+ZERO3 = np.zeros(3)
+
+
+def se2(x, y, r):
+    out = np.zeros(4)
+    lib().orc_se2_from_xyr(x, y, r, _p(out))
+    return out
+
+
+def se2_exp(v):
+    out = np.zeros(4)
+    lib().orc_se2_exp(_p(np.ascontiguousarray(v, dtype=np.float64)), _p(out))
+    return out
+
+
+def se2_mul(a, b):
+    out = np.zeros(4)
+    lib().orc_se2_mul(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+    return out
+
+
+def default_options(**kw):
+    o = PFOptions()
+    lib().orc_pf_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+class _MapBase:
+    _pre = None
+    _dtype = None
+
+    def __init__(self, handle, owned=True):
+        self.h = C.c_void_p(handle)
+        self.owned = owned
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            getattr(lib(), self._pre + "_free")(self.h)
+            self.h = None
+
+    def patch_ids(self):
+        n = getattr(lib(), self._pre + "_patch_ids")(self.h, None, 0)
+        ids = np.zeros(n, dtype=np.uint64)
+        getattr(lib(), self._pre + "_patch_ids")(self.h, _p(ids), n)
+        return ids
+
+    def patch(self, pid):
+        cells = np.zeros(1024, dtype=self._dtype)
+        mask = np.zeros(16, dtype=np.uint64)
+        r = getattr(lib(), self._pre + "_patch_read")(self.h, int(pid), _p(cells), _p(mask))
+        assert r == cells.nbytes, r
+        return cells, mask
+
+    def dump(self):
+        """{patch_id: (cells[1024], mask[16])}"""
+        return {int(p): self.patch(p) for p in self.patch_ids()}
+
+
+class DM(_MapBase):
+    _pre = "orc_dm"
+    _dtype = DIST_T
+
+    @classmethod
+    def new(cls, res=0.05, patch=32, l2_max=0.5):
+        return cls(lib().orc_dm_new(res, patch, l2_max))
+
+    def clone(self):
+        return DM(lib().orc_dm_clone(self.h))
+
+    def add(self, x, y, z=0):
+        lib().orc_dm_add_obstacle(self.h, x, y, z)
+
+    def remove(self, x, y, z=0):
+        lib().orc_dm_remove_obstacle(self.h, x, y, z)
+
+    def update(self):
+        return lib().orc_dm_update(self.h)
+
+    def max_sqdist(self):
+        return lib().orc_dm_max_sqdist(self.h)
+
+    def distance_cell(self, x, y, z=0):
+        return lib().orc_dm_distance_cell(self.h, x, y, z)
+
+    def distance(self, p, grad=False):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        g = np.zeros(3)
+        d = lib().orc_dm_distance(self.h, _p(p), _p(g) if grad else None)
+        return (d, g) if grad else d
+
+    def stats(self):
+        s = np.zeros(6, dtype=np.uint64)
+        lib().orc_dm_stats(self.h, _p(s))
+        return dict(zip(["raise_pops", "lower_pops", "lower_fired", "pushes", "max_queue", "tie_overwrites"], s.tolist()))
+
+
+class Occ(_MapBase):
+    _pre = "orc_occ"
+    _dtype = FREQ_T
+
+    @classmethod
+    def new(cls, res=0.05, patch=32):
+        return cls(lib().orc_occ_new(res, patch))
+
+    def set_free(self, x, y, z=0):
+        return bool(lib().orc_occ_set_free(self.h, x, y, z))
+
+    def set_occupied(self, x, y, z=0):
+        return bool(lib().orc_occ_set_occupied(self.h, x, y, z))
+
+    def probability(self, x, y, z=0):
+        return lib().orc_occ_probability(self.h, x, y, z)
+
+
+def compute_ray(frm, to):
+    frm = np.asarray(frm, dtype=np.uint32)
+    to = np.asarray(to, dtype=np.uint32)
+    n = lib().orc_compute_ray(_p(frm), _p(to), None, 0)
+    out = np.zeros((max(n, 1), 3), dtype=np.uint32)
+    lib().orc_compute_ray(_p(frm), _p(to), _p(out), n)
+    return out[:n]
+
+
+def w2m(p, res=0.05, patch=32):
+    out = np.zeros(3, dtype=np.uint32)
+    lib().orc_w2m(res, patch, _p(np.ascontiguousarray(p, dtype=np.float64)), _p(out))
+    return out
+
+
+def eval_(dm, pts, pose, origin=ZERO3, quat=IDENT_Q, jac=True):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    n = len(pts)
+    r = np.zeros(n)
+    J = np.zeros((n, 3)) if jac else None
+    lib().orc_eval(dm.h, _p(pts), n, _p(origin), _p(quat), _p(np.ascontiguousarray(pose)), _p(r), _p(J))
+    return (r, J) if jac else r
+
+
+def solve(dm, pts, pose, max_iter=100, origin=ZERO3, quat=IDENT_Q):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    pose = np.array(pose, dtype=np.float64)
+    ev = C.c_uint32(0)
+    it = lib().orc_solve(dm.h, _p(pts), len(pts), _p(origin), _p(quat), _p(pose), max_iter, C.byref(ev))
+    return pose, it, ev.value
+
+
+def loglik(dm, pts, pose, sigma=0.05, origin=ZERO3, quat=IDENT_Q):
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    return lib().orc_loglik(dm.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(pose)), sigma)
+
+
+class PF:
+    def __init__(self, opts):
+        self.opts = opts
+        self.P = opts.particles
+        self.h = C.c_void_p(lib().orc_pf_new(C.byref(opts)))
+        self._keep = None
+
+    def __del__(self):
+        if self.h:
+            lib().orc_pf_free(self.h)
+            self.h = None
+
+    def set_prior(self, pose4):
+        lib().orc_pf_set_prior(self.h, _p(np.ascontiguousarray(pose4)))
+
+    def count_touches(self, on=True):
+        lib().orc_pf_count_touches(self.h, 1 if on else 0)
+
+    def update(self, pts, odom4, ts=0.0, origin=ZERO3, quat=IDENT_Q):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        return bool(lib().orc_pf_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(odom4)), ts))
+
+    def times(self):
+        t = np.zeros(5)
+        rs = C.c_int(0)
+        lib().orc_pf_times(self.h, _p(t), C.byref(rs))
+        return dict(total=t[0], solving=t[1], normalizing=t[2], resampling=t[3], mapping=t[4], resampled=bool(rs.value))
+
+    def poses(self):
+        out = np.zeros((self.P, 4))
+        lib().orc_pf_get_poses(self.h, _p(out))
+        return out
+
+    def set_poses(self, poses):
+        lib().orc_pf_set_poses(self.h, _p(np.ascontiguousarray(poses, dtype=np.float64)))
+
+    def weights(self):
+        w, nw, ws = np.zeros(self.P), np.zeros(self.P), np.zeros(self.P)
+        lib().orc_pf_get_weights(self.h, _p(w), _p(nw), _p(ws))
+        return w, nw, ws
+
+    def set_weights(self, w=None, ws=None):
+        lib().orc_pf_set_weights(self.h, _p(np.ascontiguousarray(w)) if w is not None else None,
+                                 _p(np.ascontiguousarray(ws)) if ws is not None else None)
+
+    def neff(self):
+        return lib().orc_pf_neff(self.h)
+
+    def best(self):
+        return lib().orc_pf_best(self.h)
+
+    def num_resamples(self):
+        return lib().orc_pf_num_resamples(self.h)
+
+    def dm(self, i):
+        return DM(lib().orc_pf_particle_dm(self.h, i), owned=False)
+
+    def occ(self, i):
+        return Occ(lib().orc_pf_particle_occ(self.h, i), owned=False)
+
+    def counters(self, i):
+        c = np.zeros(9, dtype=np.uint64)
+        lib().orc_pf_counters(self.h, i, _p(c))
+        return dict(zip(["iterations", "evals", "ray_cells", "occ_events", "bf_processed", "n_match", "n_occ", "n_bf", "n_match_or_bf"], c.tolist()))
+
+    def last_sample_idx(self):
+        out = np.zeros(self.P, dtype=np.int32)
+        n = lib().orc_pf_last_sample_idx(self.h, _p(out), self.P)
+        return out[:n]
+
+    # stage-wise
+    def stage_set_scan(self, pts, origin=ZERO3, quat=IDENT_Q):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        lib().orc_pf_stage_set_scan(self.h, _p(pts), len(pts), _p(origin), _p(quat))
+
+    def stage_scan_match(self):
+        lib().orc_pf_stage_scan_match(self.h)
+
+    def stage_update_maps(self):
+        lib().orc_pf_stage_update_maps(self.h)
+
+    def stage_normalize(self):
+        return lib().orc_pf_stage_normalize(self.h)
+
+    def stage_resample_indices(self, u):
+        out = np.zeros(self.P, dtype=np.int32)
+        lib().orc_pf_stage_resample_indices(self.h, u, _p(out))
+        return out
+
+    def stage_resample_with(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        lib().orc_pf_stage_resample_with(self.h, _p(idx), len(idx))
+
+    def draw_from_motion(self, delta4, pose4):
+        pose = np.array(pose4, dtype=np.float64)
+        lib().orc_pf_draw_from_motion(self.h, _p(np.ascontiguousarray(delta4)), _p(pose))
+        return pose
