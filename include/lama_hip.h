@@ -1,0 +1,155 @@
+/* =====================================================================================
+ * lama_hip.h -- C-ABI of the MI355X (gfx950) particle-filter scan-matching path.
+ *
+ * This is the drop-in boundary.  The reference has no FFI layer: its seam
+ * is the C++ class API of include/lama/ (static library `iris_lama`).  The entry points below
+ * are what a host-side `lama::PFSlam2D` calls INSTEAD of the bodies of the reference's two
+ * per-particle parallel regions and of resample():
+ *
+ *   reference (file:line, relative to /root/reference)            entry point here
+ *   -----------------------------------------------------------   --------------------------
+ *   PFSlam2D::update first-scan block   src/pf_slam2d.cpp:185-228  lama_hip_pf_init
+ *   region 1: scanMatch per particle    src/pf_slam2d.cpp:254-266  lama_hip_pf_scan_match
+ *     = MatchSurface2D::eval            src/match_surface_2d.cpp:42-90
+ *     + Solver::solve / GaussNewton     src/nlls/solver.cpp:53-107, src/nlls/gauss_newton.cpp:53-86
+ *     + CauchyWeight                    src/nlls/robust_cost.cpp:66-73
+ *     + calculateLikelihood             src/pf_slam2d.cpp:393-414
+ *   resample(): particle-set copy       src/pf_slam2d.cpp:558-574  lama_hip_pf_resample
+ *   region 2: updateParticleMaps        src/pf_slam2d.cpp:292-302  lama_hip_pf_update_maps
+ *     = Map::computeRay                 src/sdm/map.cpp:198-227
+ *     + FrequencyOccupancyMap::set*     src/sdm/frequency_occupancy_map.cpp:65-91
+ *     + DynamicDistanceMap add/remove/update  src/sdm/dynamic_distance_map.cpp:160-330
+ *   getOccupancyMap()/getDistanceMap()  include/lama/pf_slam2d.h:211-225  lama_hip_pf_download_map
+ *   Particle::pose read/write           include/lama/pf_slam2d.h:77      lama_hip_pf_set_poses / _get_poses
+ *
+ * Host-side pieces that stay on the host (RNG order is part of the result): drawFromMotion
+ * (:365-391), normalize (:511-535), systematic-resampling index generation (:537-556).
+ *
+ * Conventions
+ *   - plain C, POD arguments only; no exceptions, STL, Eigen or torch types cross this boundary;
+ *   - every function returns int32_t status: LAMA_HIP_OK (0) or a negative LAMA_HIP_E_* code;
+ *     lama_hip_last_error() gives a human-readable message for the last failure on that context;
+ *   - host buffers are borrowed for the duration of the call; outputs go to caller-provided arrays;
+ *   - calls on one context must be serialised by the caller (same contract as PFSlam2D::update);
+ *   - a pose is the reference's SE2 state: 4 doubles {c, s, tx, ty} (unit complex + translation,
+ *     include/lama/sophus/se2.hpp); the scan is PointCloudXYZ (include/lama/types.h:111-120):
+ *     n x 3 doubles + sensor_origin_[3] + sensor_orientation_ quaternion {w,x,y,z}.
+ * ===================================================================================== */
+#ifndef LAMA_HIP_H
+#define LAMA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LAMA_HIP_OK 0
+#define LAMA_HIP_E_INVALID (-1)    /* bad argument / unsupported option                         */
+#define LAMA_HIP_E_HIP (-2)        /* a HIP runtime call failed                                 */
+#define LAMA_HIP_E_WINDOW (-3)     /* a cell fell outside the device map window                 */
+#define LAMA_HIP_E_CAPACITY (-4)   /* patch arena / brushfire queue capacity exceeded           */
+#define LAMA_HIP_E_STATE (-5)      /* call sequence error (e.g. scan_match before init)         */
+#define LAMA_HIP_E_NUMERIC (-6)    /* zero-norm unit complex (the reference throws SophusException) */
+
+typedef struct lama_hip_ctx lama_hip_ctx;
+
+/* Subset of PFSlam2D::Options (include/lama/pf_slam2d.h:132-185) the device path needs, plus
+ * device-side capacities (0 = default). */
+typedef struct lama_hip_cfg {
+    uint32_t particles;          /* particles owned by THIS context (one shard of the pool)       */
+    double resolution;           /* Options::resolution (0.05)                                    */
+    uint32_t patch_size;         /* Options::patch_size; only 32 is supported on the device       */
+    double l2_max;               /* Options::l2_max -> DynamicDistanceMap::setMaxDistance          */
+    double meas_sigma;           /* Options::meas_sigma (likelihood divisor, pf_slam2d.cpp:411)   */
+    uint32_t max_iter;           /* Options::max_iter                                             */
+    double truncated_ray;        /* Options::truncated_ray                                        */
+    double truncated_range;      /* Options::truncated_range                                      */
+    int32_t device;              /* HIP device ordinal                                            */
+    uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m) */
+    uint32_t dm_patch_capacity;  /* DM patches per particle  (default 256)                        */
+    uint32_t occ_patch_capacity; /* occupancy patches per particle (default 256)                  */
+    uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
+    uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */
+} lama_hip_cfg;
+
+void lama_hip_default_cfg(lama_hip_cfg* cfg);
+
+int32_t lama_hip_device_count(int32_t* count);
+
+int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg, lama_hip_ctx** out);
+void lama_hip_ctx_destroy(lama_hip_ctx* ctx);
+const char* lama_hip_last_error(const lama_hip_ctx* ctx);
+
+/* First scan (src/pf_slam2d.cpp:185-228): every particle's pose = pose0; particle 0 builds its maps
+ * from the scan (updateParticleMaps), all others become copies of particle 0. */
+int32_t lama_hip_pf_init(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
+                         const double* sensor_origin3, const double* sensor_quat_wxyz,
+                         const double* pose0);
+
+/* Particle poses, P x 4 doubles {c,s,tx,ty}. */
+int32_t lama_hip_pf_set_poses(lama_hip_ctx* ctx, const double* poses);
+int32_t lama_hip_pf_get_poses(lama_hip_ctx* ctx, double* poses);
+
+/* Region 1 (scanMatch): per particle, Gauss-Newton + Cauchy(0.15) on the particle's own distance map
+ * starting from its current pose; the refined pose replaces the particle's pose.
+ * Outputs (any may be NULL): poses_out P x 4, loglik_out P (calculateLikelihood),
+ * iters_out P (Solver iterations = applied + reverted steps). */
+int32_t lama_hip_pf_scan_match(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
+                               const double* sensor_origin3, const double* sensor_quat_wxyz,
+                               double* poses_out, double* loglik_out, int32_t* iters_out);
+
+/* resample(): new particle i := copy of old particle sample_idx[i] (pose + both maps). */
+int32_t lama_hip_pf_resample(lama_hip_ctx* ctx, const int32_t* sample_idx);
+
+/* Region 2 (updateParticleMaps): per particle ray-cast of the scan from the particle's pose into its
+ * FrequencyOccupancyMap, add/remove obstacle events into its DynamicDistanceMap, then dm->update(). */
+int32_t lama_hip_pf_update_maps(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
+                                const double* sensor_origin3, const double* sensor_quat_wxyz);
+
+/* Map download in the REFERENCE's record formats, so a host lama::Map can be rebuilt byte for byte:
+ *   kind LAMA_HIP_MAP_DISTANCE : cells are DynamicDistanceMap::distance_t (10 B:
+ *        int16 obstacle[3], uint16 sqdist, bool valid_obstacle, bool is_queued), 10240 B / patch
+ *   kind LAMA_HIP_MAP_OCCUPANCY: cells are FrequencyOccupancyMap::frequency (4 B: uint16 occupied,
+ *        uint16 visited), 4096 B / patch
+ *   patch_ids: the reference's 64-bit patch index (Map::m2p, include/lama/sdm/map.h:153-161), ascending
+ *   masks    : 16 x uint64 per patch (Container::mask, include/lama/sdm/container.h:57-65)
+ * lama_hip_pf_map_patches returns the number of patches; download fills up to `cap` patches. */
+#define LAMA_HIP_MAP_DISTANCE 0
+#define LAMA_HIP_MAP_OCCUPANCY 1
+int32_t lama_hip_pf_map_patches(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t* num_patches);
+int32_t lama_hip_pf_download_map(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap,
+                                 uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches);
+
+/* Batched evaluation on ONE particle's distance map (Loc2D::globalLocalization-style):
+ * B poses -> B log-likelihoods (calculateLikelihood) without changing any state. */
+int32_t lama_hip_match_batch(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                             const double* sensor_origin3, const double* sensor_quat_wxyz,
+                             const double* poses, uint32_t num_poses, double* loglik_out);
+
+/* Particle shipping for multi-GPU resampling (one context per GPU): serialise one particle (pose + both
+ * maps, used patches only) into a DEVICE buffer / restore it into slot `particle` of this context.
+ * export returns the number of bytes needed in *bytes when buf == NULL. */
+int32_t lama_hip_pf_export_particle(lama_hip_ctx* ctx, uint32_t particle, void* device_buf, uint64_t cap, uint64_t* bytes);
+int32_t lama_hip_pf_import_particle(lama_hip_ctx* ctx, uint32_t particle, const void* device_buf, uint64_t bytes);
+
+/* Accumulated per-kernel device time (hipEvent elapsed, on the stream the kernels run on) and work
+ * counters since the last reset; valid when cfg.profile != 0. */
+typedef struct lama_hip_counters {
+    double ms_scan_match;  uint64_t launches_scan_match;
+    double ms_update_maps; uint64_t launches_update_maps;
+    double ms_resample;    uint64_t launches_resample;
+    uint64_t gn_iterations;     /* sum over particles and calls                                    */
+    uint64_t gn_evals;          /* residual evaluations (with or without Jacobian) + likelihood     */
+    uint64_t ray_cells;         /* Bresenham cells visited                                          */
+    uint64_t bf_cells;          /* brushfire cells processed (DynamicDistanceMap::update return)     */
+    uint64_t dm_patches;        /* sum of allocated DM patches over particles (current)             */
+    uint64_t occ_patches;       /* sum of allocated occupancy patches over particles (current)      */
+} lama_hip_counters;
+int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
+int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAMA_HIP_H */

@@ -1,0 +1,255 @@
+// lama_dev.h -- device-side data model and scalar math of the MI355X scan-matching path.
+//
+// HBM layout (one "particle set"; the context keeps two and resample() copies set A -> set B,
+// mirroring particles_[2] of the reference, src/pf_slam2d.cpp:558-574):
+//
+//   per particle p (all arrays indexed [p][...], strides in DevParams):
+//     dm_dir  int16 [W*W]         window directory: patch (wy*W+wx) -> slot in the DM arena, -1 = absent
+//     occ_dir int16 [W*W]         same for the occupancy arena
+//     dm_sv   uint16[cap][1024]   DM plane A: bit15 valid_obstacle | bit14 is_queued | bits13..0 sqdist
+//     dm_obs  uint32[cap][1024]   DM plane B: int16 obstacle.x | int16 obstacle.y << 16
+//     dm_mask uint64[cap][16]     Container::mask of the DM patch
+//     occ     uint32[cap][1024]   frequency cell: uint16 occupied | uint16 visited << 16
+//     occ_mask uint64[cap][16]
+//     counts  int32 [2]           allocated DM / occupancy slots
+//
+// The reference's records are distance_t (10 B AoS) and frequency (4 B); the split DM planes keep the
+// 2 bytes the match kernel gathers (sqdist+valid) apart from the 4 bytes only the brushfire needs.
+// A cell is addressed by window-relative cell coordinates (rx, ry) = map coordinate - window origin;
+// the map coordinate itself is the reference's (offset by 42,275,904 cells) and is only
+// ever formed in fp64 / uint32, never fp32.  Unused arena slots are always all-zero (calloc semantics
+// of Container::alloc, src/sdm/container.cpp:76-95).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "lama_heap.h"
+
+namespace lama_dev {
+
+constexpr uint16_t SV_VALID = 0x8000;
+constexpr uint16_t SV_QUEUED = 0x4000;
+constexpr uint16_t SV_SQMASK = 0x3FFF;
+
+constexpr int ERR_WINDOW = 1;
+constexpr int ERR_DM_CAP = 2;
+constexpr int ERR_OCC_CAP = 4;
+constexpr int ERR_QUEUE = 8;
+constexpr int ERR_NUMERIC = 16;
+
+struct Affine {            // rows 0..2 of [R | t]
+    double R[3][3];
+    double t[3];
+};
+
+struct DevParams {
+    uint32_t P;            // particles in this context
+    uint32_t W;            // window side in patches
+    uint32_t WC;           // window side in cells (W*32)
+    uint32_t wx0, wy0;     // window origin in map cells
+    uint32_t dm_cap, occ_cap, qcap;
+    uint32_t max_sqdist;
+    uint32_t max_iter;
+    double scale, off, resolution, maxdist, meas_sigma;
+    double trunc_ray, trunc_range;
+    // particle set
+    int16_t* dm_dir;
+    int16_t* occ_dir;
+    uint16_t* dm_sv;
+    uint32_t* dm_obs;
+    uint64_t* dm_mask;
+    uint32_t* occ;
+    uint64_t* occ_mask;
+    int32_t* counts;       // [P][2]
+    // shared
+    double* poses;         // [P][4]
+    uint64_t* q_lower;     // [P][qcap]
+    uint64_t* q_raise;     // [P][qcap]
+    uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
+    int32_t* err;
+};
+
+// ------------------------------------------------------------------------------------------------
+// SE2 (unit complex + translation): include/lama/sophus/so2.hpp:168-176,205-214,322-324;
+// se2.hpp:154-157,262-265,389-411
+// ------------------------------------------------------------------------------------------------
+struct SE2 { double c, s, tx, ty; };
+
+__device__ inline bool so2_normalize(double& c, double& s)
+{
+    double length = sqrt(c * c + s * s);
+    if (length < 1e-10) return false;
+    c /= length;
+    s /= length;
+    return true;
+}
+
+// state' = SE2::exp(h) * state   (MatchSurface2D::update, src/match_surface_2d.cpp:118-122)
+__device__ inline SE2 se2_exp_mul(const double h[3], const SE2& st, bool& ok)
+{
+    const double theta = h[2];
+    double ec = cos(theta), es = sin(theta);
+    ok = so2_normalize(ec, es) && ok;
+    double a, b;   // sin(theta)/theta, (1-cos(theta))/theta
+    if (fabs(theta) < 1e-10) {
+        double theta_sq = theta * theta;
+        a = 1. - (1. / 6.) * theta_sq;
+        b = 0.5 * theta - (1. / 24.) * theta * theta_sq;
+    } else {
+        a = es / theta;
+        b = (1. - ec) / theta;
+    }
+    const double etx = a * h[0] - b * h[1];
+    const double ety = b * h[0] + a * h[1];
+    SE2 r;
+    r.tx = etx + (ec * st.tx - es * st.ty);
+    r.ty = ety + (es * st.tx + ec * st.ty);
+    r.c = ec * st.c - es * st.s;
+    r.s = ec * st.s + es * st.c;
+    ok = so2_normalize(r.c, r.s) && ok;
+    return r;
+}
+
+// fixed_tf(state) * moving_tf : Translation(x,y,0) * AngleAxis(atan2(s,c), Z) * (Translation(origin) * q)
+// (src/match_surface_2d.cpp:49-58; Eigen AngleAxis::toRotationMatrix restated for the Z axis)
+__device__ inline Affine scan_tf(const SE2& st, const Affine& m)
+{
+    const double theta = atan2(st.s, st.c);
+    const double sn = sin(theta), cs = cos(theta);
+    const double F[3][3] = {{cs, 0.0 - sn, 0.0}, {sn, cs, 0.0}, {0.0, 0.0, (1.0 - cs) + cs}};
+    const double ft[3] = {st.tx, st.ty, 0.0};
+    Affine r;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) r.R[i][j] = (F[i][0] * m.R[0][j] + F[i][1] * m.R[1][j]) + F[i][2] * m.R[2][j];
+        r.t[i] = ((F[i][0] * m.t[0] + F[i][1] * m.t[1]) + F[i][2] * m.t[2]) + ft[i];
+    }
+    return r;
+}
+
+// Eigen 3.3 LDLT<Matrix3d, Lower> with pivoting + solve (src/nlls/gauss_newton.cpp:66).
+// A: lower triangle used, indices [row][col].
+__device__ inline void ldlt3_solve(const double A[3][3], const double b[3], double x[3])
+{
+    double m[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) m[i][j] = (j <= i) ? A[i][j] : A[j][i];
+    int tr[3] = {0, 1, 2};
+    double temp[3];
+    for (int k = 0; k < 3; ++k) {
+        int big = k;
+        double best = fabs(m[k][k]);
+        for (int i = k + 1; i < 3; ++i)
+            if (fabs(m[i][i]) > best) { best = fabs(m[i][i]); big = i; }
+        tr[k] = big;
+        if (k != big) {
+            const int s = 3 - big - 1;
+            for (int j = 0; j < k; ++j) { double t = m[k][j]; m[k][j] = m[big][j]; m[big][j] = t; }
+            for (int i = 0; i < s; ++i) { double t = m[3 - s + i][k]; m[3 - s + i][k] = m[3 - s + i][big]; m[3 - s + i][big] = t; }
+            { double t = m[k][k]; m[k][k] = m[big][big]; m[big][big] = t; }
+            for (int i = k + 1; i < big; ++i) { double t = m[i][k]; m[i][k] = m[big][i]; m[big][i] = t; }
+        }
+        const int rs = 3 - k - 1;
+        if (k > 0) {
+            for (int j = 0; j < k; ++j) temp[j] = m[j][j] * m[k][j];
+            double acc = m[k][0] * temp[0];
+            for (int j = 1; j < k; ++j) acc = acc + m[k][j] * temp[j];
+            m[k][k] -= acc;
+            for (int i = 0; i < rs; ++i) {
+                double a2 = m[k + 1 + i][0] * temp[0];
+                for (int j = 1; j < k; ++j) a2 = a2 + m[k + 1 + i][j] * temp[j];
+                m[k + 1 + i][k] -= a2;
+            }
+        }
+        const double akk = m[k][k];
+        const bool pivot_ok = fabs(akk) > 0.0;
+        if (k == 0 && !pivot_ok) { tr[0] = 0; tr[1] = 1; tr[2] = 2; break; }
+        if (rs > 0 && pivot_ok)
+            for (int i = 0; i < rs; ++i) m[k + 1 + i][k] /= akk;
+    }
+    double d[3] = {b[0], b[1], b[2]};
+    for (int k = 0; k < 3; ++k)
+        if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+    d[1] -= m[1][0] * d[0];
+    d[2] -= (m[2][0] * d[0] + m[2][1] * d[1]);
+    const double tol = 1.0 / 1.7976931348623157e308;
+    for (int i = 0; i < 3; ++i) { if (fabs(m[i][i]) > tol) d[i] /= m[i][i]; else d[i] = 0.0; }
+    d[1] -= m[2][1] * d[2];
+    d[0] -= (m[1][0] * d[1] + m[2][0] * d[2]);
+    for (int k = 2; k >= 0; --k)
+        if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+    x[0] = d[0]; x[1] = d[1]; x[2] = d[2];
+}
+
+// ------------------------------------------------------------------------------------------------
+// map addressing
+// ------------------------------------------------------------------------------------------------
+// Map::w2m_nocast / w2m (include/lama/sdm/map.h:125-138): tf_ * v = scale*v + off
+__device__ inline double w2m_nocast(const DevParams& prm, double v) { return prm.scale * v + prm.off; }
+__device__ inline uint32_t w2m(const DevParams& prm, double v) { return (uint32_t)(w2m_nocast(prm, v) + 0.5); }
+
+// DynamicDistanceMap::distance(Vector3ui) (src/sdm/dynamic_distance_map.cpp:140-147) through the const
+// Map::get (src/sdm/map.cpp:414-455): absent patch / mask bit off / !valid_obstacle -> max distance.
+// An off-bit cell is still all-zero, hence reads as !valid: the mask needs no separate test.
+__device__ inline double dm_distance_cell(const DevParams& prm, const int16_t* __restrict__ dir,
+                                          const uint16_t* __restrict__ sv, uint32_t x, uint32_t y)
+{
+    const uint32_t rx = x - prm.wx0, ry = y - prm.wy0;
+    if (rx >= prm.WC || ry >= prm.WC) return prm.maxdist;
+    const int slot = dir[(ry >> 5) * prm.W + (rx >> 5)];
+    if (slot < 0) return prm.maxdist;
+    const uint16_t v = sv[(uint32_t)slot * 1024u + ((rx & 31u) | ((ry & 31u) << 5))];
+    if (!(v & SV_VALID)) return prm.maxdist;
+    return sqrt((double)(v & SV_SQMASK)) * prm.resolution;
+}
+
+// DynamicDistanceMap::distance(Vector3d, Vector3d*) 2-D branch (src/sdm/dynamic_distance_map.cpp:66-91)
+__device__ inline double dm_distance(const DevParams& prm, const int16_t* __restrict__ dir,
+                                     const uint16_t* __restrict__ sv, double wx, double wy, double* gx, double* gy)
+{
+    const double mx = w2m_nocast(prm, wx), my = w2m_nocast(prm, wy);
+    const uint32_t dx = (uint32_t)mx, dy = (uint32_t)my;
+    const double mu0 = mx - (double)dx, mu1 = my - (double)dy;
+    const double muinv0 = 1.0 - mu0, muinv1 = 1.0 - mu1;
+    const double v0 = dm_distance_cell(prm, dir, sv, dx, dy);
+    const double v1 = dm_distance_cell(prm, dir, sv, dx + 1, dy);
+    const double v2 = dm_distance_cell(prm, dir, sv, dx, dy + 1);
+    const double v3 = dm_distance_cell(prm, dir, sv, dx + 1, dy + 1);
+    const double dist = v0 * muinv0 * muinv1 + v1 * muinv1 * mu0 + v2 * muinv0 * mu1 + v3 * mu0 * mu1;
+    if (gx) {
+        *gx = -((v0 - v1) * muinv1 + (v2 - v3) * mu1) * prm.scale;
+        *gy = -((v0 - v2) * muinv0 + (v1 - v3) * mu0) * prm.scale;
+    }
+    return dist;
+}
+
+// CauchyWeight(0.15)::value (src/nlls/robust_cost.cpp:66-73)
+__device__ inline double cauchy015(double x)
+{
+    const double c_ = 1.0 / (0.15 * 0.15);
+    return (1.0 / (1.0 + x * x * c_));
+}
+
+// ------------------------------------------------------------------------------------------------
+// brushfire queue storage: first `lds_cap` entries in LDS, the rest in the particle's HBM region
+// ------------------------------------------------------------------------------------------------
+struct HybridStore {
+    uint64_t* lds;
+    uint64_t* glb;
+    uint32_t lds_cap;
+    __device__ inline uint64_t get(uint32_t i) const { return i < lds_cap ? lds[i] : glb[i]; }
+    __device__ inline void set(uint32_t i, uint64_t v) const { if (i < lds_cap) lds[i] = v; else glb[i] = v; }
+};
+
+__device__ inline uint64_t q_entry(uint32_t prio, int rx, int ry) { return ((uint64_t)prio << 32) | ((uint32_t)ry << 16) | (uint32_t)rx; }
+__device__ inline int q_rx(uint64_t e) { return (int)(e & 0xFFFFu); }
+__device__ inline int q_ry(uint64_t e) { return (int)((e >> 16) & 0xFFFFu); }
+
+__device__ inline uint32_t pack_obs(int ox, int oy) { return ((uint32_t)(uint16_t)(int16_t)ox) | (((uint32_t)(uint16_t)(int16_t)oy) << 16); }
+__device__ inline int obs_x(uint32_t o) { return (int)(int16_t)(o & 0xFFFFu); }
+__device__ inline int obs_y(uint32_t o) { return (int)(int16_t)(o >> 16); }
+
+} // namespace lama_dev

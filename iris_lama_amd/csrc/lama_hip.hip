@@ -1,0 +1,632 @@
+// lama_hip.hip -- C-ABI implementation (include/lama_hip.h) of the MI355X scan-matching path.
+// gfx950 only.  No CPU fallback: every entry point needs a HIP device and fails loudly without one.
+#include "../../include/lama_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lama_kernels.h"
+
+using namespace lama_dev;
+
+namespace {
+
+struct ParticleSet {
+    int16_t* dm_dir = nullptr; int16_t* occ_dir = nullptr;
+    uint16_t* dm_sv = nullptr; uint32_t* dm_obs = nullptr; uint64_t* dm_mask = nullptr;
+    uint32_t* occ = nullptr; uint64_t* occ_mask = nullptr;
+    int32_t* counts = nullptr;
+};
+
+} // namespace
+
+struct lama_hip_ctx {
+    lama_hip_cfg cfg;
+    std::string error;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool initialised = false;   // first scan done
+
+    uint32_t P = 0, W = 0, WC = 0, wx0 = 0, wy0 = 0;
+    uint32_t max_sqdist = 0;
+    double scale = 0, off = 0;
+
+    ParticleSet set[2];
+    int cur = 0;
+    double* d_poses = nullptr;
+    uint64_t* d_qlower = nullptr; uint64_t* d_qraise = nullptr;
+    uint64_t* d_stats = nullptr;
+    int32_t* d_err = nullptr;
+    double* d_pts = nullptr; uint32_t pts_cap = 0;
+    double* d_tfs = nullptr;
+    double* d_loglik = nullptr; int32_t* d_iters = nullptr;
+    int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
+    double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
+
+    std::vector<double> h_poses;      // host mirror of the particle poses (source of truth between calls)
+    std::vector<int32_t> h_counts;    // host mirror of counts of the current set (refreshed after map updates)
+    lama_hip_counters ctr;
+};
+
+namespace {
+
+#define HIPCHK(ctx, call)                                                                              \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) {                                                                        \
+            (ctx)->error = std::string(#call) + ": " + hipGetErrorString(e_);                           \
+            return LAMA_HIP_E_HIP;                                                                     \
+        }                                                                                              \
+    } while (0)
+
+int32_t fail(lama_hip_ctx* ctx, int32_t code, const std::string& msg)
+{
+    ctx->error = msg;
+    return code;
+}
+
+// Eigen Quaternion::toRotationMatrix restated (moving_tf = Translation(origin) * q,
+// src/match_surface_2d.cpp:49, src/pf_slam2d.cpp:397,444)
+Affine moving_tf(const double* origin3, const double* q)
+{
+    Affine a;
+    const double w = q ? q[0] : 1.0, x = q ? q[1] : 0.0, y = q ? q[2] : 0.0, z = q ? q[3] : 0.0;
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w;
+    const double txx = tx * x, txy = ty * x, txz = tz * x;
+    const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    a.R[0][0] = 1.0 - (tyy + tzz); a.R[0][1] = txy - twz;         a.R[0][2] = txz + twy;
+    a.R[1][0] = txy + twz;         a.R[1][1] = 1.0 - (txx + tzz); a.R[1][2] = tyz - twx;
+    a.R[2][0] = txz - twy;         a.R[2][1] = tyz + twx;         a.R[2][2] = 1.0 - (txx + tyy);
+    for (int i = 0; i < 3; ++i) a.t[i] = origin3 ? origin3[i] : 0.0;
+    return a;
+}
+
+// fixed_tf(pose) * moving_tf on the HOST (libm), 12 doubles [R row-major | t]
+// (src/pf_slam2d.cpp:444-451 ; Eigen AngleAxis(theta, UnitZ) restated)
+void host_scan_tf(const double* pose4, const Affine& m, double* out12)
+{
+    const double theta = std::atan2(pose4[1], pose4[0]);
+    const double sn = std::sin(theta), cs = std::cos(theta);
+    const double F[3][3] = {{cs, 0.0 - sn, 0.0}, {sn, cs, 0.0}, {0.0, 0.0, (1.0 - cs) + cs}};
+    const double ft[3] = {pose4[2], pose4[3], 0.0};
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) out12[3 * i + j] = (F[i][0] * m.R[0][j] + F[i][1] * m.R[1][j]) + F[i][2] * m.R[2][j];
+        out12[9 + i] = ((F[i][0] * m.t[0] + F[i][1] * m.t[1]) + F[i][2] * m.t[2]) + ft[i];
+    }
+}
+
+DevParams make_params(const lama_hip_ctx* c, int which)
+{
+    DevParams p;
+    p.P = c->P; p.W = c->W; p.WC = c->WC; p.wx0 = c->wx0; p.wy0 = c->wy0;
+    p.dm_cap = c->cfg.dm_patch_capacity; p.occ_cap = c->cfg.occ_patch_capacity; p.qcap = c->cfg.queue_capacity;
+    p.max_sqdist = c->max_sqdist; p.max_iter = c->cfg.max_iter;
+    p.scale = c->scale; p.off = c->off; p.resolution = c->cfg.resolution;
+    p.maxdist = std::sqrt((double)c->max_sqdist) * c->cfg.resolution;
+    p.meas_sigma = c->cfg.meas_sigma;
+    p.trunc_ray = c->cfg.truncated_ray; p.trunc_range = c->cfg.truncated_range;
+    const ParticleSet& s = c->set[which];
+    p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
+    p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.err = c->d_err;
+    return p;
+}
+
+SetPtrs set_ptrs(const ParticleSet& s)
+{
+    return SetPtrs{s.dm_dir, s.occ_dir, s.dm_sv, s.dm_obs, s.dm_mask, s.occ, s.occ_mask, s.counts};
+}
+
+int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
+{
+    if (n > c->pts_cap) {
+        if (c->d_pts) HIPCHK(c, hipFree(c->d_pts));
+        c->d_pts = nullptr;
+        c->pts_cap = std::max<uint32_t>(n, 2048);
+        HIPCHK(c, hipMalloc(&c->d_pts, sizeof(double) * 3 * c->pts_cap));
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    return LAMA_HIP_OK;
+}
+
+int32_t check_device_errors(lama_hip_ctx* c)
+{
+    int32_t e = 0;
+    HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (e == 0) return LAMA_HIP_OK;
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+    if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (raise cfg.window_patches)");
+    if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
+    if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
+    if (e & ERR_QUEUE) return fail(c, LAMA_HIP_E_CAPACITY, "brushfire queue full (raise cfg.queue_capacity)");
+    return fail(c, LAMA_HIP_E_NUMERIC, "unit complex number is (near) zero (SophusException in the reference)");
+}
+
+struct Timer {
+    lama_hip_ctx* c; double* acc; uint64_t* launches;
+    Timer(lama_hip_ctx* c_, double* acc_, uint64_t* l_) : c(c_), acc(acc_), launches(l_)
+    { if (c->cfg.profile) (void)hipEventRecord(c->ev0, c->stream); }
+    void stop()
+    {
+        if (!c->cfg.profile) return;
+        (void)hipEventRecord(c->ev1, c->stream);
+        (void)hipEventSynchronize(c->ev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+        *acc += ms; *launches += 1;
+    }
+};
+
+int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
+{
+    std::vector<double> tfs((size_t)c->P * 12);
+    for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
+    HIPCHK(c, hipMemcpyAsync(c->d_tfs, tfs.data(), sizeof(double) * tfs.size(), hipMemcpyHostToDevice, c->stream));
+    DevParams prm = make_params(c, c->cur);
+    Timer t(c, &c->ctr.ms_update_maps, &c->ctr.launches_update_maps);
+    hipLaunchKernelGGL(k_update_maps, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+    t.stop();
+    HIPCHK(c, hipGetLastError());
+    return LAMA_HIP_OK;
+}
+
+int32_t refresh_counts_and_stats(lama_hip_ctx* c, bool maps, bool match)
+{
+    std::vector<uint64_t> st((size_t)c->P * 4);
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_stats, sizeof(uint64_t) * st.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (uint32_t p = 0; p < c->P; ++p) {
+        if (match) { c->ctr.gn_iterations += st[4 * p]; c->ctr.gn_evals += st[4 * p + 1]; }
+        if (maps) { c->ctr.ray_cells += st[4 * p + 2]; c->ctr.bf_cells += st[4 * p + 3]; }
+    }
+    uint64_t dm = 0, oc = 0;
+    for (uint32_t p = 0; p < c->P; ++p) { dm += c->h_counts[2 * p]; oc += c->h_counts[2 * p + 1]; }
+    c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
+    return LAMA_HIP_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void lama_hip_default_cfg(lama_hip_cfg* cfg)
+{
+    std::memset(cfg, 0, sizeof(*cfg));
+    cfg->particles = 30;
+    cfg->resolution = 0.05;
+    cfg->patch_size = 32;
+    cfg->l2_max = 0.5;
+    cfg->meas_sigma = 0.05;
+    cfg->max_iter = 100;
+    cfg->device = 0;
+    cfg->window_patches = 128;
+    cfg->dm_patch_capacity = 256;
+    cfg->occ_patch_capacity = 256;
+    cfg->queue_capacity = 32768;
+}
+
+int32_t lama_hip_device_count(int32_t* count)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (count) *count = (e == hipSuccess) ? n : 0;
+    return e == hipSuccess ? LAMA_HIP_OK : LAMA_HIP_E_HIP;
+}
+
+const char* lama_hip_last_error(const lama_hip_ctx* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
+{
+    if (!cfg_in || !out) return LAMA_HIP_E_INVALID;
+    *out = nullptr;
+    lama_hip_cfg cfg = *cfg_in;
+    if (cfg.window_patches == 0) cfg.window_patches = 128;
+    if (cfg.dm_patch_capacity == 0) cfg.dm_patch_capacity = 256;
+    if (cfg.occ_patch_capacity == 0) cfg.occ_patch_capacity = 256;
+    if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
+    if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 2048 ||
+        (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
+        cfg.queue_capacity < (uint32_t)LQ_LDS)
+        return LAMA_HIP_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg.device < 0 || cfg.device >= ndev) return LAMA_HIP_E_HIP;
+
+    lama_hip_ctx* c = new lama_hip_ctx();
+    c->cfg = cfg;
+    std::memset(&c->ctr, 0, sizeof(c->ctr));
+    c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
+    c->scale = 1.0 / cfg.resolution;
+    c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
+    // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)
+    uint32_t md = (uint32_t)std::ceil(cfg.l2_max * c->scale);
+    c->max_sqdist = md * md;
+    if (c->max_sqdist == 0 || c->max_sqdist > SV_SQMASK) { delete c; return LAMA_HIP_E_INVALID; }
+
+#define CHK(call) do { if ((call) != hipSuccess) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; } } while (0)
+    CHK(hipSetDevice(cfg.device));
+    CHK(hipStreamCreate(&c->stream));
+    CHK(hipEventCreate(&c->ev0));
+    CHK(hipEventCreate(&c->ev1));
+    const size_t P = c->P, WW = (size_t)c->W * c->W, dc = cfg.dm_patch_capacity, oc = cfg.occ_patch_capacity;
+    for (int s = 0; s < 2; ++s) {
+        ParticleSet& ps = c->set[s];
+        CHK(hipMalloc(&ps.dm_dir, P * WW * 2));      CHK(hipMemset(ps.dm_dir, 0xFF, P * WW * 2));
+        CHK(hipMalloc(&ps.occ_dir, P * WW * 2));     CHK(hipMemset(ps.occ_dir, 0xFF, P * WW * 2));
+        CHK(hipMalloc(&ps.dm_sv, P * dc * 2048));    CHK(hipMemset(ps.dm_sv, 0, P * dc * 2048));
+        CHK(hipMalloc(&ps.dm_obs, P * dc * 4096));   CHK(hipMemset(ps.dm_obs, 0, P * dc * 4096));
+        CHK(hipMalloc(&ps.dm_mask, P * dc * 128));   CHK(hipMemset(ps.dm_mask, 0, P * dc * 128));
+        CHK(hipMalloc(&ps.occ, P * oc * 4096));      CHK(hipMemset(ps.occ, 0, P * oc * 4096));
+        CHK(hipMalloc(&ps.occ_mask, P * oc * 128));  CHK(hipMemset(ps.occ_mask, 0, P * oc * 128));
+        CHK(hipMalloc(&ps.counts, P * 2 * 4));       CHK(hipMemset(ps.counts, 0, P * 2 * 4));
+    }
+    CHK(hipMalloc(&c->d_poses, P * 4 * 8));
+    CHK(hipMalloc(&c->d_qlower, P * (size_t)cfg.queue_capacity * 8));
+    CHK(hipMalloc(&c->d_qraise, P * (size_t)cfg.queue_capacity * 8));
+    CHK(hipMalloc(&c->d_stats, P * 4 * 8));          CHK(hipMemset(c->d_stats, 0, P * 4 * 8));
+    CHK(hipMalloc(&c->d_err, 4));                    CHK(hipMemset(c->d_err, 0, 4));
+    CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
+    CHK(hipMalloc(&c->d_loglik, P * 8));
+    CHK(hipMalloc(&c->d_iters, P * 4));
+    CHK(hipMalloc(&c->d_idx, P * 4));
+    CHK(hipMalloc(&c->d_oldcounts, P * 2 * 4));
+    CHK(hipDeviceSynchronize());
+#undef CHK
+    c->h_poses.assign(P * 4, 0.0);
+    c->h_counts.assign(P * 2, 0);
+    *out = c;
+    return LAMA_HIP_OK;
+}
+
+void lama_hip_ctx_destroy(lama_hip_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < 2; ++s) {
+        ParticleSet& ps = c->set[s];
+        (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
+        (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
+    }
+    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_err); (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs); (void)hipFree(c->d_loglik);
+    (void)hipFree(c->d_iters); (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
+    (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int32_t lama_hip_pf_set_poses(lama_hip_ctx* c, const double* poses)
+{
+    if (!c || !poses) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    std::memcpy(c->h_poses.data(), poses, sizeof(double) * 4 * c->P);
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_get_poses(lama_hip_ctx* c, double* poses)
+{
+    if (!c || !poses) return LAMA_HIP_E_INVALID;
+    std::memcpy(poses, c->h_poses.data(), sizeof(double) * 4 * c->P);
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                         const double* pose0)
+{
+    if (!c || !pts || !pose0 || n == 0) return LAMA_HIP_E_INVALID;
+    if (c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_init called twice");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // centre the map window on the first pose (patch aligned)
+    const double mx = c->scale * pose0[2] + c->off, my = c->scale * pose0[3] + c->off;
+    const uint32_t px = ((uint32_t)mx) >> 5, py = ((uint32_t)my) >> 5;
+    c->wx0 = (px - c->W / 2) * 32;
+    c->wy0 = (py - c->W / 2) * 32;
+    for (uint32_t p = 0; p < c->P; ++p) std::memcpy(&c->h_poses[4 * p], pose0, sizeof(double) * 4);
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    const Affine mtf = moving_tf(origin3, quat);
+    rc = run_update_maps(c, n, mtf, 0, 1);                          // particle 0 only (pf_slam2d.cpp:204)
+    if (rc) return rc;
+    if (c->P > 1) {                                                 // copy-construct the others (:206-216)
+        std::vector<int32_t> idx(c->P, 0);
+        HIPCHK(c, hipMemcpyAsync(c->d_idx, idx.data(), sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_oldcounts, 0, sizeof(int32_t) * 2 * c->P, c->stream));
+        Timer t(c, &c->ctr.ms_resample, &c->ctr.launches_resample);
+        hipLaunchKernelGGL(k_copy_particles, dim3(c->P, 7), dim3(256), 0, c->stream, set_ptrs(c->set[c->cur]), set_ptrs(c->set[c->cur]),
+                           c->d_idx, c->d_oldcounts, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, 1);
+        t.stop();
+        HIPCHK(c, hipGetLastError());
+    }
+    rc = check_device_errors(c);
+    if (rc) return rc;
+    rc = refresh_counts_and_stats(c, true, false);
+    if (rc) return rc;
+    c->initialised = true;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                               double* poses_out, double* loglik_out, int32_t* iters_out)
+{
+    if (!c || !pts || n == 0) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_scan_match before lama_hip_pf_init");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    const Affine mtf = moving_tf(origin3, quat);
+    DevParams prm = make_params(c, c->cur);
+    {
+        Timer t(c, &c->ctr.ms_scan_match, &c->ctr.launches_scan_match);
+        hipLaunchKernelGGL(k_scan_match, dim3(c->P), dim3(SM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, mtf, c->d_loglik, c->d_iters);
+        t.stop();
+    }
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_poses.data(), c->d_poses, sizeof(double) * 4 * c->P, hipMemcpyDeviceToHost, c->stream));
+    if (loglik_out) HIPCHK(c, hipMemcpyAsync(loglik_out, c->d_loglik, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+    if (iters_out) HIPCHK(c, hipMemcpyAsync(iters_out, c->d_iters, sizeof(int32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
+    rc = check_device_errors(c);   // synchronises
+    if (rc) return rc;
+    if (poses_out) std::memcpy(poses_out, c->h_poses.data(), sizeof(double) * 4 * c->P);
+    if (c->cfg.profile) { rc = refresh_counts_and_stats(c, false, true); if (rc) return rc; }
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
+{
+    if (!c || !sample_idx) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_resample before lama_hip_pf_init");
+    for (uint32_t i = 0; i < c->P; ++i)
+        if (sample_idx[i] < 0 || (uint32_t)sample_idx[i] >= c->P) return fail(c, LAMA_HIP_E_INVALID, "sample_idx out of range");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const int dst = 1 - c->cur;
+    HIPCHK(c, hipMemcpyAsync(c->d_idx, sample_idx, sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, c->set[dst].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
+    {
+        Timer t(c, &c->ctr.ms_resample, &c->ctr.launches_resample);
+        hipLaunchKernelGGL(k_copy_particles, dim3(c->P, 7), dim3(256), 0, c->stream, set_ptrs(c->set[dst]), set_ptrs(c->set[c->cur]),
+                           c->d_idx, c->d_oldcounts, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, 0);
+        t.stop();
+    }
+    HIPCHK(c, hipGetLastError());
+    std::vector<double> np(c->h_poses.size());
+    std::vector<int32_t> nc(c->h_counts.size());
+    for (uint32_t i = 0; i < c->P; ++i) {
+        std::memcpy(&np[4 * i], &c->h_poses[4 * sample_idx[i]], sizeof(double) * 4);
+        nc[2 * i] = c->h_counts[2 * sample_idx[i]]; nc[2 * i + 1] = c->h_counts[2 * sample_idx[i] + 1];
+    }
+    c->h_poses.swap(np);
+    c->h_counts.swap(nc);
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cur = dst;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
+{
+    if (!c || !pts || n == 0) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_update_maps before lama_hip_pf_init");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    const Affine mtf = moving_tf(origin3, quat);
+    rc = run_update_maps(c, n, mtf, 0, c->P);
+    if (rc) return rc;
+    rc = check_device_errors(c);
+    if (rc) return rc;
+    return refresh_counts_and_stats(c, true, false);
+}
+
+int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
+{
+    if (!c || !num || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    *num = (uint32_t)c->h_counts[2 * particle + (kind == LAMA_HIP_MAP_OCCUPANCY ? 1 : 0)];
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap,
+                                 uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches)
+{
+    if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const ParticleSet& s = c->set[c->cur];
+    const size_t WW = (size_t)c->W * c->W;
+    const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
+    const uint32_t count = (uint32_t)c->h_counts[2 * particle + (dm ? 0 : 1)];
+    if (num_patches) *num_patches = count;
+    if (count == 0 || cap == 0) return LAMA_HIP_OK;
+    std::vector<int16_t> dir(WW);
+    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + particle * WW, WW * 2, hipMemcpyDeviceToHost));
+    // (reference patch id, slot), ascending id
+    std::vector<std::pair<uint64_t, int>> order;
+    for (uint32_t wy = 0; wy < c->W; ++wy)
+        for (uint32_t wx = 0; wx < c->W; ++wx) {
+            int slot = dir[wy * c->W + wx];
+            if (slot < 0) continue;
+            const uint64_t px = (c->wx0 >> 5) + wx, py = (c->wy0 >> 5) + wy;
+            order.emplace_back(px * 2642244ull + py, slot);                   // Map::m2p
+        }
+    std::sort(order.begin(), order.end());
+    if (order.size() != count) return fail(c, LAMA_HIP_E_STATE, "directory / count mismatch");
+    std::vector<uint64_t> hmask((size_t)count * 16);
+    HIPCHK(c, hipMemcpy(hmask.data(), (dm ? s.dm_mask : s.occ_mask) + (size_t)particle * (dm ? c->cfg.dm_patch_capacity : c->cfg.occ_patch_capacity) * 16,
+                        hmask.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<uint16_t> hsv; std::vector<uint32_t> hobs, hocc;
+    if (dm) {
+        hsv.resize((size_t)count * 1024); hobs.resize((size_t)count * 1024);
+        HIPCHK(c, hipMemcpy(hsv.data(), s.dm_sv + (size_t)particle * c->cfg.dm_patch_capacity * 1024, hsv.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hobs.data(), s.dm_obs + (size_t)particle * c->cfg.dm_patch_capacity * 1024, hobs.size() * 4, hipMemcpyDeviceToHost));
+    } else {
+        hocc.resize((size_t)count * 1024);
+        HIPCHK(c, hipMemcpy(hocc.data(), s.occ + (size_t)particle * c->cfg.occ_patch_capacity * 1024, hocc.size() * 4, hipMemcpyDeviceToHost));
+    }
+    const uint32_t nout = std::min<uint32_t>(cap, count);
+    for (uint32_t k = 0; k < nout; ++k) {
+        const int slot = order[k].second;
+        if (patch_ids) patch_ids[k] = order[k].first;
+        if (masks) std::memcpy(masks + (size_t)k * 16, &hmask[(size_t)slot * 16], 128);
+        if (!cells) continue;
+        if (dm) {
+            uint8_t* o = cells + (size_t)k * 10240;
+            for (int ci = 0; ci < 1024; ++ci) {
+                const uint16_t sv = hsv[(size_t)slot * 1024 + ci];
+                const uint32_t ob = hobs[(size_t)slot * 1024 + ci];
+                const int16_t ox = (int16_t)(ob & 0xFFFF), oy = (int16_t)(ob >> 16), oz = 0;
+                const uint16_t sq = sv & SV_SQMASK;
+                std::memcpy(o + 10 * ci + 0, &ox, 2); std::memcpy(o + 10 * ci + 2, &oy, 2); std::memcpy(o + 10 * ci + 4, &oz, 2);
+                std::memcpy(o + 10 * ci + 6, &sq, 2);
+                o[10 * ci + 8] = (sv & SV_VALID) ? 1 : 0;
+                o[10 * ci + 9] = (sv & SV_QUEUED) ? 1 : 0;
+            }
+        } else {
+            std::memcpy(cells + (size_t)k * 4096, &hocc[(size_t)slot * 1024], 4096);   // {u16 occupied, u16 visited} little endian
+        }
+    }
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3,
+                             const double* quat, const double* poses, uint32_t B, double* out)
+{
+    if (!c || !pts || !poses || !out || n == 0 || B == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_match_batch before lama_hip_pf_init");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    if (B > c->b_cap) {
+        (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+        c->d_bposes = nullptr; c->d_bout = nullptr; c->b_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_bposes, sizeof(double) * 4 * B));
+        HIPCHK(c, hipMalloc(&c->d_bout, sizeof(double) * B));
+        c->b_cap = B;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_bposes, poses, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
+    const Affine mtf = moving_tf(origin3, quat);
+    DevParams prm = make_params(c, c->cur);
+    hipLaunchKernelGGL(k_loglik_batch, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(out, c->d_bout, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
+// Particle blob layout: [pose 4 f64][counts 2 i32][dm_dir][occ_dir][dm_sv used][dm_obs used][dm_mask used][occ used][occ_mask used]
+static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
+{
+    const uint64_t WW = (uint64_t)c->W * c->W;
+    return 32 + 16 + 2 * WW * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
+}
+
+int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* buf, uint64_t cap, uint64_t* bytes)
+{
+    if (!c || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "export before init");
+    const int dmc = c->h_counts[2 * particle], occ = c->h_counts[2 * particle + 1];
+    const uint64_t need = blob_bytes(c, dmc, occ);
+    if (bytes) *bytes = need;
+    if (!buf) return LAMA_HIP_OK;
+    if (cap < need) return fail(c, LAMA_HIP_E_INVALID, "export buffer too small");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const ParticleSet& s = c->set[c->cur];
+    const uint64_t WW = (uint64_t)c->W * c->W;
+    const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
+    uint8_t* o = (uint8_t*)buf;
+    int32_t hdr[4] = {dmc, occ, 0, 0};
+    HIPCHK(c, hipMemcpyAsync(o, &c->h_poses[4 * particle], 32, hipMemcpyHostToDevice, c->stream)); o += 32;
+    HIPCHK(c, hipMemcpyAsync(o, hdr, 16, hipMemcpyHostToDevice, c->stream)); o += 16;
+    auto d2d = [&](const void* src, uint64_t nbytes) -> hipError_t {
+        hipError_t e = nbytes ? hipMemcpyAsync(o, src, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
+        o += nbytes;
+        return e;
+    };
+    HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
+    HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
+    HIPCHK(c, d2d(s.dm_sv + particle * dcap * 1024, (uint64_t)dmc * 2048));
+    HIPCHK(c, d2d(s.dm_obs + particle * dcap * 1024, (uint64_t)dmc * 4096));
+    HIPCHK(c, d2d(s.dm_mask + particle * dcap * 16, (uint64_t)dmc * 128));
+    HIPCHK(c, d2d(s.occ + particle * ocap * 1024, (uint64_t)occ * 4096));
+    HIPCHK(c, d2d(s.occ_mask + particle * ocap * 16, (uint64_t)occ * 128));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const void* buf, uint64_t bytes)
+{
+    if (!c || !buf || particle >= c->P || bytes < 48) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "import before init");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const uint8_t* in = (const uint8_t*)buf;
+    double pose[4]; int32_t hdr[4];
+    HIPCHK(c, hipMemcpy(pose, in, 32, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hdr, in + 32, 16, hipMemcpyDeviceToHost));
+    const int dmc = hdr[0], occ = hdr[1];
+    if (dmc < 0 || occ < 0 || (uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity ||
+        blob_bytes(c, dmc, occ) != bytes)
+        return fail(c, LAMA_HIP_E_INVALID, "particle blob does not match this context's geometry");
+    ParticleSet& s = c->set[c->cur];
+    const uint64_t WW = (uint64_t)c->W * c->W;
+    const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
+    const int odm = c->h_counts[2 * particle], oocc = c->h_counts[2 * particle + 1];
+    in += 48;
+    auto d2d = [&](void* dst, uint64_t nbytes) -> hipError_t {
+        hipError_t e = nbytes ? hipMemcpyAsync(dst, in, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
+        in += nbytes;
+        return e;
+    };
+    auto zero = [&](void* dst, uint64_t nbytes) -> hipError_t { return nbytes ? hipMemsetAsync(dst, 0, nbytes, c->stream) : hipSuccess; };
+    HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
+    HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
+    HIPCHK(c, d2d(s.dm_sv + particle * dcap * 1024, (uint64_t)dmc * 2048));
+    HIPCHK(c, d2d(s.dm_obs + particle * dcap * 1024, (uint64_t)dmc * 4096));
+    HIPCHK(c, d2d(s.dm_mask + particle * dcap * 16, (uint64_t)dmc * 128));
+    HIPCHK(c, d2d(s.occ + particle * ocap * 1024, (uint64_t)occ * 4096));
+    HIPCHK(c, d2d(s.occ_mask + particle * ocap * 16, (uint64_t)occ * 128));
+    if (odm > dmc) {   // keep "unused slot == zero"
+        HIPCHK(c, zero(s.dm_sv + (particle * dcap + dmc) * 1024, (uint64_t)(odm - dmc) * 2048));
+        HIPCHK(c, zero(s.dm_obs + (particle * dcap + dmc) * 1024, (uint64_t)(odm - dmc) * 4096));
+        HIPCHK(c, zero(s.dm_mask + (particle * dcap + dmc) * 16, (uint64_t)(odm - dmc) * 128));
+    }
+    if (oocc > occ) {
+        HIPCHK(c, zero(s.occ + (particle * ocap + occ) * 1024, (uint64_t)(oocc - occ) * 4096));
+        HIPCHK(c, zero(s.occ_mask + (particle * ocap + occ) * 16, (uint64_t)(oocc - occ) * 128));
+    }
+    int32_t cnt[2] = {dmc, occ};
+    HIPCHK(c, hipMemcpyAsync(s.counts + 2 * particle, cnt, 8, hipMemcpyHostToDevice, c->stream));
+    std::memcpy(&c->h_poses[4 * particle], pose, 32);
+    HIPCHK(c, hipMemcpyAsync(c->d_poses + 4 * particle, pose, 32, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->h_counts[2 * particle] = dmc; c->h_counts[2 * particle + 1] = occ;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
+{
+    if (!c || !out) return LAMA_HIP_E_INVALID;
+    *out = c->ctr;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_reset_counters(lama_hip_ctx* c)
+{
+    if (!c) return LAMA_HIP_E_INVALID;
+    const uint64_t dm = c->ctr.dm_patches, oc = c->ctr.occ_patches;
+    std::memset(&c->ctr, 0, sizeof(c->ctr));
+    c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
+    return LAMA_HIP_OK;
+}
+
+} // extern "C"
