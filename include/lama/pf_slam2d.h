@@ -1,0 +1,157 @@
+// lama/pf_slam2d.h -- host-side lama::PFSlam2D whose per-particle work runs on the MI355X.
+//
+// Same class name, Options fields, and public methods as the reference's include/lama/pf_slam2d.h:49-277
+// (update / getPose / getBestParticleIdx / getParticles / getNeff / setPrior / getTimestamps / summary ...), so
+// that a consumer such as iris_lama_ros keeps compiling.  What changed underneath:
+//   * the two per-particle regions of update() (src/pf_slam2d.cpp:254-266, 292-302), the first-scan block
+//     (:185-228) and the particle copies of resample() (:558-574) are calls into the C-ABI of
+//     include/lama_hip.h (resolved at run time from liblama_hip.so; there is NO CPU fallback -- the constructor
+//     throws std::runtime_error when the device library or a GPU is missing);
+//   * what must replay the host RNG stays on the host, statement for statement: drawFromMotion (:365-391),
+//     normalize (:511-535), systematic-resampling indices (:537-556), std::mt19937 seeded like random.cpp;
+//   * Particle::dm / Particle::occ are not host objects any more; getDistanceMap()/getOccupancyMap() are
+//     replaced by downloadDistanceMap()/downloadOccupancyMap() which return the best particle's patches in the
+//     reference's record formats (see INTEGRATION.md for rebuilding a host lama::Map from them);
+//   * Options gains `gpu_device`, `shard_rank`, `shard_world` at the END (aggregate/default use is unchanged).
+//     With shard_world > 1 one process per GPU owns a contiguous block of the particle pool and the step-wise
+//     API (updateBegin / planResample / applyResample / updateMaps) is driven by the caller with an
+//     all-gather of the per-particle log-likelihoods in between (iris_lama_amd/distributed.py).
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <memory>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "pose2d.h"
+
+struct lama_hip_ctx;
+
+namespace lama {
+
+struct HipEngine;   // function table of include/lama_hip.h resolved with dlopen
+
+class PFSlam2D {
+public:
+    struct Particle {
+        double weight = 0.0;
+        double normalized_weight = 0.0;
+        double weight_sum = 0.0;
+        Pose2D pose;
+        DynamicArray<Pose2D> poses;   // history (kept for locally owned particles, single-shard runs)
+    };
+
+    struct Summary {
+        DynamicArray<double> timestamp, time, time_solving, time_normalizing, time_resampling, time_mapping, memory;
+        std::string report() const;
+    };
+    Summary* summary = nullptr;
+
+    struct Options {
+        Options() {}
+        uint32_t particles = 30;          // (no default in the reference)
+        double srr = 0.1;
+        double str = 0.2;
+        double stt = 0.1;
+        double srt = 0.2;
+        double meas_sigma = 0.05;
+        double meas_sigma_gain = 3;
+        double trans_thresh = 0.5;
+        double rot_thresh = 0.5;
+        double l2_max = 0.5;
+        double truncated_ray = 0.0;
+        double truncated_range = 0.0;
+        double resolution = 0.05;
+        uint32_t patch_size = 32;
+        uint32_t max_iter = 100;
+        std::string strategy = "gn";       // ignored by scanMatch in the reference too (always GN, :423-427)
+        int32_t threads = -1;              // unused: the particle loop runs on the GPU
+        uint32_t seed = 0;
+        bool use_compression = false;      // unsupported on the device (288 GB HBM); must stay false
+        uint32_t cache_size = 100;
+        std::string calgorithm = "lz4";
+        bool create_summary = false;
+        // ---- additions (at the end) ----
+        int32_t gpu_device = 0;
+        uint32_t shard_rank = 0;
+        uint32_t shard_world = 1;
+        bool profile = false;              // bracket kernels with hipEvents (see lama_hip_get_counters)
+    };
+
+    explicit PFSlam2D(const Options& options = Options());
+    virtual ~PFSlam2D();
+
+    const Options& getOptions() const { return options_; }
+
+    // Whole update, single shard (shard_world == 1): same contract as the reference (returns false when the
+    // motion gate did not open).  Throws std::runtime_error on a device error.
+    bool update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp);
+
+    size_t getBestParticleIdx() const;
+    Pose2D getPose() const;
+    const std::deque<double>& getTimestamps() const { return timestamps_; }
+    // all P particles (weights are global; poses are valid for locally owned particles, see ownsParticle)
+    const std::vector<Particle>& getParticles() const { return particles_; }
+    double getNeff() const { return neff_; }
+    void setPrior(const Pose2D& prior) { pose_ = prior; }
+    uint64_t getMemoryUsage() const;
+
+    // Best particle's maps in the reference's on-host record formats; patch ids are Map::m2p indices.
+    // cells: 10240 B (distance_t) or 4096 B (frequency) per patch, masks: 16 x uint64 per patch.
+    bool downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    bool downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+
+    // ------------------------------------------------------------------ step-wise API (sharded operation)
+    enum Phase { kNoUpdate = 0, kFirstScan = 1, kMatched = 2 };
+    uint32_t localBegin() const { return lo_; }
+    uint32_t localEnd() const { return hi_; }
+    bool ownsParticle(uint32_t i) const { return i >= lo_ && i < hi_; }
+    // first scan, or predict + motion gate + scan match of the local shard; fills local log-likelihoods
+    Phase updateBegin(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp);
+    const std::vector<double>& localLogLik() const { return local_loglik_; }
+    // add the (all-gathered) per-particle log-likelihoods of ALL P particles, normalise, compute Neff;
+    // returns true and fills sample_idx (size P) when resampling is due (Neff < P/2)
+    bool planResample(const double* all_loglik, std::vector<int32_t>& sample_idx);
+    // apply sample_idx to the replicated weights and to the locally owned particles.  Slots whose source is
+    // owned by another shard must afterwards be filled with importParticle().
+    void applyResample(const std::vector<int32_t>& sample_idx);
+    void updateMaps();                                      // region 2 on the local shard
+    lama_hip_ctx* deviceContext() const { return ctx_; }    // for export/import of particles (multi-GPU)
+    const HipEngine* engine() const { return eng_.get(); }
+    uint32_t numResamples() const { return num_resamples_; }
+
+    // Exposed for tests (host logic, identical formulas to src/pf_slam2d.cpp:365-391,511-556)
+    void drawFromMotion(const Pose2D& delta, Pose2D& pose);
+    void normalize();
+    std::vector<int32_t> resampleIndices(double u01) const;
+
+private:
+    double normal(double stddev);
+    void fail(int32_t rc, const char* what) const;
+    void uploadLocalPoses();
+    void scanToArrays(const PointCloudXYZ& s);
+
+    Options options_;
+    std::shared_ptr<HipEngine> eng_;
+    lama_hip_ctx* ctx_ = nullptr;
+    std::mt19937 gen_;
+    std::vector<Particle> particles_;       // all P (weights replicated on every shard)
+    uint32_t lo_ = 0, hi_ = 0;              // locally owned block [lo, hi)
+    Pose2D odom_, pose_;
+    double acc_trans_ = 0.0, acc_rot_ = 0.0;
+    bool has_first_scan = false;
+    double neff_ = 0.0;
+    uint32_t num_resamples_ = 0;
+    std::deque<double> timestamps_;
+    PointCloudXYZ::Ptr current_surface_;
+    std::vector<double> pts_;               // n x 3
+    double origin_[3] = {0, 0, 0};
+    double quat_[4] = {1, 0, 0, 0};
+    std::vector<double> local_loglik_;
+    // summary bookkeeping
+    double t_begin_ = 0, t_solve_ = 0;
+};
+
+} // namespace lama

@@ -1,0 +1,83 @@
+// lama/types.h -- value types of the host-side mirror of the LaMa interface.
+//
+// The reference's public API is typed on Eigen3 (include/lama/types.h:48-120 of the reference) and on the
+// vendored Sophus SE2 (include/lama/sophus/se2.hpp).  Eigen is a hard external dependency there and is NOT
+// available in the build image of this repository, so:
+//   * when <Eigen/Core> is found, lama::Vector2d/Vector3d/Quaterniond ARE the Eigen types (the configuration
+//     an iris_lama_ros build uses; untested here -- see INTEGRATION.md);
+//   * otherwise the minimal stand-ins below provide exactly the members this path touches
+//     (x()/y()/z()/w(), operator[], norm()).  They are not an Eigen replacement.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <vector>
+
+#if defined(LAMA_USE_EIGEN) || (defined(__has_include) && __has_include(<Eigen/Core>) && !defined(LAMA_NO_EIGEN))
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#define LAMA_HAVE_EIGEN 1
+namespace lama {
+using Eigen::Quaterniond;
+using Eigen::Vector2d;
+using Eigen::Vector3d;
+}
+#else
+namespace lama {
+
+struct Vector2d {
+    double v[2] = {0, 0};
+    Vector2d() {}
+    Vector2d(double a, double b) { v[0] = a; v[1] = b; }
+    double& x() { return v[0]; }
+    double& y() { return v[1]; }
+    double x() const { return v[0]; }
+    double y() const { return v[1]; }
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    double norm() const { return std::sqrt(v[0] * v[0] + v[1] * v[1]); }
+};
+
+struct Vector3d {
+    double v[3] = {0, 0, 0};
+    Vector3d() {}
+    Vector3d(double a, double b, double c) { v[0] = a; v[1] = b; v[2] = c; }
+    double& x() { return v[0]; }
+    double& y() { return v[1]; }
+    double& z() { return v[2]; }
+    double x() const { return v[0]; }
+    double y() const { return v[1]; }
+    double z() const { return v[2]; }
+    double& operator[](int i) { return v[i]; }
+    double operator[](int i) const { return v[i]; }
+    static Vector3d Zero() { return Vector3d(); }
+};
+
+struct Quaterniond {
+    double w_ = 1, x_ = 0, y_ = 0, z_ = 0;
+    Quaterniond() {}
+    Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+    double w() const { return w_; }
+    double x() const { return x_; }
+    double y() const { return y_; }
+    double z() const { return z_; }
+    static Quaterniond Identity() { return Quaterniond(); }
+};
+
+} // namespace lama
+#endif
+
+namespace lama {
+
+template <class T> using DynamicArray = std::vector<T>;
+
+// include/lama/types.h:111-120 of the reference
+struct PointCloudXYZ {
+    typedef std::shared_ptr<PointCloudXYZ> Ptr;
+    std::vector<Vector3d> points;
+    Vector3d sensor_origin_ = Vector3d(0, 0, 0);
+    Quaterniond sensor_orientation_ = Quaterniond(1, 0, 0, 0);
+};
+
+} // namespace lama

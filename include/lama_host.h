@@ -1,5 +1,12 @@
-/* lama_host.h -- C surface of the host-side library (liblama_host.so).  WORK IN PROGRESS header;
- * see the full documentation block below once the PF facade lands. */
+/* =====================================================================================
+ * lama_host.h -- C surface of liblama_host.so: the host-side mirror of the reference interface
+ * (lama::PFSlam2D of include/lama/pf_slam2d.h) flattened for FFI users (Python ctypes in this repo:
+ * tests, bench.py, iris_lama_amd/distributed.py), plus the synthetic workload generator.
+ *
+ * C++ consumers (iris_lama_ros) use the classes in include/lama/ directly; this header exists because the
+ * measuring/test harness is Python.  All functions catch C++ exceptions; a negative return is an error and
+ * lama_pf_last_error() holds the message.
+ * ===================================================================================== */
 #ifndef LAMA_HOST_H
 #define LAMA_HOST_H
 #include <stdint.h>
@@ -10,6 +17,76 @@ extern "C" {
 /* Seeded synthetic corridor log.  pts: (steps+1) x beams x 3 doubles (sensor frame),
  * odom_xyr / truth_xyr: (steps+1) x 3 doubles (x, y, yaw).  truth_xyr may be NULL.  Returns 0. */
 int lama_corridor_generate(int steps, int beams, double* pts, double* odom_xyr, double* truth_xyr);
+
+/* PFSlam2D::Options (include/lama/pf_slam2d.h) as a POD. */
+typedef struct lama_pf_options {
+    uint32_t particles;
+    double srr, str, stt, srt;
+    double meas_sigma, meas_sigma_gain;
+    double trans_thresh, rot_thresh;
+    double l2_max, truncated_ray, truncated_range, resolution;
+    uint32_t patch_size, max_iter;
+    uint32_t seed;
+    int32_t create_summary;
+    int32_t gpu_device;
+    uint32_t shard_rank, shard_world;
+    int32_t profile;
+} lama_pf_options;
+
+typedef struct lama_pf lama_pf;
+
+void lama_pf_default_options(lama_pf_options* o);
+
+/* Device library used by PFSlam2D objects created afterwards.  Default (path == NULL or never called):
+ * liblama_hip.so next to liblama_host.so.  The test-suite points this at an oracle-backed test double to
+ * exercise the host/multi-rank logic on machines without a GPU; the product never calls it. */
+int lama_host_set_engine_library(const char* path);
+/* Path of the device library bound to `pf` (so callers can assert that the HIP library is the one in use). */
+const char* lama_pf_engine_origin(const lama_pf* pf);
+
+/* err (optional, errcap bytes) receives the failure message when NULL is returned. */
+lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap);
+void lama_pf_destroy(lama_pf* pf);
+const char* lama_pf_last_error(const lama_pf* pf);
+
+void lama_pf_set_prior(lama_pf* pf, double x, double y, double yaw);
+
+/* PFSlam2D::update: 1 = update done, 0 = motion gate closed, <0 = error. */
+int lama_pf_update(lama_pf* pf, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                   const double* odom_xyr, double timestamp);
+
+/* step-wise API (sharded operation), see include/lama/pf_slam2d.h */
+int lama_pf_update_begin(lama_pf* pf, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                         const double* odom_xyr, double timestamp);   /* 0 no update, 1 first scan, 2 matched */
+int lama_pf_local_range(const lama_pf* pf, uint32_t* lo, uint32_t* hi);
+int lama_pf_local_loglik(const lama_pf* pf, double* out /* hi-lo */);
+int lama_pf_plan_resample(lama_pf* pf, const double* all_loglik /* P */, int32_t* sample_idx_out /* P */); /* 1 = resample */
+int lama_pf_apply_resample(lama_pf* pf, const int32_t* sample_idx /* P */);
+int lama_pf_update_maps(lama_pf* pf);
+void* lama_pf_device_context(const lama_pf* pf);   /* lama_hip_ctx* of the local shard */
+
+/* state queries; poses are {c,s,tx,ty} for all P particles (valid for locally owned ones) */
+int lama_pf_get_poses(const lama_pf* pf, double* poses_P4);
+int lama_pf_set_pose(lama_pf* pf, uint32_t i, const double* pose4);
+int lama_pf_get_weights(const lama_pf* pf, double* weight, double* normalized_weight, double* weight_sum);
+int lama_pf_set_weights(lama_pf* pf, const double* weight, const double* weight_sum);
+double lama_pf_neff(const lama_pf* pf);
+int lama_pf_best(const lama_pf* pf);
+int lama_pf_best_pose_xyr(const lama_pf* pf, double* xyr);
+uint32_t lama_pf_num_resamples(const lama_pf* pf);
+uint64_t lama_pf_memory_usage(const lama_pf* pf);
+/* Summary::report() into buf; returns the length needed */
+int lama_pf_summary(const lama_pf* pf, char* buf, int cap);
+/* Summary buckets of the last `update` (seconds): total, solving, normalizing, resampling, mapping */
+int lama_pf_last_times(const lama_pf* pf, double* out5);
+
+/* host-logic hooks (RNG replay tests): same formulas as src/pf_slam2d.cpp:365-391, 511-556 */
+int lama_pf_draw_from_motion(lama_pf* pf, const double* delta4, double* pose4_inout);
+double lama_pf_normalize(lama_pf* pf);
+int lama_pf_resample_indices(const lama_pf* pf, double u01, int32_t* out_P);
+/* pose algebra: out = a^-1 * b (Pose2D::operator-), {c,s,tx,ty} */
+void lama_pose_minus(const double* a4, const double* b4, double* out4);
+void lama_pose_from_xyr(double x, double y, double yaw, double* out4);
 
 #ifdef __cplusplus
 }

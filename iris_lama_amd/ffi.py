@@ -57,6 +57,17 @@ def hip_lib():
             raise LamaError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         L = C.CDLL(HIP_LIB)
+        _bind_hip(L)
+        _hip = L
+    return _hip
+
+
+def hip_lib_or_none():
+    return _hip
+
+
+def _bind_hip(L):
+    if True:
         vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
         L.lama_hip_default_cfg.argtypes = [vp]
         L.lama_hip_default_cfg.restype = None
@@ -82,8 +93,6 @@ def hip_lib():
         for s in HIP_SYMBOLS:
             if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error"):
                 getattr(L, s).restype = i32
-        _hip = L
-    return _hip
 
 
 def _p(a):
@@ -122,9 +131,9 @@ class HipContext:
         self.h = h
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and not getattr(self, "_is_borrowed", False):
             self.L.lama_hip_ctx_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         self.close()
@@ -240,3 +249,233 @@ def corridor_log(steps=40, beams=1080):
     if rc != 0:
         raise LamaError("lama_corridor_generate failed")
     return pts, odom, truth
+
+
+# ------------------------------------------------------------------------------------------------ lama::PFSlam2D
+class PFOptions(C.Structure):
+    _fields_ = [("particles", C.c_uint32), ("srr", C.c_double), ("str", C.c_double), ("stt", C.c_double),
+                ("srt", C.c_double), ("meas_sigma", C.c_double), ("meas_sigma_gain", C.c_double),
+                ("trans_thresh", C.c_double), ("rot_thresh", C.c_double), ("l2_max", C.c_double),
+                ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
+                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("seed", C.c_uint32),
+                ("create_summary", C.c_int32), ("gpu_device", C.c_int32), ("shard_rank", C.c_uint32),
+                ("shard_world", C.c_uint32), ("profile", C.c_int32)]
+
+
+HOST_SYMBOLS = [
+    "lama_corridor_generate", "lama_pf_default_options", "lama_host_set_engine_library", "lama_pf_engine_origin",
+    "lama_pf_create", "lama_pf_destroy", "lama_pf_last_error", "lama_pf_set_prior", "lama_pf_update",
+    "lama_pf_update_begin", "lama_pf_local_range", "lama_pf_local_loglik", "lama_pf_plan_resample",
+    "lama_pf_apply_resample", "lama_pf_update_maps", "lama_pf_device_context", "lama_pf_get_poses",
+    "lama_pf_set_pose", "lama_pf_get_weights", "lama_pf_set_weights", "lama_pf_neff", "lama_pf_best",
+    "lama_pf_best_pose_xyr", "lama_pf_num_resamples", "lama_pf_memory_usage", "lama_pf_summary",
+    "lama_pf_last_times", "lama_pf_draw_from_motion", "lama_pf_normalize", "lama_pf_resample_indices",
+    "lama_pose_minus", "lama_pose_from_xyr",
+]
+
+
+def _bind_host(L):
+    vp, i32, u32, d = C.c_void_p, C.c_int32, C.c_uint32, C.c_double
+    sig = {
+        "lama_pf_default_options": (None, [vp]), "lama_host_set_engine_library": (i32, [C.c_char_p]),
+        "lama_pf_engine_origin": (C.c_char_p, [vp]), "lama_pf_create": (vp, [vp, vp, i32]),
+        "lama_pf_destroy": (None, [vp]), "lama_pf_last_error": (C.c_char_p, [vp]),
+        "lama_pf_set_prior": (None, [vp, d, d, d]), "lama_pf_update": (i32, [vp, vp, u32, vp, vp, vp, d]),
+        "lama_pf_update_begin": (i32, [vp, vp, u32, vp, vp, vp, d]), "lama_pf_local_range": (i32, [vp, vp, vp]),
+        "lama_pf_local_loglik": (i32, [vp, vp]), "lama_pf_plan_resample": (i32, [vp, vp, vp]),
+        "lama_pf_apply_resample": (i32, [vp, vp]), "lama_pf_update_maps": (i32, [vp]),
+        "lama_pf_device_context": (vp, [vp]), "lama_pf_get_poses": (i32, [vp, vp]),
+        "lama_pf_set_pose": (i32, [vp, u32, vp]), "lama_pf_get_weights": (i32, [vp, vp, vp, vp]),
+        "lama_pf_set_weights": (i32, [vp, vp, vp]), "lama_pf_neff": (d, [vp]), "lama_pf_best": (i32, [vp]),
+        "lama_pf_best_pose_xyr": (i32, [vp, vp]), "lama_pf_num_resamples": (u32, [vp]),
+        "lama_pf_memory_usage": (C.c_uint64, [vp]), "lama_pf_summary": (i32, [vp, vp, i32]),
+        "lama_pf_last_times": (i32, [vp, vp]), "lama_pf_draw_from_motion": (i32, [vp, vp, vp]),
+        "lama_pf_normalize": (d, [vp]), "lama_pf_resample_indices": (i32, [vp, d, vp]),
+        "lama_pose_minus": (None, [vp, vp, vp]), "lama_pose_from_xyr": (None, [d, d, d, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+
+_host_bound = False
+
+
+def _hostlib():
+    global _host_bound
+    L = host_lib()
+    if not _host_bound:
+        _bind_host(L)
+        _host_bound = True
+    return L
+
+
+def set_engine_library(path):
+    """Testing hook: bind a different implementation of the device C-ABI (None = liblama_hip.so)."""
+    rc = _hostlib().lama_host_set_engine_library(path.encode() if path else None)
+    if rc != 0:
+        raise LamaError(f"cannot bind engine library {path}")
+
+
+def pf_options(**kw):
+    o = PFOptions()
+    _hostlib().lama_pf_default_options(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def pose_from_xyr(x, y, yaw):
+    out = np.zeros(4)
+    _hostlib().lama_pose_from_xyr(float(x), float(y), float(yaw), _p(out))
+    return out
+
+
+class PFSlam2D:
+    """ctypes view of the host-side lama::PFSlam2D (include/lama/pf_slam2d.h)."""
+
+    def __init__(self, opts):
+        self.L = _hostlib()
+        self.opts = opts
+        self.P = opts.particles
+        err = C.create_string_buffer(512)
+        h = self.L.lama_pf_create(C.byref(opts), err, 512)
+        if not h:
+            raise LamaError(err.value.decode())
+        self.h = C.c_void_p(h)
+        lo, hi = C.c_uint32(0), C.c_uint32(0)
+        self.L.lama_pf_local_range(self.h, C.byref(lo), C.byref(hi))
+        self.lo, self.hi = lo.value, hi.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lama_pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LamaError(self.L.lama_pf_last_error(self.h).decode())
+        return rc
+
+    def engine_origin(self):
+        return self.L.lama_pf_engine_origin(self.h).decode()
+
+    def set_prior(self, x, y, yaw):
+        self.L.lama_pf_set_prior(self.h, float(x), float(y), float(yaw))
+
+    @staticmethod
+    def _scan(pts, origin, quat):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        origin = np.ascontiguousarray(_Z3 if origin is None else origin, dtype=np.float64)
+        quat = np.ascontiguousarray(_IDQ if quat is None else quat, dtype=np.float64)
+        return pts, origin, quat
+
+    def update(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
+        pts, origin, quat = self._scan(pts, origin, quat)
+        od = np.ascontiguousarray(odom_xyr, dtype=np.float64)
+        return bool(self._chk(self.L.lama_pf_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(od), float(ts))))
+
+    def update_begin(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
+        pts, origin, quat = self._scan(pts, origin, quat)
+        od = np.ascontiguousarray(odom_xyr, dtype=np.float64)
+        return self._chk(self.L.lama_pf_update_begin(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(od), float(ts)))
+
+    def local_loglik(self):
+        out = np.zeros(self.hi - self.lo)
+        self.L.lama_pf_local_loglik(self.h, _p(out))
+        return out
+
+    def plan_resample(self, all_loglik):
+        all_loglik = np.ascontiguousarray(all_loglik, dtype=np.float64)
+        assert all_loglik.shape == (self.P,)
+        idx = np.zeros(self.P, dtype=np.int32)
+        r = self._chk(self.L.lama_pf_plan_resample(self.h, _p(all_loglik), _p(idx)))
+        return idx if r else None
+
+    def apply_resample(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        self._chk(self.L.lama_pf_apply_resample(self.h, _p(idx)))
+
+    def update_maps(self):
+        self._chk(self.L.lama_pf_update_maps(self.h))
+
+    def device_context(self):
+        return self.L.lama_pf_device_context(self.h)
+
+    def poses(self):
+        out = np.zeros((self.P, 4))
+        self.L.lama_pf_get_poses(self.h, _p(out))
+        return out
+
+    def set_pose(self, i, pose4):
+        self._chk(self.L.lama_pf_set_pose(self.h, i, _p(np.ascontiguousarray(pose4, dtype=np.float64))))
+
+    def weights(self):
+        w, nw, ws = np.zeros(self.P), np.zeros(self.P), np.zeros(self.P)
+        self.L.lama_pf_get_weights(self.h, _p(w), _p(nw), _p(ws))
+        return w, nw, ws
+
+    def set_weights(self, w=None, ws=None):
+        self.L.lama_pf_set_weights(self.h, _p(np.ascontiguousarray(w)) if w is not None else None,
+                                   _p(np.ascontiguousarray(ws)) if ws is not None else None)
+
+    def neff(self):
+        return self.L.lama_pf_neff(self.h)
+
+    def best(self):
+        return self.L.lama_pf_best(self.h)
+
+    def best_pose_xyr(self):
+        out = np.zeros(3)
+        self.L.lama_pf_best_pose_xyr(self.h, _p(out))
+        return out
+
+    def num_resamples(self):
+        return self.L.lama_pf_num_resamples(self.h)
+
+    def memory_usage(self):
+        return self.L.lama_pf_memory_usage(self.h)
+
+    def summary(self):
+        n = self.L.lama_pf_summary(self.h, None, 0)
+        if n <= 0:
+            return ""
+        buf = C.create_string_buffer(n)
+        self.L.lama_pf_summary(self.h, buf, n)
+        return buf.value.decode()
+
+    def last_times(self):
+        t = np.zeros(5)
+        self.L.lama_pf_last_times(self.h, _p(t))
+        return dict(total=t[0], solving=t[1], normalizing=t[2], resampling=t[3], mapping=t[4])
+
+    def draw_from_motion(self, delta4, pose4):
+        pose = np.array(pose4, dtype=np.float64)
+        self._chk(self.L.lama_pf_draw_from_motion(self.h, _p(np.ascontiguousarray(delta4, dtype=np.float64)), _p(pose)))
+        return pose
+
+    def normalize(self):
+        return self.L.lama_pf_normalize(self.h)
+
+    def resample_indices(self, u):
+        out = np.zeros(self.P, dtype=np.int32)
+        self.L.lama_pf_resample_indices(self.h, float(u), _p(out))
+        return out
+
+    def hip_context(self):
+        """Borrowed HipContext view of the local shard's device context (export/import, counters, maps)."""
+        ctx = HipContext.__new__(HipContext)
+        if self.engine_origin().endswith("liblama_hip.so"):
+            ctx.L = hip_lib()
+        else:                      # test double bound through set_engine_library()
+            ctx.L = C.CDLL(self.engine_origin())
+            _bind_hip(ctx.L)
+        ctx.cfg = None
+        ctx.P = self.hi - self.lo
+        ctx.h = C.c_void_p(self.device_context())
+        ctx._is_borrowed = True
+        return ctx

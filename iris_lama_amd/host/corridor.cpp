@@ -14,7 +14,7 @@
 #include <random>
 #include <vector>
 
-#include "../../include/lama_host.h"
+#include "lama_host.h"
 
 namespace {
 

@@ -1,0 +1,64 @@
+#include "hip_engine.hpp"
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <stdexcept>
+
+namespace lama {
+
+HipEngine::~HipEngine()
+{
+    // the library stays loaded for the life of the process (HIP runtimes do not like dlclose)
+}
+
+static std::shared_ptr<HipEngine> g_override;
+void setEngineOverride(std::shared_ptr<HipEngine> e) { g_override = std::move(e); }
+std::shared_ptr<HipEngine> engineOverride() { return g_override; }
+
+static std::string siblingPath()
+{
+    Dl_info info;
+    if (dladdr((void*)&siblingPath, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k + 1) + "liblama_hip.so";
+    }
+    return "liblama_hip.so";
+}
+
+std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
+{
+    const std::string path = explicit_path.empty() ? siblingPath() : explicit_path;
+    void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!dl) throw std::runtime_error(std::string("lama: cannot load the device library ") + path + ": " + dlerror() +
+                                      " (build it with hipcc --offload-arch=gfx950; there is no CPU fallback)");
+    auto e = std::make_shared<HipEngine>();
+    e->dl = dl;
+    e->origin = path;
+#define BIND(field, sym)                                                                                  \
+    e->field = reinterpret_cast<decltype(e->field)>(dlsym(dl, #sym));                                     \
+    if (!e->field) throw std::runtime_error(std::string("lama: symbol " #sym " missing in ") + path);
+    BIND(default_cfg, lama_hip_default_cfg)
+    BIND(device_count, lama_hip_device_count)
+    BIND(ctx_create, lama_hip_ctx_create)
+    BIND(ctx_destroy, lama_hip_ctx_destroy)
+    BIND(last_error, lama_hip_last_error)
+    BIND(pf_init, lama_hip_pf_init)
+    BIND(pf_set_poses, lama_hip_pf_set_poses)
+    BIND(pf_get_poses, lama_hip_pf_get_poses)
+    BIND(pf_scan_match, lama_hip_pf_scan_match)
+    BIND(pf_resample, lama_hip_pf_resample)
+    BIND(pf_update_maps, lama_hip_pf_update_maps)
+    BIND(pf_map_patches, lama_hip_pf_map_patches)
+    BIND(pf_download_map, lama_hip_pf_download_map)
+    BIND(match_batch, lama_hip_match_batch)
+    BIND(pf_export_particle, lama_hip_pf_export_particle)
+    BIND(pf_import_particle, lama_hip_pf_import_particle)
+    BIND(get_counters, lama_hip_get_counters)
+    BIND(reset_counters, lama_hip_reset_counters)
+#undef BIND
+    return e;
+}
+
+} // namespace lama

@@ -1,0 +1,45 @@
+// hip_engine.hpp -- run-time binding of the device C-ABI (include/lama_hip.h) for the host classes.
+// The table can also be filled by a caller (tests inject a CPU engine to exercise the multi-rank logic on
+// machines without a GPU); the default loader only ever binds liblama_hip.so and throws if it cannot.
+#pragma once
+
+#include <memory>
+#include <string>
+
+#include "lama_hip.h"
+
+namespace lama {
+
+struct HipEngine {
+    void* dl = nullptr;
+    std::string origin;
+    decltype(&lama_hip_default_cfg) default_cfg = nullptr;
+    decltype(&lama_hip_device_count) device_count = nullptr;
+    decltype(&lama_hip_ctx_create) ctx_create = nullptr;
+    decltype(&lama_hip_ctx_destroy) ctx_destroy = nullptr;
+    decltype(&lama_hip_last_error) last_error = nullptr;
+    decltype(&lama_hip_pf_init) pf_init = nullptr;
+    decltype(&lama_hip_pf_set_poses) pf_set_poses = nullptr;
+    decltype(&lama_hip_pf_get_poses) pf_get_poses = nullptr;
+    decltype(&lama_hip_pf_scan_match) pf_scan_match = nullptr;
+    decltype(&lama_hip_pf_resample) pf_resample = nullptr;
+    decltype(&lama_hip_pf_update_maps) pf_update_maps = nullptr;
+    decltype(&lama_hip_pf_map_patches) pf_map_patches = nullptr;
+    decltype(&lama_hip_pf_download_map) pf_download_map = nullptr;
+    decltype(&lama_hip_match_batch) match_batch = nullptr;
+    decltype(&lama_hip_pf_export_particle) pf_export_particle = nullptr;
+    decltype(&lama_hip_pf_import_particle) pf_import_particle = nullptr;
+    decltype(&lama_hip_get_counters) get_counters = nullptr;
+    decltype(&lama_hip_reset_counters) reset_counters = nullptr;
+    ~HipEngine();
+};
+
+// Binds liblama_hip.so (next to liblama_host.so unless an explicit path is given).  Throws
+// std::runtime_error if the library or any symbol is missing.
+std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path = std::string());
+
+// Engine override used by the next PFSlam2D constructed in this process (nullptr = default loader).
+void setEngineOverride(std::shared_ptr<HipEngine> e);
+std::shared_ptr<HipEngine> engineOverride();
+
+} // namespace lama

@@ -1,0 +1,257 @@
+// host_capi.cpp -- extern "C" flattening of lama::PFSlam2D (include/lama_host.h).
+#include "lama_host.h"
+
+#include <cstring>
+#include <exception>
+#include <string>
+
+#include "hip_engine.hpp"
+#include "lama/pf_slam2d.h"
+
+using namespace lama;
+
+struct lama_pf {
+    std::unique_ptr<PFSlam2D> pf;
+    std::string error;
+    std::string origin;
+    double times[5] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+PointCloudXYZ::Ptr make_cloud(const double* pts, uint32_t n, const double* origin3, const double* quat)
+{
+    auto c = std::make_shared<PointCloudXYZ>();
+    c->points.resize(n);
+    for (uint32_t i = 0; i < n; ++i) c->points[i] = Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (origin3) c->sensor_origin_ = Vector3d(origin3[0], origin3[1], origin3[2]);
+    if (quat) c->sensor_orientation_ = Quaterniond(quat[0], quat[1], quat[2], quat[3]);
+    return c;
+}
+
+template <class F>
+int guarded(lama_pf* pf, F&& f)
+{
+    try {
+        return f();
+    } catch (const std::exception& e) {
+        pf->error = e.what();
+        return -1;
+    } catch (...) {
+        pf->error = "unknown exception";
+        return -1;
+    }
+}
+
+void collect_times(lama_pf* h, size_t before[5])
+{
+    const PFSlam2D::Summary* s = h->pf->summary;
+    if (!s) return;
+    const DynamicArray<double>* v[5] = {&s->time, &s->time_solving, &s->time_normalizing, &s->time_resampling, &s->time_mapping};
+    for (int k = 0; k < 5; ++k) h->times[k] = v[k]->size() > before[k] ? v[k]->back() : 0.0;
+}
+
+void sizes(const lama_pf* h, size_t out[5])
+{
+    const PFSlam2D::Summary* s = h->pf->summary;
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    if (!s) return;
+    out[0] = s->time.size(); out[1] = s->time_solving.size(); out[2] = s->time_normalizing.size();
+    out[3] = s->time_resampling.size(); out[4] = s->time_mapping.size();
+}
+
+} // namespace
+
+extern "C" {
+
+void lama_pf_default_options(lama_pf_options* o)
+{
+    PFSlam2D::Options d;
+    std::memset(o, 0, sizeof(*o));
+    o->particles = d.particles; o->srr = d.srr; o->str = d.str; o->stt = d.stt; o->srt = d.srt;
+    o->meas_sigma = d.meas_sigma; o->meas_sigma_gain = d.meas_sigma_gain;
+    o->trans_thresh = d.trans_thresh; o->rot_thresh = d.rot_thresh; o->l2_max = d.l2_max;
+    o->truncated_ray = d.truncated_ray; o->truncated_range = d.truncated_range; o->resolution = d.resolution;
+    o->patch_size = d.patch_size; o->max_iter = d.max_iter; o->seed = d.seed;
+    o->create_summary = 1; o->gpu_device = 0; o->shard_rank = 0; o->shard_world = 1; o->profile = 0;
+}
+
+int lama_host_set_engine_library(const char* path)
+{
+    try {
+        if (!path || !*path) { setEngineOverride(nullptr); return 0; }
+        setEngineOverride(loadHipEngine(path));
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+
+lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
+{
+    auto* h = new lama_pf;
+    try {
+        PFSlam2D::Options p;
+        p.particles = o->particles; p.srr = o->srr; p.str = o->str; p.stt = o->stt; p.srt = o->srt;
+        p.meas_sigma = o->meas_sigma; p.meas_sigma_gain = o->meas_sigma_gain;
+        p.trans_thresh = o->trans_thresh; p.rot_thresh = o->rot_thresh; p.l2_max = o->l2_max;
+        p.truncated_ray = o->truncated_ray; p.truncated_range = o->truncated_range; p.resolution = o->resolution;
+        p.patch_size = o->patch_size; p.max_iter = o->max_iter; p.seed = o->seed;
+        p.create_summary = o->create_summary != 0; p.gpu_device = o->gpu_device;
+        p.shard_rank = o->shard_rank; p.shard_world = o->shard_world; p.profile = o->profile != 0;
+        h->pf.reset(new PFSlam2D(p));
+        h->origin = h->pf->engine()->origin;
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+
+void lama_pf_destroy(lama_pf* pf) { delete pf; }
+const char* lama_pf_last_error(const lama_pf* pf) { return pf ? pf->error.c_str() : "null handle"; }
+const char* lama_pf_engine_origin(const lama_pf* pf) { return pf ? pf->origin.c_str() : ""; }
+
+void lama_pf_set_prior(lama_pf* pf, double x, double y, double yaw) { pf->pf->setPrior(Pose2D(x, y, yaw)); }
+
+int lama_pf_update(lama_pf* h, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                   const double* odom_xyr, double ts)
+{
+    return guarded(h, [&] {
+        size_t before[5]; sizes(h, before);
+        bool r = h->pf->update(make_cloud(pts, n, origin3, quat), Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2]), ts);
+        collect_times(h, before);
+        return r ? 1 : 0;
+    });
+}
+
+int lama_pf_update_begin(lama_pf* h, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                         const double* odom_xyr, double ts)
+{
+    return guarded(h, [&] { return (int)h->pf->updateBegin(make_cloud(pts, n, origin3, quat), Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2]), ts); });
+}
+
+int lama_pf_local_range(const lama_pf* h, uint32_t* lo, uint32_t* hi)
+{
+    *lo = h->pf->localBegin(); *hi = h->pf->localEnd();
+    return 0;
+}
+
+int lama_pf_local_loglik(const lama_pf* h, double* out)
+{
+    const auto& v = h->pf->localLogLik();
+    std::memcpy(out, v.data(), sizeof(double) * v.size());
+    return (int)v.size();
+}
+
+int lama_pf_plan_resample(lama_pf* h, const double* all_loglik, int32_t* idx_out)
+{
+    return guarded(h, [&] {
+        std::vector<int32_t> idx;
+        const bool r = h->pf->planResample(all_loglik, idx);
+        if (r) std::memcpy(idx_out, idx.data(), sizeof(int32_t) * idx.size());
+        return r ? 1 : 0;
+    });
+}
+
+int lama_pf_apply_resample(lama_pf* h, const int32_t* idx)
+{
+    return guarded(h, [&] {
+        std::vector<int32_t> v(idx, idx + h->pf->getOptions().particles);
+        h->pf->applyResample(v);
+        return 0;
+    });
+}
+
+int lama_pf_update_maps(lama_pf* h) { return guarded(h, [&] { h->pf->updateMaps(); return 0; }); }
+void* lama_pf_device_context(const lama_pf* h) { return (void*)h->pf->deviceContext(); }
+
+int lama_pf_get_poses(const lama_pf* h, double* out)
+{
+    const auto& ps = h->pf->getParticles();
+    for (size_t i = 0; i < ps.size(); ++i) ps[i].pose.state.toArray(out + 4 * i);
+    return (int)ps.size();
+}
+
+int lama_pf_set_pose(lama_pf* h, uint32_t i, const double* pose4)
+{
+    auto& ps = const_cast<std::vector<PFSlam2D::Particle>&>(h->pf->getParticles());
+    if (i >= ps.size()) return -1;
+    ps[i].pose.state = SE2d::fromArray(pose4);
+    return 0;
+}
+
+int lama_pf_get_weights(const lama_pf* h, double* w, double* nw, double* ws)
+{
+    const auto& ps = h->pf->getParticles();
+    for (size_t i = 0; i < ps.size(); ++i) {
+        if (w) w[i] = ps[i].weight;
+        if (nw) nw[i] = ps[i].normalized_weight;
+        if (ws) ws[i] = ps[i].weight_sum;
+    }
+    return (int)ps.size();
+}
+
+int lama_pf_set_weights(lama_pf* h, const double* w, const double* ws)
+{
+    auto& ps = const_cast<std::vector<PFSlam2D::Particle>&>(h->pf->getParticles());
+    for (size_t i = 0; i < ps.size(); ++i) {
+        if (w) ps[i].weight = w[i];
+        if (ws) ps[i].weight_sum = ws[i];
+    }
+    return 0;
+}
+
+double lama_pf_neff(const lama_pf* h) { return h->pf->getNeff(); }
+int lama_pf_best(const lama_pf* h) { return (int)h->pf->getBestParticleIdx(); }
+int lama_pf_best_pose_xyr(const lama_pf* h, double* xyr)
+{
+    const Pose2D p = h->pf->getPose();
+    xyr[0] = p.x(); xyr[1] = p.y(); xyr[2] = p.rotation();
+    return 0;
+}
+uint32_t lama_pf_num_resamples(const lama_pf* h) { return h->pf->numResamples(); }
+uint64_t lama_pf_memory_usage(const lama_pf* h) { return h->pf->getMemoryUsage(); }
+
+int lama_pf_summary(const lama_pf* h, char* buf, int cap)
+{
+    if (!h->pf->summary) return 0;
+    const std::string r = h->pf->summary->report();
+    if (buf && cap > 0) { std::strncpy(buf, r.c_str(), (size_t)cap - 1); buf[cap - 1] = 0; }
+    return (int)r.size() + 1;
+}
+
+int lama_pf_last_times(const lama_pf* h, double* out5)
+{
+    std::memcpy(out5, h->times, sizeof(h->times));
+    return 0;
+}
+
+int lama_pf_draw_from_motion(lama_pf* h, const double* delta4, double* pose4)
+{
+    return guarded(h, [&] {
+        Pose2D pose(SE2d::fromArray(pose4));
+        h->pf->drawFromMotion(Pose2D(SE2d::fromArray(delta4)), pose);
+        pose.state.toArray(pose4);
+        return 0;
+    });
+}
+
+double lama_pf_normalize(lama_pf* h) { h->pf->normalize(); return h->pf->getNeff(); }
+
+int lama_pf_resample_indices(const lama_pf* h, double u01, int32_t* out)
+{
+    const std::vector<int32_t> v = h->pf->resampleIndices(u01);
+    std::memcpy(out, v.data(), sizeof(int32_t) * v.size());
+    return (int)v.size();
+}
+
+void lama_pose_minus(const double* a4, const double* b4, double* out4)
+{
+    (Pose2D(SE2d::fromArray(a4)) - Pose2D(SE2d::fromArray(b4))).state.toArray(out4);
+}
+
+void lama_pose_from_xyr(double x, double y, double yaw, double* out4) { Pose2D(x, y, yaw).state.toArray(out4); }
+
+} // extern "C"

@@ -1,0 +1,368 @@
+// pf_slam2d.cpp -- host-side lama::PFSlam2D (include/lama/pf_slam2d.h).  The orchestration follows the
+// reference's PFSlam2D::update (src/pf_slam2d.cpp:178-312) step by step; per-particle work is delegated to the
+// device C-ABI.  Citations are relative to /root/reference.
+#include "lama/pf_slam2d.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+
+#include "hip_engine.hpp"
+
+namespace lama {
+
+namespace {
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+} // namespace
+
+PFSlam2D::PFSlam2D(const Options& options) : options_(options)
+{
+    if (options_.particles == 0) throw std::runtime_error("lama::PFSlam2D: Options::particles must be > 0");
+    if (options_.use_compression) throw std::runtime_error("lama::PFSlam2D: use_compression is not supported on the device path");
+    if (options_.shard_world == 0 || options_.shard_rank >= options_.shard_world)
+        throw std::runtime_error("lama::PFSlam2D: invalid shard_rank / shard_world");
+    // contiguous blocks: particle i lives on shard floor(i * G / P)  
+    const uint64_t P = options_.particles, G = options_.shard_world, r = options_.shard_rank;
+    lo_ = (uint32_t)((r * P + G - 1) / G);
+    hi_ = (uint32_t)(((r + 1) * P + G - 1) / G);
+    if (hi_ <= lo_) throw std::runtime_error("lama::PFSlam2D: more shards than particles");
+
+    eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+    lama_hip_cfg cfg;
+    eng_->default_cfg(&cfg);
+    cfg.particles = hi_ - lo_;
+    cfg.resolution = options_.resolution;
+    cfg.patch_size = options_.patch_size;
+    cfg.l2_max = options_.l2_max;
+    cfg.meas_sigma = options_.meas_sigma;
+    cfg.max_iter = options_.max_iter;
+    cfg.truncated_ray = options_.truncated_ray;
+    cfg.truncated_range = options_.truncated_range;
+    cfg.device = options_.gpu_device;
+    cfg.profile = options_.profile ? 1 : 0;
+    const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
+    if (rc != 0 || !ctx_) {
+        char msg[256];
+        std::snprintf(msg, sizeof(msg), "lama::PFSlam2D: lama_hip_ctx_create failed (status %d): no usable MI355X / HIP device "
+                                        "or unsupported options; there is no CPU fallback", rc);
+        throw std::runtime_error(msg);
+    }
+    particles_.assign(options_.particles, Particle());
+    local_loglik_.assign(hi_ - lo_, 0.0);
+
+    // rng seed: 0 -> random_device (src/pf_slam2d.cpp:131-134, src/random.cpp:41-49)
+    if (options_.seed == 0) options_.seed = std::random_device()();
+    gen_.seed(options_.seed);
+    if (options_.create_summary) summary = new Summary();
+}
+
+PFSlam2D::~PFSlam2D()
+{
+    if (ctx_) eng_->ctx_destroy(ctx_);
+    delete summary;
+}
+
+void PFSlam2D::fail(int32_t rc, const char* what) const
+{
+    char msg[512];
+    std::snprintf(msg, sizeof(msg), "lama::PFSlam2D: %s failed (status %d): %s", what, rc, eng_->last_error(ctx_));
+    throw std::runtime_error(msg);
+}
+
+double PFSlam2D::normal(double stddev)      // src/random.cpp:69-73: a fresh distribution per call
+{
+    std::normal_distribution<double> distribution(0.0, stddev);
+    return distribution(gen_);
+}
+
+// src/pf_slam2d.cpp:365-391
+void PFSlam2D::drawFromMotion(const Pose2D& delta, Pose2D& pose)
+{
+    double sigma, x, y, yaw;
+    const double sxy = 0.3 * options_.stt;
+    sigma = options_.stt * std::fabs(delta.x()) + options_.str * std::fabs(delta.rotation()) + sxy * std::fabs(delta.y());
+    x = delta.x() + normal(sigma);
+    sigma = options_.stt * std::fabs(delta.y()) + options_.str * std::fabs(delta.rotation()) + sxy * std::fabs(delta.x());
+    y = delta.y() + normal(sigma);
+    sigma = options_.srr * std::fabs(delta.rotation()) + options_.srt * delta.xy().norm();
+    yaw = delta.rotation() + normal(sigma);
+    yaw = std::fmod(yaw, 2 * M_PI);
+    if (yaw > M_PI) yaw -= 2 * M_PI;
+    pose += Pose2D(x, y, yaw);
+}
+
+// src/pf_slam2d.cpp:511-535
+void PFSlam2D::normalize()
+{
+    const uint32_t P = options_.particles;
+    const double gain = 1.0 / (options_.meas_sigma_gain * P);
+    double max_l = particles_[0].weight;
+    for (uint32_t i = 1; i < P; ++i)
+        if (max_l < particles_[i].weight) max_l = particles_[i].weight;
+    double sum = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        particles_[i].normalized_weight = std::exp(gain * (particles_[i].weight - max_l));
+        sum += particles_[i].normalized_weight;
+    }
+    neff_ = 0;
+    for (uint32_t i = 0; i < P; ++i) {
+        particles_[i].normalized_weight /= sum;
+        neff_ += particles_[i].normalized_weight * particles_[i].normalized_weight;
+    }
+    neff_ = 1.0 / neff_;
+}
+
+// src/pf_slam2d.cpp:537-556 (systematic resampling; `u01` is the single random::uniform() draw)
+std::vector<int32_t> PFSlam2D::resampleIndices(double u01) const
+{
+    const uint32_t P = options_.particles;
+    std::vector<int32_t> sample_idx(P);
+    const double interval = 1.0 / (double)P;
+    double target = interval * u01;
+    double cw = 0.0;
+    uint32_t n = 0;
+    for (size_t i = 0; i < P; ++i) {
+        cw += particles_[i].normalized_weight;
+        while (cw > target && n < P) {     // (n < P: the reference would write past the array)
+            sample_idx[n++] = (int32_t)i;
+            target += interval;
+        }
+    }
+    return sample_idx;
+}
+
+void PFSlam2D::scanToArrays(const PointCloudXYZ& s)
+{
+    pts_.resize(s.points.size() * 3);
+    for (size_t i = 0; i < s.points.size(); ++i) {
+        pts_[3 * i] = s.points[i].x(); pts_[3 * i + 1] = s.points[i].y(); pts_[3 * i + 2] = s.points[i].z();
+    }
+    origin_[0] = s.sensor_origin_.x(); origin_[1] = s.sensor_origin_.y(); origin_[2] = s.sensor_origin_.z();
+    quat_[0] = s.sensor_orientation_.w(); quat_[1] = s.sensor_orientation_.x();
+    quat_[2] = s.sensor_orientation_.y(); quat_[3] = s.sensor_orientation_.z();
+}
+
+void PFSlam2D::uploadLocalPoses()
+{
+    std::vector<double> buf((size_t)(hi_ - lo_) * 4);
+    for (uint32_t i = lo_; i < hi_; ++i) particles_[i].pose.state.toArray(&buf[4 * (size_t)(i - lo_)]);
+    const int32_t rc = eng_->pf_set_poses(ctx_, buf.data());
+    if (rc) fail(rc, "lama_hip_pf_set_poses");
+}
+
+PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
+{
+    if (!surface || surface->points.empty()) throw std::runtime_error("lama::PFSlam2D::update: empty scan");
+    t_begin_ = now_s();
+    current_surface_ = surface;
+    scanToArrays(*surface);
+    const uint32_t n = (uint32_t)surface->points.size();
+    const uint32_t P = options_.particles;
+
+    if (!has_first_scan) {                                                  // src/pf_slam2d.cpp:185-228
+        odom_ = odometry;
+        timestamps_.push_back(timestamp);
+        for (uint32_t i = 0; i < P; ++i) {
+            particles_[i].poses.push_back(pose_);
+            particles_[i].pose = pose_;
+            particles_[i].weight = 0.0;
+            particles_[i].weight_sum = 0.0;
+        }
+        double p0[4];
+        pose_.state.toArray(p0);
+        const int32_t rc = eng_->pf_init(ctx_, pts_.data(), n, origin_, quat_, p0);
+        if (rc) fail(rc, "lama_hip_pf_init");
+        has_first_scan = true;
+        if (summary) {
+            const double el = now_s() - t_begin_;
+            summary->timestamp.push_back(timestamp);
+            summary->time.push_back(el);
+            summary->time_mapping.push_back(el);
+            summary->memory.push_back((double)getMemoryUsage());
+        }
+        return kFirstScan;
+    }
+
+    // 1. predict from odometry: ALL particles in order, so the RNG stream does not depend on the sharding
+    Pose2D odelta = odom_ - odometry;                                       // :231
+    odom_ = odometry;
+    for (uint32_t i = 0; i < P; ++i) drawFromMotion(odelta, particles_[i].pose);
+
+    acc_trans_ += odelta.xy().norm();                                       // :239-243
+    acc_rot_ += std::fabs(odelta.rotation());
+    if (acc_trans_ <= options_.trans_thresh && acc_rot_ <= options_.rot_thresh) return kNoUpdate;
+    acc_trans_ = 0;
+    acc_rot_ = 0;
+
+    // 2. scan matching of the local shard on the device                    :252-266, :416-437
+    const double t0 = now_s();
+    uploadLocalPoses();
+    std::vector<double> poses((size_t)(hi_ - lo_) * 4);
+    const int32_t rc = eng_->pf_scan_match(ctx_, pts_.data(), n, origin_, quat_, poses.data(), local_loglik_.data(), nullptr);
+    if (rc) fail(rc, "lama_hip_pf_scan_match");
+    for (uint32_t i = lo_; i < hi_; ++i) {
+        particles_[i].pose.state = SE2d::fromArray(&poses[4 * (size_t)(i - lo_)]);
+        if (options_.shard_world == 1) particles_[i].poses.push_back(particles_[i].pose);
+    }
+    t_solve_ = now_s() - t0;
+    if (summary) summary->time_solving.push_back(t_solve_);
+    return kMatched;
+}
+
+bool PFSlam2D::planResample(const double* all_loglik, std::vector<int32_t>& sample_idx)
+{
+    const uint32_t P = options_.particles;
+    const double t0 = now_s();
+    for (uint32_t i = 0; i < P; ++i) {                                      // :434-436
+        particles_[i].weight_sum += all_loglik[i];
+        particles_[i].weight += all_loglik[i];
+    }
+    normalize();                                                            // :274
+    if (summary) summary->time_normalizing.push_back(now_s() - t0);
+    if (!(neff_ < (P * 0.5))) return false;                                 // :280
+    const double u = std::uniform_real_distribution<double>(0.0, 1.0)(gen_);   // src/random.cpp:51-55
+    sample_idx = resampleIndices(u);
+    return true;
+}
+
+void PFSlam2D::applyResample(const std::vector<int32_t>& sample_idx)
+{
+    const uint32_t P = options_.particles;
+    const double t0 = now_s();
+    std::vector<Particle> next(P);
+    for (uint32_t i = 0; i < P; ++i) {                                      // :561-570
+        const uint32_t idx = (uint32_t)sample_idx[i];
+        next[i] = particles_[idx];
+        next[i].weight = 0.0;
+        next[i].weight_sum = particles_[idx].weight_sum;
+    }
+    // device copies for the local block; remote sources get a placeholder (self) and are imported afterwards
+    std::vector<int32_t> local(hi_ - lo_);
+    for (uint32_t i = lo_; i < hi_; ++i) {
+        const uint32_t src = (uint32_t)sample_idx[i];
+        local[i - lo_] = ownsParticle(src) ? (int32_t)(src - lo_) : (int32_t)(i - lo_);
+    }
+    const int32_t rc = eng_->pf_resample(ctx_, local.data());
+    if (rc) fail(rc, "lama_hip_pf_resample");
+    particles_.swap(next);
+    ++num_resamples_;
+    if (summary) summary->time_resampling.push_back(now_s() - t0);
+}
+
+void PFSlam2D::updateMaps()
+{
+    const double t0 = now_s();
+    const uint32_t n = (uint32_t)(pts_.size() / 3);
+    const int32_t rc = eng_->pf_update_maps(ctx_, pts_.data(), n, origin_, quat_);      // :289-302
+    if (rc) fail(rc, "lama_hip_pf_update_maps");
+    if (summary) {
+        summary->time_mapping.push_back(now_s() - t0);
+        summary->time.push_back(now_s() - t_begin_);
+        summary->timestamp.push_back(timestamps_.empty() ? 0.0 : timestamps_.back());
+        summary->memory.push_back((double)getMemoryUsage());
+    }
+}
+
+bool PFSlam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
+{
+    if (options_.shard_world != 1)
+        throw std::runtime_error("lama::PFSlam2D::update: with shard_world > 1 drive the step-wise API (all-gather needed)");
+    const Phase ph = updateBegin(surface, odometry, timestamp);
+    if (ph == kNoUpdate) return false;
+    if (ph == kFirstScan) return true;
+    std::vector<int32_t> idx;
+    if (planResample(local_loglik_.data(), idx)) applyResample(idx);
+    updateMaps();
+    return true;
+}
+
+size_t PFSlam2D::getBestParticleIdx() const                                 // :314-330
+{
+    size_t best_idx = 0;
+    double best_ws = particles_[0].weight_sum;
+    for (uint32_t i = 1; i < options_.particles; ++i)
+        if (best_ws < particles_[i].weight_sum) { best_ws = particles_[i].weight_sum; best_idx = i; }
+    return best_idx;
+}
+
+Pose2D PFSlam2D::getPose() const { return particles_[getBestParticleIdx()].pose; }
+
+uint64_t PFSlam2D::getMemoryUsage() const
+{
+    lama_hip_counters c;
+    if (eng_->get_counters(ctx_, &c) != 0) return 0;
+    // patch payloads in the reference's record sizes (Container::memory, src/sdm/container.cpp:92-95)
+    return c.dm_patches * 10240ull + c.occ_patches * 4096ull;
+}
+
+static bool download(const HipEngine* e, lama_hip_ctx* ctx, uint32_t particle, int kind, size_t cell_bytes,
+                     std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks)
+{
+    uint32_t n = 0;
+    if (e->pf_map_patches(ctx, particle, kind, &n) != 0) return false;
+    ids.assign(n, 0);
+    cells.assign((size_t)n * cell_bytes * 1024, 0);
+    masks.assign((size_t)n * 16, 0);
+    uint32_t got = 0;
+    return e->pf_download_map(ctx, particle, kind, n, ids.data(), cells.data(), masks.data(), &got) == 0 && got == n;
+}
+
+bool PFSlam2D::downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{
+    if (!has_first_scan) return false;
+    const size_t b = getBestParticleIdx();
+    if (!ownsParticle((uint32_t)b)) return false;
+    return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_DISTANCE, 10, ids, cells, masks);
+}
+
+bool PFSlam2D::downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{
+    if (!has_first_scan) return false;
+    const size_t b = getBestParticleIdx();
+    if (!ownsParticle((uint32_t)b)) return false;
+    return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_OCCUPANCY, 4, ids, cells, masks);
+}
+
+// src/pf_slam2d.cpp:49-104 (same buckets; plain loops instead of Eigen::Map)
+std::string PFSlam2D::Summary::report() const
+{
+    auto stats = [](const DynamicArray<double>& v, double out[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        if (v.empty()) return;
+        double s = 0, mn = v[0], mx = v[0];
+        for (double x : v) { s += x; mn = std::min(mn, x); mx = std::max(mx, x); }
+        const double mean = s / v.size();
+        double ss = 0;
+        for (double x : v) ss += (x - mean) * (x - mean);
+        out[0] = mean * 1e3; out[1] = (v.size() > 1 ? std::sqrt(ss / (v.size() - 1)) : 0.0) * 1e3; out[2] = mn * 1e3; out[3] = mx * 1e3;
+    };
+    double t[4], ts[4], tn[4], tr[4], tm[4];
+    stats(time, t); stats(time_solving, ts); stats(time_normalizing, tn); stats(time_resampling, tr); stats(time_mapping, tm);
+    double span = 0;
+    for (double x : time) span += x;
+    const double stampdiff = timestamp.empty() ? 0.0 : timestamp.back() - timestamp.front();
+    double maxmem = 0;
+    for (double m : memory) maxmem = std::max(maxmem, m);
+    char buf[2048];
+    std::snprintf(buf, sizeof(buf),
+                  "\n LaMa PF Slam2D (MI355X) - Report\n ================================\n"
+                  " Number of updates     %zu\n Number of resamples   %zu\n Max memory usage      %.2f MiB\n"
+                  " Execution time span   %.3f s\n Execution frequency   %.2f Hz\n Realtime factor       %.2fx\n"
+                  "\n Execution time (mean +- std [min, max]) in milliseconds\n"
+                  " --------------------------------------------------------\n"
+                  " Update          %f +- %f [%f, %f]\n   Optimization  %f +- %f [%f, %f]\n   Normalizing   %f +- %f [%f, %f]\n"
+                  "   Resampling    %f +- %f [%f, %f]\n   Mapping       %f +- %f [%f, %f]\n",
+                  time.size(), time_resampling.size(), maxmem / 1024.0 / 1024.0, span,
+                  time.empty() ? 0.0 : 1.0 / (span / time.size()), span > 0 ? stampdiff / span : 0.0,
+                  t[0], t[1], t[2], t[3], ts[0], ts[1], ts[2], ts[3], tn[0], tn[1], tn[2], tn[3],
+                  tr[0], tr[1], tr[2], tr[3], tm[0], tm[1], tm[2], tm[3]);
+    return std::string(buf);
+}
+
+} // namespace lama

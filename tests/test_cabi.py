@@ -1,0 +1,59 @@
+"""The C-ABI shared libraries load and export every symbol their headers declare (no compute, no GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+import iris_lama_amd.ffi as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared(header, prefix):
+    src = open(os.path.join(ROOT, "include", header)).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", src)))
+
+
+def test_hip_library_exports_header_symbols():
+    if not os.path.exists(F.HIP_LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "iris_lama_amd"), "hip"], check=True)
+    names = _declared("lama_hip.h", "lama_hip_")
+    assert set(names) == set(F.HIP_SYMBOLS), set(names) ^ set(F.HIP_SYMBOLS)
+    L = C.CDLL(F.HIP_LIB)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_host_library_exports_header_symbols():
+    names = _declared("lama_host.h", "lama_")
+    assert set(names) == set(F.HOST_SYMBOLS), set(names) ^ set(F.HOST_SYMBOLS)
+    L = C.CDLL(F.HOST_LIB)
+    for n in names:
+        assert hasattr(L, n), n
+
+
+def test_product_fails_loudly_without_gpu():
+    if F.device_count() > 0:
+        pytest.skip("a GPU is present")
+    F.set_engine_library(None)
+    with pytest.raises(F.LamaError, match="no CPU fallback"):
+        F.PFSlam2D(F.pf_options(particles=4, seed=1))
+    with pytest.raises(F.LamaError):
+        F.HipContext(F.default_cfg(particles=4))
+
+
+def test_product_does_not_reference_oracle():
+    """Nothing under iris_lama_amd/ or include/ may include, link or load anything under oracle/."""
+    bad = []
+    for base in ("iris_lama_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".so", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"oracle/|lama_oracle|liblama_oracle|_oracle\b", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad

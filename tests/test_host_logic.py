@@ -1,0 +1,111 @@
+"""CPU tests of the HOST-side product code (liblama_host.so: lama::PFSlam2D orchestration, RNG replay,
+normalize, systematic resampling, motion model) against the oracle.  The device C-ABI is bound to the
+oracle-backed test double tests/cpu_engine (no GPU here), so a free-running trajectory must agree with the
+oracle BIT FOR BIT: any deviation is a bug in the host logic."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import iris_lama_amd.ffi as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPU_ENGINE = os.path.join(HERE, "cpu_engine", "_build", "liblama_cpu_engine.so")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def cpu_engine():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpu_engine")], check=True)
+    F.set_engine_library(CPU_ENGINE)
+    yield
+    F.set_engine_library(None)
+
+
+@pytest.mark.parametrize("P,gain,expect_resample", [(10, 3.0, False), (12, 0.01, True)])
+def test_free_running_host_matches_oracle_bitwise(P, gain, expect_resample):
+    steps = 14
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o = O.PF(O.default_options(particles=P, seed=42, meas_sigma_gain=gain))
+    o.set_prior(O.se2(*odom[0]))
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
+    assert h.engine_origin().endswith("liblama_cpu_engine.so")
+    h.set_prior(*odom[0])
+    for k in range(steps + 1):
+        ro = o.update(pts[k], O.se2(*odom[k]), float(k))
+        rh = h.update(pts[k], odom[k], float(k))
+        assert ro == rh
+        assert np.array_equal(h.poses(), o.poses()), k
+        wo, nwo, wso = o.weights()
+        wh, nwh, wsh = h.weights()
+        assert np.array_equal(wo, wh) and np.array_equal(wso, wsh), k
+        if k > 0:
+            assert np.array_equal(nwo, nwh) and o.neff() == h.neff(), k
+        assert o.best() == h.best()
+    assert o.num_resamples() == h.num_resamples()
+    assert (h.num_resamples() > 0) == expect_resample
+    # maps of the best particle, via the host class' download path, equal the oracle's
+    ctx = h.hip_context()
+    b = h.best()
+    from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+    assert_maps_equal(ctx.download_map(b, F.MAP_DISTANCE), o.dm(b).dump(), DM_FIELDS, "dm")
+    assert_maps_equal(ctx.download_map(b, F.MAP_OCCUPANCY), o.occ(b).dump(), OCC_FIELDS, "occ")
+    assert "Number of updates" in h.summary()
+
+
+def test_motion_gate_and_rng_stream():
+    """drawFromMotion runs (and consumes RNG) on every call, also when the gate stays closed
+    (src/pf_slam2d.cpp:235-243)."""
+    P = 5
+    pts, odom, _ = F.corridor_log(3, 90)
+    o = O.PF(O.default_options(particles=P, seed=9))
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=9))
+    o.set_prior(O.se2(*odom[0]))
+    h.set_prior(*odom[0])
+    assert o.update(pts[0], O.se2(*odom[0])) and h.update(pts[0], odom[0])
+    small = odom[0] + np.array([0.1, 0.0, 0.01])       # below trans_thresh / rot_thresh
+    assert not o.update(pts[1], O.se2(*small))
+    assert not h.update(pts[1], small)
+    assert np.array_equal(h.poses(), o.poses())
+    assert o.update(pts[1], O.se2(*odom[1])) and h.update(pts[1], odom[1])
+    assert np.array_equal(h.poses(), o.poses())
+
+
+def test_host_formulas_direct():
+    P = 7
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=5))
+    o = O.PF(O.default_options(particles=P, seed=5))
+    # motion model: identical RNG stream => identical draws
+    delta = O.se2(0.6, 0.02, 0.03)
+    pose = O.se2(1.0, 2.0, 0.4)
+    for _ in range(5):
+        a = o.draw_from_motion(delta, pose)
+        b = h.draw_from_motion(delta, pose)
+        assert np.array_equal(a, b)
+        pose = a
+    # normalize / systematic resampling on given weights (needs a first scan on the oracle side)
+    pts, odom, _ = F.corridor_log(0, 90)
+    o.set_prior(O.se2(*odom[0]))
+    o.update(pts[0], O.se2(*odom[0]))
+    w = np.array([-40.0, -3.0, -90.5, -3.5, -20.0, -2.0, -60.0])
+    o.set_weights(w=w)
+    h.set_weights(w=w)
+    assert o.stage_normalize() == h.normalize()
+    assert np.array_equal(o.weights()[1], h.weights()[1])
+    for u in (0.0, 0.25, 0.5, 0.999):
+        assert np.array_equal(o.stage_resample_indices(u), h.resample_indices(u))
+    # equal weights: Neff = P and identity indices at u = 0.5
+    h.set_weights(w=np.full(P, -1.5))
+    assert abs(h.normalize() - P) < 1e-9
+    assert h.resample_indices(0.5).tolist() == list(range(P))
+
+
+def test_pose_algebra():
+    a, b = O.se2(1.0, -2.0, 0.7), O.se2(0.3, 0.9, -2.5)
+    want = np.zeros(4)
+    O.lib().orc_pose_minus(O._p(a), O._p(b), O._p(want))
+    got = np.zeros(4)
+    F._hostlib().lama_pose_minus(F._p(a), F._p(b), F._p(got))
+    assert np.array_equal(got, want)
+    assert np.array_equal(F.pose_from_xyr(0.5, -0.25, 1.25), O.se2(0.5, -0.25, 1.25))
