@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- particle-scans/sec of the MI355X PFSlam2D path on the seeded synthetic corridor log.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P_per_gpu]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one PFSlam2D::update() (predict, scan-match, normalise, resample if due, map update) of ALL particles
+on one 1080-beam scan.  N = 1: BASELINE.json configs[1] (PFSlam2D, 30 particles, 1080 beams, one MI355X).
+N > 1: one process per GPU, the particle pool is sharded in contiguous blocks (30 particles per GPU: weak
+scaling), the per-scan exchange is an all-gather of the log-likelihoods (RCCL) plus particle shipping when a
+resample clones across shards.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+DM_PATCH_B = 10240 + 128    # reference record sizes: distance_t patch + mask
+OCC_PATCH_B = 4096 + 128
+
+
+def cpu_baseline(pts, odom, P, updates, warm):
+    """Oracle (CPU restatement of the reference's thread_pool path) timed on the host cores: same log, same P,
+    same updates.  Also returns the algorithmic bytes per particle-scan from the oracle's touch counters."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    cores = os.cpu_count() or 1
+    res = {}
+    for label, threads in (("pool", cores), ("serial", -1)):
+        pf = O.PF(O.default_options(particles=P, seed=42, threads=threads))
+        pf.set_prior(O.se2(*odom[0]))
+        if threads <= 1:
+            pf.count_touches(True)
+        pf.update(pts[0], O.se2(*odom[0]), 0.0)
+        t_tot, n, b_maps, b_match, b_all = 0.0, 0, 0.0, 0.0, 0.0
+        for k in range(1, warm + updates + 1):
+            t0 = time.perf_counter()
+            ok = pf.update(pts[k], O.se2(*odom[k]), float(k))
+            dt = time.perf_counter() - t0
+            if k > warm and ok:
+                t_tot += dt
+                n += 1
+                if threads <= 1:
+                    for i in range(P):
+                        c = pf.counters(i)
+                        b_maps += 2 * DM_PATCH_B * c["n_bf"] + 2 * OCC_PATCH_B * c["n_occ"]
+                        b_match += DM_PATCH_B * c["n_match"] + 72
+                        b_all += DM_PATCH_B * (c["n_match_or_bf"] + c["n_bf"]) + 2 * OCC_PATCH_B * c["n_occ"] + 72
+        res[label] = dict(value=P * n / t_tot, seconds=t_tot, updates=n)
+        if threads <= 1 and n:
+            res["bytes"] = dict(maps=b_maps / (P * n), match=b_match / (P * n), total=b_all / (P * n))
+    return cores, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--particles", type=int, default=30, help="particles per GPU")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--sweep", type=str, default="300,3000", help="extra single-GPU particle counts (N=1 only), '' to skip")
+    args = ap.parse_args()
+
+    import torch
+    import iris_lama_amd.ffi as F
+    from iris_lama_amd.distributed import ShardedPF, init_process_group
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        init_process_group("nccl")
+
+    K, W = args.steps, args.warmup
+    P_total = args.particles * world
+    pts, odom, truth = F.corridor_log(W + K, 1080)
+
+    def run(P, updates, warm, profile=True):
+        opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
+                            create_summary=1, profile=1 if profile else 0)
+        pf = ShardedPF(opts)
+        assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
+        pf.set_prior(*odom[0])
+        pf.update(pts[0], odom[0], 0.0)                       # first scan (initialisation, untimed)
+        for k in range(1, warm + 1):
+            pf.update(pts[k], odom[k], float(k))
+        ctx = pf.pf.hip_context()
+        ctx.reset_counters()
+        r0 = pf.pf.num_resamples()
+        pf.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        done = 0
+        for k in range(warm + 1, warm + updates + 1):
+            done += 1 if pf.update(pts[k], odom[k], float(k)) else 0
+        torch.cuda.synchronize()
+        pf.barrier()
+        dt = pf.max_over_ranks(time.perf_counter() - t0)
+        c = ctx.counters()
+        err = float(np.linalg.norm(pf.pf.best_pose_xyr()[:2] - truth[warm + updates][:2])) if pf.owns_best() else None
+        out = dict(P=P, seconds=dt, updates=done, value=P * done / dt, ms_per_step=1e3 * dt / max(done, 1), counters=c,
+                   resamples=pf.pf.num_resamples() - r0, pose_err_m=err)
+        pf.close()
+        return out
+
+    main_run = run(P_total, K, W)
+    assert main_run["updates"] == K, "every scan of the log must pass the motion gate"
+
+    if rank != 0:
+        return
+    c = main_run["counters"]
+    result = {
+        "metric": "particle-scans/sec", "value": main_run["value"], "unit": "particle-scans/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": main_run["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"PFSlam2D {P_total} particles ({args.particles}/GPU), 1080-beam synthetic corridor log "
+                               f"(SURVEY.md 8(d)), res 0.05 m, patch 32, l2_max 0.5, GN+Cauchy(0.15), seed 42",
+                   "particles": P_total, "beams": 1080, "parallelism": f"particle-shard x{world}",
+                   "resamples_in_timed_region": main_run["resamples"], "best_pose_error_m": main_run["pose_err_m"]},
+        "kernel_ms_per_step": {"scan_match": c["ms_scan_match"] / max(c["launches_scan_match"], 1),
+                               "update_maps": c["ms_update_maps"] / max(c["launches_update_maps"], 1),
+                               "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0},
+    }
+    cores, base = (None, None)
+    if not args.no_cpu:
+        cores, base = cpu_baseline(pts, odom, args.particles, K, W)
+        result["cpu_baseline"] = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
+                                  "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
+                                            f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s"}
+    # roofline of the dominant kernel (update_maps): algorithmic bytes per launch / mean launch duration
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_update_maps.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    if base and "bytes" in base:
+        per_ps = base["bytes"]["maps"]
+        launches = max(c["launches_update_maps"], 1)
+        dur_s = c["ms_update_maps"] / launches * 1e-3
+        achieved = per_ps * args.particles / dur_s / 1e9          # GB/s on this rank's GPU
+        result["roofline"] = {"bound": "hbm", "kernel": "k_update_maps", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
+                              "mean_launch_ms": dur_s * 1e3}
+    if world == 1 and args.sweep:
+        extra = {}
+        for P in [int(x) for x in args.sweep.split(",") if x]:
+            r = run(P, min(K, 10), 2, profile=True)
+            cc = r["counters"]
+            extra[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
+                             "update_maps_ms": cc["ms_update_maps"] / max(cc["launches_update_maps"], 1),
+                             "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1)}
+        result["other_particle_counts"] = extra
+    print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,149 @@
+"""One process per GPU: the particle pool of lama::PFSlam2D sharded in contiguous blocks.
+
+Per scan the only data-path exchange is an all-gather of the per-particle log-likelihoods (P doubles; RCCL when
+the backend is "nccl", i.e. over xGMI on an MI355X node).  Every rank then computes the same normalisation, Neff
+and -- from the same host RNG stream -- the same systematic-resampling indices.  When a resample clones a particle
+whose source lives on another shard, that particle (pose + used map patches) is shipped point-to-point with
+batched isend/irecv: systematic resampling is order preserving, so with contiguous blocks sources are local or on
+a neighbouring shard and pairwise P2P is the right primitive (a ring collective would be per-link bound).
+
+torch is plumbing here (process group, device buffers); the work is in liblama_hip.so / liblama_host.so.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ffi as F
+
+
+def init_process_group(backend="nccl"):
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+
+
+def owner_of(i, P, G):
+    """Shard that owns particle i: floor(i * G / P)  (contiguous blocks)."""
+    return (i * G) // P
+
+
+class ShardedPF:
+    def __init__(self, opts, device=None):
+        self.pf = F.PFSlam2D(opts)
+        self.world = opts.shard_world
+        self.rank = opts.shard_rank
+        self.P = opts.particles
+        if self.world > 1:
+            assert dist.is_initialized() and dist.get_world_size() == self.world and dist.get_rank() == self.rank
+            self.backend = dist.get_backend()
+        else:
+            self.backend = None
+        if device is None:
+            device = torch.device("cuda", opts.gpu_device) if self.backend == "nccl" else torch.device("cpu")
+        self.device = device                      # where the collective's tensors live (cuda for RCCL, cpu for gloo)
+        # particle blobs are written by the engine: device memory for liblama_hip.so, host memory for the test double
+        on_gpu = self.pf.engine_origin().endswith("liblama_hip.so")
+        self.blob_device = torch.device("cuda", opts.gpu_device) if on_gpu else torch.device("cpu")
+        self.blocks = [((r * self.P + self.world - 1) // self.world, ((r + 1) * self.P + self.world - 1) // self.world)
+                       for r in range(self.world)]
+        assert self.blocks[self.rank] == (self.pf.lo, self.pf.hi)
+        self.maxblk = max(hi - lo for lo, hi in self.blocks)
+        self.shipped_particles = 0
+        self.shipped_bytes = 0
+
+    def close(self):
+        self.pf.close()
+
+    def set_prior(self, x, y, yaw):
+        self.pf.set_prior(x, y, yaw)
+
+    # ------------------------------------------------------------------ collectives
+    def barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def max_over_ranks(self, x):
+        if self.world == 1:
+            return float(x)
+        t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def owns_best(self):
+        return self.pf.lo <= self.pf.best() < self.pf.hi
+
+    def _all_gather_loglik(self, local):
+        send = torch.zeros(self.maxblk, dtype=torch.float64, device=self.device)
+        send[: len(local)] = torch.from_numpy(local).to(self.device)
+        out = [torch.empty(self.maxblk, dtype=torch.float64, device=self.device) for _ in range(self.world)]
+        dist.all_gather(out, send)
+        allv = np.empty(self.P)
+        for r, (lo, hi) in enumerate(self.blocks):
+            allv[lo:hi] = out[r][: hi - lo].cpu().numpy()
+        return allv
+
+    # ------------------------------------------------------------------ resample with cross-shard clones
+    def _ship(self, idx):
+        """Returns {local slot (global index): blob tensor} for slots whose source lives on another shard."""
+        P, G = self.P, self.world
+        transfers = sorted({(owner_of(int(idx[i]), P, G), owner_of(i, P, G), int(idx[i]))
+                            for i in range(P) if owner_of(int(idx[i]), P, G) != owner_of(i, P, G)})
+        if not transfers:
+            return {}
+        ctx = self.pf.hip_context()
+        sizes = torch.zeros(len(transfers), dtype=torch.int64, device=self.device)
+        for t, (sr, dr, sp) in enumerate(transfers):
+            if sr == self.rank:
+                sizes[t] = ctx.export_bytes(sp - self.pf.lo)
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
+        sizes = sizes.cpu().tolist()
+        ops, bufs = [], {}
+        for t, (sr, dr, sp) in enumerate(transfers):
+            if sr == self.rank:
+                buf = torch.empty(sizes[t], dtype=torch.uint8, device=self.blob_device)
+                ctx.export_particle(sp - self.pf.lo, buf.data_ptr(), sizes[t])
+                buf = buf.to(self.device)
+                ops.append(dist.P2POp(dist.isend, buf, dr))
+                bufs[("s", t)] = buf
+                self.shipped_particles += 1
+                self.shipped_bytes += sizes[t]
+            elif dr == self.rank:
+                buf = torch.empty(sizes[t], dtype=torch.uint8, device=self.device)
+                ops.append(dist.P2POp(dist.irecv, buf, sr))
+                bufs[(sr, sp)] = buf
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        incoming = {}
+        for i in range(self.pf.lo, self.pf.hi):
+            src = int(idx[i])
+            sr = owner_of(src, P, G)
+            if sr != self.rank:
+                incoming[i] = bufs[(sr, src)].to(self.blob_device)
+        return incoming
+
+    # ------------------------------------------------------------------ PFSlam2D::update, sharded
+    def update(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
+        if self.world == 1:
+            return self.pf.update(pts, odom_xyr, ts, origin, quat)
+        phase = self.pf.update_begin(pts, odom_xyr, ts, origin, quat)
+        if phase == 0:
+            return False
+        if phase == 1:
+            return True
+        all_ll = self._all_gather_loglik(self.pf.local_loglik())
+        idx = self.pf.plan_resample(all_ll)
+        if idx is not None:
+            incoming = self._ship(idx)
+            self.pf.apply_resample(idx)
+            if incoming:
+                ctx = self.pf.hip_context()
+                for i, buf in incoming.items():
+                    ctx.import_particle(i - self.pf.lo, buf.data_ptr(), buf.numel())
+                    # the host mirror of the pose travels inside the blob; refresh it
+                poses = ctx.get_poses()
+                for i in incoming:
+                    self.pf.set_pose(i, poses[i - self.pf.lo])
+        self.pf.update_maps()
+        return True

@@ -5,7 +5,8 @@
 //             x = 5,9,13,17,21,25 with y alternating 0.8 / 3.2
 //   sensor  : `beams` beams over 270 deg (-135 .. +135, step 270/beams), max range 30 m,
 //             range noise N(0, 0.01 m) from std::mt19937(1234); points (r cos phi, r sin phi, 0)
-//   path    : start (2,2,0), `steps` steps of 0.6 m along +x, yaw_k = 0.05 sin(0.3 k)
+//   path    : start (2,2,0), steps of 0.6 m along +x up to x = 26 (k = 40), then back and forth (the robot
+//             reverses, triangle wave of period 80); yaw_k = 0.05 sin(0.3 k)
 //   odometry: truth composed with per-step drift N(0,0.01 m) on x and N(0,0.002 rad) on yaw,
 //             cumulative, std::mt19937(4321)
 // This is workload generation, not part of the reference (which ships no data).
@@ -64,7 +65,9 @@ extern "C" int lama_corridor_generate(int steps, int beams, double* pts, double*
     double ox = 0, oy = 0, oyaw = 0;     // odometry pose
     double px = 0, py = 0, pyaw = 0;     // previous true pose
     for (int k = 0; k <= steps; ++k) {
-        const double tx = 2.0 + 0.6 * k, ty = 2.0, tyaw = 0.05 * std::sin(0.3 * k);
+        const int kk = k % 80;
+        const int tri = kk <= 40 ? kk : 80 - kk;
+        const double tx = 2.0 + 0.6 * tri, ty = 2.0, tyaw = 0.05 * std::sin(0.3 * k);
         if (truth_xyr) { truth_xyr[3 * k] = tx; truth_xyr[3 * k + 1] = ty; truth_xyr[3 * k + 2] = tyaw; }
         if (k == 0) {
             ox = tx; oy = ty; oyaw = tyaw;

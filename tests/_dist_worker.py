@@ -1,0 +1,43 @@
+"""Worker for the world_size>1 tests: runs the sharded PFSlam2D driver on one rank and dumps what it owns."""
+import os
+import pickle
+import sys
+
+import numpy as np
+
+
+def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir, gpu):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import torch
+    import torch.distributed as dist
+    import iris_lama_amd.ffi as F
+    from iris_lama_amd.distributed import ShardedPF
+
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if engine_path:
+        F.set_engine_library(engine_path)
+    pts, odom, _ = F.corridor_log(steps, beams)
+    opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=0)
+    pf = ShardedPF(opts, device=torch.device("cpu") if backend == "gloo" else None)
+    pf.set_prior(*odom[0])
+    hist = []
+    for k in range(steps + 1):
+        ok = pf.update(pts[k], odom[k], float(k))
+        w, nw, ws = pf.pf.weights()
+        hist.append(dict(ok=ok, poses=pf.pf.poses()[pf.pf.lo:pf.pf.hi].copy(), w=w.copy(), ws=ws.copy(), neff=pf.pf.neff(),
+                         best=pf.pf.best()))
+    ctx = pf.pf.hip_context()
+    maps = {}
+    for i in range(pf.pf.lo, pf.pf.hi):
+        maps[i] = (ctx.download_map(i - pf.pf.lo, F.MAP_DISTANCE), ctx.download_map(i - pf.pf.lo, F.MAP_OCCUPANCY))
+    res = dict(lo=pf.pf.lo, hi=pf.pf.hi, hist=hist, maps=maps, resamples=pf.pf.num_resamples(), shipped=pf.shipped_particles,
+               origin=pf.pf.engine_origin())
+    with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
+        pickle.dump(res, f)
+    dist.barrier()
+    pf.close()
+    dist.destroy_process_group()

@@ -1,0 +1,71 @@
+"""world_size-2/3 `gloo` tests of the sharded driver (iris_lama_amd/distributed.py) on CPU.
+
+The device C-ABI is bound to the oracle-backed test double, so what is under test is the product's HOST logic:
+block partition, all-gather of log-likelihoods, identical normalise/resample decisions on every rank, and the
+point-to-point shipping of particles cloned across shards.  Requirement: results are bit-identical
+for every G -- checked against the single-process oracle."""
+import os
+import pickle
+import socket
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+import _oracle as O
+from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+from _dist_worker import run
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPU_ENGINE = os.path.join(HERE, "cpu_engine", "_build", "liblama_cpu_engine.so")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("world,P", [(2, 10), (3, 11)])
+def test_sharded_equals_single_process_oracle(world, P):
+    import iris_lama_amd.ffi as F
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpu_engine")], check=True)
+    steps, beams, gain = 10, 360, 0.01          # gain 0.01 forces resampling (and cross-shard clones)
+    out = tempfile.mkdtemp()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=run, args=(r, world, port, "gloo", CPU_ENGINE, P, steps, beams, gain, out, 0)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [pickle.load(open(os.path.join(out, f"rank{r}.pkl"), "rb")) for r in range(world)]
+
+    pts, odom, _ = F.corridor_log(steps, beams)
+    o = O.PF(O.default_options(particles=P, seed=42, meas_sigma_gain=gain))
+    o.set_prior(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        ok = o.update(pts[k], O.se2(*odom[k]), float(k))
+        w, nw, ws = o.weights()
+        for r in res:
+            h = r["hist"][k]
+            assert h["ok"] == ok
+            assert np.array_equal(h["poses"], o.poses()[r["lo"]:r["hi"]]), (k, r["lo"])
+            assert np.array_equal(h["w"], w) and np.array_equal(h["ws"], ws)
+            if k > 0:
+                assert h["neff"] == o.neff()
+            assert h["best"] == o.best()
+    assert o.num_resamples() > 0
+    assert all(r["resamples"] == o.num_resamples() for r in res)
+    assert sum(r["shipped"] for r in res) > 0, "the test must exercise cross-shard particle shipping"
+    assert sorted((r["lo"], r["hi"]) for r in res)[0][0] == 0 and max(r["hi"] for r in res) == P
+    for r in res:
+        assert r["origin"].endswith("liblama_cpu_engine.so")
+        for i, (dm, occ) in r["maps"].items():
+            assert_maps_equal(dm, o.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+            assert_maps_equal(occ, o.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
