@@ -132,6 +132,8 @@ def main():
                    "resamples_in_timed_region": main_run["resamples"], "best_pose_error_m": main_run["pose_err_m"]},
         "kernel_ms_per_step": {"scan_match": c["ms_scan_match"] / max(c["launches_scan_match"], 1),
                                "update_maps": c["ms_update_maps"] / max(c["launches_update_maps"], 1),
+                               "raycast": c["ms_raycast"] / max(c["launches_raycast"], 1),
+                               "brushfire": c["ms_brushfire"] / max(c["launches_brushfire"], 1),
                                "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0},
     }
     cores, base = (None, None)
@@ -164,6 +166,8 @@ def main():
             cc = r["counters"]
             extra[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
                              "update_maps_ms": cc["ms_update_maps"] / max(cc["launches_update_maps"], 1),
+                             "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1),
+                             "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1)}
         result["other_particle_counts"] = extra
     print(json.dumps(result))

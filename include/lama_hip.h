@@ -66,7 +66,7 @@ typedef struct lama_hip_cfg {
     double truncated_ray;        /* Options::truncated_ray                                        */
     double truncated_range;      /* Options::truncated_range                                      */
     int32_t device;              /* HIP device ordinal                                            */
-    uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m) */
+    uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m; multiple of 8, <= 248) */
     uint32_t dm_patch_capacity;  /* DM patches per particle  (default 256)                        */
     uint32_t occ_patch_capacity; /* occupancy patches per particle (default 256)                  */
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
@@ -137,7 +137,9 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* ctx, uint32_t particle, const 
  * counters since the last reset; valid when cfg.profile != 0. */
 typedef struct lama_hip_counters {
     double ms_scan_match;  uint64_t launches_scan_match;
-    double ms_update_maps; uint64_t launches_update_maps;
+    double ms_update_maps; uint64_t launches_update_maps;   /* = raycast + brushfire */
+    double ms_raycast;     uint64_t launches_raycast;
+    double ms_brushfire;   uint64_t launches_brushfire;
     double ms_resample;    uint64_t launches_resample;
     uint64_t gn_iterations;     /* sum over particles and calls                                    */
     uint64_t gn_evals;          /* residual evaluations (with or without Jacobian) + likelihood     */

@@ -65,8 +65,11 @@ struct DevParams {
     double* poses;         // [P][4]
     uint64_t* q_lower;     // [P][qcap]
     uint64_t* q_raise;     // [P][qcap]
+    uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
+    uint32_t* slow;        // [P] 1 = k_brushfire handed this particle to k_brushfire_slow
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
+    uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused
 };
 
 // ------------------------------------------------------------------------------------------------

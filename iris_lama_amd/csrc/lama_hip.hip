@@ -42,6 +42,9 @@ struct lama_hip_ctx {
     double* d_poses = nullptr;
     uint64_t* d_qlower = nullptr; uint64_t* d_qraise = nullptr;
     uint64_t* d_stats = nullptr;
+    uint32_t* d_qsizes = nullptr;
+    uint64_t* d_dbg = nullptr;
+    uint32_t* d_slow = nullptr;
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0;
     double* d_tfs = nullptr;
@@ -115,7 +118,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     const ParticleSet& s = c->set[which];
     p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
-    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.err = c->d_err;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
     return p;
 }
 
@@ -171,10 +174,21 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
     HIPCHK(c, hipMemcpyAsync(c->d_tfs, tfs.data(), sizeof(double) * tfs.size(), hipMemcpyHostToDevice, c->stream));
     DevParams prm = make_params(c, c->cur);
-    Timer t(c, &c->ctr.ms_update_maps, &c->ctr.launches_update_maps);
-    hipLaunchKernelGGL(k_update_maps, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
-    t.stop();
+    {
+        Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
+        hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+        t.stop();
+    }
     HIPCHK(c, hipGetLastError());
+    {
+        Timer t(c, &c->ctr.ms_brushfire, &c->ctr.launches_brushfire);
+        hipLaunchKernelGGL(k_brushfire, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        t.stop();
+    }
+    HIPCHK(c, hipGetLastError());
+    c->ctr.ms_update_maps = c->ctr.ms_raycast + c->ctr.ms_brushfire;
+    c->ctr.launches_update_maps = c->ctr.launches_raycast;
     return LAMA_HIP_OK;
 }
 
@@ -233,7 +247,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     if (cfg.dm_patch_capacity == 0) cfg.dm_patch_capacity = 256;
     if (cfg.occ_patch_capacity == 0) cfg.occ_patch_capacity = 256;
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
-    if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 2048 ||
+    if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_LDS)
         return LAMA_HIP_E_INVALID;
@@ -272,6 +286,9 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qlower, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_qraise, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_stats, P * 4 * 8));          CHK(hipMemset(c->d_stats, 0, P * 4 * 8));
+    CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
+    CHK(hipMalloc(&c->d_dbg, P * 8 * 8));            CHK(hipMemset(c->d_dbg, 0, P * 8 * 8));
+    CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
     CHK(hipMalloc(&c->d_err, 4));                    CHK(hipMemset(c->d_err, 0, 4));
     CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
     CHK(hipMalloc(&c->d_loglik, P * 8));
@@ -296,7 +313,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats);
+    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow);
     (void)hipFree(c->d_err); (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs); (void)hipFree(c->d_loglik);
     (void)hipFree(c->d_iters); (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -494,6 +511,11 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
             }
         } else {
             std::memcpy(cells + (size_t)k * 4096, &hocc[(size_t)slot * 1024], 4096);   // {u16 occupied, u16 visited} little endian
+            if (masks) {   // Container mask of an occupancy cell = "visited != 0" (plus the plane bits set on uint16 wrap)
+                uint64_t* mk = masks + (size_t)k * 16;
+                for (int ci = 0; ci < 1024; ++ci)
+                    if (hocc[(size_t)slot * 1024 + ci] >> 16) mk[ci >> 6] |= 1ull << (ci & 63);
+            }
         }
     }
     return LAMA_HIP_OK;
@@ -610,6 +632,14 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     HIPCHK(c, hipMemcpyAsync(c->d_poses + 4 * particle, pose, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_counts[2 * particle] = dmc; c->h_counts[2 * particle + 1] = occ;
+    return LAMA_HIP_OK;
+}
+
+// profiling builds only (-DLAMA_PROFILE_BF): per-particle cycle counters of the last k_brushfire launch
+int32_t lama_hip_debug_cycles(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
+{
+    if (!c || !out) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipMemcpy(out, c->d_dbg, sizeof(uint64_t) * 8 * c->P, hipMemcpyDeviceToHost));
     return LAMA_HIP_OK;
 }
 

@@ -3,8 +3,8 @@
 //   k_scan_match   : region 1 of PFSlam2D::update (src/pf_slam2d.cpp:254-266): one workgroup per particle,
 //                    whole Gauss-Newton loop on the device, wave-shuffle reduction of the 10 normal-
 //                    equation scalars, fp64 (map coordinates are ~4.2e7 cells: fp32 is not an option).
-//   k_update_maps  : region 2 (src/pf_slam2d.cpp:292-302): ray-cast + occupancy counters + obstacle events
-//                    + exact dynamic brushfire, one wave per particle.
+//   k_raycast      : region 2a (src/pf_slam2d.cpp:458-505): ray-cast + occupancy counters + obstacle events,
+//   k_brushfire    : region 2b (:508): exact dynamic brushfire; both one wave per particle.
 //   k_copy_particles: resample() / first-scan cloning (src/pf_slam2d.cpp:204-216, 558-574).
 //   k_loglik_batch : calculateLikelihood for B poses on one map (src/pf_slam2d.cpp:393-414).
 //
@@ -227,34 +227,56 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_update_maps -- PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:439-509), one wave per particle.
+// Map update = PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:439-509), two kernels, one wave per particle:
+//   k_raycast   : beams in order; hit cell + Bresenham cells 64 at a time -> uint16 counters, add/remove
+//                 obstacle events applied to the DM cells and appended to the lower/raise queues in HBM;
+//   k_brushfire : DynamicDistanceMap::update (src/sdm/dynamic_distance_map.cpp:160-197), exact.
 //
-// Exactness contract: the uint16 counters AND the order of add/remove obstacle events AND the order in
-// which the brushfire pops equal-priority cells are those of the reference's sequential code, so the
-// resulting maps are bit-identical (cells, obstacle offsets, flags, masks, patch sets).
-//   * beams are processed in order; within a beam the hit cell first (lane 0), then the Bresenham cells
-//     64 at a time (cells of one ray are distinct => plain RMW, no atomics); the closed form
+// Exactness contract: the counters AND the order of add/remove obstacle events AND the order in which the
+// brushfire pops equal-priority cells are those of the reference's sequential code, so the resulting maps are
+// bit-identical (cells, obstacle offsets, flags, masks, patch sets).
+//   * cells of one ray are distinct => plain RMW, no atomics; the closed form
 //     steps_j(t) = floor((2 t |d_j| + n) / (2 n)) replays Map::computeRay (src/sdm/map.cpp:198-227);
-//   * events are appended to the raise/lower queues in (beam, step) order via ballot ranks (priority 0
-//     => libstdc++ push_heap leaves them at the end);
-//   * DynamicDistanceMap::update (src/sdm/dynamic_distance_map.cpp:160-197) runs on lane 0 with the
-//     libstdc++-exact heap of lama_heap.h.
+//   * the beam's hit (-> lower queue) and its ray cells (-> raise queue) touch distinct cells and distinct
+//     queues, so they share one 64-lane section (lane 0 of the first section is the hit);
+//   * events are appended in (beam, step) order via ballot ranks (priority 0 => libstdc++ push_heap leaves
+//     them at the end of the heap array);
+//   * the brushfire pops one cell at a time through the libstdc++-exact heap of lama_heap.h (LDS resident);
+//     the work of one pop is spread over 5 lanes (cell + 4 neighbours) with all loads of a round issued
+//     together; only the queue pushes are serialised, in the reference's neighbour order.
 // ------------------------------------------------------------------------------------------------
-struct UMState {
-    const DevParams& prm;
-    int p;
-    int16_t* dm_dir; int16_t* occ_dir;
-    uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
-    uint32_t* occ; uint64_t* occ_mask;
-    int dm_count, occ_count;       // wave-uniform
+constexpr uint32_t DC_EMPTY = 0xFFFFFFFFu;
+constexpr int DC_SIZE = 512;
+
+// direct-mapped LDS cache of window-directory entries: (pidx << 16) | uint16(slot).  The index tiles the window
+// in 32 x 16 patch blocks (51 m x 25 m) so that neighbouring patches never evict each other.
+struct DirCache {
+    uint32_t* e;
+    const int16_t* dir;
+    uint32_t W;
+    __device__ inline uint32_t index(uint32_t pidx) const
+    {
+        const uint32_t wy = pidx / W, wx = pidx - wy * W;
+        return (wx & 31u) | ((wy & 15u) << 5);
+    }
+    __device__ inline int lookup(uint32_t pidx) const
+    {
+        const uint32_t k = index(pidx);
+        const uint32_t v = e[k];
+        if ((v >> 16) == pidx && v != DC_EMPTY) return (int)(int16_t)(v & 0xFFFFu);
+        const int slot = dir[pidx];
+        e[k] = (pidx << 16) | (uint32_t)(uint16_t)(int16_t)slot;
+        return slot;
+    }
+    __device__ inline void update(uint32_t pidx, int slot) const { e[index(pidx)] = (pidx << 16) | (uint32_t)(uint16_t)(int16_t)slot; }
 };
 
 // Wave-cooperative "non-const Map::get" patch lookup (src/sdm/map.cpp:371-412): every lane with `want`
 // gets the slot of window patch `pidx`, allocating missing patches once per distinct patch.
 // Must be called by all 64 lanes.  Returns -1 on capacity overflow.
-__device__ inline int coop_slot(int16_t* dir, int& count, int cap, bool want, uint32_t pidx, int errbit, int32_t* err)
+__device__ inline int coop_slot(const DirCache& dc, int16_t* dir, int& count, int cap, bool want, uint32_t pidx, int errbit, int32_t* err)
 {
-    int slot = want ? (int)dir[pidx] : 0;
+    int slot = want ? dc.lookup(pidx) : 0;
     bool need = want && slot < 0;
     unsigned long long m = __ballot(need);
     while (m) {
@@ -263,7 +285,7 @@ __device__ inline int coop_slot(int16_t* dir, int& count, int cap, bool want, ui
         int ns;
         if (count < cap) { ns = count; ++count; } else { ns = -1; }
         if ((int)(threadIdx.x & 63) == leader) {
-            if (ns >= 0) dir[lp] = (int16_t)ns; else atomicOr(err, errbit);
+            if (ns >= 0) { dir[lp] = (int16_t)ns; dc.update(lp, ns); } else atomicOr(err, errbit);
         }
         if (need && pidx == lp) { slot = ns; need = false; }
         m = __ballot(need);
@@ -271,137 +293,10 @@ __device__ inline int coop_slot(int16_t* dir, int& count, int cap, bool want, ui
     return slot;
 }
 
-struct BfCtx {
-    const DevParams& prm;
-    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
-    int& count;
-    HybridStore lower, raise;
-    uint32_t nl, nr;     // queue sizes
-    uint64_t processed;
-};
-
-// serial (single-lane) non-const get on the DM: allocate + set mask bit; returns slot*1024+cell or -1
-__device__ inline int bf_get(BfCtx& c, int rx, int ry)
+__global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const double* __restrict__ pts, int n,
+                                                       const double* __restrict__ tfs /*[P][12]*/, int first_particle)
 {
-    if ((uint32_t)rx >= c.prm.WC || (uint32_t)ry >= c.prm.WC) { atomicOr(c.prm.err, ERR_WINDOW); return -1; }
-    const uint32_t pidx = ((uint32_t)ry >> 5) * c.prm.W + ((uint32_t)rx >> 5);
-    int slot = c.dir[pidx];
-    if (slot < 0) {
-        if (c.count >= (int)c.prm.dm_cap) { atomicOr(c.prm.err, ERR_DM_CAP); return -1; }
-        slot = c.count++;
-        c.dir[pidx] = (int16_t)slot;
-    }
-    const uint32_t ci = ((uint32_t)rx & 31u) | (((uint32_t)ry & 31u) << 5);
-    uint64_t* w = c.mask + (size_t)slot * 16 + (ci >> 6);
-    const uint64_t bit = 1ull << (ci & 63);
-    const uint64_t cur = *w;
-    if (!(cur & bit)) *w = cur | bit;
-    return slot * 1024 + (int)ci;
-}
-
-__device__ inline void bf_push(BfCtx& c, bool to_lower, uint32_t prio, int rx, int ry)
-{
-    uint32_t& n = to_lower ? c.nl : c.nr;
-    if (n >= c.prm.qcap) { atomicOr(c.prm.err, ERR_QUEUE); return; }
-    if (to_lower) heap_push(c.lower, c.nl, q_entry(prio, rx, ry));
-    else heap_push(c.raise, c.nr, q_entry(prio, rx, ry));
-}
-
-// DynamicDistanceMap::raise (src/sdm/dynamic_distance_map.cpp:244-279)
-__device__ inline void bf_raise(BfCtx& c, int rx, int ry, int cur)
-{
-    const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int nx = rx + DX[i], ny = ry + DY[i];
-        const int nc = bf_get(c, nx, ny);
-        if (nc < 0) continue;
-        const uint16_t s = c.sv[nc];
-        if ((s & SV_QUEUED) || !(s & SV_VALID)) continue;
-        const uint32_t no = c.obs[nc];
-        const int oc = bf_get(c, nx + obs_x(no), ny + obs_y(no));
-        if (oc < 0) continue;
-        if (!(c.sv[oc] & SV_VALID)) {
-            bf_push(c, false, s & SV_SQMASK, nx, ny);
-            c.sv[nc] = SV_QUEUED;          // sqdist 0, !valid, queued
-            c.obs[nc] = 0;
-        } else {                            // (!is_queued already known)
-            bf_push(c, true, s & SV_SQMASK, nx, ny);
-            c.sv[nc] = s | SV_QUEUED;
-        }
-    }
-    c.sv[cur] &= (uint16_t)~SV_QUEUED;
-}
-
-// DynamicDistanceMap::lower (src/sdm/dynamic_distance_map.cpp:281-330)
-__device__ inline void bf_lower(BfCtx& c, int rx, int ry, int cur)
-{
-    const uint16_t s = c.sv[cur];
-    if (!(s & SV_QUEUED)) return;
-    const uint32_t co = c.obs[cur];
-    const int cox = obs_x(co), coy = obs_y(co);
-    const int obx = rx + cox, oby = ry + coy;      // absolute (window) position of the carried obstacle
-    const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (DX[i] * cox > 0 || DY[i] * coy > 0) continue;          // only away from the obstacle (:296)
-        const int nx = rx + DX[i], ny = ry + DY[i];
-        const int nc = bf_get(c, nx, ny);
-        if (nc < 0) continue;
-        const uint16_t ns = c.sv[nc];
-        const int ddx = nx - obx, ddy = ny - oby;
-        const uint32_t new_sq = (uint32_t)(ddx * ddx + ddy * ddy);
-        const uint32_t cmp = (ns & SV_VALID) ? (uint32_t)(ns & SV_SQMASK) : c.prm.max_sqdist;
-        bool over = new_sq < cmp;
-        if (!over && new_sq == (uint32_t)(ns & SV_SQMASK)) {         // :311-317
-            const uint32_t nobs = c.obs[nc];
-            const int oc = bf_get(c, nx + obs_x(nobs), ny + obs_y(nobs));
-            if (oc >= 0) {
-                const uint16_t os = c.sv[oc];
-                if (!(ns & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
-            }
-        }
-        if (over) {
-            bf_push(c, true, new_sq, nx, ny);
-            c.sv[nc] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
-            c.obs[nc] = pack_obs(obx - nx, oby - ny);
-        }
-    }
-    c.sv[cur] &= (uint16_t)~SV_QUEUED;
-}
-
-// DynamicDistanceMap::update (src/sdm/dynamic_distance_map.cpp:160-197)
-__device__ inline void bf_update(BfCtx& c)
-{
-    while (c.nr > 0) {
-        const uint64_t e = heap_pop(c.raise, c.nr);
-        const int rx = q_rx(e), ry = q_ry(e);
-        const int cur = bf_get(c, rx, ry);
-        ++c.processed;
-        if (cur < 0) continue;
-        bf_raise(c, rx, ry, cur);
-    }
-    while (c.nl > 0) {
-        const uint64_t e = heap_pop(c.lower, c.nl);
-        const int rx = q_rx(e), ry = q_ry(e);
-        const int cur = bf_get(c, rx, ry);
-        ++c.processed;
-        if (cur < 0) continue;
-        const uint16_t s = c.sv[cur];
-        if (s & SV_VALID) {
-            const uint32_t o = c.obs[cur];
-            const int oc = bf_get(c, rx + obs_x(o), ry + obs_y(o));
-            if (oc < 0) continue;
-            if ((c.sv[oc] & SV_SQMASK) == 0) bf_lower(c, rx, ry, cur);   // :191 (valid NOT tested)
-        }
-    }
-}
-
-__global__ __launch_bounds__(UM_BLOCK) void k_update_maps(DevParams prm, const double* __restrict__ pts, int n,
-                                                           const double* __restrict__ tfs /*[P][12]*/, int first_particle)
-{
-    __shared__ uint64_t lds_lower[LQ_LDS];
-    __shared__ uint64_t lds_raise[RQ_LDS];
+    __shared__ uint32_t lds_dc[2 * DC_SIZE];
     const int p = first_particle + blockIdx.x;
     const int lane = threadIdx.x;
     const size_t WW = (size_t)prm.W * prm.W;
@@ -412,10 +307,13 @@ __global__ __launch_bounds__(UM_BLOCK) void k_update_maps(DevParams prm, const d
     uint64_t* dm_mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
     uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
     uint64_t* occ_mask = prm.occ_mask + (size_t)p * prm.occ_cap * 16;
+    uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
+    uint64_t* q_raise = prm.q_raise + (size_t)p * prm.qcap;
     int dm_count = prm.counts[2 * p], occ_count = prm.counts[2 * p + 1];
+    for (int k = lane; k < 2 * DC_SIZE; k += UM_BLOCK) lds_dc[k] = DC_EMPTY;
+    __syncthreads();
+    const DirCache occ_dc{lds_dc, occ_dir, prm.W}, dm_dc{lds_dc + DC_SIZE, dm_dir, prm.W};
 
-    HybridStore lower{lds_lower, prm.q_lower + (size_t)p * prm.qcap, (uint32_t)LQ_LDS};
-    HybridStore raise{lds_raise, prm.q_raise + (size_t)p * prm.qcap, (uint32_t)RQ_LDS};
     uint32_t nl = 0, nr = 0;            // wave-uniform queue sizes
     uint64_t ray_cells = 0;
 
@@ -458,126 +356,557 @@ __global__ __launch_bounds__(UM_BLOCK) void k_update_maps(DevParams prm, const d
         const uint32_t mhx = w2m(prm, hx), mhy = w2m(prm, hy), mhz = w2m(prm, hz);
         const uint32_t msx = w2m(prm, sx), msy = w2m(prm, sy), msz = w2m(prm, sz);
 
-        // ---- hit cell: setOccupied -> addObstacle (lane 0) ------------------------------- :493-498
-        {
-            const uint32_t rx = mhx - prm.wx0, ry = mhy - prm.wy0;
-            const bool inwin = rx < prm.WC && ry < prm.WC;
-            if (mark_hit && !inwin && lane == 0) atomicOr(prm.err, ERR_WINDOW);
-            const bool want = mark_hit && inwin && lane == 0;
-            const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5);
-            const uint32_t ci = (rx & 31u) | ((ry & 31u) << 5);
-            const int slot = coop_slot(occ_dir, occ_count, (int)prm.occ_cap, want, pidx, ERR_OCC_CAP, prm.err);
-            bool changed = false;
-            if (want && slot >= 0) {
-                uint32_t* cell = occ + (size_t)slot * 1024 + ci;
-                const uint32_t v = *cell;
-                uint32_t o = v & 0xFFFFu, vis = v >> 16;
-                const bool occupied = vis != 0 && 4u * o > vis;             // prob > 0.25
-                o = (o + 1) & 0xFFFFu; vis = (vis + 1) & 0xFFFFu;
-                *cell = o | (vis << 16);
-                changed = !occupied && (vis != 0 && 4u * o > vis);
-                uint64_t* w = occ_mask + (size_t)slot * 16 + (ci >> 6);
-                const uint64_t bit = 1ull << (ci & 63);
-                if (!(*w & bit)) *w |= bit;
-            }
-            const int dslot = coop_slot(dm_dir, dm_count, (int)prm.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
-            bool push = false;
-            if (changed && dslot >= 0) {                                    // addObstacle :212-226
-                uint64_t* w = dm_mask + (size_t)dslot * 16 + (ci >> 6);
-                const uint64_t bit = 1ull << (ci & 63);
-                if (!(*w & bit)) *w |= bit;
-                const uint32_t di = (uint32_t)dslot * 1024u + ci;
-                const uint16_t s = dm_sv[di];
-                if (!((s & SV_VALID) && (s & SV_SQMASK) == 0)) {
-                    dm_sv[di] = (uint16_t)(SV_VALID | SV_QUEUED);
-                    dm_obs[di] = 0;
-                    push = true;
-                }
-            }
-            const unsigned long long pm = __ballot(push);
-            if (pm) {
-                if (nl >= prm.qcap) { if (lane == 0) atomicOr(prm.err, ERR_QUEUE); }
-                else { if (push) lower.set(nl, q_entry(0, (int)rx, (int)ry)); nl += 1; }
-            }
-        }
-
-        // ---- free cells: computeRay(w2m(start), mhit, setFree -> removeObstacle) --------- :500-504
         const int64_t d0 = (int64_t)mhx - (int64_t)msx, d1 = (int64_t)mhy - (int64_t)msy, d2 = (int64_t)mhz - (int64_t)msz;
         const int64_t a0 = d0 < 0 ? -d0 : d0, a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
         const int64_t nn = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2);
         const int s0 = d0 < 0 ? -1 : 1, s1 = d1 < 0 ? -1 : 1;
-        const int steps = (int)nn - 1;                       // cells t = 1 .. n-1
-        if (steps > 0) ray_cells += (uint64_t)steps;
-        for (int base = 0; base < steps; base += 64) {
-            const int t = base + lane + 1;
-            const bool act = t <= steps;
-            const int64_t st0 = (2 * (int64_t)t * a0 + nn) / (2 * nn);
-            const int64_t st1 = (2 * (int64_t)t * a1 + nn) / (2 * nn);
-            const uint32_t cx = (uint32_t)((int64_t)msx + s0 * st0), cy = (uint32_t)((int64_t)msy + s1 * st1);
+        const int steps = nn > 0 ? (int)nn - 1 : 0;          // free cells t = 1 .. n-1 (src/sdm/map.cpp:198-227)
+        ray_cells += (uint64_t)steps;
+
+        // sections of 64 lanes over t = 0 (the hit cell, :493-498) , 1 .. steps (the free cells, :500-504)
+        for (int base = 0; base <= steps; base += 64) {
+            const int t = base + lane;
+            const bool is_hit = t == 0;
+            const bool act = is_hit ? mark_hit : (t <= steps);
+            uint32_t cx, cy;
+            if (is_hit) { cx = mhx; cy = mhy; }
+            else {
+                const int64_t st0 = (2 * (int64_t)t * a0 + nn) / (2 * (nn > 0 ? nn : 1));
+                const int64_t st1 = (2 * (int64_t)t * a1 + nn) / (2 * (nn > 0 ? nn : 1));
+                cx = (uint32_t)((int64_t)msx + s0 * st0); cy = (uint32_t)((int64_t)msy + s1 * st1);
+            }
             const uint32_t rx = cx - prm.wx0, ry = cy - prm.wy0;
             const bool inwin = rx < prm.WC && ry < prm.WC;
             if (act && !inwin) atomicOr(prm.err, ERR_WINDOW);
             const bool want = act && inwin;
             const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5);
             const uint32_t ci = (rx & 31u) | ((ry & 31u) << 5);
-            const int slot = coop_slot(occ_dir, occ_count, (int)prm.occ_cap, want, pidx, ERR_OCC_CAP, prm.err);
+            const int slot = coop_slot(occ_dc, occ_dir, occ_count, (int)prm.occ_cap, want, pidx, ERR_OCC_CAP, prm.err);
             bool changed = false;
-            if (want && slot >= 0) {                                        // setFree :65-74
+            if (want && slot >= 0) {
                 uint32_t* cell = occ + (size_t)slot * 1024 + ci;
                 const uint32_t v = *cell;
-                const uint32_t o = v & 0xFFFFu;
-                uint32_t vis = v >> 16;
-                const bool was_free = vis != 0 && 4u * o < vis;             // prob < 0.25
-                vis = (vis + 1) & 0xFFFFu;
+                uint32_t o = v & 0xFFFFu, vis = v >> 16;
+                if (is_hit) {                                               // setOccupied (frequency_occupancy_map.cpp:81-91)
+                    const bool occupied = vis != 0 && 4u * o > vis;         // prob > 0.25
+                    o = (o + 1) & 0xFFFFu; vis = (vis + 1) & 0xFFFFu;
+                    changed = !occupied && (vis != 0 && 4u * o > vis);
+                } else {                                                    // setFree (:65-74)
+                    const bool was_free = vis != 0 && 4u * o < vis;         // prob < 0.25
+                    vis = (vis + 1) & 0xFFFFu;
+                    changed = !was_free && (vis != 0 && 4u * o < vis);
+                }
                 *cell = o | (vis << 16);
-                changed = !was_free && (vis != 0 && 4u * o < vis);
-                const uint64_t bit = 1ull << (ci & 63);
-                uint64_t* w = occ_mask + (size_t)slot * 16 + (ci >> 6);
-                if (!(*w & bit)) atomicOr((unsigned long long*)w, (unsigned long long)bit);
+                // Container mask bit of an occupancy cell == "visited != 0"; only a uint16 wrap needs the plane
+                if (vis == 0) atomicOr((unsigned long long*)(occ_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
             }
-            const int dslot = coop_slot(dm_dir, dm_count, (int)prm.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
+            const int dslot = coop_slot(dm_dc, dm_dir, dm_count, (int)prm.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
             bool push = false;
-            if (changed && dslot >= 0) {                                    // removeObstacle :228-242
+            if (changed && dslot >= 0) {
                 const uint64_t bit = 1ull << (ci & 63);
                 uint64_t* w = dm_mask + (size_t)dslot * 16 + (ci >> 6);
                 if (!(*w & bit)) atomicOr((unsigned long long*)w, (unsigned long long)bit);
                 const uint32_t di = (uint32_t)dslot * 1024u + ci;
                 const uint16_t s = dm_sv[di];
-                if ((s & SV_VALID) && (s & SV_SQMASK) == 0) {
-                    dm_sv[di] = SV_QUEUED;
-                    dm_obs[di] = 0;
-                    push = true;
+                const bool is_obstacle = (s & SV_VALID) && (s & SV_SQMASK) == 0;
+                if (is_hit) {                                               // addObstacle (dynamic_distance_map.cpp:212-226)
+                    if (!is_obstacle) { dm_sv[di] = (uint16_t)(SV_VALID | SV_QUEUED); dm_obs[di] = 0; push = true; }
+                } else {                                                    // removeObstacle (:228-242)
+                    if (is_obstacle) { dm_sv[di] = SV_QUEUED; dm_obs[di] = 0; push = true; }
                 }
             }
             const unsigned long long pm = __ballot(push);
             if (pm) {
-                const int cnt = __popcll(pm);
-                if (nr + (uint32_t)cnt > prm.qcap) { if (lane == 0) atomicOr(prm.err, ERR_QUEUE); }
-                else {
-                    if (push) {
-                        const int rank = __popcll(pm & ((1ull << lane) - 1ull));
-                        raise.set(nr + (uint32_t)rank, q_entry(0, (int)rx, (int)ry));
+                const unsigned long long pm_hit = (base == 0) ? (pm & 1ull) : 0ull;
+                const unsigned long long pm_ray = pm & ~pm_hit;
+                if (pm_hit) {
+                    if (nl >= prm.qcap) { if (lane == 0) atomicOr(prm.err, ERR_QUEUE); }
+                    else { if (push && is_hit) q_lower[nl] = q_entry(0, (int)rx, (int)ry); nl += 1; }
+                }
+                if (pm_ray) {
+                    const int cnt = __popcll(pm_ray);
+                    if (nr + (uint32_t)cnt > prm.qcap) { if (lane == 0) atomicOr(prm.err, ERR_QUEUE); }
+                    else {
+                        if (push && !is_hit) {
+                            const int rank = __popcll(pm_ray & ((1ull << lane) - 1ull));
+                            q_raise[nr + (uint32_t)rank] = q_entry(0, (int)rx, (int)ry);
+                        }
+                        nr += (uint32_t)cnt;
                     }
-                    nr += (uint32_t)cnt;
                 }
             }
         }
         // make this beam's stores visible to the next beam's loads (same wave: ordering only)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
-    __syncthreads();
-
-    // ---- dm->update() : exact sequential brushfire on lane 0 -------------------------------- :508
-    uint64_t processed = 0;
     if (lane == 0) {
-        BfCtx c{prm, dm_dir, dm_sv, dm_obs, dm_mask, dm_count, lower, raise, nl, nr, 0};
-        bf_update(c);
-        processed = c.processed;
         prm.counts[2 * p] = dm_count;
         prm.counts[2 * p + 1] = occ_count;
+        prm.qsizes[2 * p] = nl;
+        prm.qsizes[2 * p + 1] = nr;
         prm.stats[4 * p + 2] = ray_cells;
-        prm.stats[4 * p + 3] = processed;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_brushfire -- DynamicDistanceMap::update / raise / lower (src/sdm/dynamic_distance_map.cpp:160-197,
+// 244-279, 281-330).  One wave per particle; lane 4 owns the popped cell, lanes 0..3 its 4-neighbours in the
+// reference's order (+x, +y, -x, -y).
+//
+// Which get() calls of the reference have side effects (patch allocation + mask bit, src/sdm/map.cpp:371-412)?
+//   - the popped cell: none (it was get()-ed when it was queued);
+//   - obstacle cells reached through a valid cell's offset: none (an obstacle was get()-ed when it was added;
+//     a cleared cell has offset 0 = itself);
+//   - the neighbours: YES -- all four in raise(), and in lower() those that pass the "away from the obstacle"
+//     test, and only when lower() really runs.  They are prefetched side-effect free and the allocation /
+//     mask update is applied once the decision is known.
+// ------------------------------------------------------------------------------------------------
+#ifdef LAMA_PROFILE_BF
+#define BFT(k) do { const uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define BFT(k) do {} while (0)
+#endif
+
+struct BfLds {
+    uint64_t lower[LQ_LDS];
+    uint64_t raise[RQ_LDS];
+    uint32_t dc[DC_SIZE];
+};
+
+// ---- LDS-resident libstdc++ heap (same algorithm as lama_heap.h).  All heap state is wave-uniform: every lane
+// executes the code, lane 0 stores.  The sift-down of pop() is resumable so that the two global load rounds of a
+// brushfire pop can be issued in between and complete underneath it.
+struct PopState { uint32_t hole, child, len; uint64_t value; bool active; };
+
+__device__ inline void lds_pop_begin(const uint64_t* h, uint32_t& size, PopState& st)
+{
+    --size;
+    st.active = size > 0;
+    st.len = size; st.hole = 0; st.child = 0;
+    st.value = st.active ? h[size] : 0;
+}
+// One "gather chunk" of __adjust_heap's first loop: instead of a chain of dependent LDS reads (one per level) the
+// wave loads the whole 5-level subtree below the hole with ONE ds_read -- lane L holds the node at relative heap
+// position L (children of L are 2L+1, 2L+2; absolute index hole * 2^depth(L) + L) -- and walks it with
+// v_readlane (scalar decisions).
+__device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane)
+{
+    if (!st.active) return;
+    const uint32_t lim = (st.len - 1) / 2;
+    if (!(st.child < lim)) return;
+    const uint32_t H = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
+    const int d = 31 - __clz(lane + 1);
+    const uint32_t idx = (H << d) + (uint32_t)lane;
+    const uint64_t v = (lane < 63 && idx < st.len) ? h[idx] : 0ull;
+    const int vhi = (int)(uint32_t)(v >> 32), vlo = (int)(uint32_t)v;
+    int rel = 0;
+    uint32_t child = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.child), hole = H;
+    const uint32_t slim = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim);
+#pragma unroll 1
+    for (int lev = 0; lev < 5; ++lev) {
+        if (!(child < slim)) break;
+        child = 2 * (child + 1);
+        int rl = 2 * (rel + 1);
+        const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane(vhi, rl);
+        const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane(vhi, rl - 1);
+        if (pr > pl) { child--; rl--; }                       // comp(right, left): take the left child
+        const uint32_t chi = (uint32_t)__builtin_amdgcn_readlane(vhi, rl);
+        const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane(vlo, rl);
+        if (lane == 0) h[hole] = ((uint64_t)chi << 32) | clo;
+        hole = child;
+        rel = rl;
+    }
+    st.child = child;
+    st.hole = hole;
+}
+__device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane)
+{
+    if (!st.active) return;
+    const bool writer = lane == 0;
+    const uint32_t lim = (st.len - 1) / 2;
+    while (st.child < lim) lds_pop_chunk(h, st, lane);
+    if ((st.len & 1) == 0 && st.child == (st.len - 2) / 2) {
+        st.child = 2 * (st.child + 1);
+        if (writer) h[st.hole] = h[st.child - 1];
+        st.hole = st.child - 1;
+    }
+    // __push_heap(first, hole, 0, value)
+    uint32_t hole = st.hole;
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) / 2;
+        const uint64_t pv = h[parent];
+        if (!heap_comp(pv, st.value)) break;
+        if (writer) h[hole] = pv;
+        hole = parent;
+    }
+    if (writer) h[hole] = st.value;
+}
+__device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t value, bool writer)
+{
+    uint32_t hole = size++;
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) / 2;
+        const uint64_t pv = h[parent];
+        if (!heap_comp(pv, value)) break;
+        if (writer) h[hole] = pv;
+        hole = parent;
+    }
+    if (writer) h[hole] = value;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_brushfire -- DynamicDistanceMap::update / raise / lower (src/sdm/dynamic_distance_map.cpp:160-197,
+// 244-279, 281-330).  One wave per particle; lane 4 owns the popped cell, lanes 0..3 its 4-neighbours in the
+// reference's order (+x, +y, -x, -y).  Queues live in LDS; a particle whose queue would not fit is handed,
+// state intact, to k_brushfire_slow (generic code, queues in HBM) through prm.slow[p].
+//
+// Which get() calls of the reference have side effects (patch allocation + mask bit, src/sdm/map.cpp:371-412)?
+//   - the popped cell: none (it was get()-ed when it was queued);
+//   - obstacle cells reached through a valid cell's offset: none (an obstacle was get()-ed when it was added;
+//     a cleared cell has offset 0 = itself);
+//   - the neighbours: YES -- all four in raise(), and in lower() those that pass the "away from the obstacle"
+//     test, and only when lower() really runs.  They are prefetched side-effect free and the allocation /
+//     mask update is applied once the decision is known.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
+{
+    __shared__ BfLds sh;
+    const int p = first_particle + blockIdx.x;
+    const int lane = threadIdx.x;
+    const size_t WW = (size_t)prm.W * prm.W;
+    int16_t* dir = prm.dm_dir + (size_t)p * WW;
+    uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
+    uint32_t* obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
+    uint64_t* mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
+    uint64_t* g_lower = prm.q_lower + (size_t)p * prm.qcap;
+    uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
+    int count = prm.counts[2 * p];
+    uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
+    if (lane == 0) { prm.stats[4 * p + 3] = 0; prm.slow[p] = 0; }
+    if (nl == 0 && nr == 0) return;
+    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (lane == 0) prm.slow[p] = 1; return; }
+
+    for (int k = lane; k < DC_SIZE; k += UM_BLOCK) sh.dc[k] = DC_EMPTY;
+    for (uint32_t k = lane; k < nl; k += UM_BLOCK) sh.lower[k] = g_lower[k];
+    for (uint32_t k = lane; k < nr; k += UM_BLOCK) sh.raise[k] = g_raise[k];
+    __syncthreads();
+    const DirCache dc{sh.dc, dir, prm.W};
+
+    const int ddx = lane == 0 ? 1 : (lane == 2 ? -1 : 0), ddy = lane == 1 ? 1 : (lane == 3 ? -1 : 0);
+    const bool is_cur = lane == 4, is_nb = lane < 4;
+    uint64_t processed = 0;
+    bool spill = false;
+#ifdef LAMA_PROFILE_BF
+    uint64_t prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tprev = __builtin_readcyclecounter();
+#endif
+
+    // round A: every role lane loads its own cell (side-effect free)
+    #define BF_LOAD_A()                                                                                     \
+        const int x = rx + ddx, y = ry + ddy;                                                               \
+        const bool role = lane < 5;                                                                         \
+        const bool inwin = (uint32_t)x < prm.WC && (uint32_t)y < prm.WC;                                    \
+        const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);                              \
+        const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);                               \
+        int slot = (role && inwin) ? dc.lookup(pidx) : -1;                                                  \
+        uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;                                                   \
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; }
+    // round B: the cell my offset points to (obstacle cell); offset 0 -> myself
+    #define BF_LOAD_B()                                                                                     \
+        const int ox = x + obs_x(ob), oy = y + obs_y(ob);                                                   \
+        uint16_t os = 0;                                                                                    \
+        {                                                                                                   \
+            const bool oin = role && slot >= 0 && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC;           \
+            const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);                       \
+            const int oslot = oin ? dc.lookup(opidx) : -1;                                                  \
+            if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))]; \
+        }
+    // pop() of the LDS heap H with both load rounds issued underneath the sift-down
+    #define BF_POP_WITH_LOADS(H, N)                                                                         \
+        BF_LOAD_A()                                                                                         \
+        BFT(1);                                                                                             \
+        PopState ps_;                                                                                       \
+        lds_pop_begin(H, N, ps_);                                                                           \
+        lds_pop_chunk(H, ps_, lane);                                                                        \
+        BF_LOAD_B()                                                                                         \
+        lds_pop_finish(H, ps_, lane);                                                                       \
+        BFT(2);
+
+    // ---- raise wave ------------------------------------------------------------------------- :162-173
+    while (nr > 0) {
+        if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { spill = true; break; }
+        const uint64_t e = sh.raise[0];                  // priority_queue::top(); the cell loads below are in
+        const int rx = q_rx(e), ry = q_ry(e);            // flight while pop() sifts the heap in LDS
+        ++processed;
+        BF_POP_WITH_LOADS(sh.raise, nr)
+        // neighbours: get() = allocate + mask bit (all four)
+        if (is_nb && !inwin) atomicOr(prm.err, ERR_WINDOW);
+        const bool nb = is_nb && inwin;
+        const bool fresh = nb && slot < 0;
+        if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+        const bool nbok = nb && slot >= 0;
+        if (nbok) {
+            const uint64_t bit = 1ull << (ci & 63);
+            if (fresh || !(mw & bit)) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
+        }
+        // :253  skip queued or invalid neighbours
+        const bool cand = nbok && !(s & SV_QUEUED) && (s & SV_VALID);
+        bool ovalid = (os & SV_VALID) != 0;
+        // sequential semantics: neighbour i is handled before j > i; if i gets cleared and j's offset points
+        // at i, j must see i as invalid (only possible through stale offsets; replayed here to stay exact)
+        bool clear = cand && !ovalid;
+        #pragma unroll 1
+        for (int i = 0; i < 3; ++i) {
+            const int cxi = __builtin_amdgcn_readlane(x, i), cyi = __builtin_amdgcn_readlane(y, i);
+            const bool ci_clear = __builtin_amdgcn_readlane((int)clear, i) != 0;
+            if (lane > i && lane < 4 && cand && ci_clear && ox == cxi && oy == cyi) { ovalid = false; clear = true; }
+        }
+        const bool to_raise = cand && !ovalid;           // :262-268
+        const bool to_lower = cand && ovalid;            // :269-272
+        #pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const bool r_i = __builtin_amdgcn_readlane((int)to_raise, i) != 0, l_i = __builtin_amdgcn_readlane((int)to_lower, i) != 0;
+            if (r_i || l_i) {
+                const uint32_t prio = (uint32_t)__builtin_amdgcn_readlane((int)(s & SV_SQMASK), i);
+                const uint64_t ent = q_entry(prio, __builtin_amdgcn_readlane(x, i), __builtin_amdgcn_readlane(y, i));
+                if (r_i) lds_push(sh.raise, nr, ent, lane == 0); else lds_push(sh.lower, nl, ent, lane == 0);
+            }
+        }
+        if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0; }
+        if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
+        if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+
+    // ---- lower wave ------------------------------------------------------------------------- :175-194
+    BFT(7);
+    while (!spill && nl > 0) {
+        if (nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
+        const uint64_t e = sh.lower[0];
+        const int rx = q_rx(e), ry = q_ry(e);
+        ++processed;
+        BFT(0);
+        BF_POP_WITH_LOADS(sh.lower, nl)
+        const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
+        const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
+        const uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)os, 4);
+        // :183-192  valid, its obstacle still has sqdist 0 (valid NOT tested), and lower() :283 still queued
+        const bool fire = (cs & SV_VALID) && (cos_ & SV_SQMASK) == 0 && (cs & SV_QUEUED);
+        BFT(3);
+        if (fire) {
+            const int cox = obs_x(cob), coy = obs_y(cob);
+            const int obx = rx + cox, oby = ry + coy;
+            const bool away = is_nb && !(ddx * cox > 0 || ddy * coy > 0);             // :296
+            if (away && !inwin) atomicOr(prm.err, ERR_WINDOW);
+            const bool nb = away && inwin;
+            const bool fresh = nb && slot < 0;
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            const bool nbok = nb && slot >= 0;
+            if (nbok) {
+                const uint64_t bit = 1ull << (ci & 63);
+                if (fresh || !(mw & bit)) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
+            }
+            const int qx = x - obx, qy = y - oby;
+            const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
+            const uint32_t cmp = (s & SV_VALID) ? (uint32_t)(s & SV_SQMASK) : prm.max_sqdist;
+            bool over = nbok && new_sq < cmp;
+            if (nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK)) {                // :311-317
+                if (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
+            }
+            BFT(4);
+            // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
+            // to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply
+            // appended, exactly what the sequential push_heap calls would have done.
+            const unsigned long long om = __ballot(over);
+            const int ocnt = __popcll(om);
+            bool done = ocnt == 0;
+            if (!done && nl >= 4) {
+                const uint32_t pos = nl + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
+                bool stop = true;
+                if (over) stop = !((uint32_t)(sh.lower[(pos - 1) / 2] >> 32) > new_sq);
+                if (__ballot(!stop) == 0) {
+                    if (over) sh.lower[pos] = q_entry(new_sq, x, y);
+                    nl += (uint32_t)ocnt;
+                    done = true;
+                }
+            }
+            if (!done) {
+                #pragma unroll 1
+                for (int i = 0; i < 4; ++i) {
+                    if (__builtin_amdgcn_readlane((int)over, i)) {
+                        const uint32_t prio = (uint32_t)__builtin_amdgcn_readlane((int)new_sq, i);
+                        lds_push(sh.lower, nl, q_entry(prio, __builtin_amdgcn_readlane(x, i), __builtin_amdgcn_readlane(y, i)), lane == 0);
+                    }
+                }
+            }
+            if (over) {
+                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
+            }
+            BFT(5);
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        BFT(6);
+    }
+    #undef BF_LOAD_A
+    #undef BF_LOAD_B
+    #undef BF_POP_WITH_LOADS
+    if (spill) {      // hand the particle over, state intact, to k_brushfire_slow
+        __syncthreads();
+        for (uint32_t k = lane; k < nl; k += UM_BLOCK) g_lower[k] = sh.lower[k];
+        for (uint32_t k = lane; k < nr; k += UM_BLOCK) g_raise[k] = sh.raise[k];
+    }
+    if (lane == 0) {
+        prm.counts[2 * p] = count;
+        prm.stats[4 * p + 3] = processed;
+        if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; prm.slow[p] = 1; }
+#ifdef LAMA_PROFILE_BF
+        for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_brushfire_slow -- generic single-lane DynamicDistanceMap::update with both queues in HBM (libstdc++ heap of
+// lama_heap.h).  Runs only for particles k_brushfire flagged (queue larger than its LDS window, e.g. the very
+// first scan of a large open space) and resumes exactly where it stopped.
+// ------------------------------------------------------------------------------------------------
+struct GlobalStore {
+    uint64_t* g;
+    __device__ inline uint64_t get(uint32_t i) const { return g[i]; }
+    __device__ inline void set(uint32_t i, uint64_t v) const { g[i] = v; }
+};
+
+struct BfCtx {
+    const DevParams& prm;
+    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
+    int count;
+    GlobalStore lower, raise;
+    uint32_t nl, nr;
+    uint64_t processed;
+};
+
+// serial non-const Map::get on the DM (src/sdm/map.cpp:371-412): allocate + set mask bit; returns slot*1024+cell or -1
+__device__ inline int bf_get(BfCtx& c, int rx, int ry)
+{
+    if ((uint32_t)rx >= c.prm.WC || (uint32_t)ry >= c.prm.WC) { atomicOr(c.prm.err, ERR_WINDOW); return -1; }
+    const uint32_t pidx = ((uint32_t)ry >> 5) * c.prm.W + ((uint32_t)rx >> 5);
+    int slot = c.dir[pidx];
+    if (slot < 0) {
+        if (c.count >= (int)c.prm.dm_cap) { atomicOr(c.prm.err, ERR_DM_CAP); return -1; }
+        slot = c.count++;
+        c.dir[pidx] = (int16_t)slot;
+    }
+    const uint32_t ci = ((uint32_t)rx & 31u) | (((uint32_t)ry & 31u) << 5);
+    uint64_t* w = c.mask + (size_t)slot * 16 + (ci >> 6);
+    const uint64_t bit = 1ull << (ci & 63);
+    const uint64_t cur = *w;
+    if (!(cur & bit)) *w = cur | bit;
+    return slot * 1024 + (int)ci;
+}
+
+__device__ inline void bf_push(BfCtx& c, bool to_lower, uint32_t prio, int rx, int ry)
+{
+    uint32_t& n = to_lower ? c.nl : c.nr;
+    if (n >= c.prm.qcap) { atomicOr(c.prm.err, ERR_QUEUE); return; }
+    if (to_lower) heap_push(c.lower, c.nl, q_entry(prio, rx, ry));
+    else heap_push(c.raise, c.nr, q_entry(prio, rx, ry));
+}
+
+__device__ __noinline__ void bf_raise(BfCtx& c, int rx, int ry, int cur)            // :244-279
+{
+    const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+    for (int i = 0; i < 4; ++i) {
+        const int nx = rx + DX[i], ny = ry + DY[i];
+        const int nc = bf_get(c, nx, ny);
+        if (nc < 0) continue;
+        const uint16_t s = c.sv[nc];
+        if ((s & SV_QUEUED) || !(s & SV_VALID)) continue;
+        const uint32_t no = c.obs[nc];
+        const int oc = bf_get(c, nx + obs_x(no), ny + obs_y(no));
+        if (oc < 0) continue;
+        if (!(c.sv[oc] & SV_VALID)) {
+            bf_push(c, false, s & SV_SQMASK, nx, ny);
+            c.sv[nc] = SV_QUEUED;
+            c.obs[nc] = 0;
+        } else {
+            bf_push(c, true, s & SV_SQMASK, nx, ny);
+            c.sv[nc] = s | SV_QUEUED;
+        }
+    }
+    c.sv[cur] &= (uint16_t)~SV_QUEUED;
+}
+
+__device__ __noinline__ void bf_lower(BfCtx& c, int rx, int ry, int cur)            // :281-330
+{
+    const uint16_t s = c.sv[cur];
+    if (!(s & SV_QUEUED)) return;
+    const uint32_t co = c.obs[cur];
+    const int cox = obs_x(co), coy = obs_y(co);
+    const int obx = rx + cox, oby = ry + coy;
+    const int DX[4] = {1, 0, -1, 0}, DY[4] = {0, 1, 0, -1};
+    for (int i = 0; i < 4; ++i) {
+        if (DX[i] * cox > 0 || DY[i] * coy > 0) continue;
+        const int nx = rx + DX[i], ny = ry + DY[i];
+        const int nc = bf_get(c, nx, ny);
+        if (nc < 0) continue;
+        const uint16_t ns = c.sv[nc];
+        const int qx = nx - obx, qy = ny - oby;
+        const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
+        const uint32_t cmp = (ns & SV_VALID) ? (uint32_t)(ns & SV_SQMASK) : c.prm.max_sqdist;
+        bool over = new_sq < cmp;
+        if (!over && new_sq == (uint32_t)(ns & SV_SQMASK)) {
+            const uint32_t nobs = c.obs[nc];
+            const int oc = bf_get(c, nx + obs_x(nobs), ny + obs_y(nobs));
+            if (oc >= 0) {
+                const uint16_t os = c.sv[oc];
+                if (!(ns & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
+            }
+        }
+        if (over) {
+            bf_push(c, true, new_sq, nx, ny);
+            c.sv[nc] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+            c.obs[nc] = pack_obs(obx - nx, oby - ny);
+        }
+    }
+    c.sv[cur] &= (uint16_t)~SV_QUEUED;
+}
+
+__global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int first_particle)
+{
+    const int p = first_particle + blockIdx.x;
+    if (prm.slow[p] == 0 || threadIdx.x != 0) return;
+    const size_t WW = (size_t)prm.W * prm.W;
+    BfCtx c{prm, prm.dm_dir + (size_t)p * WW, prm.dm_sv + (size_t)p * prm.dm_cap * 1024, prm.dm_obs + (size_t)p * prm.dm_cap * 1024,
+            prm.dm_mask + (size_t)p * prm.dm_cap * 16, prm.counts[2 * p],
+            GlobalStore{prm.q_lower + (size_t)p * prm.qcap}, GlobalStore{prm.q_raise + (size_t)p * prm.qcap},
+            prm.qsizes[2 * p], prm.qsizes[2 * p + 1], 0};
+    while (c.nr > 0) {                                                              // :162-173
+        const uint64_t e = heap_pop(c.raise, c.nr);
+        const int rx = q_rx(e), ry = q_ry(e);
+        const int cur = bf_get(c, rx, ry);
+        ++c.processed;
+        if (cur < 0) continue;
+        bf_raise(c, rx, ry, cur);
+    }
+    while (c.nl > 0) {                                                              // :175-194
+        const uint64_t e = heap_pop(c.lower, c.nl);
+        const int rx = q_rx(e), ry = q_ry(e);
+        const int cur = bf_get(c, rx, ry);
+        ++c.processed;
+        if (cur < 0) continue;
+        const uint16_t s = c.sv[cur];
+        if (s & SV_VALID) {
+            const uint32_t o = c.obs[cur];
+            const int oc = bf_get(c, rx + obs_x(o), ry + obs_y(o));
+            if (oc < 0) continue;
+            if ((c.sv[oc] & SV_SQMASK) == 0) bf_lower(c, rx, ry, cur);               // :191 (valid NOT tested)
+        }
+    }
+    prm.counts[2 * p] = c.count;
+    prm.stats[4 * p + 3] += c.processed;
+    prm.slow[p] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

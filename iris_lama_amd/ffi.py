@@ -30,6 +30,8 @@ class HipCfg(C.Structure):
 class HipCounters(C.Structure):
     _fields_ = [("ms_scan_match", C.c_double), ("launches_scan_match", C.c_uint64),
                 ("ms_update_maps", C.c_double), ("launches_update_maps", C.c_uint64),
+                ("ms_raycast", C.c_double), ("launches_raycast", C.c_uint64),
+                ("ms_brushfire", C.c_double), ("launches_brushfire", C.c_uint64),
                 ("ms_resample", C.c_double), ("launches_resample", C.c_uint64),
                 ("gn_iterations", C.c_uint64), ("gn_evals", C.c_uint64), ("ray_cells", C.c_uint64),
                 ("bf_cells", C.c_uint64), ("dm_patches", C.c_uint64), ("occ_patches", C.c_uint64)]

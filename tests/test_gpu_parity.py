@@ -178,3 +178,35 @@ def test_sharded_two_ranks_one_gpu_gloo(F):
             assert_maps_equal(dm, c.download_map(i, F.MAP_DISTANCE), DM_FIELDS, f"dm p{i}")
             assert_maps_equal(occ, c.download_map(i, F.MAP_OCCUPANCY), OCC_FIELDS, f"occ p{i}")
     h.close()
+
+
+@pytest.mark.parametrize("radius", [4.0, 8.0, 12.0, 20.0])
+def test_large_queue_paths_round_room(F, radius):
+    """Round rooms of growing radius: the brushfire queue outgrows its LDS window, first mid-run (spill to
+    k_brushfire_slow) and then from the start; the maps must stay bit-exact on every path."""
+    n = 1080
+    ang = np.deg2rad(-135.0 + 0.25 * np.arange(n))
+    rng = np.random.default_rng(int(radius))
+    r = radius + rng.normal(0, 0.01, n)
+    pts = np.stack([r * np.cos(ang), r * np.sin(ang), np.zeros(n)], axis=1)
+    pose0 = O.se2(0.3, -0.2, 0.1)
+    P = 3
+    pf = O.PF(O.default_options(particles=P, seed=1))
+    pf.set_prior(pose0)
+    pf.update(pts, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024))
+    ctx.init(pts, pose0)
+    # second scan from slightly different poses: removals (raise wave) + additions
+    r2 = radius + rng.normal(0, 0.01, n)
+    pts2 = np.stack([r2 * np.cos(ang), r2 * np.sin(ang), np.zeros(n)], axis=1)
+    poses = np.stack([O.se2_mul(pose0, O.se2(0.05 * i, -0.03 * i, 0.01 * i)) for i in range(P)])
+    pf.set_poses(poses)
+    pf.stage_set_scan(pts2)
+    pf.stage_update_maps()
+    ctx.set_poses(poses)
+    ctx.update_maps(pts2)
+    for i in range(P):
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+    print("radius", radius, "oracle max queue", pf.dm(0).stats()["max_queue"])
+    ctx.close()
