@@ -39,7 +39,7 @@ def cpu_baseline(pts, odom, P, updates, warm):
         if threads <= 1:
             pf.count_touches(True)
         pf.update(pts[0], O.se2(*odom[0]), 0.0)
-        t_tot, n, b_maps, b_match, b_all = 0.0, 0, 0.0, 0.0, 0.0
+        t_tot, n, b_maps, b_match, b_all, b_bf, b_ray = 0.0, 0, 0.0, 0.0, 0.0, 0.0, 0.0
         for k in range(1, warm + updates + 1):
             t0 = time.perf_counter()
             ok = pf.update(pts[k], O.se2(*odom[k]), float(k))
@@ -51,11 +51,14 @@ def cpu_baseline(pts, odom, P, updates, warm):
                     for i in range(P):
                         c = pf.counters(i)
                         b_maps += 2 * DM_PATCH_B * c["n_bf"] + 2 * OCC_PATCH_B * c["n_occ"]
+                        b_bf += 2 * DM_PATCH_B * c["n_bf"]
+                        b_ray += 2 * OCC_PATCH_B * c["n_occ"]
                         b_match += DM_PATCH_B * c["n_match"] + 72
                         b_all += DM_PATCH_B * (c["n_match_or_bf"] + c["n_bf"]) + 2 * OCC_PATCH_B * c["n_occ"] + 72
         res[label] = dict(value=P * n / t_tot, seconds=t_tot, updates=n)
         if threads <= 1 and n:
-            res["bytes"] = dict(maps=b_maps / (P * n), match=b_match / (P * n), total=b_all / (P * n))
+            res["bytes"] = dict(maps=b_maps / (P * n), match=b_match / (P * n), total=b_all / (P * n),
+                                brushfire=b_bf / (P * n), raycast=b_ray / (P * n))
     return cores, res
 
 
@@ -142,20 +145,22 @@ def main():
         result["cpu_baseline"] = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
                                   "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
                                             f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s"}
-    # roofline of the dominant kernel (update_maps): algorithmic bytes per launch / mean launch duration
+    # roofline of the dominant kernel (k_brushfire): algorithmic bytes per launch / mean launch duration.
+    # Algorithmic bytes (reference record sizes): every DM patch the brushfire touches is read
+    # and written once = 2 x 10,368 B x n(S_bf) per particle-scan, n(S_bf) counted by the oracle on the same log.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_update_maps.json")
+    tpath = os.path.join(ROOT, "profiles", "pmc_brushfire.json")
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     if base and "bytes" in base:
-        per_ps = base["bytes"]["maps"]
-        launches = max(c["launches_update_maps"], 1)
-        dur_s = c["ms_update_maps"] / launches * 1e-3
+        per_ps = base["bytes"]["brushfire"]
+        launches = max(c["launches_brushfire"], 1)
+        dur_s = c["ms_brushfire"] / launches * 1e-3
         achieved = per_ps * args.particles / dur_s / 1e9          # GB/s on this rank's GPU
-        result["roofline"] = {"bound": "hbm", "kernel": "k_update_maps", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire<1024,256>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
                               "mean_launch_ms": dur_s * 1e3}

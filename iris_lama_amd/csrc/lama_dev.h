@@ -247,7 +247,15 @@ struct HybridStore {
     __device__ inline void set(uint32_t i, uint64_t v) const { if (i < lds_cap) lds[i] = v; else glb[i] = v; }
 };
 
-__device__ inline uint64_t q_entry(uint32_t prio, int rx, int ry) { return ((uint64_t)prio << 32) | ((uint32_t)ry << 16) | (uint32_t)rx; }
+// queue entry: [63:48] priority | [47:40] oy+128 | [39:32] ox+128 | [31:16] ry | [15:0] rx.  (ox, oy) = the obstacle
+// offset the cell had when it was queued: lets a pop fetch the obstacle cell in the same round as the cell itself.
+__device__ inline uint64_t q_entry(uint32_t prio, int rx, int ry, int ox = 0, int oy = 0)
+{
+    return ((uint64_t)prio << 48) | ((uint64_t)(uint32_t)((oy + 128) & 0xFF) << 40) | ((uint64_t)(uint32_t)((ox + 128) & 0xFF) << 32) |
+           ((uint32_t)ry << 16) | (uint32_t)rx;
+}
+__device__ inline int q_ox(uint64_t e) { return (int)((e >> 32) & 0xFFu) - 128; }
+__device__ inline int q_oy(uint64_t e) { return (int)((e >> 40) & 0xFFu) - 128; }
 __device__ inline int q_rx(uint64_t e) { return (int)(e & 0xFFFFu); }
 __device__ inline int q_ry(uint64_t e) { return (int)((e >> 16) & 0xFFFFu); }
 

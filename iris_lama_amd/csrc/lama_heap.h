@@ -9,8 +9,9 @@
 // always taking the child that compares "larger" under comp (ties -> right child), then sift-up.
 // compare_prio(l, r) = l.first > r.first, i.e. only the priority is compared, never the location.
 //
-// Entry encoding: bits 63..32 priority (squared distance), bits 31..0 location (ry << 16 | rx,
-// window-relative cell coordinates).  Storage is abstracted so the same code runs on an LDS-backed
+// Entry encoding: bits 63..48 priority (squared distance), bits 47..32 payload that is NOT compared (the
+// obstacle offset the cell carried when it was queued, see lama_kernels.h), bits 31..0 location
+// (ry << 16 | rx, window-relative cell coordinates).  Storage is abstracted so the same code runs on an LDS-backed
 // array with global-memory overflow on the device and on a plain array in the CPU unit test.
 #pragma once
 #include <stdint.h>
@@ -25,7 +26,7 @@
 
 namespace lama_dev {
 
-LAMA_HD uint32_t heap_prio(uint64_t e) { return (uint32_t)(e >> 32); }
+LAMA_HD uint32_t heap_prio(uint64_t e) { return (uint32_t)(e >> 48); }
 // compare_prio(left, right): left.first > right.first
 LAMA_HD bool heap_comp(uint64_t l, uint64_t r) { return heap_prio(l) > heap_prio(r); }
 

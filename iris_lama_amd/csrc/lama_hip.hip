@@ -182,7 +182,10 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     HIPCHK(c, hipGetLastError());
     {
         Timer t(c, &c->ctr.ms_brushfire, &c->ctr.launches_brushfire);
-        hipLaunchKernelGGL(k_brushfire, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
+        // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
+        hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         t.stop();
     }
@@ -249,7 +252,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
-        cfg.queue_capacity < (uint32_t)LQ_LDS)
+        cfg.queue_capacity < (uint32_t)LQ_BIG)
         return LAMA_HIP_E_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg.device < 0 || cfg.device >= ndev) return LAMA_HIP_E_HIP;
@@ -263,7 +266,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)
     uint32_t md = (uint32_t)std::ceil(cfg.l2_max * c->scale);
     c->max_sqdist = md * md;
-    if (c->max_sqdist == 0 || c->max_sqdist > SV_SQMASK) { delete c; return LAMA_HIP_E_INVALID; }
+    if (c->max_sqdist == 0 || md > 127) { delete c; return LAMA_HIP_E_INVALID; }   // offsets are carried as int8, sqdist in 14 bits
 
 #define CHK(call) do { if ((call) != hipSuccess) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; } } while (0)
     CHK(hipSetDevice(cfg.device));

@@ -16,8 +16,9 @@ namespace lama_dev {
 
 constexpr int SM_BLOCK = 256;       // scan-match workgroup: 4 waves
 constexpr int UM_BLOCK = 64;        // update-maps workgroup: 1 wave
-constexpr int LQ_LDS = 3072;        // lower-queue entries kept in LDS (24 KiB)
-constexpr int RQ_LDS = 1024;        // raise-queue entries kept in LDS (8 KiB)
+// brushfire queue windows in LDS (entries): a small one for throughput (many waves per CU) and a big resume stage
+constexpr int LQ_SMALL = 1024, RQ_SMALL = 256;     // 8 + 2 KiB
+constexpr int LQ_BIG = 8192, RQ_BIG = 2048;        // 64 + 16 KiB
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (fixed shape => results do not depend on how particles are sharded)
@@ -248,17 +249,13 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
 constexpr uint32_t DC_EMPTY = 0xFFFFFFFFu;
 constexpr int DC_SIZE = 512;
 
-// direct-mapped LDS cache of window-directory entries: (pidx << 16) | uint16(slot).  The index tiles the window
-// in 32 x 16 patch blocks (51 m x 25 m) so that neighbouring patches never evict each other.
+// direct-mapped LDS cache of window-directory entries: (pidx << 16) | uint16(slot), XOR-folded index
 struct DirCache {
     uint32_t* e;
     const int16_t* dir;
     uint32_t W;
-    __device__ inline uint32_t index(uint32_t pidx) const
-    {
-        const uint32_t wy = pidx / W, wx = pidx - wy * W;
-        return (wx & 31u) | ((wy & 15u) << 5);
-    }
+    // pidx = wy * W + wx with W a multiple of 8: (pidx & 7) = wx & 7; fold the rest without a division
+    __device__ inline uint32_t index(uint32_t pidx) const { return (pidx ^ (pidx >> 9) ^ (pidx >> 5)) & (DC_SIZE - 1); }
     __device__ inline int lookup(uint32_t pidx) const
     {
         const uint32_t k = index(pidx);
@@ -467,9 +464,10 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 #define BFT(k) do {} while (0)
 #endif
 
+template <int LQ, int RQ>
 struct BfLds {
-    uint64_t lower[LQ_LDS];
-    uint64_t raise[RQ_LDS];
+    uint64_t lower[LQ];
+    uint64_t raise[RQ];
     uint32_t dc[DC_SIZE];
 };
 
@@ -485,39 +483,44 @@ __device__ inline void lds_pop_begin(const uint64_t* h, uint32_t& size, PopState
     st.len = size; st.hole = 0; st.child = 0;
     st.value = st.active ? h[size] : 0;
 }
-// One "gather chunk" of __adjust_heap's first loop: instead of a chain of dependent LDS reads (one per level) the
-// wave loads the whole 5-level subtree below the hole with ONE ds_read -- lane L holds the node at relative heap
-// position L (children of L are 2L+1, 2L+2; absolute index hole * 2^depth(L) + L) -- and walks it with
-// v_readlane (scalar decisions).
+// One "gather chunk" of __adjust_heap's first loop.  All heap state is wave-uniform, so instead of a chain of
+// dependent LDS reads (one per level) the wave loads the whole 5-level subtree below the hole at once: lane L
+// holds the node at relative heap position L (children of L are 2L+1 and 2L+2; absolute index
+// hole * 2^depth(L) + L) plus the priorities of its two children.  Every lane decides locally which child
+// __adjust_heap would take (`comp(right, left)` -> left, else right); a ballot turns that into a bit mask and the
+// root-to-leaf path is chased with ~4 scalar instructions per level.  The moved entries are written with a single
+// ds_write: each node on the path stores itself into its parent's slot.
 __device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane)
 {
     if (!st.active) return;
-    const uint32_t lim = (st.len - 1) / 2;
-    if (!(st.child < lim)) return;
+    const uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)((st.len - 1) / 2));
     const uint32_t H = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
+    if (!(H < lim)) return;
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
     const int d = 31 - __clz(lane + 1);
-    const uint32_t idx = (H << d) + (uint32_t)lane;
-    const uint64_t v = (lane < 63 && idx < st.len) ? h[idx] : 0ull;
-    const int vhi = (int)(uint32_t)(v >> 32), vlo = (int)(uint32_t)v;
+    const uint32_t idx = (H << d) + (uint32_t)lane;                 // absolute heap index of my node
+    const bool have = lane < 63 && idx < len;
+    const bool inner = have && idx < lim;                           // both children exist
+    uint64_t v = 0; uint32_t pl = 0, pr = 0;
+    if (have) v = h[idx];
+    if (inner) { pl = heap_prio(h[2 * idx + 1]); pr = heap_prio(h[2 * idx + 2]); }
+    const bool take_left = pr > pl;                                 // comp(right, left)
+    const unsigned long long leftm = __ballot(inner && take_left);  // bit L: node L passes the hole to its LEFT child
+    const unsigned long long innerm = __ballot(inner);
+    // chase: at most 5 levels inside this gather (children of lanes >= 31 are not loaded)
+    unsigned long long pathm = 0;
     int rel = 0;
-    uint32_t child = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.child), hole = H;
-    const uint32_t slim = (uint32_t)__builtin_amdgcn_readfirstlane((int)lim);
-#pragma unroll 1
+#pragma unroll
     for (int lev = 0; lev < 5; ++lev) {
-        if (!(child < slim)) break;
-        child = 2 * (child + 1);
-        int rl = 2 * (rel + 1);
-        const uint32_t pr = (uint32_t)__builtin_amdgcn_readlane(vhi, rl);
-        const uint32_t pl = (uint32_t)__builtin_amdgcn_readlane(vhi, rl - 1);
-        if (pr > pl) { child--; rl--; }                       // comp(right, left): take the left child
-        const uint32_t chi = (uint32_t)__builtin_amdgcn_readlane(vhi, rl);
-        const uint32_t clo = (uint32_t)__builtin_amdgcn_readlane(vlo, rl);
-        if (lane == 0) h[hole] = ((uint64_t)chi << 32) | clo;
-        hole = child;
-        rel = rl;
+        if (!((innerm >> rel) & 1ull)) break;
+        rel = ((leftm >> rel) & 1ull) ? 2 * rel + 1 : 2 * rel + 2;
+        pathm |= 1ull << rel;
     }
-    st.child = child;
-    st.hole = hole;
+    if ((pathm >> lane) & 1ull) h[(idx - 1) >> 1] = v;              // first[hole] = first[child], all levels at once
+    // new hole = last node of the path
+    const uint32_t dd = 31 - __clz(rel + 1);
+    st.hole = (H << dd) + (uint32_t)rel;
+    st.child = st.hole;
 }
 __device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane)
 {
@@ -568,10 +571,12 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 //     test, and only when lower() really runs.  They are prefetched side-effect free and the allocation /
 //     mask update is applied once the decision is known.
 // ------------------------------------------------------------------------------------------------
+template <int LQ_LDS, int RQ_LDS, bool RESUME>
 __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
-    __shared__ BfLds sh;
+    __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     const int p = first_particle + blockIdx.x;
+    if (RESUME && prm.slow[p] == 0) return;              // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x;
     const size_t WW = (size_t)prm.W * prm.W;
     int16_t* dir = prm.dm_dir + (size_t)p * WW;
@@ -582,7 +587,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
     int count = prm.counts[2 * p];
     uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
-    if (lane == 0) { prm.stats[4 * p + 3] = 0; prm.slow[p] = 0; }
+    if (lane == 0) { if (!RESUME) prm.stats[4 * p + 3] = 0; prm.slow[p] = 0; }
     if (nl == 0 && nr == 0) return;
     if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (lane == 0) prm.slow[p] = 1; return; }
 
@@ -668,8 +673,10 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
             const bool r_i = __builtin_amdgcn_readlane((int)to_raise, i) != 0, l_i = __builtin_amdgcn_readlane((int)to_lower, i) != 0;
             if (r_i || l_i) {
                 const uint32_t prio = (uint32_t)__builtin_amdgcn_readlane((int)(s & SV_SQMASK), i);
-                const uint64_t ent = q_entry(prio, __builtin_amdgcn_readlane(x, i), __builtin_amdgcn_readlane(y, i));
-                if (r_i) lds_push(sh.raise, nr, ent, lane == 0); else lds_push(sh.lower, nl, ent, lane == 0);
+                const int ex = __builtin_amdgcn_readlane(x, i), ey = __builtin_amdgcn_readlane(y, i);
+                const uint32_t eo = (uint32_t)__builtin_amdgcn_readlane((int)ob, i);
+                if (r_i) lds_push(sh.raise, nr, q_entry(prio, ex, ey), lane == 0);
+                else lds_push(sh.lower, nl, q_entry(prio, ex, ey, obs_x(eo), obs_y(eo)), lane == 0);
             }
         }
         if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0; }
@@ -686,10 +693,34 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
         const int rx = q_rx(e), ry = q_ry(e);
         ++processed;
         BFT(0);
-        BF_POP_WITH_LOADS(sh.lower, nl)
+        // ONE load round: lanes 0..4 their own cell, lane 5 the obstacle cell the entry says the popped cell points to
+        const bool is_oc = lane == 5;
+        const int x = rx + (is_oc ? q_ox(e) : ddx), y = ry + (is_oc ? q_oy(e) : ddy);
+        const bool role = lane < 6;
+        const bool inwin = (uint32_t)x < prm.WC && (uint32_t)y < prm.WC;
+        const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
+        const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
+        int slot = (role && inwin) ? dc.lookup(pidx) : -1;
+        uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) { ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; } }
+        BFT(1);
+        PopState ps_;
+        lds_pop_begin(sh.lower, nl, ps_);
+        lds_pop_finish(sh.lower, ps_, lane);
+        BFT(2);
         const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
         const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
-        const uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)os, 4);
+        uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)s, 5);
+        if (obs_x(cob) != q_ox(e) || obs_y(cob) != q_oy(e)) {
+            // stale entry (the cell was overwritten after it was queued): fetch the obstacle cell it points to now
+            const int ox2 = rx + obs_x(cob), oy2 = ry + obs_y(cob);
+            uint16_t t = 0;
+            if ((uint32_t)ox2 < prm.WC && (uint32_t)oy2 < prm.WC) {
+                const int os2 = dc.lookup(((uint32_t)oy2 >> 5) * prm.W + ((uint32_t)ox2 >> 5));
+                if (os2 >= 0) t = sv[os2 * 1024 + (int)(((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5))];
+            }
+            cos_ = t;
+        }
         // :183-192  valid, its obstacle still has sqdist 0 (valid NOT tested), and lower() :283 still queued
         const bool fire = (cs & SV_VALID) && (cos_ & SV_SQMASK) == 0 && (cs & SV_QUEUED);
         BFT(3);
@@ -710,8 +741,17 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
             const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
             const uint32_t cmp = (s & SV_VALID) ? (uint32_t)(s & SV_SQMASK) : prm.max_sqdist;
             bool over = nbok && new_sq < cmp;
-            if (nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK)) {                // :311-317
-                if (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
+            const bool tie = nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK);     // :311-317
+            if (__ballot(tie)) {
+                uint16_t os = 0;
+                if (tie) {
+                    const int ox = x + obs_x(ob), oy = y + obs_y(ob);
+                    if ((uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) {
+                        const int oslot = dc.lookup(((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5));
+                        if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))];
+                    }
+                    if (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
+                }
             }
             BFT(4);
             // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
@@ -723,9 +763,9 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
             if (!done && nl >= 4) {
                 const uint32_t pos = nl + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
                 bool stop = true;
-                if (over) stop = !((uint32_t)(sh.lower[(pos - 1) / 2] >> 32) > new_sq);
+                if (over) stop = !(heap_prio(sh.lower[(pos - 1) / 2]) > new_sq);
                 if (__ballot(!stop) == 0) {
-                    if (over) sh.lower[pos] = q_entry(new_sq, x, y);
+                    if (over) sh.lower[pos] = q_entry(new_sq, x, y, obx - x, oby - y);
                     nl += (uint32_t)ocnt;
                     done = true;
                 }
@@ -735,7 +775,8 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
                 for (int i = 0; i < 4; ++i) {
                     if (__builtin_amdgcn_readlane((int)over, i)) {
                         const uint32_t prio = (uint32_t)__builtin_amdgcn_readlane((int)new_sq, i);
-                        lds_push(sh.lower, nl, q_entry(prio, __builtin_amdgcn_readlane(x, i), __builtin_amdgcn_readlane(y, i)), lane == 0);
+                        const int ex = __builtin_amdgcn_readlane(x, i), ey = __builtin_amdgcn_readlane(y, i);
+                        lds_push(sh.lower, nl, q_entry(prio, ex, ey, obx - ex, oby - ey), lane == 0);
                     }
                 }
             }
@@ -759,7 +800,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
     }
     if (lane == 0) {
         prm.counts[2 * p] = count;
-        prm.stats[4 * p + 3] = processed;
+        prm.stats[4 * p + 3] += processed;
         if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; prm.slow[p] = 1; }
 #ifdef LAMA_PROFILE_BF
         for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];

@@ -503,6 +503,7 @@ static_assert(sizeof(distance_t) == 10, "distance_t must be 10 bytes (SURVEY A.9
 
 struct BrushfireStats {
     uint64_t raise_pops = 0, lower_pops = 0, lower_fired = 0, pushes = 0, max_queue = 0, tie_overwrites = 0;
+    uint64_t max_queue_last = 0;   // of the last update() only
 };
 
 class DynamicDistanceMap : public Map {
@@ -577,8 +578,10 @@ public:
     uint32_t update()                                              // :160-197
     {
         uint32_t processed = 0;
+        stats.max_queue_last = 0;
         while (!raise_.empty()) {
             stats.max_queue = std::max<uint64_t>(stats.max_queue, raise_.size() + lower_.size());
+            stats.max_queue_last = std::max<uint64_t>(stats.max_queue_last, std::max(raise_.size(), lower_.size()));
             V3u location = raise_.top().second; raise_.pop();
             distance_t* current = (distance_t*)get(location);
             ++processed; ++stats.raise_pops;
@@ -586,6 +589,7 @@ public:
         }
         while (!lower_.empty()) {
             stats.max_queue = std::max<uint64_t>(stats.max_queue, lower_.size());
+            stats.max_queue_last = std::max<uint64_t>(stats.max_queue_last, lower_.size());
             V3u location = lower_.top().second; lower_.pop();
             distance_t* current = (distance_t*)get(location);
             ++processed; ++stats.lower_pops;

@@ -136,10 +136,10 @@ double orc_dm_distance(void* h, const double* p3, double* grad3)
 }
 int orc_dm_patch_ids(void* h, uint64_t* ids, int cap) { return patch_ids((const DynamicDistanceMap*)h, ids, cap); }
 int orc_dm_patch_read(void* h, uint64_t id, uint8_t* cells, uint64_t* mask) { return patch_read((const DynamicDistanceMap*)h, id, cells, mask); }
-void orc_dm_stats(void* h, uint64_t* out6)
+void orc_dm_stats(void* h, uint64_t* out6 /* 7 values */)
 {
     const BrushfireStats& s = ((DynamicDistanceMap*)h)->stats;
-    out6[0] = s.raise_pops; out6[1] = s.lower_pops; out6[2] = s.lower_fired; out6[3] = s.pushes; out6[4] = s.max_queue; out6[5] = s.tie_overwrites;
+    out6[0] = s.raise_pops; out6[1] = s.lower_pops; out6[2] = s.lower_fired; out6[3] = s.pushes; out6[4] = s.max_queue; out6[5] = s.tie_overwrites; out6[6] = s.max_queue_last;
 }
 
 // ---------------------------------------------------------------- FrequencyOccupancyMap

@@ -167,9 +167,9 @@ class DM(_MapBase):
         return (d, g) if grad else d
 
     def stats(self):
-        s = np.zeros(6, dtype=np.uint64)
+        s = np.zeros(7, dtype=np.uint64)
         lib().orc_dm_stats(self.h, _p(s))
-        return dict(zip(["raise_pops", "lower_pops", "lower_fired", "pushes", "max_queue", "tie_overwrites"], s.tolist()))
+        return dict(zip(["raise_pops", "lower_pops", "lower_fired", "pushes", "max_queue", "tie_overwrites", "max_queue_last"], s.tolist()))
 
 
 class Occ(_MapBase):

@@ -29,7 +29,7 @@ extern "C" int heap_replay(const int32_t* ops, int n, uint32_t* out_dev, uint32_
     int k = 0;
     for (int i = 0; i < n; ++i) {
         if (ops[i] >= 0) {
-            lama_dev::heap_push(st, size, ((uint64_t)(uint32_t)ops[i] << 32) | (uint32_t)i);
+            lama_dev::heap_push(st, size, ((uint64_t)(uint32_t)ops[i] << 48) | (uint32_t)i);
             pq.push({ops[i], V3{(uint32_t)i, 0, 0}});
         } else if (size > 0) {
             out_dev[k] = (uint32_t)(lama_dev::heap_pop(st, size) & 0xFFFFFFFFu);

@@ -1,0 +1,17 @@
+#!/bin/bash
+# Round-1 profiling recipe (run on the GPU box through gpurun).  Writes under gpurun_out/; the summaries that
+# matter are copied into profiles/ afterwards.
+#   pass 1: kernel trace + stats of the default bench command
+#   pass 2/3: PMC counters (separate runs, no tracing domains besides the kernel trace)
+set -x
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+OUT=$PWD/gpurun_out/prof_r01
+mkdir -p "$OUT"
+CMD="python bench.py --steps 30 --warmup 5 --no-cpu --sweep="
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r01 -- $CMD > "$OUT/bench_trace.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o r01 -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o r01 -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_sq" -o r01 -- $CMD > "$OUT/bench_pmc_sq.log" 2>&1
+find "$OUT" -name "*.csv" | head -40
+ls -la "$OUT"/*
