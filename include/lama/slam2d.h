@@ -1,0 +1,75 @@
+// lama/slam2d.h -- host-side lama::Slam2D (online SLAM: one pose, one map pair) on the MI355X path.
+//
+// Same class name, Options fields and public methods as the reference's include/lama/slam2d.h:57-188; the body of
+// update() follows src/slam2d.cpp:143-198.  Scan matching (MatchSurface2D + Solve, :172-175) and updateMaps()
+// (:247-321) run on the device through the C-ABI of include/lama_hip.h with a one-particle context -- the same
+// kernels as PFSlam2D.  Differences: getOccupancyMap()/getDistanceMap() become downloadOccupancyMap()/
+// downloadDistanceMap(); strategy "lm" and transient_map are not supported on the device (constructor throws);
+// there is no CPU fallback.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "pose2d.h"
+
+struct lama_hip_ctx;
+
+namespace lama {
+
+struct HipEngine;
+
+class Slam2D {
+public:
+    struct Options {
+        Options() {}
+        double trans_thresh = 0.5;
+        double rot_thresh = 0.5;
+        double l2_max = 0.5;
+        double truncated_ray = 0.0;
+        double truncated_range = 0.0;
+        double resolution = 0.05;
+        uint32_t patch_size = 32;
+        uint32_t max_iter = 100;
+        std::string strategy = "gn";
+        bool use_compression = false;
+        uint32_t cache_size = 100;
+        std::string calgorithm = "lz4";
+        bool transient_map = false;
+        bool create_summary = false;
+        // ---- additions ----
+        int32_t gpu_device = 0;
+    };
+
+    explicit Slam2D(const Options& options = Options());
+    virtual ~Slam2D();
+
+    bool enoughMotion(const Pose2D& odometry);
+    bool update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp);
+
+    uint64_t getMemoryUsage() const;
+    uint32_t getNumberOfProcessedCells() const { return number_of_proccessed_cells_; }
+    uint32_t getLastIterations() const { return last_iterations_; }
+
+    void setPose(const Pose2D& pose) { pose_ = pose; }
+    Pose2D getPose() const { return pose_; }
+
+    bool downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    bool downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    lama_hip_ctx* deviceContext() const { return ctx_; }
+    const HipEngine* engine() const { return eng_.get(); }
+
+private:
+    void fail(int32_t rc, const char* what) const;
+    std::shared_ptr<HipEngine> eng_;
+    lama_hip_ctx* ctx_ = nullptr;
+    Pose2D odom_, pose_;
+    double trans_thresh_, rot_thresh_;
+    bool has_first_scan = false;
+    uint32_t number_of_proccessed_cells_ = 0;
+    uint32_t last_iterations_ = 0;
+};
+
+} // namespace lama

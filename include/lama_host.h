@@ -88,6 +88,28 @@ int lama_pf_resample_indices(const lama_pf* pf, double u01, int32_t* out_P);
 void lama_pose_minus(const double* a4, const double* b4, double* out4);
 void lama_pose_from_xyr(double x, double y, double yaw, double* out4);
 
+/* ---- lama::Slam2D (include/lama/slam2d.h), flattened ---- */
+typedef struct lama_slam lama_slam;
+typedef struct lama_slam_options {
+    double trans_thresh, rot_thresh, l2_max, truncated_ray, truncated_range, resolution;
+    uint32_t patch_size, max_iter;
+    int32_t gpu_device;
+} lama_slam_options;
+void lama_slam_default_options(lama_slam_options* o);
+lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap);
+void lama_slam_destroy(lama_slam* s);
+const char* lama_slam_last_error(const lama_slam* s);
+void lama_slam_set_pose(lama_slam* s, double x, double y, double yaw);
+int lama_slam_get_pose(const lama_slam* s, double* pose4);
+/* Slam2D::update: 1 = update done, 0 = not enough motion, <0 = error */
+int lama_slam_update(lama_slam* s, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                     const double* odom_xyr, double timestamp);
+int lama_slam_enough_motion(lama_slam* s, const double* odom_xyr);
+uint32_t lama_slam_processed_cells(const lama_slam* s);
+uint32_t lama_slam_iterations(const lama_slam* s);
+void* lama_slam_device_context(const lama_slam* s);
+const char* lama_slam_engine_origin(const lama_slam* s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -273,6 +273,9 @@ HOST_SYMBOLS = [
     "lama_pf_best_pose_xyr", "lama_pf_num_resamples", "lama_pf_memory_usage", "lama_pf_summary",
     "lama_pf_last_times", "lama_pf_draw_from_motion", "lama_pf_normalize", "lama_pf_resample_indices",
     "lama_pose_minus", "lama_pose_from_xyr",
+    "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
+    "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
+    "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin",
 ]
 
 
@@ -294,6 +297,12 @@ def _bind_host(L):
         "lama_pf_last_times": (i32, [vp, vp]), "lama_pf_draw_from_motion": (i32, [vp, vp, vp]),
         "lama_pf_normalize": (d, [vp]), "lama_pf_resample_indices": (i32, [vp, d, vp]),
         "lama_pose_minus": (None, [vp, vp, vp]), "lama_pose_from_xyr": (None, [d, d, d, vp]),
+        "lama_slam_default_options": (None, [vp]), "lama_slam_create": (vp, [vp, vp, i32]), "lama_slam_destroy": (None, [vp]),
+        "lama_slam_last_error": (C.c_char_p, [vp]), "lama_slam_set_pose": (None, [vp, d, d, d]),
+        "lama_slam_get_pose": (i32, [vp, vp]), "lama_slam_update": (i32, [vp, vp, u32, vp, vp, vp, d]),
+        "lama_slam_enough_motion": (i32, [vp, vp]), "lama_slam_processed_cells": (u32, [vp]),
+        "lama_slam_iterations": (u32, [vp]), "lama_slam_device_context": (vp, [vp]),
+        "lama_slam_engine_origin": (C.c_char_p, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -479,5 +488,76 @@ class PFSlam2D:
         ctx.cfg = None
         ctx.P = self.hi - self.lo
         ctx.h = C.c_void_p(self.device_context())
+        ctx._is_borrowed = True
+        return ctx
+
+
+class SlamOptions(C.Structure):
+    _fields_ = [("trans_thresh", C.c_double), ("rot_thresh", C.c_double), ("l2_max", C.c_double),
+                ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
+                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("gpu_device", C.c_int32)]
+
+
+class Slam2D:
+    """ctypes view of the host-side lama::Slam2D (include/lama/slam2d.h): online SLAM, one pose + one map pair."""
+
+    def __init__(self, **kw):
+        self.L = _hostlib()
+        o = SlamOptions()
+        self.L.lama_slam_default_options(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        err = C.create_string_buffer(512)
+        h = self.L.lama_slam_create(C.byref(o), err, 512)
+        if not h:
+            raise LamaError(err.value.decode())
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lama_slam_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def engine_origin(self):
+        return self.L.lama_slam_engine_origin(self.h).decode()
+
+    def set_pose(self, x, y, yaw):
+        self.L.lama_slam_set_pose(self.h, float(x), float(y), float(yaw))
+
+    def pose(self):
+        out = np.zeros(4)
+        self.L.lama_slam_get_pose(self.h, _p(out))
+        return out
+
+    def update(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
+        pts, origin, quat = PFSlam2D._scan(pts, origin, quat)
+        od = np.ascontiguousarray(odom_xyr, dtype=np.float64)
+        rc = self.L.lama_slam_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(od), float(ts))
+        if rc < 0:
+            raise LamaError(self.L.lama_slam_last_error(self.h).decode())
+        return bool(rc)
+
+    def enough_motion(self, odom_xyr):
+        return bool(self.L.lama_slam_enough_motion(self.h, _p(np.ascontiguousarray(odom_xyr, dtype=np.float64))))
+
+    def processed_cells(self):
+        return self.L.lama_slam_processed_cells(self.h)
+
+    def iterations(self):
+        return self.L.lama_slam_iterations(self.h)
+
+    def hip_context(self):
+        ctx = HipContext.__new__(HipContext)
+        if self.engine_origin().endswith("liblama_hip.so"):
+            ctx.L = hip_lib()
+        else:
+            ctx.L = C.CDLL(self.engine_origin())
+            _bind_hip(ctx.L)
+        ctx.cfg = None
+        ctx.P = 1
+        ctx.h = C.c_void_p(self.L.lama_slam_device_context(self.h))
         ctx._is_borrowed = True
         return ctx

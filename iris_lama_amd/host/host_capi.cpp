@@ -7,6 +7,7 @@
 
 #include "hip_engine.hpp"
 #include "lama/pf_slam2d.h"
+#include "lama/slam2d.h"
 
 using namespace lama;
 
@@ -253,5 +254,52 @@ void lama_pose_minus(const double* a4, const double* b4, double* out4)
 }
 
 void lama_pose_from_xyr(double x, double y, double yaw, double* out4) { Pose2D(x, y, yaw).state.toArray(out4); }
+
+// ------------------------------------------------------------------ Slam2D
+struct lama_slam {
+    std::unique_ptr<Slam2D> s;
+    std::string error, origin;
+};
+
+void lama_slam_default_options(lama_slam_options* o)
+{
+    Slam2D::Options d;
+    o->trans_thresh = d.trans_thresh; o->rot_thresh = d.rot_thresh; o->l2_max = d.l2_max; o->truncated_ray = d.truncated_ray;
+    o->truncated_range = d.truncated_range; o->resolution = d.resolution; o->patch_size = d.patch_size; o->max_iter = d.max_iter;
+    o->gpu_device = 0;
+}
+
+lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap)
+{
+    auto* h = new lama_slam;
+    try {
+        Slam2D::Options p;
+        p.trans_thresh = o->trans_thresh; p.rot_thresh = o->rot_thresh; p.l2_max = o->l2_max; p.truncated_ray = o->truncated_ray;
+        p.truncated_range = o->truncated_range; p.resolution = o->resolution; p.patch_size = o->patch_size; p.max_iter = o->max_iter;
+        p.gpu_device = o->gpu_device;
+        h->s.reset(new Slam2D(p));
+        h->origin = h->s->engine()->origin;
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+void lama_slam_destroy(lama_slam* s) { delete s; }
+const char* lama_slam_last_error(const lama_slam* s) { return s ? s->error.c_str() : "null handle"; }
+const char* lama_slam_engine_origin(const lama_slam* s) { return s ? s->origin.c_str() : ""; }
+void lama_slam_set_pose(lama_slam* s, double x, double y, double yaw) { s->s->setPose(Pose2D(x, y, yaw)); }
+int lama_slam_get_pose(const lama_slam* s, double* pose4) { s->s->getPose().state.toArray(pose4); return 0; }
+int lama_slam_update(lama_slam* h, const double* pts, uint32_t n, const double* origin3, const double* quat, const double* odom_xyr, double ts)
+{
+    try {
+        return h->s->update(make_cloud(pts, n, origin3, quat), Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2]), ts) ? 1 : 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
+int lama_slam_enough_motion(lama_slam* h, const double* odom_xyr) { return h->s->enoughMotion(Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2])) ? 1 : 0; }
+uint32_t lama_slam_processed_cells(const lama_slam* h) { return h->s->getNumberOfProcessedCells(); }
+uint32_t lama_slam_iterations(const lama_slam* h) { return h->s->getLastIterations(); }
+void* lama_slam_device_context(const lama_slam* h) { return (void*)h->s->deviceContext(); }
 
 } // extern "C"

@@ -1,0 +1,122 @@
+// slam2d.cpp -- host-side lama::Slam2D (include/lama/slam2d.h); orchestration of src/slam2d.cpp:143-198.
+#include "lama/slam2d.h"
+
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+#include "hip_engine.hpp"
+
+namespace lama {
+
+namespace {
+void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], double q[4])
+{
+    pts.resize(s.points.size() * 3);
+    for (size_t i = 0; i < s.points.size(); ++i) { pts[3 * i] = s.points[i].x(); pts[3 * i + 1] = s.points[i].y(); pts[3 * i + 2] = s.points[i].z(); }
+    o[0] = s.sensor_origin_.x(); o[1] = s.sensor_origin_.y(); o[2] = s.sensor_origin_.z();
+    q[0] = s.sensor_orientation_.w(); q[1] = s.sensor_orientation_.x(); q[2] = s.sensor_orientation_.y(); q[3] = s.sensor_orientation_.z();
+}
+} // namespace
+
+Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.rot_thresh)
+{
+    if (o.strategy == "lm") throw std::runtime_error("lama::Slam2D: strategy \"lm\" is not available on the device path");   // src/slam2d.cpp:226-233
+    if (o.use_compression || o.transient_map) throw std::runtime_error("lama::Slam2D: use_compression / transient_map are not supported on the device path");
+    eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+    lama_hip_cfg cfg;
+    eng_->default_cfg(&cfg);
+    cfg.particles = 1;
+    cfg.resolution = o.resolution; cfg.patch_size = o.patch_size; cfg.l2_max = o.l2_max; cfg.max_iter = o.max_iter;
+    cfg.truncated_ray = o.truncated_ray; cfg.truncated_range = o.truncated_range; cfg.device = o.gpu_device;
+    cfg.meas_sigma = 0.05;                       // unused by Slam2D (no likelihood)
+    const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
+    if (rc != 0 || !ctx_) {
+        char msg[200];
+        std::snprintf(msg, sizeof(msg), "lama::Slam2D: lama_hip_ctx_create failed (status %d): no usable MI355X / HIP device; there is no CPU fallback", rc);
+        throw std::runtime_error(msg);
+    }
+}
+
+Slam2D::~Slam2D() { if (ctx_) eng_->ctx_destroy(ctx_); }
+
+void Slam2D::fail(int32_t rc, const char* what) const
+{
+    char msg[512];
+    std::snprintf(msg, sizeof(msg), "lama::Slam2D: %s failed (status %d): %s", what, rc, eng_->last_error(ctx_));
+    throw std::runtime_error(msg);
+}
+
+bool Slam2D::enoughMotion(const Pose2D& odometry)                 // src/slam2d.cpp:129-141
+{
+    if (!has_first_scan) return true;
+    Pose2D odelta = odom_ - odometry;
+    if (odelta.xy().norm() <= trans_thresh_ && std::abs(odelta.rotation()) <= rot_thresh_) return false;
+    return true;
+}
+
+bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double /*timestamp*/)
+{
+    if (!surface || surface->points.empty()) throw std::runtime_error("lama::Slam2D::update: empty scan");
+    std::vector<double> pts;
+    double o[3], q[4], p[4];
+    scan_arrays(*surface, pts, o, q);
+    const uint32_t n = (uint32_t)surface->points.size();
+    lama_hip_counters c0, c1;
+
+    if (!has_first_scan) {                                        // :147-160
+        odom_ = odometry;
+        pose_.state.toArray(p);
+        int32_t rc = eng_->pf_init(ctx_, pts.data(), n, o, q, p); // updateMaps(surface) at pose_
+        if (rc) fail(rc, "lama_hip_pf_init");
+        if (eng_->get_counters(ctx_, &c1) == 0) number_of_proccessed_cells_ = (uint32_t)c1.bf_cells;
+        has_first_scan = true;
+        return true;
+    }
+    // 1. predict from odometry                                    :163-173
+    Pose2D odelta = odom_ - odometry;
+    Pose2D ppose = pose_ + odelta;
+    if (odelta.xy().norm() <= trans_thresh_ && std::abs(odelta.rotation()) <= rot_thresh_) return false;
+    pose_ = ppose;
+    odom_ = odometry;
+    // 2. optimise                                                 :175-181
+    pose_.state.toArray(p);
+    int32_t rc = eng_->pf_set_poses(ctx_, p);
+    if (rc) fail(rc, "lama_hip_pf_set_poses");
+    int32_t iters = 0;
+    rc = eng_->pf_scan_match(ctx_, pts.data(), n, o, q, p, nullptr, &iters);
+    if (rc) fail(rc, "lama_hip_pf_scan_match");
+    pose_.state = SE2d::fromArray(p);
+    last_iterations_ = (uint32_t)iters;
+    // 3. update maps                                              :184-186
+    (void)eng_->get_counters(ctx_, &c0);
+    rc = eng_->pf_update_maps(ctx_, pts.data(), n, o, q);
+    if (rc) fail(rc, "lama_hip_pf_update_maps");
+    if (eng_->get_counters(ctx_, &c1) == 0) number_of_proccessed_cells_ = (uint32_t)(c1.bf_cells - c0.bf_cells);
+    return true;
+}
+
+uint64_t Slam2D::getMemoryUsage() const
+{
+    lama_hip_counters c;
+    if (eng_->get_counters(ctx_, &c) != 0) return 0;
+    return c.dm_patches * 10240ull + c.occ_patches * 4096ull;
+}
+
+static bool dl(const HipEngine* e, lama_hip_ctx* ctx, int kind, size_t cell_bytes, std::vector<uint64_t>& ids,
+               std::vector<uint8_t>& cells, std::vector<uint64_t>& masks)
+{
+    uint32_t n = 0;
+    if (e->pf_map_patches(ctx, 0, kind, &n) != 0) return false;
+    ids.assign(n, 0); cells.assign((size_t)n * cell_bytes * 1024, 0); masks.assign((size_t)n * 16, 0);
+    uint32_t got = 0;
+    return e->pf_download_map(ctx, 0, kind, n, ids.data(), cells.data(), masks.data(), &got) == 0 && got == n;
+}
+
+bool Slam2D::downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{ return has_first_scan && dl(eng_.get(), ctx_, LAMA_HIP_MAP_DISTANCE, 10, ids, cells, masks); }
+
+bool Slam2D::downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{ return has_first_scan && dl(eng_.get(), ctx_, LAMA_HIP_MAP_OCCUPANCY, 4, ids, cells, masks); }
+
+} // namespace lama

@@ -880,6 +880,60 @@ inline SolveStats solve_gn(MatchSurface2D& problem, uint32_t max_iterations, con
 }
 
 // -------------------------------------------------------------------------------------
+// Map update shared by PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:439-509) and Slam2D::updateMaps
+// (src/slam2d.cpp:247-321, identical statement for statement except the transient-map pruning): ray-cast the scan
+// from `pose` into the occupancy map, forward obstacle events to the distance map, then dm.update().
+// -------------------------------------------------------------------------------------
+inline uint32_t update_maps_body(DynamicDistanceMap& dm, FrequencyOccupancyMap& occ, const Scan& surface, const SE2& pose,
+                                 double truncated_ray_, double truncated_range_, uint64_t* ray_cells_out = nullptr,
+                                 uint64_t* events_out = nullptr)
+{
+    Affine3 mtf = moving_tf(surface);
+    Affine3 ftf = fixed_tf(pose);
+    Affine3 tf = affine_mul(ftf, mtf);
+    V3d wso{tf.t[0], tf.t[1], tf.t[2]};
+    uint64_t ray_cells = 0, events = 0;
+    const size_t num_points = surface.points.size();
+    for (size_t i = 0; i < num_points; ++i) {
+        V3d start = wso;
+        V3d hit = affine_apply(tf, surface.points[i]);
+        V3d AB{0, 0, 0};
+        double ray_length = 1.0;
+        bool mark_hit = true;
+        if (truncated_range_ > 0.0) {                               // :467-479
+            AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
+            ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
+            if (truncated_range_ < ray_length) {
+                hit = V3d{start.x + AB.x / ray_length * truncated_range_, start.y + AB.y / ray_length * truncated_range_, start.z + AB.z / ray_length * truncated_range_};
+                mark_hit = false;
+            }
+        }
+        if (mark_hit && (truncated_ray_ > 0.0)) {                   // :481-491
+            if (truncated_range_ == 0.0) {
+                AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
+                ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
+            }
+            if (truncated_ray_ < ray_length)
+                start = V3d{hit.x - AB.x / ray_length * truncated_ray_, hit.y - AB.y / ray_length * truncated_ray_, hit.z - AB.z / ray_length * truncated_ray_};
+        }
+        V3u mhit = occ.w2m(hit);                                    // :493
+        if (mark_hit) {
+            bool changed = occ.setOccupied(mhit);
+            if (changed) { dm.addObstacle(mhit); ++events; }
+        }
+        occ.computeRay(occ.w2m(start), mhit, [&](const V3u& coord) {
+            ++ray_cells;
+            bool changed = occ.setFree(coord);
+            if (changed) { dm.removeObstacle(coord); ++events; }
+        });
+    }
+    uint32_t processed = dm.update();                               // :508
+    if (ray_cells_out) *ray_cells_out = ray_cells;
+    if (events_out) *events_out = events;
+    return processed;
+}
+
+// -------------------------------------------------------------------------------------
 // ThreadPool -- same dispatch MODEL as src/thread_pool.cpp:52-114 (one task per particle per
 // region, wait() barrier); plain mutex queue instead of moodycamel (vendor lib, not restated).
 // -------------------------------------------------------------------------------------
@@ -1154,46 +1208,9 @@ public:
             particle->occ->reset_cache(); particle->dm->reset_cache();
             particle->occ->touch_rw = &t_occ; particle->dm->touch_rw = &t_bf;
         }
-        Affine3 mtf = moving_tf(surface);
-        Affine3 ftf = fixed_tf(particle->pose);
-        Affine3 tf = affine_mul(ftf, mtf);
-        V3d wso{tf.t[0], tf.t[1], tf.t[2]};
         uint64_t ray_cells = 0, events = 0;
-        const size_t num_points = surface.points.size();
-        for (size_t i = 0; i < num_points; ++i) {
-            V3d start = wso;
-            V3d hit = affine_apply(tf, surface.points[i]);
-            V3d AB{0, 0, 0};
-            double ray_length = 1.0;
-            bool mark_hit = true;
-            if (truncated_range_ > 0.0) {                               // :467-479
-                AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
-                ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
-                if (truncated_range_ < ray_length) {
-                    hit = V3d{start.x + AB.x / ray_length * truncated_range_, start.y + AB.y / ray_length * truncated_range_, start.z + AB.z / ray_length * truncated_range_};
-                    mark_hit = false;
-                }
-            }
-            if (mark_hit && (truncated_ray_ > 0.0)) {                   // :481-491
-                if (truncated_range_ == 0.0) {
-                    AB = V3d{hit.x - start.x, hit.y - start.y, hit.z - start.z};
-                    ray_length = std::sqrt(AB.x * AB.x + AB.y * AB.y + AB.z * AB.z);
-                }
-                if (truncated_ray_ < ray_length)
-                    start = V3d{hit.x - AB.x / ray_length * truncated_ray_, hit.y - AB.y / ray_length * truncated_ray_, hit.z - AB.z / ray_length * truncated_ray_};
-            }
-            V3u mhit = particle->occ->w2m(hit);                         // :493
-            if (mark_hit) {
-                bool changed = particle->occ->setOccupied(mhit);
-                if (changed) { particle->dm->addObstacle(mhit); ++events; }
-            }
-            particle->occ->computeRay(particle->occ->w2m(start), mhit, [&](const V3u& coord) {
-                ++ray_cells;
-                bool changed = particle->occ->setFree(coord);
-                if (changed) { particle->dm->removeObstacle(coord); ++events; }
-            });
-        }
-        uint32_t processed = particle->dm->update();                    // :508
+        uint32_t processed = update_maps_body(*particle->dm, *particle->occ, surface, particle->pose, truncated_ray_, truncated_range_,
+                                              &ray_cells, &events);
         particle->ctr.ray_cells = ray_cells;
         particle->ctr.occ_events = events;
         particle->ctr.bf_processed = processed;
@@ -1301,6 +1318,77 @@ private:
     std::deque<double> timestamps_;
     const Scan* current_surface_ = nullptr;
     std::unique_ptr<ThreadPool> thread_pool_;
+};
+
+// -------------------------------------------------------------------------------------
+// Slam2D  (include/lama/slam2d.h:91-188, src/slam2d.cpp:92-198, 247-321).  Online SLAM = one pose, one map pair.
+// Strategy "gn" only (GaussNewton + CauchyWeight(0.15), src/slam2d.cpp:103-106); transient_map pruning
+// (:322-373) is out of scope.
+// -------------------------------------------------------------------------------------
+struct SlamOptions {                                    // slam2d.h:91-125
+    double trans_thresh = 0.5, rot_thresh = 0.5;
+    double l2_max = 0.5;
+    double truncated_ray = 0.0, truncated_range = 0.0;
+    double resolution = 0.05;
+    uint32_t patch_size = 32;
+    uint32_t max_iter = 100;
+};
+
+class Slam2D {
+public:
+    explicit Slam2D(const SlamOptions& o) : opt_(o), dm_(o.resolution, o.patch_size), occ_(o.resolution, o.patch_size)
+    {
+        dm_.setMaxDistance(o.l2_max);                                   // src/slam2d.cpp:94-95
+    }
+    void setPose(const SE2& p) { pose_ = p; }
+    SE2 getPose() const { return pose_; }
+    uint32_t getNumberOfProcessedCells() const { return processed_; }
+    DynamicDistanceMap& dm() { return dm_; }
+    FrequencyOccupancyMap& occ() { return occ_; }
+    SolveStats last_solve;
+
+    bool enoughMotion(const SE2& odometry) const                        // :129-141
+    {
+        if (!has_first_scan) return true;
+        SE2 odelta = pose_minus(odom_, odometry);
+        if (std::sqrt(odelta.tx * odelta.tx + odelta.ty * odelta.ty) <= opt_.trans_thresh && std::fabs(se2_rotation(odelta)) <= opt_.rot_thresh)
+            return false;
+        return true;
+    }
+
+    bool update(const Scan& surface, const SE2& odometry, double /*timestamp*/)   // :143-198
+    {
+        if (!has_first_scan) {
+            odom_ = odometry;
+            updateMaps(surface);
+            has_first_scan = true;
+            return true;
+        }
+        SE2 odelta = pose_minus(odom_, odometry);
+        SE2 ppose = pose_plus(pose_, odelta);
+        if (std::sqrt(odelta.tx * odelta.tx + odelta.ty * odelta.ty) <= opt_.trans_thresh && std::fabs(se2_rotation(odelta)) <= opt_.rot_thresh)
+            return false;
+        pose_ = ppose;
+        odom_ = odometry;
+        MatchSurface2D ms(&dm_, &surface, pose_);
+        CauchyWeight cauchy(0.15);
+        last_solve = solve_gn(ms, opt_.max_iter, cauchy);
+        pose_ = ms.state_;
+        updateMaps(surface);
+        return true;
+    }
+
+private:
+    void updateMaps(const Scan& surface)                                // :247-321
+    {
+        processed_ = update_maps_body(dm_, occ_, surface, pose_, opt_.truncated_ray, opt_.truncated_range);
+    }
+    SlamOptions opt_;
+    DynamicDistanceMap dm_;
+    FrequencyOccupancyMap occ_;
+    SE2 odom_, pose_;
+    bool has_first_scan = false;
+    uint32_t processed_ = 0;
 };
 
 } // namespace orc

@@ -319,4 +319,32 @@ void orc_pf_draw_from_motion(void* h, const double* delta4, double* pose4)
     se2_to(p, pose4);
 }
 
+
+// ---------------------------------------------------------------- Slam2D
+struct SlamBox { std::unique_ptr<Slam2D> s; Scan scan; };
+void* orc_slam_new(double trans_thresh, double rot_thresh, double l2_max, double truncated_ray, double truncated_range,
+                   double resolution, uint32_t patch_size, uint32_t max_iter)
+{
+    SlamOptions o;
+    o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.truncated_ray = truncated_ray;
+    o.truncated_range = truncated_range; o.resolution = resolution; o.patch_size = patch_size; o.max_iter = max_iter;
+    auto* b = new SlamBox;
+    b->s.reset(new Slam2D(o));
+    return b;
+}
+void orc_slam_free(void* h) { delete (SlamBox*)h; }
+void orc_slam_set_pose(void* h, const double* pose4) { ((SlamBox*)h)->s->setPose(se2_of(pose4)); }
+void orc_slam_get_pose(void* h, double* pose4) { se2_to(((SlamBox*)h)->s->getPose(), pose4); }
+int orc_slam_update(void* h, const double* pts, int n, const double* origin3, const double* quat4, const double* odom4, double ts)
+{
+    SlamBox* b = (SlamBox*)h;
+    b->scan = make_scan(pts, n, origin3, quat4);
+    return b->s->update(b->scan, se2_of(odom4), ts) ? 1 : 0;
+}
+int orc_slam_enough_motion(void* h, const double* odom4) { return ((SlamBox*)h)->s->enoughMotion(se2_of(odom4)) ? 1 : 0; }
+uint32_t orc_slam_processed_cells(void* h) { return ((SlamBox*)h)->s->getNumberOfProcessedCells(); }
+uint32_t orc_slam_iterations(void* h) { return ((SlamBox*)h)->s->last_solve.iterations; }
+void* orc_slam_dm(void* h) { return &((SlamBox*)h)->s->dm(); }       // borrowed
+void* orc_slam_occ(void* h) { return &((SlamBox*)h)->s->occ(); }     // borrowed
+
 } // extern "C"

@@ -64,6 +64,11 @@ def lib():
             "orc_scan_tf": (None, [vp, vp, vp, vp]), "orc_ldlt3_solve": (None, [vp, vp, vp]),
             "orc_se2_exp": (None, [vp, vp]), "orc_se2_mul": (None, [vp, vp, vp]), "orc_se2_inverse": (None, [vp, vp]),
             "orc_pose_minus": (None, [vp, vp, vp]),
+            "orc_slam_new": (vp, [d, d, d, d, d, d, u32, u32]), "orc_slam_free": (None, [vp]),
+            "orc_slam_set_pose": (None, [vp, vp]), "orc_slam_get_pose": (None, [vp, vp]),
+            "orc_slam_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "orc_slam_enough_motion": (i32, [vp, vp]),
+            "orc_slam_processed_cells": (u32, [vp]), "orc_slam_iterations": (u32, [vp]),
+            "orc_slam_dm": (vp, [vp]), "orc_slam_occ": (vp, [vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -324,3 +329,44 @@ class PF:
         pose = np.array(pose4, dtype=np.float64)
         lib().orc_pf_draw_from_motion(self.h, _p(np.ascontiguousarray(delta4)), _p(pose))
         return pose
+
+
+class Slam:
+    """Oracle Slam2D (src/slam2d.cpp)."""
+
+    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=0.5, truncated_ray=0.0, truncated_range=0.0,
+                 resolution=0.05, patch_size=32, max_iter=100):
+        self.h = C.c_void_p(lib().orc_slam_new(trans_thresh, rot_thresh, l2_max, truncated_ray, truncated_range,
+                                               resolution, patch_size, max_iter))
+
+    def __del__(self):
+        if self.h:
+            lib().orc_slam_free(self.h)
+            self.h = None
+
+    def set_pose(self, pose4):
+        lib().orc_slam_set_pose(self.h, _p(np.ascontiguousarray(pose4, dtype=np.float64)))
+
+    def pose(self):
+        out = np.zeros(4)
+        lib().orc_slam_get_pose(self.h, _p(out))
+        return out
+
+    def update(self, pts, odom4, ts=0.0, origin=ZERO3, quat=IDENT_Q):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        return bool(lib().orc_slam_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(odom4)), ts))
+
+    def enough_motion(self, odom4):
+        return bool(lib().orc_slam_enough_motion(self.h, _p(np.ascontiguousarray(odom4))))
+
+    def processed_cells(self):
+        return lib().orc_slam_processed_cells(self.h)
+
+    def iterations(self):
+        return lib().orc_slam_iterations(self.h)
+
+    def dm(self):
+        return DM(lib().orc_slam_dm(self.h), owned=False)
+
+    def occ(self):
+        return Occ(lib().orc_slam_occ(self.h), owned=False)

@@ -210,3 +210,27 @@ def test_large_queue_paths_round_room(F, radius):
         assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
     print("radius", radius, "oracle max queue", pf.dm(0).stats()["max_queue"])
     ctx.close()
+
+
+def test_slam2d_online_gpu_vs_oracle(F):
+    """cfg 4: lama::Slam2D on the GPU (one-particle context, same kernels) free running next to the oracle's Slam2D."""
+    steps = 20
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    h = F.Slam2D()
+    assert h.engine_origin().endswith("liblama_hip.so")
+    o = O.Slam()
+    h.set_pose(*odom[0])
+    o.set_pose(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        assert h.update(pts[k], odom[k], float(k)) == o.update(pts[k], O.se2(*odom[k]), float(k))
+        d = np.abs(h.pose() - o.pose()).max()
+        assert d < 1e-7, (k, d)
+        if k > 0:
+            assert h.iterations() == o.iterations()
+        g = h.pose()
+        assert np.hypot(g[2] - truth[k][0], g[3] - truth[k][1]) < 0.03
+    # the maps agree bit for bit as long as the poses did not flip a cell; at 1e-7 m they do not on this log
+    ctx = h.hip_context()
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "slam occ")
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "slam dm")
+    h.close()

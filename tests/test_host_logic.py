@@ -109,3 +109,29 @@ def test_pose_algebra():
     F._hostlib().lama_pose_minus(F._p(a), F._p(b), F._p(got))
     assert np.array_equal(got, want)
     assert np.array_equal(F.pose_from_xyr(0.5, -0.25, 1.25), O.se2(0.5, -0.25, 1.25))
+
+
+def test_slam2d_host_matches_oracle_bitwise():
+    """lama::Slam2D (cfg 4: online SLAM = P=1 path) host orchestration vs the oracle restatement of src/slam2d.cpp."""
+    steps = 10
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o = O.Slam()
+    h = F.Slam2D()
+    assert h.engine_origin().endswith("liblama_cpu_engine.so")
+    o.set_pose(O.se2(*odom[0]))
+    h.set_pose(*odom[0])
+    for k in range(steps + 1):
+        od = odom[k]
+        assert o.enough_motion(O.se2(*od)) == h.enough_motion(od)
+        assert o.update(pts[k], O.se2(*od), float(k)) == h.update(pts[k], od, float(k))
+        assert np.array_equal(o.pose(), h.pose()), k
+        if k > 0:
+            assert o.iterations() == h.iterations()
+    # below-threshold motion: no update, pose untouched
+    small = odom[steps] + np.array([0.1, 0.0, 0.01])
+    assert not o.update(pts[steps], O.se2(*small)) and not h.update(pts[steps], small)
+    assert np.array_equal(o.pose(), h.pose())
+    ctx = h.hip_context()
+    from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "dm")
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "occ")
