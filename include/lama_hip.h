@@ -71,6 +71,9 @@ typedef struct lama_hip_cfg {
     uint32_t occ_patch_capacity; /* occupancy patches per particle (default 256)                  */
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
     uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */
+    uint32_t active_capacity;    /* parallel ray-cast: max. order-sensitive cell visits per particle and scan (default 8192) */
+    uint32_t sequential_raycast; /* ray-cast kernel: 0 = auto (parallel up to 1024 particles per call, beam-sequential above),
+                                    1 = always beam-sequential, 2 = always parallel; all bit-identical */
 } lama_hip_cfg;
 
 void lama_hip_default_cfg(lama_hip_cfg* cfg);

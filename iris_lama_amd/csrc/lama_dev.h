@@ -66,7 +66,11 @@ struct DevParams {
     uint64_t* q_lower;     // [P][qcap]
     uint64_t* q_raise;     // [P][qcap]
     uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
-    uint32_t* slow;        // [P] 1 = k_brushfire handed this particle to k_brushfire_slow
+    uint32_t* slow;        // [P] 1 = a stage handed this particle to the next (bigger / slower) stage
+    uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
+    uint32_t* act_count;   // [P]
+    uint64_t* occ_hit;     // [P][occ_cap][16] one bit per occupancy cell: hit in the current scan (all zero between scans)
+    uint32_t act_cap;
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
     uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused

@@ -45,6 +45,7 @@ struct lama_hip_ctx {
     uint32_t* d_qsizes = nullptr;
     uint64_t* d_dbg = nullptr;
     uint32_t* d_slow = nullptr;
+    uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0;
     double* d_tfs = nullptr;
@@ -119,6 +120,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
+    p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     return p;
 }
 
@@ -176,7 +178,17 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     DevParams prm = make_params(c, c->cur);
     {
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
-        hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+        // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
+        if (c->cfg.sequential_raycast == 1 || (c->cfg.sequential_raycast == 0 && count > 1024)) {
+            hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+        } else {
+            (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
+            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+            hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + RAY_BEAMS_PER_BLOCK - 1) / RAY_BEAMS_PER_BLOCK), dim3(256), 0, c->stream, prm,
+                               c->d_pts, (int)n, c->d_tfs, (int)first);
+            hipLaunchKernelGGL((k_ray_replay<2048, 2048, false>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_ray_replay<8192, 8192, true>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
+        }
         t.stop();
     }
     HIPCHK(c, hipGetLastError());
@@ -229,6 +241,7 @@ void lama_hip_default_cfg(lama_hip_cfg* cfg)
     cfg->dm_patch_capacity = 256;
     cfg->occ_patch_capacity = 256;
     cfg->queue_capacity = 32768;
+    cfg->active_capacity = 8192;
 }
 
 int32_t lama_hip_device_count(int32_t* count)
@@ -250,6 +263,8 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     if (cfg.dm_patch_capacity == 0) cfg.dm_patch_capacity = 256;
     if (cfg.occ_patch_capacity == 0) cfg.occ_patch_capacity = 256;
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
+    if (cfg.active_capacity == 0) cfg.active_capacity = 8192;
+    if (cfg.active_capacity > 8192) cfg.active_capacity = 8192;      // largest k_ray_replay stage
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)
@@ -292,6 +307,9 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 8 * 8));            CHK(hipMemset(c->d_dbg, 0, P * 8 * 8));
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
+    CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
+    CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
+    CHK(hipMalloc(&c->d_occ_hit, P * oc * 128));     CHK(hipMemset(c->d_occ_hit, 0, P * oc * 128));
     CHK(hipMalloc(&c->d_err, 4));                    CHK(hipMemset(c->d_err, 0, 4));
     CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
     CHK(hipMalloc(&c->d_loglik, P * 8));
@@ -316,7 +334,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow);
+    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
     (void)hipFree(c->d_err); (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs); (void)hipFree(c->d_loglik);
     (void)hipFree(c->d_iters); (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);

@@ -357,8 +357,13 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
         const int64_t a0 = d0 < 0 ? -d0 : d0, a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
         const int64_t nn = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2);
         const int s0 = d0 < 0 ? -1 : 1, s1 = d1 < 0 ? -1 : 1;
-        const int steps = nn > 0 ? (int)nn - 1 : 0;          // free cells t = 1 .. n-1 (src/sdm/map.cpp:198-227)
+        int steps = nn > 0 ? (int)nn - 1 : 0;                // free cells t = 1 .. n-1 (src/sdm/map.cpp:198-227)
+        if (nn >= 8192) { if (lane == 0) atomicOr(prm.err, ERR_WINDOW); steps = 0; }   // longer than any window: cannot fit
         ray_cells += (uint64_t)steps;
+        // steps_j(t) = floor((2 t a_j + n) / (2 n)) without a per-lane division: n < 2^13 so the numerator is < 2^27 and
+        // q = (num * M) >> 42 with M = floor(2^42 / (2n)) + 1 is exact (num * 2n < 2^42); one division per beam.
+        const uint64_t magic = (1ull << 42) / (uint64_t)(2 * (nn > 0 ? nn : 1)) + 1ull;
+        const uint32_t ua0 = (uint32_t)a0, ua1 = (uint32_t)a1, un = (uint32_t)nn;
 
         // sections of 64 lanes over t = 0 (the hit cell, :493-498) , 1 .. steps (the free cells, :500-504)
         for (int base = 0; base <= steps; base += 64) {
@@ -368,9 +373,9 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
             uint32_t cx, cy;
             if (is_hit) { cx = mhx; cy = mhy; }
             else {
-                const int64_t st0 = (2 * (int64_t)t * a0 + nn) / (2 * (nn > 0 ? nn : 1));
-                const int64_t st1 = (2 * (int64_t)t * a1 + nn) / (2 * (nn > 0 ? nn : 1));
-                cx = (uint32_t)((int64_t)msx + s0 * st0); cy = (uint32_t)((int64_t)msy + s1 * st1);
+                const uint32_t st0 = (uint32_t)(((uint64_t)(2u * (uint32_t)t * ua0 + un) * magic) >> 42);
+                const uint32_t st1 = (uint32_t)(((uint64_t)(2u * (uint32_t)t * ua1 + un) * magic) >> 42);
+                cx = msx + (uint32_t)(s0 * (int)st0); cy = msy + (uint32_t)(s1 * (int)st1);
             }
             const uint32_t rx = cx - prm.wx0, ry = cy - prm.wy0;
             const bool inwin = rx < prm.WC && ry < prm.WC;
@@ -949,6 +954,10 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
     prm.stats[4 * p + 3] += c.processed;
     prm.slow[p] = 0;
 }
+
+} // namespace lama_dev
+#include "lama_raycast_par.h"
+namespace lama_dev {
 
 // ------------------------------------------------------------------------------------------------
 // k_copy_particles -- dst particle i := src particle idx[i] (directories, counts, used slots of every

@@ -1,0 +1,357 @@
+// lama_raycast_par.h -- parallel EXACT ray-cast of PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:458-505).
+//
+// k_raycast (lama_kernels.h) walks the 1080 beams of a particle one after the other because the reference's
+// result is order dependent in one respect only: WHICH visit of a cell crosses the 0.25 occupancy threshold
+// decides where the add/remove-obstacle event lands in the brushfire queues.  The uint16 counters themselves
+// commute.  This file splits the work accordingly:
+//
+//   k_ray_hits   (thread / beam)   : the hit cells of this scan are flagged (one bit per cell) and queued as
+//                                    "active" visits;
+//   k_ray_visits (wave / 4 beams)  : every free-cell visit (beam, t) in parallel.  A visit is INERT when its cell
+//                                    is not hit in this scan and is already free (4*occupied < visited: a miss can
+//                                    never raise an event, src/sdm/frequency_occupancy_map.cpp:65-74) or brand new
+//                                    (visited == 0: its first miss always raises removeObstacle, which is a no-op
+//                                    on the distance map apart from get()'s patch allocation + mask bit): inert
+//                                    visits are one atomicAdd.  All other visits (cells hit in this scan, cells at
+//                                    or above the threshold) are ACTIVE: appended to a list, the cell untouched;
+//   k_ray_replay (workgroup / particle): sorts the active list by (cell, beam, step), replays every active cell's
+//                                    visits in the reference's order from the untouched (occupied, visited) state
+//                                    -- one thread per cell, cells in parallel -- applies add/removeObstacle to the
+//                                    distance-map cell, then sorts the resulting events by (beam, step) and writes
+//                                    the lower/raise queues exactly as the sequential code would have pushed them.
+//
+// Exactness caveat (documented in DESIGN.md): a cell whose uint16 `visited` counter wraps to 0 inside a scan
+// (65,536 visits) is treated like the reference does for the counters, but a wrap can make an "inert" cell active
+// mid-scan; the sequential kernel (cfg.sequential_raycast) is exact there too.
+#pragma once
+#include "lama_dev.h"
+
+namespace lama_dev {
+
+constexpr int RAY_BEAMS_PER_BLOCK = 16;      // k_ray_visits: 4 waves x 4 beams
+constexpr int RP_BLOCK = 256;
+
+// ---- directory entry (int16 inside an aligned 32-bit word) with lock-free allocation ----------------------
+// -1 = absent, -2 = being allocated, -3 = allocation failed (arena full), >= 0 = slot (never changes afterwards)
+__device__ inline int dir_get_or_alloc(int16_t* dir, uint32_t pidx, int32_t* count, int cap, int errbit, int32_t* err)
+{
+    int s = dir[pidx];
+    if (s >= 0) return s;
+    uint32_t* w = reinterpret_cast<uint32_t*>(dir) + (pidx >> 1);
+    const int sh = (int)(pidx & 1u) * 16;
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s = (int)(int16_t)((v >> sh) & 0xFFFFu);
+        if (s >= 0) return s;
+        if (s == -3) return -1;
+        if (s == -1) {
+            const uint32_t locked = (v & ~(0xFFFFu << sh)) | (0xFFFEu << sh);
+            if (atomicCAS(w, v, locked) == v) {
+                int ns = atomicAdd(count, 1);
+                if (ns >= cap) { atomicSub(count, 1); atomicOr(err, errbit); ns = -3; }
+                for (;;) {      // publish our half (the other half may change concurrently)
+                    const uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t nv = (cur & ~(0xFFFFu << sh)) | (((uint32_t)(uint16_t)(int16_t)ns) << sh);
+                    if (atomicCAS(w, cur, nv) == cur) break;
+                }
+                return ns >= 0 ? ns : -1;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct BeamGeom {
+    uint32_t mhx, mhy, msx, msy;   // hit / start cell (map coordinates)
+    uint32_t a0, a1, nn;           // |delta| per axis, n = max over the three axes
+    int s0, s1;
+    bool mark_hit;
+    int steps;
+    uint64_t magic;
+};
+
+// hit / start cells of one beam (src/pf_slam2d.cpp:463-493), identical arithmetic to k_raycast
+__device__ inline BeamGeom beam_geometry(const DevParams& prm, const double* T, double px, double py, double pz)
+{
+    double hx = ((T[0] * px + T[1] * py) + T[2] * pz) + T[9];
+    double hy = ((T[3] * px + T[4] * py) + T[5] * pz) + T[10];
+    double hz = ((T[6] * px + T[7] * py) + T[8] * pz) + T[11];
+    double sx = T[9], sy = T[10], sz = T[11];
+    double abx = 0, aby = 0, abz = 0, ray_length = 1.0;
+    BeamGeom g;
+    g.mark_hit = true;
+    if (prm.trunc_range > 0.0) {
+        abx = hx - sx; aby = hy - sy; abz = hz - sz;
+        ray_length = sqrt((abx * abx + aby * aby) + abz * abz);
+        if (prm.trunc_range < ray_length) {
+            hx = sx + abx / ray_length * prm.trunc_range;
+            hy = sy + aby / ray_length * prm.trunc_range;
+            hz = sz + abz / ray_length * prm.trunc_range;
+            g.mark_hit = false;
+        }
+    }
+    if (g.mark_hit && prm.trunc_ray > 0.0) {
+        if (prm.trunc_range == 0.0) {
+            abx = hx - sx; aby = hy - sy; abz = hz - sz;
+            ray_length = sqrt((abx * abx + aby * aby) + abz * abz);
+        }
+        if (prm.trunc_ray < ray_length) {
+            sx = hx - abx / ray_length * prm.trunc_ray;
+            sy = hy - aby / ray_length * prm.trunc_ray;
+            sz = hz - abz / ray_length * prm.trunc_ray;
+        }
+    }
+    g.mhx = w2m(prm, hx); g.mhy = w2m(prm, hy);
+    g.msx = w2m(prm, sx); g.msy = w2m(prm, sy);
+    const uint32_t mhz = w2m(prm, hz), msz = w2m(prm, sz);
+    const int64_t d0 = (int64_t)g.mhx - (int64_t)g.msx, d1 = (int64_t)g.mhy - (int64_t)g.msy, d2 = (int64_t)mhz - (int64_t)msz;
+    const int64_t a0 = d0 < 0 ? -d0 : d0, a1 = d1 < 0 ? -d1 : d1, a2 = d2 < 0 ? -d2 : d2;
+    const int64_t nn = a0 > a1 ? (a0 > a2 ? a0 : a2) : (a1 > a2 ? a1 : a2);
+    g.s0 = d0 < 0 ? -1 : 1; g.s1 = d1 < 0 ? -1 : 1;
+    g.a0 = (uint32_t)a0; g.a1 = (uint32_t)a1; g.nn = (uint32_t)(nn > 0xFFFFFFFFll ? 0xFFFFFFFFll : nn);
+    g.steps = nn > 0 ? (int)g.nn - 1 : 0;
+    if (nn >= 8192) g.steps = -1;                       // longer than any window
+    g.magic = (1ull << 42) / (uint64_t)(2 * (nn > 0 && nn < 8192 ? nn : 1)) + 1ull;
+    return g;
+}
+
+// active-visit key: (cellkey << 24) | seq, cellkey = ry << 13 | rx, seq = beam << 13 | t  (t = 0: the hit)
+__device__ inline uint64_t act_key(uint32_t rx, uint32_t ry, uint32_t beam, uint32_t t)
+{
+    return ((uint64_t)((ry << 13) | rx) << 24) | (uint64_t)((beam << 13) | t);
+}
+
+__device__ inline void act_append(const DevParams& prm, int p, uint64_t key)
+{
+    const uint32_t k = atomicAdd(prm.act_count + p, 1u);
+    if (k < prm.act_cap) prm.act[(size_t)p * prm.act_cap + k] = key;
+    else atomicOr(prm.err, ERR_QUEUE);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* __restrict__ pts, int n,
+                                                   const double* __restrict__ tfs, int first_particle)
+{
+    const int p = first_particle + blockIdx.x;
+    const int i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t WW = (size_t)prm.W * prm.W;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
+    const BeamGeom g = beam_geometry(prm, T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    if (g.steps < 0) { atomicOr(prm.err, ERR_WINDOW); return; }
+    if (g.steps > 0) atomicAdd((unsigned long long*)(prm.stats + 4 * p + 2), (unsigned long long)g.steps);
+    if (!g.mark_hit) return;
+    const uint32_t rx = g.mhx - prm.wx0, ry = g.mhy - prm.wy0;
+    if (rx >= prm.WC || ry >= prm.WC) { atomicOr(prm.err, ERR_WINDOW); return; }
+    const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
+    const int slot = dir_get_or_alloc(prm.occ_dir + (size_t)p * WW, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+    if (slot < 0) return;
+    atomicOr((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), 1ull << (ci & 63));
+    act_append(prm, p, act_key(rx, ry, (uint32_t)i, 0u));
+}
+
+__global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double* __restrict__ pts, int n,
+                                                     const double* __restrict__ tfs, int first_particle)
+{
+    const int p = first_particle + blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t WW = (size_t)prm.W * prm.W;
+    int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
+    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
+    uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    double T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
+    const int b0 = blockIdx.y * RAY_BEAMS_PER_BLOCK + wave * (RAY_BEAMS_PER_BLOCK / 4);
+    for (int bi = 0; bi < RAY_BEAMS_PER_BLOCK / 4; ++bi) {
+        const int i = b0 + bi;
+        if (i >= n) break;
+        const BeamGeom g = beam_geometry(prm, T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        for (int base = 0; base < g.steps; base += 64) {
+            const int t = base + lane + 1;
+            if (t > g.steps) continue;
+            const uint32_t st0 = (uint32_t)(((uint64_t)(2u * (uint32_t)t * g.a0 + g.nn) * g.magic) >> 42);
+            const uint32_t st1 = (uint32_t)(((uint64_t)(2u * (uint32_t)t * g.a1 + g.nn) * g.magic) >> 42);
+            const uint32_t cx = g.msx + (uint32_t)(g.s0 * (int)st0), cy = g.msy + (uint32_t)(g.s1 * (int)st1);
+            const uint32_t rx = cx - prm.wx0, ry = cy - prm.wy0;
+            if (rx >= prm.WC || ry >= prm.WC) { atomicOr(prm.err, ERR_WINDOW); continue; }
+            const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
+            const int slot = dir_get_or_alloc(occ_dir, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+            if (slot < 0) continue;
+            const uint64_t bit = 1ull << (ci & 63);
+            const bool hitcell = (prm.occ_hit[((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)] & bit) != 0;
+            uint32_t* cell = occ + (size_t)slot * 1024 + ci;
+            const uint32_t v = *cell;
+            const uint32_t o0 = v & 0xFFFFu, v0 = v >> 16;
+            const bool inert = !hitcell && (v0 == 0 ? o0 == 0 : 4u * o0 < v0);
+            if (inert && v0 != 0 && v0 < 0xF000u) {
+                atomicAdd(cell, 0x10000u);                                   // visited++ (setFree): no event, no wrap possible
+            } else if (inert) {
+                const uint32_t old = atomicAdd(cell, 0x10000u);              // visited++ (setFree, no event possible ...)
+                if (old == 0) {                                              // ... except the first miss of a new cell:
+                    // removeObstacle on a cell that cannot be an obstacle = get(): patch allocation + mask bit (:228-234)
+                    const int ds = dir_get_or_alloc(dm_dir, pidx, prm.counts + 2 * p, (int)prm.dm_cap, ERR_DM_CAP, prm.err);
+                    if (ds >= 0) atomicOr((unsigned long long*)(prm.dm_mask + ((size_t)p * prm.dm_cap + ds) * 16 + (ci >> 6)), (unsigned long long)bit);
+                }
+                if ((old >> 16) == 0xFFFFu)                                  // uint16 wrap: keep the Container mask bit
+                    atomicOr((unsigned long long*)(prm.occ_mask + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), (unsigned long long)bit);
+            } else {
+                act_append(prm, p, act_key(rx, ry, (uint32_t)i, (uint32_t)t));
+            }
+        }
+    }
+}
+
+// ---- in-LDS bitonic sort (ascending) of m = 2^k keys by RP_BLOCK threads ---------------------------------
+__device__ inline void bitonic_sort(uint64_t* a, uint32_t m)
+{
+    for (uint32_t k = 2; k <= m; k <<= 1) {
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < m; i += RP_BLOCK) {
+                const uint32_t ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int SORT_CAP, int EV_CAP>
+struct ReplayLds {
+    uint64_t keys[SORT_CAP];
+    uint64_t ev[EV_CAP];
+    uint32_t ev_n;
+    uint32_t nadd, nrem;
+};
+
+// event: (seq << 32) | (is_add << 31) | cellkey
+template <int SORT_CAP, int EV_CAP, bool RESUME>
+__global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int first_particle)
+{
+    __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
+    const int p = first_particle + blockIdx.x;
+    const uint32_t n = prm.act_count[p];
+    if (RESUME && prm.slow[p] == 0) return;
+    if (n > prm.act_cap) return;                              // overflow already reported by act_append
+    if (n > (uint32_t)SORT_CAP) {                             // hand over to the next (bigger) stage
+        if (threadIdx.x == 0) { if (RESUME) atomicOr(prm.err, ERR_QUEUE); else prm.slow[p] = 1; }
+        return;
+    }
+    const size_t WW = (size_t)prm.W * prm.W;
+    int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
+    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
+    uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    uint16_t* dm_sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
+    uint32_t* dm_obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
+    uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
+    uint64_t* q_raise = prm.q_raise + (size_t)p * prm.qcap;
+
+    uint32_t m = 1;
+    while (m < n) m <<= 1;
+    const uint64_t* src = prm.act + (size_t)p * prm.act_cap;
+    for (uint32_t i = threadIdx.x; i < m; i += RP_BLOCK) sh.keys[i] = i < n ? src[i] : ~0ull;
+    if (threadIdx.x == 0) { sh.ev_n = 0; sh.nadd = 0; sh.nrem = 0; }
+    __syncthreads();
+    if (m > 1) bitonic_sort(sh.keys, m);
+
+    // ---- per-cell replay in the reference's visit order (one thread per active cell) ----
+    for (uint32_t i = threadIdx.x; i < n; i += RP_BLOCK) {
+        const uint64_t k0 = sh.keys[i];
+        const uint32_t ck = (uint32_t)(k0 >> 24);
+        if (i > 0 && (uint32_t)(sh.keys[i - 1] >> 24) == ck) continue;      // not the first visit of its cell
+        const uint32_t rx = ck & 8191u, ry = ck >> 13;
+        const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
+        const uint64_t bit = 1ull << (ci & 63);
+        const int slot = occ_dir[pidx];                                     // allocated by k_ray_hits / k_ray_visits
+        if (slot < 0) continue;
+        uint32_t* cell = occ + (size_t)slot * 1024 + ci;
+        const uint32_t v = *cell;
+        uint32_t o = v & 0xFFFFu, vis = v >> 16;
+        bool dm_loaded = false, dirty = false, had_hit = false;
+        int dslot = -1;
+        uint16_t s = 0;
+        for (uint32_t j = i; j < n; ++j) {
+            const uint64_t kj = sh.keys[j];
+            if ((uint32_t)(kj >> 24) != ck) break;
+            const uint32_t seq = (uint32_t)(kj & 0xFFFFFFu);
+            const bool is_hit = (seq & 8191u) == 0;
+            bool changed;
+            if (is_hit) {                                                   // setOccupied (frequency_occupancy_map.cpp:81-91)
+                had_hit = true;
+                const bool occupied = vis != 0 && 4u * o > vis;
+                o = (o + 1) & 0xFFFFu; vis = (vis + 1) & 0xFFFFu;
+                changed = !occupied && (vis != 0 && 4u * o > vis);
+            } else {                                                        // setFree (:65-74)
+                const bool was_free = vis != 0 && 4u * o < vis;
+                vis = (vis + 1) & 0xFFFFu;
+                changed = !was_free && (vis != 0 && 4u * o < vis);
+            }
+            if (vis == 0) atomicOr((unsigned long long*)(prm.occ_mask + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), (unsigned long long)bit);
+            if (!changed) continue;
+            if (!dm_loaded) {                                               // add/removeObstacle: get() = allocate + mask bit
+                dslot = dir_get_or_alloc(dm_dir, pidx, prm.counts + 2 * p, (int)prm.dm_cap, ERR_DM_CAP, prm.err);
+                dm_loaded = true;
+                if (dslot >= 0) {
+                    atomicOr((unsigned long long*)(prm.dm_mask + ((size_t)p * prm.dm_cap + dslot) * 16 + (ci >> 6)), (unsigned long long)bit);
+                    s = dm_sv[dslot * 1024 + (int)ci];
+                }
+            }
+            if (dslot < 0) continue;
+            const bool is_obstacle = (s & SV_VALID) && (s & SV_SQMASK) == 0;
+            bool emit = false;
+            if (is_hit && !is_obstacle) { s = (uint16_t)(SV_VALID | SV_QUEUED); emit = true; }     // addObstacle :212-226
+            if (!is_hit && is_obstacle) { s = SV_QUEUED; emit = true; }                            // removeObstacle :228-242
+            if (emit) {
+                dirty = true;
+                const uint32_t e = atomicAdd(&sh.ev_n, 1u);
+                if (e < (uint32_t)EV_CAP) sh.ev[e] = ((uint64_t)seq << 32) | ((uint64_t)(is_hit ? 1u : 0u) << 31) | ck;
+                else atomicOr(prm.err, ERR_QUEUE);
+            }
+        }
+        *cell = o | (vis << 16);
+        if (dirty) { dm_sv[dslot * 1024 + (int)ci] = s; dm_obs[dslot * 1024 + (int)ci] = 0; }
+        if (had_hit) atomicAnd((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), ~(unsigned long long)bit);
+    }
+    __syncthreads();
+
+    // ---- events in (beam, step) order -> lower (adds) / raise (removes) queues ----
+    const uint32_t ne = sh.ev_n < (uint32_t)EV_CAP ? sh.ev_n : (uint32_t)EV_CAP;
+    uint32_t me = 1;
+    while (me < ne) me <<= 1;
+    for (uint32_t i = ne + threadIdx.x; i < me; i += RP_BLOCK) sh.ev[i] = ~0ull;
+    __syncthreads();
+    if (me > 1) bitonic_sort(sh.ev, me);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t nadd = 0, nrem = 0;
+        for (uint32_t base = 0; base < ne; base += 64) {
+            const uint32_t i = base + lane;
+            const bool act = i < ne;
+            const uint64_t e = act ? sh.ev[i] : 0ull;
+            const bool is_add = act && ((e >> 31) & 1ull);
+            const bool is_rem = act && !is_add;
+            const unsigned long long ma = __ballot(is_add), mr = __ballot(is_rem);
+            const uint32_t ck = (uint32_t)(e & 0x3FFFFFFu);
+            const int rx = (int)(ck & 8191u), ry = (int)(ck >> 13);
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            if (is_add) { const uint32_t k = nadd + (uint32_t)__popcll(ma & lt); if (k < prm.qcap) q_lower[k] = q_entry(0, rx, ry); else atomicOr(prm.err, ERR_QUEUE); }
+            if (is_rem) { const uint32_t k = nrem + (uint32_t)__popcll(mr & lt); if (k < prm.qcap) q_raise[k] = q_entry(0, rx, ry); else atomicOr(prm.err, ERR_QUEUE); }
+            nadd += (uint32_t)__popcll(ma);
+            nrem += (uint32_t)__popcll(mr);
+        }
+        if (lane == 0) {
+            prm.qsizes[2 * p] = nadd < prm.qcap ? nadd : prm.qcap;
+            prm.qsizes[2 * p + 1] = nrem < prm.qcap ? nrem : prm.qcap;
+            prm.act_count[p] = 0;
+            prm.slow[p] = 0;
+        }
+    }
+}
+
+} // namespace lama_dev

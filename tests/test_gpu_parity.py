@@ -37,8 +37,8 @@ def _angle(p):
     return np.arctan2(p[..., 1], p[..., 0])
 
 
-@pytest.mark.parametrize("P,steps", [(8, 12), (40, 4)])
-def test_stagewise_parity_corridor(F, P, steps):
+@pytest.mark.parametrize("P,steps,seq_ray", [(8, 12, 2), (8, 12, 1), (40, 4, 0)])
+def test_stagewise_parity_corridor(F, P, steps, seq_ray):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
     opts = O.default_options(particles=P, seed=7)
@@ -47,7 +47,7 @@ def test_stagewise_parity_corridor(F, P, steps):
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
 
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray))
     ctx.init(pts[0], pose0)
     for i in (0, P - 1):
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"init occ p{i}")
@@ -180,8 +180,9 @@ def test_sharded_two_ranks_one_gpu_gloo(F):
     h.close()
 
 
+@pytest.mark.parametrize("seq_ray", [2, 1])
 @pytest.mark.parametrize("radius", [4.0, 8.0, 12.0, 20.0])
-def test_large_queue_paths_round_room(F, radius):
+def test_large_queue_paths_round_room(F, radius, seq_ray):
     """Round rooms of growing radius: the brushfire queue outgrows its LDS window, first mid-run (spill to
     k_brushfire_slow) and then from the start; the maps must stay bit-exact on every path."""
     n = 1080
@@ -194,7 +195,7 @@ def test_large_queue_paths_round_room(F, radius):
     pf = O.PF(O.default_options(particles=P, seed=1))
     pf.set_prior(pose0)
     pf.update(pts, pose0)
-    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024))
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024, sequential_raycast=seq_ray))
     ctx.init(pts, pose0)
     # second scan from slightly different poses: removals (raise wave) + additions
     r2 = radius + rng.normal(0, 0.01, n)
