@@ -1,0 +1,112 @@
+// lama/loc2d.h -- host-side lama::Loc2D (localisation on a fixed map) on the MI355X path.
+//
+// Same class name, Options fields and public methods as the reference's include/lama/loc2d.h:47-165; update()
+// follows src/loc2d.cpp:126-192.  The public members `occupancy_map` / `distance_map` of the reference are host maps
+// that consumers (iris_lama_ros' loc2d_ros) fill cell by cell before the first update; here they are small proxies
+// with the methods that use needs (w2m, setFree/setOccupied/setUnknown, addObstacle, update, setMaxDistance): the
+// obstacle cells are buffered on the host and DynamicDistanceMap::addObstacle + update() run on the device when
+// distance_map->update() is called.  Scan matching with covariance (Solve(..., &cov)) and the RMSE run on the device
+// (lama_hip_match_solve).  Not available on the device path: strategy "lm", globalLocalization /
+// triggerGlobalLocalization (:249-286) and cov_blend > 0 (addSamplingCovariance, :199-247) -- they throw.
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "pose2d.h"
+
+struct lama_hip_ctx;
+
+namespace lama {
+
+struct HipEngine;
+
+struct Vector3ui {
+    uint32_t v[3] = {0, 0, 0};
+    Vector3ui() {}
+    Vector3ui(uint32_t a, uint32_t b, uint32_t c) { v[0] = a; v[1] = b; v[2] = c; }
+    uint32_t& operator()(int i) { return v[i]; }
+    uint32_t operator()(int i) const { return v[i]; }
+    uint32_t& operator[](int i) { return v[i]; }
+    uint32_t operator[](int i) const { return v[i]; }
+};
+
+struct Matrix3d_ {      // 3x3 row-major stand-in for Eigen::Matrix3d (getCovar)
+    double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double operator()(int r, int c) const { return m[3 * r + c]; }
+    double& operator()(int r, int c) { return m[3 * r + c]; }
+};
+
+class Loc2D {
+public:
+    struct Options {
+        Options();
+        double trans_thresh, rot_thresh, l2_max, resolution;
+        uint32_t patch_size, max_iter;
+        std::string strategy;
+        uint32_t gloc_particles, gloc_iters;
+        double gloc_thresh, cov_blend;
+        int32_t gpu_device = 0;      // addition
+    };
+
+    // Map::w2m of the reference (include/lama/sdm/map.h:125-126) for both proxies
+    struct MapProxy {
+        double resolution = 0.05, scale = 20.0;
+        Vector3ui w2m(const Vector3d& p) const;
+    };
+    struct OccupancyMapProxy : MapProxy {          // SimpleOccupancyMap: int8 tri-state kept on the host
+        bool setFree(const Vector3ui& c);
+        bool setOccupied(const Vector3ui& c);
+        bool setUnknown(const Vector3ui& c);
+        bool isFree(const Vector3ui& c) const;
+        bool isOccupied(const Vector3ui& c) const;
+        std::unordered_map<uint64_t, int8_t> cells;
+    };
+    struct DistanceMapProxy : MapProxy {
+        void setMaxDistance(double d) { l2_max = d; }
+        void addObstacle(const Vector3ui& c) { pending.push_back(c(0)); pending.push_back(c(1)); }
+        uint32_t update();                          // uploads the pending obstacles, runs the brushfire on the device
+        double l2_max = 1.0;
+        std::vector<uint32_t> pending;
+        Loc2D* owner = nullptr;
+    };
+
+    OccupancyMapProxy* occupancy_map = nullptr;
+    DistanceMapProxy* distance_map = nullptr;
+
+    Loc2D() = default;
+    void Init(const Options& options = Options());
+    virtual ~Loc2D();
+
+    bool enoughMotion(const Pose2D& odometry);
+    bool update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp, bool force_update = false);
+    void triggerGlobalLocalization();
+    void setPose(const Pose2D& pose) { pose_ = pose; has_first_scan = false; }
+    const Pose2D& getPose() const { return pose_; }
+    const Matrix3d_& getCovar() const { return cov_; }
+    double getRMSE() const { return rmse_; }
+    bool globalLocalizationIsActive() const { return false; }
+    uint32_t getLastIterations() const { return last_iterations_; }
+    lama_hip_ctx* deviceContext() const { return ctx_; }
+    const HipEngine* engine() const { return eng_.get(); }
+
+private:
+    friend struct DistanceMapProxy;
+    void ensureContext();
+    void solve(const PointCloudXYZ& surface, bool do_solve);
+    void fail(int32_t rc, const char* what) const;
+
+    Options opt_;
+    std::shared_ptr<HipEngine> eng_;
+    lama_hip_ctx* ctx_ = nullptr;
+    Pose2D odom_, pose_;
+    Matrix3d_ cov_;
+    double rmse_ = 0.0;
+    bool has_first_scan = false;
+    uint32_t last_iterations_ = 0;
+};
+
+} // namespace lama

@@ -130,6 +130,18 @@ int32_t lama_hip_match_batch(lama_hip_ctx* ctx, uint32_t particle, const double*
                              const double* sensor_origin3, const double* sensor_quat_wxyz,
                              const double* poses, uint32_t num_poses, double* loglik_out);
 
+/* Static-map localisation support (Loc2D, src/loc2d.cpp:61-192) on a one-particle context:
+ *  lama_hip_map_add_obstacles: DynamicDistanceMap::addObstacle for every cell of the list (map coordinates as
+ *      returned by Map::w2m, x then y, in the given order) followed by dm->update().  On a context that has not seen
+ *      lama_hip_pf_init it also places the map window (centred on the first cell).
+ *  lama_hip_match_solve: Solve(GaussNewton + Cauchy(0.15), MatchSurface2D(dm, scan, pose), &cov): pose_inout {c,s,tx,ty};
+ *      out7 = lower triangle of J^T J (weighted J at the solution: 00,10,11,20,21,22) and the sum of squared unweighted
+ *      residuals; iters_out = solver iterations.  do_solve == 0 only evaluates at the given pose. */
+int32_t lama_hip_map_add_obstacles(lama_hip_ctx* ctx, uint32_t particle, const uint32_t* cells_xy, uint32_t n);
+int32_t lama_hip_match_solve(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                             const double* sensor_origin3, const double* sensor_quat_wxyz, double* pose_inout,
+                             double* out7, int32_t* iters_out, int32_t do_solve);
+
 /* Particle shipping for multi-GPU resampling (one context per GPU): serialise one particle (pose + both
  * maps, used patches only) into a DEVICE buffer / restore it into slot `particle` of this context.
  * export returns the number of bytes needed in *bytes when buf == NULL. */

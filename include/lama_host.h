@@ -110,6 +110,23 @@ uint32_t lama_slam_iterations(const lama_slam* s);
 void* lama_slam_device_context(const lama_slam* s);
 const char* lama_slam_engine_origin(const lama_slam* s);
 
+/* ---- lama::Loc2D (include/lama/loc2d.h), flattened ---- */
+typedef struct lama_loc lama_loc;
+lama_loc* lama_loc_create(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                          int32_t gpu_device, char* err, int errcap);
+void lama_loc_destroy(lama_loc* l);
+const char* lama_loc_last_error(const lama_loc* l);
+const char* lama_loc_engine_origin(const lama_loc* l);
+/* distance_map->addObstacle(w2m(x, y)) for every world point, then distance_map->update() */
+int lama_loc_set_obstacles_world(lama_loc* l, const double* xy, uint32_t n);
+void lama_loc_set_pose(lama_loc* l, double x, double y, double yaw);
+int lama_loc_get_pose(const lama_loc* l, double* pose4);
+int lama_loc_update(lama_loc* l, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                    const double* odom_xyr, double timestamp, int force_update);   /* 1 / 0 / <0 */
+int lama_loc_covar(const lama_loc* l, double* out9);
+double lama_loc_rmse(const lama_loc* l);
+uint32_t lama_loc_iterations(const lama_loc* l);
+
 #ifdef __cplusplus
 }
 #endif

@@ -567,6 +567,68 @@ int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* p
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uint32_t* cells_xy, uint32_t n)
+{
+    if (!c || !cells_xy || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!c->initialised) {
+        c->wx0 = ((cells_xy[0] >> 5) - c->W / 2) * 32;
+        c->wy0 = ((cells_xy[1] >> 5) - c->W / 2) * 32;
+        for (uint32_t p = 0; p < c->P; ++p) { c->h_poses[4 * p] = 1.0; c->h_poses[4 * p + 1] = 0.0; c->h_poses[4 * p + 2] = 0.0; c->h_poses[4 * p + 3] = 0.0; }
+        HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
+        c->initialised = true;
+    }
+    uint32_t* d_cells = nullptr;
+    HIPCHK(c, hipMalloc(&d_cells, sizeof(uint32_t) * 2 * (size_t)n));
+    HIPCHK(c, hipMemcpyAsync(d_cells, cells_xy, sizeof(uint32_t) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    DevParams prm = make_params(c, c->cur);
+    // queue capacity bounds one batch of additions; larger lists go in slices (each followed by dm->update(): adding
+    // obstacles then updating in slices yields the same distance map only if no slice boundary matters -- so a list
+    // longer than the queue is rejected instead)
+    if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
+    hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
+    hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false>), dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
+    hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true>), dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
+    hipLaunchKernelGGL(k_brushfire_slow, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
+    HIPCHK(c, hipGetLastError());
+    int32_t rc = check_device_errors(c);
+    (void)hipFree(d_cells);
+    if (rc) return rc;
+    return refresh_counts_and_stats(c, true, false);
+}
+
+int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                             double* pose_inout, double* out7, int32_t* iters_out, int32_t do_solve)
+{
+    if (!c || !pts || !pose_inout || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_match_solve before a map exists");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    if (c->b_cap < 4) {
+        (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+        c->d_bposes = nullptr; c->d_bout = nullptr; c->b_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_bposes, sizeof(double) * 4 * 16));
+        HIPCHK(c, hipMalloc(&c->d_bout, sizeof(double) * 16));
+        c->b_cap = 16;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_bposes, pose_inout, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream));
+    const Affine mtf = moving_tf(origin3, quat);
+    DevParams prm = make_params(c, c->cur);
+    hipLaunchKernelGGL(k_match_solve, dim3(1), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout,
+                       c->d_iters, (int)do_solve);
+    HIPCHK(c, hipGetLastError());
+    double o7[7]; int32_t it = 0;
+    HIPCHK(c, hipMemcpyAsync(pose_inout, c->d_bposes, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(o7, c->d_bout, sizeof(double) * 7, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&it, c->d_iters, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    rc = check_device_errors(c);
+    if (rc) return rc;
+    if (out7) std::memcpy(out7, o7, sizeof(o7));
+    if (iters_out) *iters_out = it;
+    return LAMA_HIP_OK;
+}
+
 // Particle blob layout: [pose 4 f64][counts 2 i32][dm_dir][occ_dir][dm_sv used][dm_obs used][dm_mask used][occ used][occ_mask used]
 static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
 {

@@ -102,28 +102,15 @@ struct SMShared {
 };
 
 // ------------------------------------------------------------------------------------------------
-// k_scan_match: PFSlam2D::scanMatch (src/pf_slam2d.cpp:416-437) for every particle of the shard.
-// Solver::solve loop (src/nlls/solver.cpp:67-107) with GaussNewton (gauss_newton.cpp:53-91).
+// Solver::solve loop (src/nlls/solver.cpp:67-107) with GaussNewton (src/nlls/gauss_newton.cpp:53-91) and
+// CauchyWeight(0.15), executed by one workgroup on the problem (dir, sv, pts, state in sh.state).
+// On return sh.state / sh.tf hold the solution; returns the iteration count (applied + reverted steps).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const double* __restrict__ pts, int n, Affine mtf,
-                                                          double* __restrict__ loglik_out, int32_t* __restrict__ iters_out)
+__device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, const uint16_t* sv, const double* __restrict__ pts, int n,
+                                    const Affine& mtf, SMShared& sh, uint32_t& evals)
 {
-    __shared__ SMShared sh;
-    const int p = blockIdx.x;
-    const int16_t* dir = prm.dm_dir + (size_t)p * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
     const double eps1 = 1e-4, eps2 = 1e-4;
-
-    if (threadIdx.x == 0) {
-        const double* q = prm.poses + 4 * p;
-        sh.state = SE2{q[0], q[1], q[2], q[3]};
-        sh.tf = scan_tf(sh.state, mtf);
-        sh.ctl = 0;
-    }
-    __syncthreads();
-
-    uint32_t iter = 0, evals = 0;
-    bool numeric_ok = true;
+    uint32_t iter = 0;
     while (iter < prm.max_iter) {
         // 1. residuals + Jacobian at the current state, weighted, reduced
         double acc[10];
@@ -166,10 +153,9 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
             const Affine tf = sh.tf;
             eval_beams_res(prm, dir, sv, pts, n, tf, a2);
         }
-        block_sum<2>(a2, sh.red, sh.tot + 0);   // tot[9] (chi2) is overwritten? no: tot[0..1] only
+        block_sum<2>(a2, sh.red, sh.tot);        // writes tot[0..1]; chi2 of step 1 stays in tot[9]
         ++evals;
         if (threadIdx.x == 0) {
-            // NB: block_sum<2> wrote tot[0..1]; chi2 of step 1 was tot[9] (untouched)
             const double dF = sh.tot[9] - sh.tot[0];
             int stop = 0;
             if (!(dF > 0)) {
@@ -186,7 +172,28 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
         __syncthreads();
         if (sh.ctl) break;
     }
-    (void)numeric_ok;
+    return iter;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_scan_match: PFSlam2D::scanMatch (src/pf_slam2d.cpp:416-437) for every particle of the shard.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const double* __restrict__ pts, int n, Affine mtf,
+                                                          double* __restrict__ loglik_out, int32_t* __restrict__ iters_out)
+{
+    __shared__ SMShared sh;
+    const int p = blockIdx.x;
+    const int16_t* dir = prm.dm_dir + (size_t)p * prm.W * prm.W;
+    const uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
+    if (threadIdx.x == 0) {
+        const double* q = prm.poses + 4 * p;
+        sh.state = SE2{q[0], q[1], q[2], q[3]};
+        sh.tf = scan_tf(sh.state, mtf);
+        sh.ctl = 0;
+    }
+    __syncthreads();
+    uint32_t evals = 0;
+    const uint32_t iter = gn_solve(prm, dir, sv, pts, n, mtf, sh, evals);
     // likelihood at the final state (pf_slam2d.cpp:433-436)
     double a2[2];
     {
@@ -202,6 +209,51 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
         iters_out[p] = (int32_t)iter;
         prm.stats[4 * p + 0] = iter;
         prm.stats[4 * p + 1] = evals;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_match_solve: Solve(options, MatchSurface2D(dm, scan, pose), &cov) as Loc2D::update uses it
+// (src/loc2d.cpp:168-180): pose in/out, plus what the covariance and the RMSE need at the solution:
+//   out[0..5] lower triangle of J^T J with J weighted (Solver::solve cov branch, src/nlls/solver.cpp:109-116)
+//   out[6]    sum of squared UNWEIGHTED residuals (RMSE, src/loc2d.cpp:178-180)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int particle, const double* __restrict__ pts, int n, Affine mtf,
+                                                           double* __restrict__ pose_io, double* __restrict__ out7, int32_t* __restrict__ iters_out,
+                                                           int do_solve)
+{
+    __shared__ SMShared sh;
+    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
+    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    if (threadIdx.x == 0) {
+        sh.state = SE2{pose_io[0], pose_io[1], pose_io[2], pose_io[3]};
+        sh.tf = scan_tf(sh.state, mtf);
+        sh.ctl = 0;
+    }
+    __syncthreads();
+    uint32_t evals = 0;
+    const uint32_t iter = do_solve ? gn_solve(prm, dir, sv, pts, n, mtf, sh, evals) : 0u;
+    double acc[10];
+    const Affine tf = sh.tf;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += SM_BLOCK) {
+        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
+        const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
+        double gx, gy;
+        const double r = dm_distance(prm, dir, sv, hx, hy, &gx, &gy);
+        const double w = sqrt(cauchy015(r));
+        const double j0 = gx * w, j1 = gy * w, j2 = (gy * hx - gx * hy) * w;
+        acc[0] += j0 * j0; acc[1] += j1 * j0; acc[2] += j1 * j1;
+        acc[3] += j2 * j0; acc[4] += j2 * j1; acc[5] += j2 * j2;
+        acc[6] += r * r;
+    }
+    block_sum<10>(acc, sh.red, sh.tot);
+    if (threadIdx.x == 0) {
+        pose_io[0] = sh.state.c; pose_io[1] = sh.state.s; pose_io[2] = sh.state.tx; pose_io[3] = sh.state.ty;
+        for (int k = 0; k < 7; ++k) out7[k] = sh.tot[k];
+        iters_out[0] = (int32_t)iter;
     }
 }
 
@@ -958,6 +1010,64 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
 } // namespace lama_dev
 #include "lama_raycast_par.h"
 namespace lama_dev {
+
+// ------------------------------------------------------------------------------------------------
+// k_dm_add_obstacles -- DynamicDistanceMap::addObstacle (src/sdm/dynamic_distance_map.cpp:212-226) for a list of map
+// cells, in the given order, on one particle's distance map (Loc2D builds its static map this way); the brushfire
+// stages then run dm->update().  One wave; 64 cells per step; pushes appended in list order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, int p, const uint32_t* __restrict__ cells_xy, uint32_t n)
+{
+    __shared__ uint32_t lds_dc[DC_SIZE];
+    const int lane = threadIdx.x;
+    const size_t WW = (size_t)prm.W * prm.W;
+    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
+    uint16_t* dm_sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
+    uint32_t* dm_obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
+    uint64_t* dm_mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
+    uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
+    int dm_count = prm.counts[2 * p];
+    for (int k = lane; k < DC_SIZE; k += UM_BLOCK) lds_dc[k] = DC_EMPTY;
+    __syncthreads();
+    const DirCache dc{lds_dc, dm_dir, prm.W};
+    uint32_t nl = 0;
+    for (uint32_t base = 0; base < n; base += 64) {
+        const uint32_t i = base + lane;
+        const bool act = i < n;
+        const uint32_t rx = (act ? cells_xy[2 * i] : 0u) - prm.wx0, ry = (act ? cells_xy[2 * i + 1] : 0u) - prm.wy0;
+        const bool inwin = rx < prm.WC && ry < prm.WC;
+        if (act && !inwin) atomicOr(prm.err, ERR_WINDOW);
+        const bool want = act && inwin;
+        const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
+        const int slot = coop_slot(dc, dm_dir, dm_count, (int)prm.dm_cap, want, pidx, ERR_DM_CAP, prm.err);
+        // duplicates inside one 64-cell step: the first occurrence wins (a later addObstacle of the same cell returns early)
+        bool first = true;
+        for (int l = 0; l < 63; ++l) {       // executed by all lanes (uniform control flow around the shuffles)
+            const uint32_t ox = __shfl(rx, l, 64), oy = __shfl(ry, l, 64);
+            const int ow = __shfl((int)want, l, 64);
+            if (l < lane && ow && ox == rx && oy == ry) first = false;
+        }
+        bool push = false;
+        if (want && slot >= 0) {
+            atomicOr((unsigned long long*)(dm_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
+            const uint16_t s = dm_sv[slot * 1024 + (int)ci];
+            if (first && !((s & SV_VALID) && (s & SV_SQMASK) == 0)) {
+                dm_sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED);
+                dm_obs[slot * 1024 + (int)ci] = 0;
+                push = true;
+            }
+        }
+        const unsigned long long pm = __ballot(push);
+        const int cnt = __popcll(pm);
+        if (nl + (uint32_t)cnt > prm.qcap) { if (lane == 0) atomicOr(prm.err, ERR_QUEUE); }
+        else {
+            if (push) q_lower[nl + (uint32_t)__popcll(pm & ((1ull << lane) - 1ull))] = q_entry(0, (int)rx, (int)ry);
+            nl += (uint32_t)cnt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    if (lane == 0) { prm.counts[2 * p] = dm_count; prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = 0; }
+}
 
 // ------------------------------------------------------------------------------------------------
 // k_copy_particles -- dst particle i := src particle idx[i] (directories, counts, used slots of every

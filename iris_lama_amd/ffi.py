@@ -47,6 +47,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_scan_match", "lama_hip_pf_resample", "lama_hip_pf_update_maps", "lama_hip_pf_map_patches",
     "lama_hip_pf_download_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
+    "lama_hip_map_add_obstacles", "lama_hip_match_solve",
 ]
 
 _hip = None
@@ -93,6 +94,8 @@ def _bind_hip(L):
         L.lama_hip_pf_import_particle.argtypes = [vp, u32, vp, u64]
         L.lama_hip_get_counters.argtypes = [vp, vp]
         L.lama_hip_reset_counters.argtypes = [vp]
+        L.lama_hip_map_add_obstacles.argtypes = [vp, u32, vp, u32]
+        L.lama_hip_match_solve.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32]
         for s in HIP_SYMBOLS:
             if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error"):
                 getattr(L, s).restype = i32
@@ -205,6 +208,20 @@ class HipContext:
         self._chk(self.L.lama_hip_match_batch(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(poses), len(poses), _p(out)))
         return out
 
+    def add_obstacles(self, particle, cells_xy):
+        cells = np.ascontiguousarray(cells_xy, dtype=np.uint32).reshape(-1, 2)
+        self._chk(self.L.lama_hip_map_add_obstacles(self.h, particle, _p(cells), len(cells)))
+
+    def match_solve(self, particle, pts, pose4, origin=None, quat=None, solve=True):
+        """-> (pose, JtJ lower [00,10,11,20,21,22], sum r^2 (unweighted), iterations)"""
+        pts, origin, quat = self._scan(pts, origin, quat)
+        pose = np.array(pose4, dtype=np.float64)
+        out = np.zeros(7)
+        it = C.c_int32(0)
+        self._chk(self.L.lama_hip_match_solve(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(pose), _p(out),
+                                              C.byref(it), 1 if solve else 0))
+        return pose, out[:6].copy(), float(out[6]), it.value
+
     def export_bytes(self, particle):
         n = C.c_uint64(0)
         self._chk(self.L.lama_hip_pf_export_particle(self.h, particle, None, 0, C.byref(n)))
@@ -277,6 +294,8 @@ HOST_SYMBOLS = [
     "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
     "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
     "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin",
+    "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
+    "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
 ]
 
 
@@ -304,6 +323,11 @@ def _bind_host(L):
         "lama_slam_enough_motion": (i32, [vp, vp]), "lama_slam_processed_cells": (u32, [vp]),
         "lama_slam_iterations": (u32, [vp]), "lama_slam_device_context": (vp, [vp]),
         "lama_slam_engine_origin": (C.c_char_p, [vp]),
+        "lama_loc_create": (vp, [d, d, d, d, u32, i32, vp, i32]), "lama_loc_destroy": (None, [vp]),
+        "lama_loc_last_error": (C.c_char_p, [vp]), "lama_loc_engine_origin": (C.c_char_p, [vp]),
+        "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_set_pose": (None, [vp, d, d, d]),
+        "lama_loc_get_pose": (i32, [vp, vp]), "lama_loc_update": (i32, [vp, vp, u32, vp, vp, vp, d, i32]),
+        "lama_loc_covar": (i32, [vp, vp]), "lama_loc_rmse": (d, [vp]), "lama_loc_iterations": (u32, [vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -562,3 +586,59 @@ class Slam2D:
         ctx.h = C.c_void_p(self.L.lama_slam_device_context(self.h))
         ctx._is_borrowed = True
         return ctx
+
+
+class Loc2D:
+    """ctypes view of the host-side lama::Loc2D (include/lama/loc2d.h): localisation on a fixed distance map."""
+
+    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, max_iter=100, gpu_device=0):
+        self.L = _hostlib()
+        err = C.create_string_buffer(512)
+        h = self.L.lama_loc_create(trans_thresh, rot_thresh, l2_max, resolution, max_iter, gpu_device, err, 512)
+        if not h:
+            raise LamaError(err.value.decode())
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lama_loc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise LamaError(self.L.lama_loc_last_error(self.h).decode())
+        return rc
+
+    def engine_origin(self):
+        return self.L.lama_loc_engine_origin(self.h).decode()
+
+    def set_obstacles_world(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        self._chk(self.L.lama_loc_set_obstacles_world(self.h, _p(xy), len(xy)))
+
+    def set_pose(self, x, y, yaw):
+        self.L.lama_loc_set_pose(self.h, float(x), float(y), float(yaw))
+
+    def pose(self):
+        out = np.zeros(4)
+        self.L.lama_loc_get_pose(self.h, _p(out))
+        return out
+
+    def update(self, pts, odom_xyr, ts=0.0, force=False, origin=None, quat=None):
+        pts, origin, quat = PFSlam2D._scan(pts, origin, quat)
+        od = np.ascontiguousarray(odom_xyr, dtype=np.float64)
+        return bool(self._chk(self.L.lama_loc_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(od), float(ts), 1 if force else 0)))
+
+    def covar(self):
+        out = np.zeros(9)
+        self.L.lama_loc_covar(self.h, _p(out))
+        return out.reshape(3, 3)
+
+    def rmse(self):
+        return self.L.lama_loc_rmse(self.h)
+
+    def iterations(self):
+        return self.L.lama_loc_iterations(self.h)

@@ -57,6 +57,8 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(pf_import_particle, lama_hip_pf_import_particle)
     BIND(get_counters, lama_hip_get_counters)
     BIND(reset_counters, lama_hip_reset_counters)
+    BIND(map_add_obstacles, lama_hip_map_add_obstacles)
+    BIND(match_solve, lama_hip_match_solve)
 #undef BIND
     return e;
 }

@@ -31,6 +31,8 @@ struct HipEngine {
     decltype(&lama_hip_pf_import_particle) pf_import_particle = nullptr;
     decltype(&lama_hip_get_counters) get_counters = nullptr;
     decltype(&lama_hip_reset_counters) reset_counters = nullptr;
+    decltype(&lama_hip_map_add_obstacles) map_add_obstacles = nullptr;
+    decltype(&lama_hip_match_solve) match_solve = nullptr;
     ~HipEngine();
 };
 

@@ -7,6 +7,7 @@
 
 #include "hip_engine.hpp"
 #include "lama/pf_slam2d.h"
+#include "lama/loc2d.h"
 #include "lama/slam2d.h"
 
 using namespace lama;
@@ -301,5 +302,55 @@ int lama_slam_enough_motion(lama_slam* h, const double* odom_xyr) { return h->s-
 uint32_t lama_slam_processed_cells(const lama_slam* h) { return h->s->getNumberOfProcessedCells(); }
 uint32_t lama_slam_iterations(const lama_slam* h) { return h->s->getLastIterations(); }
 void* lama_slam_device_context(const lama_slam* h) { return (void*)h->s->deviceContext(); }
+
+
+// ------------------------------------------------------------------ Loc2D
+struct lama_loc {
+    Loc2D l;
+    std::string error;
+};
+
+lama_loc* lama_loc_create(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                          int32_t gpu_device, char* err, int errcap)
+{
+    auto* h = new lama_loc;
+    try {
+        Loc2D::Options o;
+        o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.max_iter = max_iter;
+        o.gpu_device = gpu_device;
+        h->l.Init(o);
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+void lama_loc_destroy(lama_loc* l) { delete l; }
+const char* lama_loc_last_error(const lama_loc* l) { return l ? l->error.c_str() : "null handle"; }
+const char* lama_loc_engine_origin(const lama_loc* l) { return (l && l->l.engine()) ? l->l.engine()->origin.c_str() : ""; }
+int lama_loc_set_obstacles_world(lama_loc* h, const double* xy, uint32_t n)
+{
+    try {
+        for (uint32_t i = 0; i < n; ++i) {
+            const Vector3ui c = h->l.distance_map->w2m(Vector3d(xy[2 * i], xy[2 * i + 1], 0.0));
+            h->l.occupancy_map->setOccupied(c);
+            h->l.distance_map->addObstacle(c);
+        }
+        h->l.distance_map->update();
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
+void lama_loc_set_pose(lama_loc* h, double x, double y, double yaw) { h->l.setPose(Pose2D(x, y, yaw)); }
+int lama_loc_get_pose(const lama_loc* h, double* pose4) { h->l.getPose().state.toArray(pose4); return 0; }
+int lama_loc_update(lama_loc* h, const double* pts, uint32_t n, const double* origin3, const double* quat, const double* odom_xyr, double ts, int force)
+{
+    try {
+        return h->l.update(make_cloud(pts, n, origin3, quat), Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2]), ts, force != 0) ? 1 : 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
+int lama_loc_covar(const lama_loc* h, double* out9) { std::memcpy(out9, h->l.getCovar().m, 72); return 0; }
+double lama_loc_rmse(const lama_loc* h) { return h->l.getRMSE(); }
+uint32_t lama_loc_iterations(const lama_loc* h) { return h->l.getLastIterations(); }
 
 } // extern "C"

@@ -1391,4 +1391,135 @@ private:
     uint32_t processed_ = 0;
 };
 
+// -------------------------------------------------------------------------------------
+// Loc2D  (include/lama/loc2d.h:47-165, src/loc2d.cpp:46-192): localisation on a fixed distance map.
+// Restated: Init, setPose, enoughMotion, update() incl. Solve(..., &cov) and RMSE.  globalLocalization (:249-286)
+// and addSamplingCovariance (:199-247, cov_blend = 0 by default) are out of scope.
+// -------------------------------------------------------------------------------------
+// Solver::calculateCovariance (src/nlls/solver.cpp:133-150): rank of J by column-pivoted Householder QR
+// (Eigen ColPivHouseholderQR, threshold = epsilon * max(rows, cols) relative to the largest pivot); full rank ->
+// (J^T J)^-1, else V diag(sv > 1e-3 ? 1/sv^2 : 3.0) V^T from the SVD of J.
+inline int colpiv_qr_rank(std::vector<double> J /*n x 3 row-major, copied*/, size_t n)
+{
+    double r[3];
+    int perm[3] = {0, 1, 2};
+    for (int k = 0; k < 3; ++k) {
+        int best = k; double bn = -1;
+        for (int c = k; c < 3; ++c) { double s2 = 0; for (size_t i = k; i < n; ++i) s2 += J[3 * i + perm[c]] * J[3 * i + perm[c]]; if (s2 > bn) { bn = s2; best = c; } }
+        std::swap(perm[k], perm[best]);
+        const int c = perm[k];
+        double norm = std::sqrt(bn);
+        if (norm == 0) { r[k] = 0; continue; }
+        const double x0 = J[3 * k + c];
+        const double alpha = x0 > 0 ? -norm : norm;
+        std::vector<double> v(n - k);
+        for (size_t i = k; i < n; ++i) v[i - k] = J[3 * i + c];
+        v[0] -= alpha;
+        double vn2 = 0; for (double t : v) vn2 += t * t;
+        if (vn2 > 0)
+            for (int cc = k; cc < 3; ++cc) {
+                const int col = perm[cc];
+                double dot = 0; for (size_t i = k; i < n; ++i) dot += v[i - k] * J[3 * i + col];
+                const double f = 2.0 * dot / vn2;
+                for (size_t i = k; i < n; ++i) J[3 * i + col] -= f * v[i - k];
+            }
+        r[k] = std::fabs(alpha);
+    }
+    const double maxp = std::max(r[0], std::max(r[1], r[2]));
+    const double thr = 2.220446049250313e-16 * (double)std::max<size_t>(n, 3) * maxp;
+    int rank = 0;
+    for (int k = 0; k < 3; ++k) if (r[k] > thr) ++rank;
+    return rank;
+}
+
+inline void inverse3(const double A[3][3], double out[9])
+{
+    const double a = A[0][0], b = A[0][1], c = A[0][2], d = A[1][0], e = A[1][1], f = A[1][2], g = A[2][0], h = A[2][1], i = A[2][2];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    out[0] = (e * i - f * h) / det; out[1] = (c * h - b * i) / det; out[2] = (b * f - c * e) / det;
+    out[3] = (f * g - d * i) / det; out[4] = (a * i - c * g) / det; out[5] = (c * d - a * f) / det;
+    out[6] = (d * h - e * g) / det; out[7] = (b * g - a * h) / det; out[8] = (a * e - b * d) / det;
+}
+
+struct LocOptions {                                     // src/loc2d.cpp:46-58
+    double trans_thresh = 0.5, rot_thresh = 0.5, l2_max = 1.0, resolution = 0.05;
+    uint32_t patch_size = 32, max_iter = 100;
+};
+
+class Loc2D {
+public:
+    explicit Loc2D(const LocOptions& o) : opt_(o), dm_(o.resolution, o.patch_size)     // Init :61-108
+    {
+        dm_.setMaxDistance(o.l2_max);
+        for (int k = 0; k < 9; ++k) cov_[k] = (k % 4 == 0) ? 1.0 : 0.0;
+    }
+    DynamicDistanceMap& dm() { return dm_; }
+    void setPose(const SE2& p) { pose_ = p; has_first_scan = false; }                  // loc2d.h:136-137
+    SE2 getPose() const { return pose_; }
+    const double* getCovar() const { return cov_; }
+    double getRMSE() const { return rmse_; }
+    uint32_t lastIterations() const { return iters_; }
+    bool rankDeficient() const { return rank_deficient_; }
+
+    bool enoughMotion(const SE2& odometry) const                                       // :113-124
+    {
+        if (!has_first_scan) return true;
+        SE2 odelta = pose_minus(odom_, odometry);
+        if (std::sqrt(odelta.tx * odelta.tx + odelta.ty * odelta.ty) <= opt_.trans_thresh && std::fabs(se2_rotation(odelta)) <= opt_.rot_thresh) return false;
+        return true;
+    }
+
+    bool update(const Scan& surface, const SE2& odometry, double, bool force_update = false)   // :126-192
+    {
+        if (!has_first_scan) {
+            odom_ = odometry;
+            has_first_scan = true;
+            if (!force_update) return true;
+            rmse_ = rmse_at(surface, pose_);
+        }
+        SE2 odelta = pose_minus(odom_, odometry);
+        SE2 ppose = pose_plus(pose_, odelta);
+        if (!force_update && !enoughMotion(odometry)) return false;
+        pose_ = ppose;
+        odom_ = odometry;
+        MatchSurface2D ms(&dm_, &surface, pose_);
+        CauchyWeight cauchy(0.15);
+        SolveStats st = solve_gn(ms, opt_.max_iter, cauchy);
+        iters_ = st.iterations;
+        // covariance branch of Solver::solve (src/nlls/solver.cpp:109-116)
+        std::vector<double> r, J;
+        ms.eval(r, &J);
+        for (size_t i = 0; i < r.size(); ++i) {
+            const double w = std::sqrt(cauchy.value(r[i]));
+            J[3 * i] *= w; J[3 * i + 1] *= w; J[3 * i + 2] *= w;
+        }
+        double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (size_t i = 0; i < r.size(); ++i)
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] += J[3 * i + a] * J[3 * i + b];
+        rank_deficient_ = colpiv_qr_rank(J, r.size()) != 3;
+        if (!rank_deficient_) inverse3(A, cov_);
+        pose_ = ms.state_;
+        rmse_ = rmse_at(surface, pose_);
+        return true;
+    }
+
+private:
+    double rmse_at(const Scan& surface, const SE2& pose) const                          // :139-142, :178-180
+    {
+        MatchSurface2D ms(&dm_, &surface, pose);
+        std::vector<double> r;
+        ms.eval(r, nullptr);
+        double s2 = 0;
+        for (double x : r) s2 += x * x;
+        return std::sqrt(s2 / ((double)(surface.points.size() - 1)));
+    }
+    LocOptions opt_;
+    DynamicDistanceMap dm_;
+    SE2 odom_, pose_;
+    double cov_[9];
+    double rmse_ = 0.0;
+    uint32_t iters_ = 0;
+    bool has_first_scan = false, rank_deficient_ = false;
+};
+
 } // namespace orc

@@ -347,4 +347,29 @@ uint32_t orc_slam_iterations(void* h) { return ((SlamBox*)h)->s->last_solve.iter
 void* orc_slam_dm(void* h) { return &((SlamBox*)h)->s->dm(); }       // borrowed
 void* orc_slam_occ(void* h) { return &((SlamBox*)h)->s->occ(); }     // borrowed
 
+
+// ---------------------------------------------------------------- Loc2D
+struct LocBox { std::unique_ptr<Loc2D> l; Scan scan; };
+void* orc_loc_new(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t patch_size, uint32_t max_iter)
+{
+    LocOptions o;
+    o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.patch_size = patch_size; o.max_iter = max_iter;
+    auto* b = new LocBox;
+    b->l.reset(new Loc2D(o));
+    return b;
+}
+void orc_loc_free(void* h) { delete (LocBox*)h; }
+void* orc_loc_dm(void* h) { return &((LocBox*)h)->l->dm(); }            // borrowed: fill with orc_dm_add_obstacle + orc_dm_update
+void orc_loc_set_pose(void* h, const double* pose4) { ((LocBox*)h)->l->setPose(se2_of(pose4)); }
+void orc_loc_get_pose(void* h, double* pose4) { se2_to(((LocBox*)h)->l->getPose(), pose4); }
+int orc_loc_update(void* h, const double* pts, int n, const double* origin3, const double* quat4, const double* odom4, double ts, int force)
+{
+    LocBox* b = (LocBox*)h;
+    b->scan = make_scan(pts, n, origin3, quat4);
+    return b->l->update(b->scan, se2_of(odom4), ts, force != 0) ? 1 : 0;
+}
+void orc_loc_covar(void* h, double* out9) { std::memcpy(out9, ((LocBox*)h)->l->getCovar(), 72); }
+double orc_loc_rmse(void* h) { return ((LocBox*)h)->l->getRMSE(); }
+uint32_t orc_loc_iterations(void* h) { return ((LocBox*)h)->l->lastIterations(); }
+
 } // extern "C"

@@ -69,6 +69,10 @@ def lib():
             "orc_slam_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "orc_slam_enough_motion": (i32, [vp, vp]),
             "orc_slam_processed_cells": (u32, [vp]), "orc_slam_iterations": (u32, [vp]),
             "orc_slam_dm": (vp, [vp]), "orc_slam_occ": (vp, [vp]),
+            "orc_loc_new": (vp, [d, d, d, d, u32, u32]), "orc_loc_free": (None, [vp]), "orc_loc_dm": (vp, [vp]),
+            "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
+            "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
+            "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -370,3 +374,41 @@ class Slam:
 
     def occ(self):
         return Occ(lib().orc_slam_occ(self.h), owned=False)
+
+
+class Loc:
+    """Oracle Loc2D (src/loc2d.cpp) without global localisation."""
+
+    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, patch_size=32, max_iter=100):
+        self.h = C.c_void_p(lib().orc_loc_new(trans_thresh, rot_thresh, l2_max, resolution, patch_size, max_iter))
+
+    def __del__(self):
+        if self.h:
+            lib().orc_loc_free(self.h)
+            self.h = None
+
+    def dm(self):
+        return DM(lib().orc_loc_dm(self.h), owned=False)
+
+    def set_pose(self, pose4):
+        lib().orc_loc_set_pose(self.h, _p(np.ascontiguousarray(pose4, dtype=np.float64)))
+
+    def pose(self):
+        out = np.zeros(4)
+        lib().orc_loc_get_pose(self.h, _p(out))
+        return out
+
+    def update(self, pts, odom4, ts=0.0, force=False, origin=ZERO3, quat=IDENT_Q):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        return bool(lib().orc_loc_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(odom4)), ts, 1 if force else 0))
+
+    def covar(self):
+        out = np.zeros(9)
+        lib().orc_loc_covar(self.h, _p(out))
+        return out.reshape(3, 3)
+
+    def rmse(self):
+        return lib().orc_loc_rmse(self.h)
+
+    def iterations(self):
+        return lib().orc_loc_iterations(self.h)

@@ -1,0 +1,22 @@
+"""Synthetic static maps for the Loc2D tests: obstacle points (world metres, one per 0.05 m cell) of the corridor world."""
+import numpy as np
+
+
+def corridor_obstacles(res=0.05):
+    pts = []
+
+    def seg(x0, y0, x1, y1):
+        n = int(round(max(abs(x1 - x0), abs(y1 - y0)) / res)) + 1
+        for k in range(n):
+            t = k / max(n - 1, 1)
+            pts.append((x0 + t * (x1 - x0), y0 + t * (y1 - y0)))
+
+    def box(xa, ya, xb, yb):
+        seg(xa, ya, xb, ya); seg(xb, ya, xb, yb); seg(xb, yb, xa, yb); seg(xa, yb, xa, ya)
+
+    box(0.0, 0.0, 28.0, 4.0)
+    for k in range(6):
+        cx = 5.0 + 4.0 * k
+        cy = 0.8 if k % 2 == 0 else 3.2
+        box(cx - 0.2, cy - 0.2, cx + 0.2, cy + 0.2)
+    return np.array(pts)

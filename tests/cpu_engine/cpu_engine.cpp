@@ -249,4 +249,43 @@ int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
 }
 int32_t lama_hip_reset_counters(lama_hip_ctx* c) { std::memset(&c->ctr, 0, sizeof(c->ctr)); return LAMA_HIP_OK; }
 
+
+int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uint32_t* cells_xy, uint32_t n)
+{
+    if (!c->init) {
+        for (uint32_t i = 0; i < c->cfg.particles; ++i) {
+            c->dm[i] = std::make_shared<DynamicDistanceMap>(c->cfg.resolution, c->cfg.patch_size);
+            c->dm[i]->setMaxDistance(c->cfg.l2_max);
+            c->occ[i] = std::make_shared<FrequencyOccupancyMap>(c->cfg.resolution, c->cfg.patch_size);
+        }
+        c->init = true;
+    }
+    for (uint32_t k = 0; k < n; ++k) c->dm[particle]->addObstacle(V3u{cells_xy[2 * k], cells_xy[2 * k + 1], 0});
+    c->dm[particle]->update();
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                             double* pose, double* out7, int32_t* iters, int32_t do_solve)
+{
+    Scan s = make_scan(pts, n, origin, quat);
+    MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(pose));
+    CauchyWeight cauchy(0.15);
+    SolveStats st;
+    if (do_solve) st = solve_gn(ms, c->cfg.max_iter, cauchy);
+    std::vector<double> r, J;
+    ms.eval(r, &J);
+    double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, s2 = 0;
+    for (size_t i = 0; i < r.size(); ++i) {
+        const double w = std::sqrt(cauchy.value(r[i]));
+        const double j[3] = {J[3 * i] * w, J[3 * i + 1] * w, J[3 * i + 2] * w};
+        for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] += j[a] * j[b];
+        s2 += r[i] * r[i];
+    }
+    se2_to(ms.state_, pose);
+    if (out7) { out7[0] = A[0][0]; out7[1] = A[1][0]; out7[2] = A[1][1]; out7[3] = A[2][0]; out7[4] = A[2][1]; out7[5] = A[2][2]; out7[6] = s2; }
+    if (iters) *iters = (int32_t)st.iterations;
+    return LAMA_HIP_OK;
+}
+
 } // extern "C"

@@ -235,3 +235,31 @@ def test_slam2d_online_gpu_vs_oracle(F):
     assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "slam occ")
     assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "slam dm")
     h.close()
+
+
+def test_loc2d_gpu_vs_oracle(F):
+    """cfg 1: lama::Loc2D on the device (static distance map built by addObstacle + brushfire on the GPU, solve with
+    covariance and RMSE) against the oracle."""
+    from _worlds import corridor_obstacles
+    obst = corridor_obstacles()
+    steps = 12
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    o = O.Loc()
+    dm = o.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    h = F.Loc2D()
+    h.set_obstacles_world(obst)
+    assert h.engine_origin().endswith("liblama_hip.so")
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    o.set_pose(O.se2(*start))
+    h.set_pose(*start)
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k), force=(k == 0)) == h.update(pts[k], odom[k], float(k), force=(k == 0))
+        assert np.abs(o.pose() - h.pose()).max() < 1e-7, k
+        assert o.iterations() == h.iterations()
+        assert abs(o.rmse() - h.rmse()) < 1e-9
+        assert np.allclose(o.covar(), h.covar(), rtol=1e-6, atol=1e-12)
+    h.close()

@@ -135,3 +135,35 @@ def test_slam2d_host_matches_oracle_bitwise():
     from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
     assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "dm")
     assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "occ")
+
+
+def test_loc2d_host_matches_oracle():
+    """cfg 1: lama::Loc2D (predict + Solve with covariance + RMSE on a pre-built 0.05 m distance map) vs the oracle
+    restatement of src/loc2d.cpp (engine = oracle-backed double, so the poses must agree bit for bit)."""
+    from _worlds import corridor_obstacles
+    obst = corridor_obstacles()
+    steps = 8
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o = O.Loc()
+    dm = o.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    h = F.Loc2D()
+    h.set_obstacles_world(obst)
+    assert h.engine_origin().endswith("liblama_cpu_engine.so")
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    o.set_pose(O.se2(*start))
+    h.set_pose(*start)
+    for k in range(steps + 1):
+        ro = o.update(pts[k], O.se2(*odom[k]), float(k), force=(k == 0))
+        rh = h.update(pts[k], odom[k], float(k), force=(k == 0))
+        assert ro == rh
+        assert np.array_equal(o.pose(), h.pose()), k
+        assert o.iterations() == h.iterations()
+        assert abs(o.rmse() - h.rmse()) <= 1e-15 * max(1.0, o.rmse())
+        assert np.allclose(o.covar(), h.covar(), rtol=1e-9, atol=0)
+        g = h.pose()
+        assert np.hypot(g[2] - truth[k][0], g[3] - truth[k][1]) < 0.05
+    assert h.rmse() < 0.05
