@@ -91,9 +91,9 @@ def main():
     P_total = args.particles * world
     pts, odom, truth = F.corridor_log(W + K, 1080)
 
-    def run(P, updates, warm, profile=True):
+    def run(P, updates, warm, profile=True, brushfire_mode=0):
         opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
-                            create_summary=1, profile=1 if profile else 0)
+                            create_summary=1, profile=1 if profile else 0, brushfire_mode=brushfire_mode)
         pf = ShardedPF(opts)
         assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
         pf.set_prior(*odom[0])
@@ -175,6 +175,16 @@ def main():
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1)}
         result["other_particle_counts"] = extra
+        # opt-in level-synchronous brushfire (cfg.brushfire_mode = 1; NOT bit-identical to the reference in the obstacle
+        # offsets of tie cells) -- reported for information, never as `value`
+        canon = {}
+        for P in [args.particles] + [int(x) for x in args.sweep.split(",") if x]:
+            r = run(P, min(K, 10) if P != args.particles else K, W if P == args.particles else 2, profile=True, brushfire_mode=1)
+            cc = r["counters"]
+            canon[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
+                             "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
+                             "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1)}
+        result["canonical_brushfire_mode"] = canon
     print(json.dumps(result))
 
 

@@ -78,6 +78,7 @@ public:
         uint32_t shard_rank = 0;
         uint32_t shard_world = 1;
         bool profile = false;              // bracket kernels with hipEvents (see lama_hip_get_counters)
+        uint32_t brushfire_mode = 0;       // 0 exact (default), 1 level-synchronous canonical tie rule (lama_hip.h)
     };
 
     explicit PFSlam2D(const Options& options = Options());

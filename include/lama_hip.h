@@ -74,6 +74,9 @@ typedef struct lama_hip_cfg {
     uint32_t active_capacity;    /* parallel ray-cast: max. order-sensitive cell visits per particle and scan (default 8192) */
     uint32_t sequential_raycast; /* ray-cast kernel: 0 = auto (parallel up to 1024 particles per call, beam-sequential above),
                                     1 = always beam-sequential, 2 = always parallel; all bit-identical */
+    uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
+                                    1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
+                                        the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */
 } lama_hip_cfg;
 
 void lama_hip_default_cfg(lama_hip_cfg* cfg);

@@ -31,6 +31,7 @@ typedef struct lama_pf_options {
     int32_t gpu_device;
     uint32_t shard_rank, shard_world;
     int32_t profile;
+    uint32_t brushfire_mode;
 } lama_pf_options;
 
 typedef struct lama_pf lama_pf;

@@ -179,10 +179,10 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     {
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
+        (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
         if (c->cfg.sequential_raycast == 1 || (c->cfg.sequential_raycast == 0 && count > 1024)) {
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
-            (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
             hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
             hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + RAY_BEAMS_PER_BLOCK - 1) / RAY_BEAMS_PER_BLOCK), dim3(256), 0, c->stream, prm,
                                c->d_pts, (int)n, c->d_tfs, (int)first);
@@ -194,6 +194,8 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     HIPCHK(c, hipGetLastError());
     {
         Timer t(c, &c->ctr.ms_brushfire, &c->ctr.launches_brushfire);
+        if (c->cfg.brushfire_mode == 1)     // opt-in parallel variant; whatever it leaves (qsizes != 0) falls through to the exact stages
+            hipLaunchKernelGGL(k_brushfire_canon, dim3(count), dim3(CN_BLOCK), 0, c->stream, prm, (int)first);
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
         prm.counts[2 * p + 1] = occ_count;
         prm.qsizes[2 * p] = nl;
         prm.qsizes[2 * p + 1] = nr;
-        prm.stats[4 * p + 2] = ray_cells;
+        prm.stats[4 * p + 2] += ray_cells;
     }
 }
 
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
     int count = prm.counts[2 * p];
     uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
-    if (lane == 0) { if (!RESUME) prm.stats[4 * p + 3] = 0; prm.slow[p] = 0; }
+    if (lane == 0) prm.slow[p] = 0;
     if (nl == 0 && nr == 0) return;
     if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (lane == 0) prm.slow[p] = 1; return; }
 
@@ -1009,6 +1009,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
 
 } // namespace lama_dev
 #include "lama_raycast_par.h"
+#include "lama_brushfire_canon.h"
 namespace lama_dev {
 
 // ------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ class HipCfg(C.Structure):
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("device", C.c_int32),
                 ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32),
                 ("occ_patch_capacity", C.c_uint32), ("queue_capacity", C.c_uint32), ("profile", C.c_uint32),
-                ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32)]
+                ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32), ("brushfire_mode", C.c_uint32)]
 
 
 class HipCounters(C.Structure):
@@ -279,7 +279,7 @@ class PFOptions(C.Structure):
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
                 ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("seed", C.c_uint32),
                 ("create_summary", C.c_int32), ("gpu_device", C.c_int32), ("shard_rank", C.c_uint32),
-                ("shard_world", C.c_uint32), ("profile", C.c_int32)]
+                ("shard_world", C.c_uint32), ("profile", C.c_int32), ("brushfire_mode", C.c_uint32)]
 
 
 HOST_SYMBOLS = [

@@ -101,6 +101,7 @@ lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
         p.patch_size = o->patch_size; p.max_iter = o->max_iter; p.seed = o->seed;
         p.create_summary = o->create_summary != 0; p.gpu_device = o->gpu_device;
         p.shard_rank = o->shard_rank; p.shard_world = o->shard_world; p.profile = o->profile != 0;
+        p.brushfire_mode = o->brushfire_mode;
         h->pf.reset(new PFSlam2D(p));
         h->origin = h->pf->engine()->origin;
         return h;

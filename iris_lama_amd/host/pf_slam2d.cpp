@@ -46,6 +46,7 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
     cfg.truncated_range = options_.truncated_range;
     cfg.device = options_.gpu_device;
     cfg.profile = options_.profile ? 1 : 0;
+    cfg.brushfire_mode = options_.brushfire_mode;
     const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
     if (rc != 0 || !ctx_) {
         char msg[256];

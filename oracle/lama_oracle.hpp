@@ -506,12 +506,15 @@ struct BrushfireStats {
     uint64_t max_queue_last = 0;   // of the last update() only
 };
 
+// test switch: maps created while this is set use update_canonical() (see there); never set for parity claims
+inline bool& canonical_default() { static bool v = false; return v; }
+
 class DynamicDistanceMap : public Map {
 public:
     DynamicDistanceMap(double res, uint32_t patch_size = 32)       // :36-47
-        : Map(res, sizeof(distance_t), patch_size), max_sqdist_(100) {}
+        : Map(res, sizeof(distance_t), patch_size), max_sqdist_(100) { canonical = canonical_default(); }
     DynamicDistanceMap(const DynamicDistanceMap& o)                // :49-61 (queues NOT copied)
-        : Map(o), max_sqdist_(o.max_sqdist_) {}
+        : Map(o), canonical(o.canonical), max_sqdist_(o.max_sqdist_) {}
 
     uint32_t max_sqdist() const { return max_sqdist_; }
 
@@ -577,6 +580,7 @@ public:
 
     uint32_t update()                                              // :160-197
     {
+        if (canonical) return update_canonical();
         uint32_t processed = 0;
         stats.max_queue_last = 0;
         while (!raise_.empty()) {
@@ -605,6 +609,106 @@ public:
     }
 
     BrushfireStats stats;
+
+    // ---------------------------------------------------------------------------------------------------------
+    // NOT the reference's algorithm: level-synchronous variant of update() with a canonical tie rule, kept here to
+    // MEASURE how far an order-independent (hence parallelisable) brushfire deviates from the faithful one above.
+    // Raise wave: breadth-first rounds, decisions taken on the state at the start of a round.  Lower wave: all
+    // queued cells of one priority level fire "simultaneously"; offers to the same neighbour are folded in the order
+    // (smaller candidate first, then direction index of the offering move), using the reference's overwrite rule.
+    // ---------------------------------------------------------------------------------------------------------
+    uint32_t update_canonical()
+    {
+        uint32_t processed = 0;
+        std::vector<V3u> frontier;
+        while (!raise_.empty()) { frontier.push_back(raise_.top().second); raise_.pop(); }
+        std::vector<std::vector<V3u>> bucket(max_sqdist_ + 1);
+        while (!lower_.empty()) { bucket[std::min<uint32_t>((uint32_t)lower_.top().first, max_sqdist_)].push_back(lower_.top().second); lower_.pop(); }
+        auto key = [](const V3u& c) { return ((uint64_t)c.y << 32) | c.x; };
+        while (!frontier.empty()) {
+            std::sort(frontier.begin(), frontier.end(), [&](const V3u& a, const V3u& b) { return key(a) < key(b); });
+            struct Dec { V3u n; bool ovalid; };
+            std::vector<Dec> decs;
+            for (const V3u& loc : frontier) {
+                ++processed;
+                for (int i = 0; i < 4; ++i) {
+                    int64_t d[3]; delta(i, d);
+                    V3u nl{(uint32_t)((int64_t)loc.x + d[0]), (uint32_t)((int64_t)loc.y + d[1]), loc.z};
+                    distance_t* n = (distance_t*)get(nl);
+                    if (n->is_queued || !n->valid_obstacle) continue;
+                    V3u obs = offs(nl, n->obstacle);
+                    const distance_t* o = (distance_t*)get(obs);
+                    decs.push_back({nl, o->valid_obstacle});
+                }
+            }
+            std::vector<V3u> next;
+            for (const Dec& dc : decs) {
+                distance_t* n = (distance_t*)get(dc.n);
+                if (n->is_queued || !n->valid_obstacle) continue;       // already handled through another neighbour
+                if (!dc.ovalid) {
+                    next.push_back(dc.n);
+                    n->sqdist = 0; n->obstacle[0] = n->obstacle[1] = n->obstacle[2] = 0; n->valid_obstacle = false; n->is_queued = true;
+                } else {
+                    bucket[n->sqdist].push_back(dc.n);
+                    n->is_queued = true;
+                }
+            }
+            for (const V3u& loc : frontier) ((distance_t*)get(loc))->is_queued = false;
+            frontier.swap(next);
+        }
+        for (uint32_t lev = 0; lev < max_sqdist_; ++lev) {
+            std::vector<V3u>& ent = bucket[lev];
+            if (ent.empty()) continue;
+            std::sort(ent.begin(), ent.end(), [&](const V3u& a, const V3u& b) { return key(a) < key(b); });
+            ent.erase(std::unique(ent.begin(), ent.end(), [](const V3u& a, const V3u& b) { return a == b; }), ent.end());
+            struct Offer { V3u n; uint32_t cand; int dir; int16_t ox, oy; };
+            std::vector<Offer> offers;
+            std::vector<V3u> fired;
+            for (const V3u& loc : ent) {
+                ++processed;
+                distance_t* cur = (distance_t*)get(loc);
+                if (!cur->valid_obstacle) continue;
+                V3u obs = offs(loc, cur->obstacle);
+                const distance_t* oc = (distance_t*)get(obs);
+                cur = (distance_t*)get(loc);
+                if (oc->sqdist != 0 || !cur->is_queued) continue;
+                fired.push_back(loc);
+                for (int i = 0; i < 4; ++i) {
+                    int64_t d[3]; delta(i, d);
+                    if (d[0] * cur->obstacle[0] > 0 || d[1] * cur->obstacle[1] > 0) continue;
+                    V3u nl{(uint32_t)((int64_t)loc.x + d[0]), (uint32_t)((int64_t)loc.y + d[1]), loc.z};
+                    (void)get(nl);
+                    cur = (distance_t*)get(loc);
+                    const int64_t ox = (int64_t)loc.x + cur->obstacle[0], oy = (int64_t)loc.y + cur->obstacle[1];
+                    const int64_t dx = (int64_t)nl.x - ox, dy = (int64_t)nl.y - oy;
+                    offers.push_back({nl, (uint32_t)(dx * dx + dy * dy), i, (int16_t)(ox - (int64_t)nl.x), (int16_t)(oy - (int64_t)nl.y)});
+                }
+            }
+            std::sort(offers.begin(), offers.end(), [&](const Offer& a, const Offer& b) {
+                if (key(a.n) != key(b.n)) return key(a.n) < key(b.n);
+                if (a.cand != b.cand) return a.cand < b.cand;
+                return a.dir < b.dir;
+            });
+            for (const Offer& of : offers) {
+                distance_t* n = (distance_t*)get(of.n);
+                const uint32_t cmp = n->valid_obstacle ? n->sqdist : max_sqdist_;
+                bool over = of.cand < cmp;
+                if (!over && of.cand == n->sqdist) {
+                    V3u nobs = offs(of.n, n->obstacle);
+                    const distance_t* o = (distance_t*)get(nobs);
+                    n = (distance_t*)get(of.n);
+                    if (!n->valid_obstacle || !(o->valid_obstacle && o->sqdist == 0)) over = true;
+                }
+                if (over) {
+                    bucket[std::min<uint32_t>(of.cand, max_sqdist_)].push_back(of.n);
+                    n->sqdist = (uint16_t)of.cand; n->valid_obstacle = true; n->obstacle[0] = of.ox; n->obstacle[1] = of.oy; n->obstacle[2] = 0; n->is_queued = true;
+                }
+            }
+            for (const V3u& loc : fired) ((distance_t*)get(loc))->is_queued = false;
+        }
+        return processed;
+    }
+    bool canonical = false;     // when set, update() dispatches to update_canonical() (experiments only)
 
 private:
     typedef std::pair<int, V3u> queue_pair_t;                      // .h:90

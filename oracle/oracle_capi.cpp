@@ -123,6 +123,8 @@ uint32_t orc_dm_max_sqdist(void* h) { return ((DynamicDistanceMap*)h)->max_sqdis
 void orc_dm_add_obstacle(void* h, uint32_t x, uint32_t y, uint32_t z) { ((DynamicDistanceMap*)h)->addObstacle(V3u{x, y, z}); }
 void orc_dm_remove_obstacle(void* h, uint32_t x, uint32_t y, uint32_t z) { ((DynamicDistanceMap*)h)->removeObstacle(V3u{x, y, z}); }
 uint32_t orc_dm_update(void* h) { return ((DynamicDistanceMap*)h)->update(); }
+void orc_set_canonical_default(int on) { canonical_default() = on != 0; }
+void orc_dm_set_canonical(void* h, int on) { ((DynamicDistanceMap*)h)->canonical = on != 0; }
 double orc_dm_distance_cell(void* h, uint32_t x, uint32_t y, uint32_t z)
 {
     return ((const DynamicDistanceMap*)h)->distance(V3u{x, y, z});

@@ -86,6 +86,11 @@ IDENT_Q = np.array([1.0, 0, 0, 0])
 ZERO3 = np.zeros(3)
 
 
+def set_canonical_default(on):
+    """Maps created afterwards use the level-synchronous brushfire variant (NOT the reference's tie order)."""
+    lib().orc_set_canonical_default(1 if on else 0)
+
+
 def se2(x, y, r):
     out = np.zeros(4)
     lib().orc_se2_from_xyr(x, y, r, _p(out))
