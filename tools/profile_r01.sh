@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-1 profiling recipe (run on the GPU box through gpurun).  Writes under gpurun_out/; the summaries that
-# matter are copied into profiles/ afterwards.
-#   pass 1: kernel trace + stats of the default bench command
-#   pass 2/3: PMC counters (separate runs, no tracing domains besides the kernel trace)
+# Round-1 profiling recipe (run on the GPU box through gpurun).  Writes under gpurun_out/; tools/summarize_rocprof.py
+# turns the rocpd databases into the committed summaries under profiles/.
+#   pass 1: kernel trace + stats of the default bench command (exact brushfire, P = 30)
+#   pass 2-4: PMC counters in separate runs (no tracing domains besides the kernel trace)
 set -x
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -13,5 +13,4 @@ rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r01 -- $CMD > "$OUT/bench_tr
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o r01 -- $CMD > "$OUT/bench_pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o r01 -- $CMD > "$OUT/bench_pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT -d "$OUT/pmc_sq" -o r01 -- $CMD > "$OUT/bench_pmc_sq.log" 2>&1
-find "$OUT" -name "*.csv" | head -40
 ls -la "$OUT"/*
