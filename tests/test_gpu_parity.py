@@ -312,3 +312,75 @@ def test_canonical_brushfire_mode(F):
     # the distance VALUE may differ only in rare cells where the tie order leaks into a distance (measured: ~1e-6 of the cells)
     assert dist_cells <= 1e-5 * total_cells
     ctx.close()
+
+
+@pytest.mark.parametrize("trunc_ray,trunc_range", [(0.0, 0.0), (3.0, 0.0), (0.0, 6.0), (2.5, 8.0)])
+@pytest.mark.parametrize("seq_ray", [1, 2])
+def test_options_truncation_and_sensor_frame(F, trunc_ray, trunc_range, seq_ray):
+    """Non-default options of the path: truncated_ray / truncated_range (src/pf_slam2d.cpp:467-491), a sensor mounted
+    off-centre with a yaw+roll orientation and points with z != 0 (moving_tf, 3-axis Bresenham count)."""
+    steps, P = 5, 3
+    pts, odom, truth = F.corridor_log(steps, 540)
+    rng = np.random.default_rng(3)
+    pts = pts.copy()
+    pts[:, :, 2] = rng.normal(0, 0.02, size=pts.shape[:2])           # slightly non-planar returns
+    origin = np.array([0.2, -0.1, 0.3])
+    yaw, roll = 0.15, 0.05
+    qz = np.array([np.cos(yaw / 2), 0, 0, np.sin(yaw / 2)])
+    qx = np.array([np.cos(roll / 2), np.sin(roll / 2), 0, 0])
+    quat = np.array([qz[0] * qx[0] - qz[3] * qx[3] * 0, qz[0] * qx[1], qz[3] * qx[1], qz[3] * qx[0]])   # q = qz * qx
+    quat = quat / np.linalg.norm(quat)
+    opts = O.default_options(particles=P, seed=5, truncated_ray=trunc_ray, truncated_range=trunc_range)
+    pf = O.PF(opts)
+    pose0 = O.se2(*odom[0])
+    pf.set_prior(pose0)
+    assert pf.update(pts[0], pose0, 0.0, origin=origin, quat=quat)
+    ctx = F.HipContext(F.default_cfg(particles=P, truncated_ray=trunc_ray, truncated_range=trunc_range, sequential_raycast=seq_ray))
+    ctx.init(pts[0], pose0, origin=origin, quat=quat)
+    for k in range(0, steps + 1):
+        if k > 0:
+            start = _perturbed(rng, O.se2(*truth[k]), P, 0.02, 0.005)
+            pf.set_poses(start)
+            pf.set_weights(w=np.zeros(P), ws=np.zeros(P))
+            pf.stage_set_scan(pts[k], origin=origin, quat=quat)
+            pf.stage_scan_match()
+            ctx.set_poses(start)
+            g_poses, g_ll, g_it = ctx.scan_match(pts[k], origin=origin, quat=quat)
+            o_poses = pf.poses()
+            same = g_it == np.array([pf.counters(i)["iterations"] for i in range(P)])
+            assert np.abs(g_poses - o_poses)[same].max() < 1e-8
+            assert np.allclose(g_ll[same], pf.weights()[0][same], rtol=1e-9)
+            ctx.set_poses(o_poses)
+            pf.stage_update_maps()
+            ctx.update_maps(pts[k], origin=origin, quat=quat)
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    ctx.close()
+
+
+def test_tiny_and_degenerate_scans(F):
+    """Edge cases: one particle, scans of 1..3 beams, a beam that ends in the sensor's own cell (from == to), duplicates."""
+    pose0 = O.se2(0.0, 0.0, 0.0)
+    scans = [np.array([[1.0, 0.0, 0.0]]),
+             np.array([[0.01, 0.01, 0.0], [2.0, 0.5, 0.0]]),                 # first beam: hit cell == start cell
+             np.array([[1.0, 0.0, 0.0], [1.0, 0.0, 0.0], [1.001, 0.001, 0.0]])]  # duplicate beams
+    pf = O.PF(O.default_options(particles=1, seed=1))
+    pf.set_prior(pose0)
+    pf.update(scans[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=1))
+    ctx.init(scans[0], pose0)
+    for k, sc in enumerate(scans[1:] + scans):
+        pose = O.se2(0.02 * k, -0.01 * k, 0.03 * k)
+        pf.set_poses(pose[None])
+        pf.stage_set_scan(sc)
+        pf.stage_update_maps()
+        ctx.set_poses(pose[None])
+        ctx.update_maps(sc)
+        assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), pf.occ(0).dump(), OCC_FIELDS, f"tiny {k} occ")
+        assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), pf.dm(0).dump(), DM_FIELDS, f"tiny {k} dm")
+        pf.stage_scan_match()
+        g_poses, g_ll, g_it = ctx.scan_match(sc)
+        assert np.abs(g_poses - pf.poses()).max() < 1e-8
+        ctx.set_poses(pf.poses())
+    ctx.close()
