@@ -153,6 +153,7 @@ private:
     std::vector<double> local_loglik_;
     // summary bookkeeping
     double t_begin_ = 0, t_solve_ = 0;
+    bool scan_resident_ = false;
 };
 
 } // namespace lama

@@ -109,7 +109,8 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* ctx, const double* pts_xyz, uint32_
 int32_t lama_hip_pf_resample(lama_hip_ctx* ctx, const int32_t* sample_idx);
 
 /* Region 2 (updateParticleMaps): per particle ray-cast of the scan from the particle's pose into its
- * FrequencyOccupancyMap, add/remove obstacle events into its DynamicDistanceMap, then dm->update(). */
+ * FrequencyOccupancyMap, add/remove obstacle events into its DynamicDistanceMap, then dm->update().
+ * pts_xyz may be NULL to reuse the scan (same n) uploaded by the preceding lama_hip_pf_scan_match call. */
 int32_t lama_hip_pf_update_maps(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
                                 const double* sensor_origin3, const double* sensor_quat_wxyz);
 

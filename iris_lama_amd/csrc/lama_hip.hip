@@ -31,6 +31,10 @@ struct lama_hip_ctx {
     std::string error;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct PendingTimer { hipEvent_t a, b; double* acc; uint64_t* launches; };
+    std::vector<hipEvent_t> ev_pool;            // pairs handed out by Timer, resolved after the call's final sync
+    std::vector<PendingTimer> pending;
+    size_t ev_used = 0;
     bool initialised = false;   // first scan done
 
     uint32_t P = 0, W = 0, WC = 0, wx0 = 0, wy0 = 0;
@@ -47,7 +51,8 @@ struct lama_hip_ctx {
     uint32_t* d_slow = nullptr;
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     int32_t* d_err = nullptr;
-    double* d_pts = nullptr; uint32_t pts_cap = 0;
+    double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
+    std::vector<uint64_t> h_stats;
     double* d_tfs = nullptr;
     double* d_loglik = nullptr; int32_t* d_iters = nullptr;
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
@@ -131,6 +136,11 @@ SetPtrs set_ptrs(const ParticleSet& s)
 
 int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
 {
+    if (!pts) {      // reuse the scan uploaded by the previous call (same scan for scan_match and update_maps)
+        if (c->last_n == 0 || n != c->last_n) return fail(c, LAMA_HIP_E_INVALID, "pts == NULL but no matching scan is resident");
+        return LAMA_HIP_OK;
+    }
+    c->last_n = n;
     if (n > c->pts_cap) {
         if (c->d_pts) HIPCHK(c, hipFree(c->d_pts));
         c->d_pts = nullptr;
@@ -141,34 +151,77 @@ int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
     return LAMA_HIP_OK;
 }
 
-int32_t check_device_errors(lama_hip_ctx* c)
+void resolve_timers(lama_hip_ctx* c);
+
+// End of an API call: one stream synchronisation that brings back the device error word and, when asked, the
+// per-particle patch counts and statistics (a single host round trip per call).
+int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false)
 {
     int32_t e = 0;
+    const bool stats = maps || match;
+    if (stats) {
+        c->h_stats.resize((size_t)c->P * 4);
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (e == 0) return LAMA_HIP_OK;
-    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
-    if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (raise cfg.window_patches)");
-    if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
-    if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
-    if (e & ERR_QUEUE) return fail(c, LAMA_HIP_E_CAPACITY, "brushfire queue full (raise cfg.queue_capacity)");
-    return fail(c, LAMA_HIP_E_NUMERIC, "unit complex number is (near) zero (SophusException in the reference)");
+    resolve_timers(c);
+    if (e != 0) {
+        HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+        if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (raise cfg.window_patches)");
+        if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
+        if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
+        if (e & ERR_QUEUE) return fail(c, LAMA_HIP_E_CAPACITY, "brushfire queue full (raise cfg.queue_capacity)");
+        return fail(c, LAMA_HIP_E_NUMERIC, "unit complex number is (near) zero (SophusException in the reference)");
+    }
+    if (stats) {
+        const std::vector<uint64_t>& st = c->h_stats;
+        uint64_t dm = 0, oc = 0;
+        for (uint32_t p = 0; p < c->P; ++p) {
+            if (match) { c->ctr.gn_iterations += st[4 * p]; c->ctr.gn_evals += st[4 * p + 1]; }
+            if (maps) { c->ctr.ray_cells += st[4 * p + 2]; c->ctr.bf_cells += st[4 * p + 3]; }
+            dm += c->h_counts[2 * p]; oc += c->h_counts[2 * p + 1];
+        }
+        c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
+    }
+    return LAMA_HIP_OK;
 }
 
+// hipEvent bracket around a kernel group; resolved (elapsed time read) by resolve_timers() after the API call's final
+// stream synchronisation, so profiling adds no host round trips.
 struct Timer {
-    lama_hip_ctx* c; double* acc; uint64_t* launches;
+    lama_hip_ctx* c; double* acc; uint64_t* launches; hipEvent_t a = nullptr, b = nullptr;
     Timer(lama_hip_ctx* c_, double* acc_, uint64_t* l_) : c(c_), acc(acc_), launches(l_)
-    { if (c->cfg.profile) (void)hipEventRecord(c->ev0, c->stream); }
+    {
+        if (!c->cfg.profile) return;
+        if (c->ev_used + 2 > c->ev_pool.size()) {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+            c->ev_pool.push_back(e0); c->ev_pool.push_back(e1);
+        }
+        a = c->ev_pool[c->ev_used++]; b = c->ev_pool[c->ev_used++];
+        (void)hipEventRecord(a, c->stream);
+    }
     void stop()
     {
         if (!c->cfg.profile) return;
-        (void)hipEventRecord(c->ev1, c->stream);
-        (void)hipEventSynchronize(c->ev1);
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-        *acc += ms; *launches += 1;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back({a, b, acc, launches});
     }
 };
+
+void resolve_timers(lama_hip_ctx* c)      // call after the stream has been synchronised
+{
+    for (auto& t : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { *t.acc += ms; *t.launches += 1; }
+    }
+    c->pending.clear();
+    c->ev_used = 0;
+    c->ctr.ms_update_maps = c->ctr.ms_raycast + c->ctr.ms_brushfire;
+    c->ctr.launches_update_maps = c->ctr.launches_raycast;
+}
 
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
 {
@@ -204,26 +257,9 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         t.stop();
     }
     HIPCHK(c, hipGetLastError());
-    c->ctr.ms_update_maps = c->ctr.ms_raycast + c->ctr.ms_brushfire;
-    c->ctr.launches_update_maps = c->ctr.launches_raycast;
     return LAMA_HIP_OK;
 }
 
-int32_t refresh_counts_and_stats(lama_hip_ctx* c, bool maps, bool match)
-{
-    std::vector<uint64_t> st((size_t)c->P * 4);
-    HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(st.data(), c->d_stats, sizeof(uint64_t) * st.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (uint32_t p = 0; p < c->P; ++p) {
-        if (match) { c->ctr.gn_iterations += st[4 * p]; c->ctr.gn_evals += st[4 * p + 1]; }
-        if (maps) { c->ctr.ray_cells += st[4 * p + 2]; c->ctr.bf_cells += st[4 * p + 3]; }
-    }
-    uint64_t dm = 0, oc = 0;
-    for (uint32_t p = 0; p < c->P; ++p) { dm += c->h_counts[2 * p]; oc += c->h_counts[2 * p + 1]; }
-    c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
-    return LAMA_HIP_OK;
-}
 
 } // namespace
 
@@ -340,6 +376,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     (void)hipFree(c->d_err); (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs); (void)hipFree(c->d_loglik);
     (void)hipFree(c->d_iters); (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -351,8 +388,8 @@ int32_t lama_hip_pf_set_poses(lama_hip_ctx* c, const double* poses)
     if (!c || !poses) return LAMA_HIP_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     std::memcpy(c->h_poses.data(), poses, sizeof(double) * 4 * c->P);
+    // asynchronous: the source is the context's own host mirror, which stays valid; later calls are stream ordered
     HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     return LAMA_HIP_OK;
 }
 
@@ -391,9 +428,7 @@ int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const d
         t.stop();
         HIPCHK(c, hipGetLastError());
     }
-    rc = check_device_errors(c);
-    if (rc) return rc;
-    rc = refresh_counts_and_stats(c, true, false);
+    rc = check_device_errors(c, true, false);
     if (rc) return rc;
     c->initialised = true;
     return LAMA_HIP_OK;
@@ -418,10 +453,9 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     HIPCHK(c, hipMemcpyAsync(c->h_poses.data(), c->d_poses, sizeof(double) * 4 * c->P, hipMemcpyDeviceToHost, c->stream));
     if (loglik_out) HIPCHK(c, hipMemcpyAsync(loglik_out, c->d_loglik, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
     if (iters_out) HIPCHK(c, hipMemcpyAsync(iters_out, c->d_iters, sizeof(int32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
-    rc = check_device_errors(c);   // synchronises
+    rc = check_device_errors(c, false, c->cfg.profile != 0);   // synchronises
     if (rc) return rc;
     if (poses_out) std::memcpy(poses_out, c->h_poses.data(), sizeof(double) * 4 * c->P);
-    if (c->cfg.profile) { rc = refresh_counts_and_stats(c, false, true); if (rc) return rc; }
     return LAMA_HIP_OK;
 }
 
@@ -458,7 +492,7 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
 
 int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
 {
-    if (!c || !pts || n == 0) return LAMA_HIP_E_INVALID;
+    if (!c || n == 0) return LAMA_HIP_E_INVALID;
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_update_maps before lama_hip_pf_init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -466,9 +500,7 @@ int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, 
     const Affine mtf = moving_tf(origin3, quat);
     rc = run_update_maps(c, n, mtf, 0, c->P);
     if (rc) return rc;
-    rc = check_device_errors(c);
-    if (rc) return rc;
-    return refresh_counts_and_stats(c, true, false);
+    return check_device_errors(c, true, false);
 }
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
@@ -593,10 +625,9 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true>), dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
     hipLaunchKernelGGL(k_brushfire_slow, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
     HIPCHK(c, hipGetLastError());
-    int32_t rc = check_device_errors(c);
+    int32_t rc = check_device_errors(c, true, false);
     (void)hipFree(d_cells);
-    if (rc) return rc;
-    return refresh_counts_and_stats(c, true, false);
+    return rc;
 }
 
 int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,

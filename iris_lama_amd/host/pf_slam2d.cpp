@@ -161,6 +161,7 @@ PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const P
 {
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::PFSlam2D::update: empty scan");
     t_begin_ = now_s();
+    scan_resident_ = false;
     current_surface_ = surface;
     scanToArrays(*surface);
     const uint32_t n = (uint32_t)surface->points.size();
@@ -207,6 +208,7 @@ PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const P
     std::vector<double> poses((size_t)(hi_ - lo_) * 4);
     const int32_t rc = eng_->pf_scan_match(ctx_, pts_.data(), n, origin_, quat_, poses.data(), local_loglik_.data(), nullptr);
     if (rc) fail(rc, "lama_hip_pf_scan_match");
+    scan_resident_ = true;
     for (uint32_t i = lo_; i < hi_; ++i) {
         particles_[i].pose.state = SE2d::fromArray(&poses[4 * (size_t)(i - lo_)]);
         if (options_.shard_world == 1) particles_[i].poses.push_back(particles_[i].pose);
@@ -260,7 +262,8 @@ void PFSlam2D::updateMaps()
 {
     const double t0 = now_s();
     const uint32_t n = (uint32_t)(pts_.size() / 3);
-    const int32_t rc = eng_->pf_update_maps(ctx_, pts_.data(), n, origin_, quat_);      // :289-302
+    // the scan is already resident on the device (uploaded by scan_match of this update)
+    const int32_t rc = eng_->pf_update_maps(ctx_, scan_resident_ ? nullptr : pts_.data(), n, origin_, quat_);      // :289-302
     if (rc) fail(rc, "lama_hip_pf_update_maps");
     if (summary) {
         summary->time_mapping.push_back(now_s() - t0);

@@ -23,6 +23,7 @@ struct lama_hip_ctx {
     std::vector<std::shared_ptr<DynamicDistanceMap>> dm;
     std::vector<std::shared_ptr<FrequencyOccupancyMap>> occ;
     std::unique_ptr<PFSlam2D> tool;   // borrowed for scanMatch / updateParticleMaps bodies
+    Scan last_scan;
     lama_hip_counters ctr;
 };
 
@@ -113,6 +114,7 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
 {
     if (!c->init) { c->error = "scan_match before init"; return LAMA_HIP_E_STATE; }
     Scan s = make_scan(pts, n, origin, quat);
+    c->last_scan = s;
     c->tool->stage_set_scan(s);
     for (uint32_t i = 0; i < c->cfg.particles; ++i) {
         Particle p;
@@ -143,7 +145,7 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* idx)
 
 int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
 {
-    Scan s = make_scan(pts, n, origin, quat);
+    Scan s = pts ? make_scan(pts, n, origin, quat) : c->last_scan;
     c->tool->stage_set_scan(s);
     for (uint32_t i = 0; i < c->cfg.particles; ++i) {
         Particle p;
