@@ -77,6 +77,8 @@ typedef struct lama_hip_cfg {
     uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
                                     1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
                                         the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */
+    uint32_t brushfire_waves;    /* exact brushfire: 0 = auto (a helper wave per particle for the heap up to 768 particles per
+                                    call), 1 = one wave per particle, 2 = always with the helper wave; all bit-identical */
 } lama_hip_cfg;
 
 void lama_hip_default_cfg(lama_hip_cfg* cfg);

@@ -251,8 +251,14 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL(k_brushfire_canon, dim3(count), dim3(CN_BLOCK), 0, c->stream, prm, (int)first);
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
-        hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
-        hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
+        if (c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES)) {
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+        } else {
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         t.stop();
     }
@@ -621,8 +627,8 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     // longer than the queue is rejected instead)
     if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
     hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
-    hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false>), dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
-    hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true>), dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
+    hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);
+    hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);
     hipLaunchKernelGGL(k_brushfire_slow, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
     HIPCHK(c, hipGetLastError());
     int32_t rc = check_device_errors(c, true, false);

@@ -19,6 +19,7 @@ constexpr int UM_BLOCK = 64;        // update-maps workgroup: 1 wave
 // brushfire queue windows in LDS (entries): a small one for throughput (many waves per CU) and a big resume stage
 constexpr int LQ_SMALL = 1024, RQ_SMALL = 256;     // 8 + 2 KiB
 constexpr int LQ_BIG = 8192, RQ_BIG = 2048;        // 64 + 16 KiB
+constexpr uint32_t BF_TW_MAX_PARTICLES = 768;     // up to 3 two-wave workgroups per CU; beyond that the waves of other particles hide the latency
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (fixed shape => results do not depend on how particles are sharded)
@@ -526,7 +527,9 @@ struct BfLds {
     uint64_t lower[LQ];
     uint64_t raise[RQ];
     uint32_t dc[DC_SIZE];
+    uint32_t cmd;          // TW: heap length the helper wave has to pop, or BF_CMD_EXIT
 };
+constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
 // ---- LDS-resident libstdc++ heap (same algorithm as lama_heap.h).  All heap state is wave-uniform: every lane
 // executes the code, lane 0 stores.  The sift-down of pop() is resumable so that the two global load rounds of a
@@ -541,13 +544,20 @@ __device__ inline void lds_pop_begin(const uint64_t* h, uint32_t& size, PopState
     st.value = st.active ? h[size] : 0;
 }
 // One "gather chunk" of __adjust_heap's first loop.  All heap state is wave-uniform, so instead of a chain of
-// dependent LDS reads (one per level) the wave loads the whole 5-level subtree below the hole at once: lane L
+// dependent LDS reads (one per level) the wave looks at the whole 6-level subtree below the hole at once: lane L
 // holds the node at relative heap position L (children of L are 2L+1 and 2L+2; absolute index
-// hole * 2^depth(L) + L) plus the priorities of its two children.  Every lane decides locally which child
-// __adjust_heap would take (`comp(right, left)` -> left, else right); a ballot turns that into a bit mask and the
-// root-to-leaf path is chased with ~4 scalar instructions per level.  The moved entries are written with a single
-// ds_write: each node on the path stores itself into its parent's slot.
-__device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane)
+// hole * 2^depth(L) + L) and the priority of its sibling.  Every lane decides locally whether __adjust_heap,
+// standing on its parent, would step to it (`comp(right, left)` -> left, else right; the parent must have both
+// children); a ballot turns that into a mask and a lane is on the hole's path iff the bits of ALL its ancestors
+// are set -- one AND/compare against a per-lane constant (`anc`), no serial chase.  The moved entries are written
+// with a single ds_write: each node on the path stores itself into its parent's slot.
+__device__ __forceinline__ uint64_t lds_pop_ancestors(int lane)
+{
+    uint64_t anc = 0;
+    if (lane < 63) for (int a = lane; a > 0; a = (a - 1) >> 1) anc |= 1ull << a;
+    return anc;
+}
+__device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane, uint64_t anc)
 {
     if (!st.active) return;
     const uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)((st.len - 1) / 2));
@@ -556,35 +566,31 @@ __device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lan
     const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
     const int d = 31 - __clz(lane + 1);
     const uint32_t idx = (H << d) + (uint32_t)lane;                 // absolute heap index of my node
-    const bool have = lane < 63 && idx < len;
-    const bool inner = have && idx < lim;                           // both children exist
-    uint64_t v = 0; uint32_t pl = 0, pr = 0;
+    const bool have = lane >= 1 && lane < 63 && idx < len;
+    const bool cand = have && ((idx - 1) >> 1) < lim;               // my parent has both children
+    uint64_t v = 0; uint32_t psib = 0;
     if (have) v = h[idx];
-    if (inner) { pl = heap_prio(h[2 * idx + 1]); pr = heap_prio(h[2 * idx + 2]); }
-    const bool take_left = pr > pl;                                 // comp(right, left)
-    const unsigned long long leftm = __ballot(inner && take_left);  // bit L: node L passes the hole to its LEFT child
-    const unsigned long long innerm = __ballot(inner);
-    // chase: at most 5 levels inside this gather (children of lanes >= 31 are not loaded)
-    unsigned long long pathm = 0;
-    int rel = 0;
-#pragma unroll
-    for (int lev = 0; lev < 5; ++lev) {
-        if (!((innerm >> rel) & 1ull)) break;
-        rel = ((leftm >> rel) & 1ull) ? 2 * rel + 1 : 2 * rel + 2;
-        pathm |= 1ull << rel;
-    }
-    if ((pathm >> lane) & 1ull) h[(idx - 1) >> 1] = v;              // first[hole] = first[child], all levels at once
-    // new hole = last node of the path
+    const bool is_left = (idx & 1u) != 0;
+    if (cand) psib = heap_prio(h[is_left ? idx + 1 : idx - 1]);
+    const uint32_t pme = heap_prio(v);
+    // __adjust_heap: child = right; if (comp(right, left)) child = left   with comp(a, b) = prio(a) > prio(b)
+    const bool step_to_me = cand && (is_left ? psib > pme : !(pme > psib));
+    const unsigned long long okm = __ballot(step_to_me);
+    const bool onpath = have && (okm & anc) == anc;
+    const unsigned long long pathm = __ballot(onpath);
+    if (onpath) h[(idx - 1) >> 1] = v;                               // first[hole] = first[child], all levels at once
+    // new hole = deepest node of the path (the highest lane: lanes are numbered level by level)
+    const int rel = pathm ? 63 - __clzll((long long)pathm) : 0;
     const uint32_t dd = 31 - __clz(rel + 1);
     st.hole = (H << dd) + (uint32_t)rel;
     st.child = st.hole;
 }
-__device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane)
+__device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane, uint64_t anc)
 {
     if (!st.active) return;
     const bool writer = lane == 0;
     const uint32_t lim = (st.len - 1) / 2;
-    while (st.child < lim) lds_pop_chunk(h, st, lane);
+    while (st.child < lim) lds_pop_chunk(h, st, lane, anc);
     if ((st.len & 1) == 0 && st.child == (st.len - 2) / 2) {
         st.child = 2 * (st.child + 1);
         if (writer) h[st.hole] = h[st.child - 1];
@@ -628,13 +634,19 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 //     test, and only when lower() really runs.  They are prefetched side-effect free and the allocation /
 //     mask update is applied once the decision is known.
 // ------------------------------------------------------------------------------------------------
-template <int LQ_LDS, int RQ_LDS, bool RESUME>
-__global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
+//
+// TW ("two waves", used while the particle count leaves CUs idle): the kernel is bound by the instruction issue
+// rate of its single wave, so the lower wave's pop() -- a pure LDS heap sift-down, ~45 % of the instructions of
+// one iteration -- is handed to a helper wave on another SIMD of the CU and runs concurrently with the cell
+// loads and the lower() decision.  Two workgroup barriers per pop: "heap consistent, top taken" and "pop done".
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+__global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     const int p = first_particle + blockIdx.x;
     if (RESUME && prm.slow[p] == 0) return;              // resume stage: only particles an earlier stage handed over
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
     const size_t WW = (size_t)prm.W * prm.W;
     int16_t* dir = prm.dm_dir + (size_t)p * WW;
     uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
@@ -644,14 +656,27 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
     int count = prm.counts[2 * p];
     uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
-    if (lane == 0) prm.slow[p] = 0;
+    if (tid == 0) prm.slow[p] = 0;
     if (nl == 0 && nr == 0) return;
-    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (lane == 0) prm.slow[p] = 1; return; }
+    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) prm.slow[p] = 1; return; }
 
-    for (int k = lane; k < DC_SIZE; k += UM_BLOCK) sh.dc[k] = DC_EMPTY;
-    for (uint32_t k = lane; k < nl; k += UM_BLOCK) sh.lower[k] = g_lower[k];
-    for (uint32_t k = lane; k < nr; k += UM_BLOCK) sh.raise[k] = g_raise[k];
+    for (int k = tid; k < DC_SIZE; k += nthreads) sh.dc[k] = DC_EMPTY;
+    for (uint32_t k = tid; k < nl; k += nthreads) sh.lower[k] = g_lower[k];
+    for (uint32_t k = tid; k < nr; k += nthreads) sh.raise[k] = g_raise[k];
     __syncthreads();
+    const uint64_t anc = lds_pop_ancestors(lane);
+    if (TW && tid >= UM_BLOCK) {
+        // helper wave: pop() of the lower queue on request
+        for (;;) {
+            __syncthreads();                                   // S: heap consistent, the main wave has taken top()
+            uint32_t n = sh.cmd;
+            if (n == BF_CMD_EXIT) return;
+            PopState ps_;
+            lds_pop_begin(sh.lower, n, ps_);
+            lds_pop_finish(sh.lower, ps_, lane, anc);
+            __syncthreads();                                   // D: pop done
+        }
+    }
     const DirCache dc{sh.dc, dir, prm.W};
 
     const int ddx = lane == 0 ? 1 : (lane == 2 ? -1 : 0), ddy = lane == 1 ? 1 : (lane == 3 ? -1 : 0);
@@ -689,9 +714,9 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
         BFT(1);                                                                                             \
         PopState ps_;                                                                                       \
         lds_pop_begin(H, N, ps_);                                                                           \
-        lds_pop_chunk(H, ps_, lane);                                                                        \
+        lds_pop_chunk(H, ps_, lane, anc);                                                                   \
         BF_LOAD_B()                                                                                         \
-        lds_pop_finish(H, ps_, lane);                                                                       \
+        lds_pop_finish(H, ps_, lane, anc);                                                                  \
         BFT(2);
 
     // ---- raise wave ------------------------------------------------------------------------- :162-173
@@ -747,6 +772,10 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
     while (!spill && nl > 0) {
         if (nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
         const uint64_t e = sh.lower[0];
+        if (TW) {
+            if (lane == 0) sh.cmd = nl;
+            __syncthreads();                                   // S
+        }
         const int rx = q_rx(e), ry = q_ry(e);
         ++processed;
         BFT(0);
@@ -761,9 +790,13 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
         uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;
         if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) { ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; } }
         BFT(1);
-        PopState ps_;
-        lds_pop_begin(sh.lower, nl, ps_);
-        lds_pop_finish(sh.lower, ps_, lane);
+        if (TW) {
+            --nl;                                              // the helper wave pops
+        } else {
+            PopState ps_;
+            lds_pop_begin(sh.lower, nl, ps_);
+            lds_pop_finish(sh.lower, ps_, lane, anc);
+        }
         BFT(2);
         const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
         const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
@@ -810,7 +843,13 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
                     if (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
                 }
             }
+            if (over) {
+                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
+            }
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
             BFT(4);
+            if (TW) __syncthreads();                           // D: the helper's pop is complete
             // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
             // to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply
             // appended, exactly what the sequential push_heap calls would have done.
@@ -837,15 +876,16 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire(DevParams prm, int first
                     }
                 }
             }
-            if (over) {
-                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
-                obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
-            }
             BFT(5);
-            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
+        } else if (TW) {
+            __syncthreads();                                   // D
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         BFT(6);
+    }
+    if (TW) {
+        if (lane == 0) sh.cmd = BF_CMD_EXIT;
+        __syncthreads();                                       // S: releases the helper wave
     }
     #undef BF_LOAD_A
     #undef BF_LOAD_B

@@ -25,7 +25,8 @@ class HipCfg(C.Structure):
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("device", C.c_int32),
                 ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32),
                 ("occ_patch_capacity", C.c_uint32), ("queue_capacity", C.c_uint32), ("profile", C.c_uint32),
-                ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32), ("brushfire_mode", C.c_uint32)]
+                ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32), ("brushfire_mode", C.c_uint32),
+                ("brushfire_waves", C.c_uint32)]
 
 
 class HipCounters(C.Structure):

@@ -37,8 +37,8 @@ def _angle(p):
     return np.arctan2(p[..., 1], p[..., 0])
 
 
-@pytest.mark.parametrize("P,steps,seq_ray", [(8, 12, 2), (8, 12, 1), (40, 4, 0)])
-def test_stagewise_parity_corridor(F, P, steps, seq_ray):
+@pytest.mark.parametrize("P,steps,seq_ray,bf_waves", [(8, 12, 2, 0), (8, 12, 1, 1), (40, 4, 0, 2), (40, 4, 0, 1)])
+def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
     opts = O.default_options(particles=P, seed=7)
@@ -47,7 +47,7 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray):
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
 
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray))
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves))
     ctx.init(pts[0], pose0)
     for i in (0, P - 1):
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"init occ p{i}")
@@ -195,7 +195,9 @@ def test_large_queue_paths_round_room(F, radius, seq_ray):
     pf = O.PF(O.default_options(particles=P, seed=1))
     pf.set_prior(pose0)
     pf.update(pts, pose0)
-    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024, sequential_raycast=seq_ray))
+    # seq_ray 2 -> helper-wave brushfire (auto), seq_ray 1 -> single-wave brushfire: spill paths of both
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024, sequential_raycast=seq_ray,
+                                     brushfire_waves=0 if seq_ray == 2 else 1))
     ctx.init(pts, pose0)
     # second scan from slightly different poses: removals (raise wave) + additions
     r2 = radius + rng.normal(0, 0.01, n)
