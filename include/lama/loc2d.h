@@ -3,11 +3,12 @@
 // Same class name, Options fields and public methods as the reference's include/lama/loc2d.h:47-165; update()
 // follows src/loc2d.cpp:126-192.  The public members `occupancy_map` / `distance_map` of the reference are host maps
 // that consumers (iris_lama_ros' loc2d_ros) fill cell by cell before the first update; here they are small proxies
-// with the methods that use needs (w2m, setFree/setOccupied/setUnknown, addObstacle, update, setMaxDistance): the
-// obstacle cells are buffered on the host and DynamicDistanceMap::addObstacle + update() run on the device when
-// distance_map->update() is called.  Scan matching with covariance (Solve(..., &cov)) and the RMSE run on the device
-// (lama_hip_match_solve).  Not available on the device path: strategy "lm", globalLocalization /
-// triggerGlobalLocalization (:249-286) and cov_blend > 0 (addSamplingCovariance, :199-247) -- they throw.
+// with the methods that use needs (w2m, setFree/setOccupied/setUnknown, isFree, bounds, addObstacle, update,
+// setMaxDistance): the obstacle cells are buffered on the host and DynamicDistanceMap::addObstacle + update() run on
+// the device when distance_map->update() is called.  On the device: scan matching with covariance
+// (Solve(..., &cov)) and the RMSE (lama_hip_match_solve), the candidate evaluation of globalLocalization (:249-286,
+// lama_hip_eval_batch; the candidates are drawn on the host from lama::random like the reference) and the likelihood
+// samples of addSamplingCovariance (:199-247, lama_hip_map_sample_likelihood).  Not available: strategy "lm" (throws).
 #pragma once
 
 #include <cstdint>
@@ -62,7 +63,10 @@ public:
         bool setOccupied(const Vector3ui& c);
         bool setUnknown(const Vector3ui& c);
         bool isFree(const Vector3ui& c) const;
+        bool isFree(const Vector3d& p) const { return isFree(w2m(p)); }
         bool isOccupied(const Vector3ui& c) const;
+        // Map::bounds (src/sdm/map.cpp:139-157, include/lama/sdm/map.h:221-225): the allocated patches' extent in world units
+        void bounds(Vector3d& min, Vector3d& max) const;
         std::unordered_map<uint64_t, int8_t> cells;
     };
     struct DistanceMapProxy : MapProxy {
@@ -88,7 +92,11 @@ public:
     const Pose2D& getPose() const { return pose_; }
     const Matrix3d_& getCovar() const { return cov_; }
     double getRMSE() const { return rmse_; }
-    bool globalLocalizationIsActive() const { return false; }
+    bool globalLocalizationIsActive() const { return do_global_localization_; }
+    // candidates and errors of the last globalLocalization call (instrumentation for the parity tests)
+    const std::vector<double>& lastGlocPoses() const { return gloc_poses_; }
+    const std::vector<double>& lastGlocErrors() const { return gloc_errors_; }
+    const std::vector<double>& lastSamplingLikelihoods() const { return sampling_l_; }
     uint32_t getLastIterations() const { return last_iterations_; }
     lama_hip_ctx* deviceContext() const { return ctx_; }
     const HipEngine* engine() const { return eng_.get(); }
@@ -97,6 +105,8 @@ private:
     friend struct DistanceMapProxy;
     void ensureContext();
     void solve(const PointCloudXYZ& surface, bool do_solve);
+    void globalLocalization(const PointCloudXYZ& surface);
+    void addSamplingCovariance(const PointCloudXYZ& surface);
     void fail(int32_t rc, const char* what) const;
 
     Options opt_;
@@ -107,6 +117,11 @@ private:
     double rmse_ = 0.0;
     bool has_first_scan = false;
     uint32_t last_iterations_ = 0;
+    bool do_global_localization_ = false;
+    uint32_t gloc_cur_iter_ = 0;
+    double cov_blend_ = 0.0;
+    std::vector<Vector2d> sampling_steps_;
+    std::vector<double> gloc_poses_, gloc_errors_, sampling_l_;
 };
 
 } // namespace lama

@@ -136,6 +136,21 @@ int32_t lama_hip_match_batch(lama_hip_ctx* ctx, uint32_t particle, const double*
                              const double* sensor_origin3, const double* sensor_quat_wxyz,
                              const double* poses, uint32_t num_poses, double* loglik_out);
 
+/* Loc2D::globalLocalization's candidate evaluation (src/loc2d.cpp:249-286, the loop body :271-284): for each of the
+ * B poses {c, s, tx, ty} the squared norm of MatchSurface2D's residuals (bilinear distance per point, no robust
+ * weight; src/match_surface_2d.cpp:58-101) on `particle`'s distance map, and/or the particle filter's log-likelihood
+ * (either output may be NULL).  No state changes.  The candidates themselves are drawn on the host (random::uniform). */
+int32_t lama_hip_eval_batch(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                            const double* sensor_origin3, const double* sensor_quat_wxyz,
+                            const double* poses, uint32_t num_poses, double* sqnorm_out, double* loglik_out);
+
+/* Loc2D::addSamplingCovariance's likelihood samples (src/loc2d.cpp:199-234): for each of the K world positions
+ * xy[k] the scan is placed there with heading `yaw`; every `point_step`-th point (0, step, 2 step, ...; at most 128
+ * of them) looks up the NON-interpolated distance d and l_out[k] = sum exp(-d^2 / 0.01)^3, summed in point order. */
+int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                                       const double* sensor_origin3, const double* sensor_quat_wxyz, double yaw,
+                                       const double* xy, uint32_t num_samples, uint32_t point_step, double* l_out);
+
 /* Static-map localisation support (Loc2D, src/loc2d.cpp:61-192) on a one-particle context:
  *  lama_hip_map_add_obstacles: DynamicDistanceMap::addObstacle for every cell of the list (map coordinates as
  *      returned by Map::w2m, x then y, in the given order) followed by dm->update().  On a context that has not seen
@@ -168,6 +183,7 @@ typedef struct lama_hip_counters {
     uint64_t bf_cells;          /* brushfire cells processed (DynamicDistanceMap::update return)     */
     uint64_t dm_patches;        /* sum of allocated DM patches over particles (current)             */
     uint64_t occ_patches;       /* sum of allocated occupancy patches over particles (current)      */
+    double ms_eval_batch;  uint64_t launches_eval_batch;     /* lama_hip_eval_batch                   */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

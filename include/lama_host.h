@@ -127,6 +127,20 @@ int lama_loc_update(lama_loc* l, const double* pts_xyz, uint32_t n, const double
 int lama_loc_covar(const lama_loc* l, double* out9);
 double lama_loc_rmse(const lama_loc* l);
 uint32_t lama_loc_iterations(const lama_loc* l);
+/* global localisation / sampling covariance (src/loc2d.cpp:194-286) */
+lama_loc* lama_loc_create2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                           uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend,
+                           int32_t gpu_device, char* err, int errcap);
+/* occupancy_map->setFree / setUnknown / setOccupied on map cells (x, y pairs); state -1 / 0 / 1 */
+int lama_loc_occ_set_cells(lama_loc* l, const uint32_t* cells_xy, uint32_t n, int state);
+int lama_loc_occ_bounds(const lama_loc* l, double* out6);
+void lama_loc_trigger_global_localization(lama_loc* l);
+int lama_loc_global_localization_active(const lama_loc* l);
+uint32_t lama_loc_gloc_candidates(const lama_loc* l, double* poses4, double* errors, uint32_t cap);
+uint32_t lama_loc_sampling_likelihoods(const lama_loc* l, double* out, uint32_t cap);
+/* lama::random (include/lama/random.h) */
+void lama_random_set_seed(uint32_t seed);
+double lama_random_uniform(void);
 
 #ifdef __cplusplus
 }

@@ -607,6 +607,75 @@ int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* p
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_eval_batch(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3,
+                            const double* quat, const double* poses, uint32_t B, double* sqnorm_out, double* loglik_out)
+{
+    if (!c || !poses || (!sqnorm_out && !loglik_out) || n == 0 || B == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_eval_batch before the map exists");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    if (2 * B > c->b_cap) {
+        (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+        c->d_bposes = nullptr; c->d_bout = nullptr; c->b_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_bposes, sizeof(double) * 4 * 2 * B));
+        HIPCHK(c, hipMalloc(&c->d_bout, sizeof(double) * 2 * B));
+        c->b_cap = 2 * B;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_bposes, poses, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
+    const Affine mtf = moving_tf(origin3, quat);
+    DevParams prm = make_params(c, c->cur);
+    {
+        Timer t(c, &c->ctr.ms_eval_batch, &c->ctr.launches_eval_batch);
+        hipLaunchKernelGGL(k_eval_batch, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes,
+                           c->d_bout, c->d_bout + B);
+        t.stop();
+    }
+    HIPCHK(c, hipGetLastError());
+    if (sqnorm_out) HIPCHK(c, hipMemcpyAsync(sqnorm_out, c->d_bout, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    if (loglik_out) HIPCHK(c, hipMemcpyAsync(loglik_out, c->d_bout + B, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timers(c);
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3,
+                                       const double* quat, double yaw, const double* xy, uint32_t K, uint32_t point_step, double* l_out)
+{
+    if (!c || !xy || !l_out || n == 0 || K == 0 || point_step == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_map_sample_likelihood before the map exists");
+    if ((n + point_step - 1) / point_step > (uint32_t)SL_MAX_TERMS) return fail(c, LAMA_HIP_E_INVALID, "more than 128 sampled points per pose");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    if (2 * K > c->b_cap) {
+        (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
+        c->d_bposes = nullptr; c->d_bout = nullptr; c->b_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_bposes, sizeof(double) * 4 * 2 * K));
+        HIPCHK(c, hipMalloc(&c->d_bout, sizeof(double) * 2 * K));
+        c->b_cap = 2 * K;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_bposes, xy, sizeof(double) * 2 * K, hipMemcpyHostToDevice, c->stream));
+    // (Translation(x, y, 0) * AngleAxis(yaw, Z)) * moving_tf without the per-sample translation (src/loc2d.cpp:211-224)
+    const Affine mtf = moving_tf(origin3, quat);
+    const double sn = std::sin(yaw), cs = std::cos(yaw);          // Eigen AngleAxis(yaw, UnitZ), as in host_scan_tf
+    Affine fixed;
+    const double F[3][3] = {{cs, 0.0 - sn, 0.0}, {sn, cs, 0.0}, {0.0, 0.0, (1.0 - cs) + cs}};
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) fixed.R[i][j] = F[i][j]; fixed.t[i] = 0.0; }
+    Affine base;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) base.R[i][j] = (fixed.R[i][0] * mtf.R[0][j] + fixed.R[i][1] * mtf.R[1][j]) + fixed.R[i][2] * mtf.R[2][j];
+        base.t[i] = (fixed.R[i][0] * mtf.t[0] + fixed.R[i][1] * mtf.t[1]) + fixed.R[i][2] * mtf.t[2];
+    }
+    DevParams prm = make_params(c, c->cur);
+    hipLaunchKernelGGL(k_sample_likelihood, dim3(K), dim3(64), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, (int)point_step, base,
+                       c->d_bposes, c->d_bout);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(l_out, c->d_bout, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
 int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uint32_t* cells_xy, uint32_t n)
 {
     if (!c || !cells_xy || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;

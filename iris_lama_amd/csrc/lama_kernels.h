@@ -280,6 +280,72 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
     if (threadIdx.x == 0) out[b] = tot[1];
 }
 
+// Loc2D::globalLocalization's inner evaluation (src/loc2d.cpp:275-280): B candidate poses against particle
+// `particle`'s distance map -> squared norm of MatchSurface2D's residuals (no robust weight) and, for free, the
+// particle filter's log-likelihood.  One workgroup per pose; the map is shared by all B workgroups (L2 resident).
+__global__ __launch_bounds__(SM_BLOCK) void k_eval_batch(DevParams prm, int particle, const double* __restrict__ pts, int n,
+                                                          Affine mtf, const double* __restrict__ poses,
+                                                          double* __restrict__ sqnorm_out, double* __restrict__ loglik_out)
+{
+    __shared__ double red[(SM_BLOCK / 64) * 2];
+    __shared__ double tot[2];
+    __shared__ Affine tfs;
+    const int b = blockIdx.x;
+    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
+    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    if (threadIdx.x == 0) {
+        const double* q = poses + 4 * b;
+        tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
+    }
+    __syncthreads();
+    const Affine tf = tfs;
+    double a2[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += SM_BLOCK) {
+        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
+        const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
+        const double d = dm_distance(prm, dir, sv, hx, hy, nullptr, nullptr);
+        a2[0] += d * d;
+        a2[1] += -(d * d) / prm.meas_sigma;
+    }
+    block_sum<2>(a2, red, tot);
+    if (threadIdx.x == 0) {
+        if (sqnorm_out) sqnorm_out[b] = tot[0];
+        if (loglik_out) loglik_out[b] = tot[1];
+    }
+}
+
+// Loc2D::addSamplingCovariance's inner loop (src/loc2d.cpp:217-234): for sample translation k the scan is placed at
+// `base` (rotation and sensor offset, computed on the host) shifted by xy[k]; every `step`-th point looks up the
+// NON-interpolated distance and contributes exp(-d^2/0.01)^3.  One wave per sample; the <= 128 terms are summed in
+// point order by one lane (the reference's sequential sum).
+constexpr int SL_MAX_TERMS = 128;
+__global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int particle, const double* __restrict__ pts, int n, int step,
+                                                          Affine base, const double* __restrict__ xy, double* __restrict__ l_out)
+{
+    __shared__ double terms[SL_MAX_TERMS];
+    const int k = blockIdx.x;
+    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
+    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const double tx = base.t[0] + xy[2 * k], ty = base.t[1] + xy[2 * k + 1];
+    const int nterms = (n + step - 1) / step;
+    for (int j = threadIdx.x; j < nterms; j += 64) {
+        const int i = j * step;
+        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+        const double hx = ((base.R[0][0] * px + base.R[0][1] * py) + base.R[0][2] * pz) + tx;
+        const double hy = ((base.R[1][0] * px + base.R[1][1] * py) + base.R[1][2] * pz) + ty;
+        const double dist = dm_distance_cell(prm, dir, sv, w2m(prm, hx), w2m(prm, hy));
+        const double e = exp(-(dist * dist) / 0.01);
+        terms[j] = e * e * e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double l = 0.0;
+        for (int j = 0; j < nterms; ++j) l += terms[j];
+        l_out[k] = l;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Map update = PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:439-509), two kernels, one wave per particle:
 //   k_raycast   : beams in order; hit cell + Bresenham cells 64 at a time -> uint16 counters, add/remove

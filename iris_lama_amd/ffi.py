@@ -36,7 +36,8 @@ class HipCounters(C.Structure):
                 ("ms_brushfire", C.c_double), ("launches_brushfire", C.c_uint64),
                 ("ms_resample", C.c_double), ("launches_resample", C.c_uint64),
                 ("gn_iterations", C.c_uint64), ("gn_evals", C.c_uint64), ("ray_cells", C.c_uint64),
-                ("bf_cells", C.c_uint64), ("dm_patches", C.c_uint64), ("occ_patches", C.c_uint64)]
+                ("bf_cells", C.c_uint64), ("dm_patches", C.c_uint64), ("occ_patches", C.c_uint64),
+                ("ms_eval_batch", C.c_double), ("launches_eval_batch", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -48,7 +49,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_scan_match", "lama_hip_pf_resample", "lama_hip_pf_update_maps", "lama_hip_pf_map_patches",
     "lama_hip_pf_download_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
-    "lama_hip_map_add_obstacles", "lama_hip_match_solve",
+    "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
 ]
 
 _hip = None
@@ -97,6 +98,8 @@ def _bind_hip(L):
         L.lama_hip_reset_counters.argtypes = [vp]
         L.lama_hip_map_add_obstacles.argtypes = [vp, u32, vp, u32]
         L.lama_hip_match_solve.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32]
+        L.lama_hip_eval_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.lama_hip_map_sample_likelihood.argtypes = [vp, u32, vp, u32, vp, vp, C.c_double, vp, u32, u32, vp]
         for s in HIP_SYMBOLS:
             if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error"):
                 getattr(L, s).restype = i32
@@ -209,6 +212,22 @@ class HipContext:
         self._chk(self.L.lama_hip_match_batch(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(poses), len(poses), _p(out)))
         return out
 
+    def eval_batch(self, particle, pts, poses, origin=None, quat=None):
+        """-> (squared residual norm, log-likelihood) per pose (Loc2D::globalLocalization's candidate evaluation)"""
+        pts, origin, quat = self._scan(pts, origin, quat)
+        poses = np.ascontiguousarray(poses, dtype=np.float64)
+        sq, ll = np.zeros(len(poses)), np.zeros(len(poses))
+        self._chk(self.L.lama_hip_eval_batch(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(poses), len(poses), _p(sq), _p(ll)))
+        return sq, ll
+
+    def sample_likelihood(self, particle, pts, yaw, xy, point_step, origin=None, quat=None):
+        pts, origin, quat = self._scan(pts, origin, quat)
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros(len(xy))
+        self._chk(self.L.lama_hip_map_sample_likelihood(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), float(yaw), _p(xy),
+                                                        len(xy), int(point_step), _p(out)))
+        return out
+
     def add_obstacles(self, particle, cells_xy):
         cells = np.ascontiguousarray(cells_xy, dtype=np.uint32).reshape(-1, 2)
         self._chk(self.L.lama_hip_map_add_obstacles(self.h, particle, _p(cells), len(cells)))
@@ -297,6 +316,9 @@ HOST_SYMBOLS = [
     "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
+    "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
+    "lama_loc_global_localization_active", "lama_loc_gloc_candidates", "lama_loc_sampling_likelihoods",
+    "lama_random_set_seed", "lama_random_uniform",
 ]
 
 
@@ -329,6 +351,11 @@ def _bind_host(L):
         "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_set_pose": (None, [vp, d, d, d]),
         "lama_loc_get_pose": (i32, [vp, vp]), "lama_loc_update": (i32, [vp, vp, u32, vp, vp, vp, d, i32]),
         "lama_loc_covar": (i32, [vp, vp]), "lama_loc_rmse": (d, [vp]), "lama_loc_iterations": (u32, [vp]),
+        "lama_loc_create2": (vp, [d, d, d, d, u32, u32, u32, d, d, i32, vp, i32]),
+        "lama_loc_occ_set_cells": (i32, [vp, vp, u32, i32]), "lama_loc_occ_bounds": (i32, [vp, vp]),
+        "lama_loc_trigger_global_localization": (None, [vp]), "lama_loc_global_localization_active": (i32, [vp]),
+        "lama_loc_gloc_candidates": (u32, [vp, vp, vp, u32]), "lama_loc_sampling_likelihoods": (u32, [vp, vp, u32]),
+        "lama_random_set_seed": (None, [u32]), "lama_random_uniform": (d, []),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -592,10 +619,12 @@ class Slam2D:
 class Loc2D:
     """ctypes view of the host-side lama::Loc2D (include/lama/loc2d.h): localisation on a fixed distance map."""
 
-    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, max_iter=100, gpu_device=0):
+    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, max_iter=100, gpu_device=0,
+                 gloc_particles=3000, gloc_iters=10, gloc_thresh=0.15, cov_blend=0.0):
         self.L = _hostlib()
         err = C.create_string_buffer(512)
-        h = self.L.lama_loc_create(trans_thresh, rot_thresh, l2_max, resolution, max_iter, gpu_device, err, 512)
+        h = self.L.lama_loc_create2(trans_thresh, rot_thresh, l2_max, resolution, max_iter, gloc_particles, gloc_iters,
+                                    gloc_thresh, cov_blend, gpu_device, err, 512)
         if not h:
             raise LamaError(err.value.decode())
         self.h = C.c_void_p(h)
@@ -643,3 +672,39 @@ class Loc2D:
 
     def iterations(self):
         return self.L.lama_loc_iterations(self.h)
+
+    # ---- global localisation / sampling covariance (src/loc2d.cpp:194-286)
+    def occ_set_cells(self, cells_xy, state):
+        """occupancy_map->setFree (-1) / setUnknown (0) / setOccupied (1) on map cells."""
+        cells = np.ascontiguousarray(cells_xy, dtype=np.uint32).reshape(-1, 2)
+        self._chk(self.L.lama_loc_occ_set_cells(self.h, _p(cells), len(cells), int(state)))
+
+    def occ_bounds(self):
+        out = np.zeros(6)
+        self.L.lama_loc_occ_bounds(self.h, _p(out))
+        return out[:3].copy(), out[3:].copy()
+
+    def trigger_global_localization(self):
+        self.L.lama_loc_trigger_global_localization(self.h)
+
+    def global_localization_active(self):
+        return bool(self.L.lama_loc_global_localization_active(self.h))
+
+    def gloc_candidates(self):
+        n = self.L.lama_loc_gloc_candidates(self.h, None, None, 0)
+        poses, err = np.zeros((n, 4)), np.zeros(n)
+        if n:
+            self.L.lama_loc_gloc_candidates(self.h, _p(poses), _p(err), n)
+        return poses, err
+
+    def sampling_likelihoods(self):
+        n = self.L.lama_loc_sampling_likelihoods(self.h, None, 0)
+        out = np.zeros(n)
+        if n:
+            self.L.lama_loc_sampling_likelihoods(self.h, _p(out), n)
+        return out
+
+
+def random_set_seed(seed):
+    """lama::random::setSeed (process-wide generator used by Loc2D::globalLocalization)."""
+    _hostlib().lama_random_set_seed(int(seed))

@@ -59,6 +59,8 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(reset_counters, lama_hip_reset_counters)
     BIND(map_add_obstacles, lama_hip_map_add_obstacles)
     BIND(match_solve, lama_hip_match_solve)
+    BIND(eval_batch, lama_hip_eval_batch)
+    BIND(map_sample_likelihood, lama_hip_map_sample_likelihood)
 #undef BIND
     return e;
 }

@@ -8,6 +8,7 @@
 #include "hip_engine.hpp"
 #include "lama/pf_slam2d.h"
 #include "lama/loc2d.h"
+#include "lama/random.h"
 #include "lama/slam2d.h"
 
 using namespace lama;
@@ -353,5 +354,58 @@ int lama_loc_update(lama_loc* h, const double* pts, uint32_t n, const double* or
 int lama_loc_covar(const lama_loc* h, double* out9) { std::memcpy(out9, h->l.getCovar().m, 72); return 0; }
 double lama_loc_rmse(const lama_loc* h) { return h->l.getRMSE(); }
 uint32_t lama_loc_iterations(const lama_loc* h) { return h->l.getLastIterations(); }
+
+lama_loc* lama_loc_create2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                           uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend,
+                           int32_t gpu_device, char* err, int errcap)
+{
+    auto* h = new lama_loc;
+    try {
+        Loc2D::Options o;
+        o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.max_iter = max_iter;
+        o.gloc_particles = gloc_particles; o.gloc_iters = gloc_iters; o.gloc_thresh = gloc_thresh; o.cov_blend = cov_blend;
+        o.gpu_device = gpu_device;
+        h->l.Init(o);
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+int lama_loc_occ_set_cells(lama_loc* h, const uint32_t* cells_xy, uint32_t n, int state)
+{
+    for (uint32_t i = 0; i < n; ++i) {
+        const Vector3ui c(cells_xy[2 * i], cells_xy[2 * i + 1], 0);
+        if (state < 0) h->l.occupancy_map->setFree(c); else if (state > 0) h->l.occupancy_map->setOccupied(c); else h->l.occupancy_map->setUnknown(c);
+    }
+    return 0;
+}
+int lama_loc_occ_bounds(const lama_loc* h, double* out6)
+{
+    Vector3d a, b;
+    h->l.occupancy_map->bounds(a, b);
+    for (int i = 0; i < 3; ++i) { out6[i] = a[i]; out6[3 + i] = b[i]; }
+    return 0;
+}
+void lama_loc_trigger_global_localization(lama_loc* h) { h->l.triggerGlobalLocalization(); }
+int lama_loc_global_localization_active(const lama_loc* h) { return h->l.globalLocalizationIsActive() ? 1 : 0; }
+uint32_t lama_loc_gloc_candidates(const lama_loc* h, double* poses4, double* errors, uint32_t cap)
+{
+    const uint32_t n = (uint32_t)h->l.lastGlocErrors().size();
+    for (uint32_t i = 0; i < n && i < cap; ++i) {
+        for (int k = 0; k < 4; ++k) poses4[4 * i + k] = h->l.lastGlocPoses()[4 * i + k];
+        errors[i] = h->l.lastGlocErrors()[i];
+    }
+    return n;
+}
+uint32_t lama_loc_sampling_likelihoods(const lama_loc* h, double* out, uint32_t cap)
+{
+    const uint32_t n = (uint32_t)h->l.lastSamplingLikelihoods().size();
+    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = h->l.lastSamplingLikelihoods()[i];
+    return n;
+}
+void lama_random_set_seed(uint32_t seed) { lama::random::setSeed(seed); }
+double lama_random_uniform(void) { return lama::random::uniform(); }
 
 } // extern "C"

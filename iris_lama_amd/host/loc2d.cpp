@@ -2,10 +2,13 @@
 #include "lama/loc2d.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
+#include <limits>
 #include <stdexcept>
 
 #include "hip_engine.hpp"
+#include "lama/random.h"
 
 namespace lama {
 
@@ -32,7 +35,6 @@ bool Loc2D::OccupancyMapProxy::isOccupied(const Vector3ui& c) const { auto it = 
 void Loc2D::Init(const Options& o)
 {
     if (o.strategy == "lm") throw std::runtime_error("lama::Loc2D: strategy \"lm\" is not available on the device path");
-    if (o.cov_blend > 0.0) throw std::runtime_error("lama::Loc2D: cov_blend > 0 (sampling covariance) is not available on the device path");
     opt_ = o;
     delete occupancy_map; delete distance_map;
     occupancy_map = new OccupancyMapProxy;
@@ -44,6 +46,36 @@ void Loc2D::Init(const Options& o)
     rmse_ = 0.0;
     cov_ = Matrix3d_();
     has_first_scan = false;
+    do_global_localization_ = false;                                   // :80-90
+    gloc_cur_iter_ = 0;
+    cov_blend_ = std::max(std::min(o.cov_blend, 1.0), 0.0);
+    if (!sampling_steps_.empty()) return;                              // :93-107
+    const double sstep = distance_map->resolution;
+    sampling_steps_.push_back(Vector2d(0.0, 0.0));
+    for (int i = 1; i <= 20; ++i) {
+        sampling_steps_.push_back(Vector2d(i * sstep, 0.0));   sampling_steps_.push_back(Vector2d(0.0, i * sstep));
+        sampling_steps_.push_back(Vector2d(-i * sstep, 0.0));  sampling_steps_.push_back(Vector2d(0.0, -i * sstep));
+        sampling_steps_.push_back(Vector2d(i * sstep, i * sstep));   sampling_steps_.push_back(Vector2d(-i * sstep, i * sstep));
+        sampling_steps_.push_back(Vector2d(i * sstep, -i * sstep));  sampling_steps_.push_back(Vector2d(-i * sstep, -i * sstep));
+    }
+}
+
+// Map::bounds: min/max patch anchor over the allocated patches, max + patch_length, then m2w = tf_inv_ * m with
+// Eigen's affine inverse of Translation(off) * Scaling(s) (linear = (s*s) * (1 / ((s*s)*s)), translation = -(linear*off))
+void Loc2D::OccupancyMapProxy::bounds(Vector3d& mn, Vector3d& mx) const
+{
+    uint32_t lo[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, hi[2] = {0, 0};
+    for (const auto& kv : cells) {
+        const uint32_t ax = (uint32_t)(kv.first >> 32) & ~31u, ay = (uint32_t)(kv.first & 0xFFFFFFFFu) & ~31u;
+        lo[0] = std::min(lo[0], ax); lo[1] = std::min(lo[1], ay);
+        hi[0] = std::max(hi[0], ax); hi[1] = std::max(hi[1], ay);
+    }
+    const uint32_t zlo = cells.empty() ? 0xFFFFFFFFu : 0u, zhi = 0u + 32u;      // 2-D: the z anchor of every patch is 0
+    hi[0] += 32; hi[1] += 32;
+    const double off = double(2642244ull >> 1) * 32.0;
+    const double l = (scale * scale) * (1.0 / ((scale * scale) * scale)), t = -(l * off);
+    mn = Vector3d(l * (double)lo[0] + t, l * (double)lo[1] + t, l * (double)zlo + t);
+    mx = Vector3d(l * (double)hi[0] + t, l * (double)hi[1] + t, l * (double)zhi + t);
 }
 
 Loc2D::~Loc2D()
@@ -129,6 +161,7 @@ void Loc2D::solve(const PointCloudXYZ& s, bool do_solve)
         last_iterations_ = (uint32_t)iters;
         double c9[9];
         if (inverse_sym3(out7, c9)) for (int k = 0; k < 9; ++k) cov_.m[k] = c9[k];      // rank-deficient J: covariance left unchanged
+        if (cov_blend_ > 0.0) addSamplingCovariance(s);                                 // :175-176
     }
     rmse_ = std::sqrt(out7[6] / ((double)(s.points.size() - 1)));                       // :178-180
 }
@@ -148,13 +181,98 @@ bool Loc2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, do
     if (!force_update && !enoughMotion(odometry)) return false; // :151-152
     pose_ = ppose;
     odom_ = odometry;
-    solve(*surface, true);                                      // :168-180
+    if (do_global_localization_) {                              // :157-168
+        if (gloc_cur_iter_ < opt_.gloc_iters) {
+            ++gloc_cur_iter_;
+            globalLocalization(*surface);
+        } else {
+            do_global_localization_ = false;
+            gloc_cur_iter_ = 0;
+        }
+    }
+    solve(*surface, true);                                      // :170-180 (cov, optional sampling covariance, rmse)
+    if (do_global_localization_ && rmse_ < opt_.gloc_thresh) {  // :182-189
+        do_global_localization_ = false;
+        gloc_cur_iter_ = 0;
+    }
     return true;
 }
 
-void Loc2D::triggerGlobalLocalization()
+void Loc2D::triggerGlobalLocalization() { do_global_localization_ = true; }      // :194-197
+
+static void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], double q[4])
 {
-    throw std::runtime_error("lama::Loc2D::triggerGlobalLocalization is not available on the device path yet");
+    pts.resize(s.points.size() * 3);
+    for (size_t i = 0; i < s.points.size(); ++i) { pts[3 * i] = s.points[i].x(); pts[3 * i + 1] = s.points[i].y(); pts[3 * i + 2] = s.points[i].z(); }
+    o[0] = s.sensor_origin_.x(); o[1] = s.sensor_origin_.y(); o[2] = s.sensor_origin_.z();
+    q[0] = s.sensor_orientation_.w(); q[1] = s.sensor_orientation_.x(); q[2] = s.sensor_orientation_.y(); q[3] = s.sensor_orientation_.z();
+}
+
+// :249-286.  The candidates are drawn exactly like the reference (x, y until the cell is free in the occupancy map,
+// then the heading; lama::random's stream); their squared residual norms come from the device in one batch and the
+// FIRST smallest one wins (the reference's strict `<`).
+void Loc2D::globalLocalization(const PointCloudXYZ& surface)
+{
+    ensureContext();
+    Vector3d mn, mx;
+    occupancy_map->bounds(mn, mx);
+    const double diff0 = mx[0] - mn[0], diff1 = mx[1] - mn[1];
+    const uint32_t B = opt_.gloc_particles;
+    if (B == 0) return;
+    if (occupancy_map->cells.empty()) throw std::runtime_error("lama::Loc2D::globalLocalization: the occupancy map has no free cell");
+    bool any_free = false;
+    for (const auto& kv : occupancy_map->cells) if (kv.second == -1) { any_free = true; break; }
+    if (!any_free) throw std::runtime_error("lama::Loc2D::globalLocalization: the occupancy map has no free cell");
+    gloc_poses_.assign((size_t)4 * B, 0.0);
+    gloc_errors_.assign(B, 0.0);
+    for (uint32_t i = 0; i < B; ++i) {
+        double x, y, a;
+        for (;;) {
+            x = mn[0] + random::uniform() * diff0;
+            y = mn[1] + random::uniform() * diff1;
+            if (!occupancy_map->isFree(Vector3d(x, y, 0.0))) continue;
+            a = random::uniform() * 2 * M_PI - M_PI;
+            break;
+        }
+        Pose2D(x, y, a).state.toArray(&gloc_poses_[4 * i]);
+    }
+    std::vector<double> pts; double o[3], q[4];
+    scan_arrays(surface, pts, o, q);
+    const int32_t rc = eng_->eval_batch(ctx_, 0, pts.data(), (uint32_t)surface.points.size(), o, q, gloc_poses_.data(), B, gloc_errors_.data(), nullptr);
+    if (rc) fail(rc, "lama_hip_eval_batch");
+    double best_error = std::numeric_limits<double>::max();
+    for (uint32_t i = 0; i < B; ++i)
+        if (gloc_errors_[i] < best_error) { best_error = gloc_errors_[i]; pose_.state = SE2d::fromArray(&gloc_poses_[4 * i]); }
+}
+
+// :199-247 (Olson 2009).  The 161 likelihood samples come from the device, the 2x2 statistics are accumulated here in
+// the reference's order.
+void Loc2D::addSamplingCovariance(const PointCloudXYZ& surface)
+{
+    const size_t num_points = surface.points.size();
+    const size_t step = std::max(num_points / 100, size_t(1));
+    const size_t K = sampling_steps_.size();
+    std::vector<double> xy(2 * K);
+    for (size_t i = 0; i < K; ++i) { xy[2 * i] = pose_.x() + sampling_steps_[i].x(); xy[2 * i + 1] = pose_.y() + sampling_steps_[i].y(); }
+    sampling_l_.assign(K, 0.0);
+    std::vector<double> pts; double o[3], q[4];
+    scan_arrays(surface, pts, o, q);
+    const int32_t rc = eng_->map_sample_likelihood(ctx_, 0, pts.data(), (uint32_t)num_points, o, q, pose_.rotation(), xy.data(), (uint32_t)K,
+                                                   (uint32_t)step, sampling_l_.data());
+    if (rc) fail(rc, "lama_hip_map_sample_likelihood");
+    double Km[2][2] = {{0, 0}, {0, 0}}, u[2] = {0, 0}, s = 0;
+    for (size_t i = 0; i < K; ++i) {
+        const double x = xy[2 * i], y = xy[2 * i + 1], l = sampling_l_[i];
+        Km[0][0] = Km[0][0] + x * x * l; Km[0][1] = Km[0][1] + x * y * l;
+        Km[1][0] = Km[1][0] + y * x * l; Km[1][1] = Km[1][1] + y * y * l;
+        u[0] = u[0] + x * l; u[1] = u[1] + y * l;
+        s = s + l;
+    }
+    const double a1 = 1.0 / s, a2 = 1.0 / (s * s);
+    const double sc[2][2] = {{a1 * Km[0][0] - a2 * u[0] * u[0], a1 * Km[0][1] - a2 * u[0] * u[1]},
+                             {a1 * Km[1][0] - a2 * u[1] * u[0], a1 * Km[1][1] - a2 * u[1] * u[1]}};
+    const double alpha = cov_blend_;
+    for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) cov_(r, c) = alpha * sc[r][c] + (1.0 - alpha) * cov_(r, c);
 }
 
 } // namespace lama

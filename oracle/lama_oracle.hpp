@@ -29,6 +29,8 @@
 // =====================================================================================
 #pragma once
 
+#include <array>
+#include <limits>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -355,6 +357,33 @@ public:
         return V3u{uint32_t((idx / UNIVERSAL_CONSTANT) << log2dim), uint32_t((idx % UNIVERSAL_CONSTANT) << log2dim), 0};
     }
 
+    // map.h:147-148: tf_inv_ * m with tf_inv_ = tf_.inverse() (map.cpp:59).  Eigen's affine inverse of
+    // Translation(off) * Scaling(s): linear = 3x3 cofactor inverse of diag(s,s,s) -> (s*s) * (1 / ((s*s)*s)),
+    // translation = -(linear * off)  (published algorithm, Eigen 3.3 Inverse_SSE/InverseImpl.h compute_inverse_size3)
+    inline double tf_inv_linear() const { return (scale * scale) * (1.0 / ((scale * scale) * scale)); }
+    inline V3d m2w(const V3u& c) const
+    {
+        const double l = tf_inv_linear(), t = -(l * off);
+        return V3d{l * (double)c.x + t, l * (double)c.y + t, l * (double)c.z + t};
+    }
+    // map.cpp:139-157 (integer bounds of the allocated patches) and map.h:221-225 (world bounds)
+    void bounds(V3u& mn, V3u& mx) const
+    {
+        mn = V3u{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        mx = V3u{0, 0, 0};
+        for (auto& kv : patches) {
+            const V3u a = p2m(kv.first);
+            mn.x = std::min(mn.x, a.x); mn.y = std::min(mn.y, a.y); mn.z = std::min(mn.z, a.z);
+            mx.x = std::max(mx.x, a.x); mx.y = std::max(mx.y, a.y); mx.z = std::max(mx.z, a.z);
+        }
+        mx.x += patch_length; mx.y += patch_length; mx.z += patch_length;
+    }
+    void bounds(V3d& mn, V3d& mx) const
+    {
+        V3u a, b; bounds(a, b);
+        mn = m2w(a); mx = m2w(b);
+    }
+
     // map.cpp:371-412 (non-compressed branch) + COWPtr::operator-> detach (cow_ptr.h:86-114)
     uint8_t* get(const V3u& c)
     {
@@ -492,6 +521,29 @@ public:
 //                      src/sdm/dynamic_distance_map.cpp:36-330)
 // -------------------------------------------------------------------------------------
 #pragma pack(push, 1)
+// -------------------------------------------------------------------------------------
+// SimpleOccupancyMap  (src/sdm/simple_occupancy_map.cpp:36-131): int8 tri-state cell, -1 free / 0 unknown / 1 occupied
+// -------------------------------------------------------------------------------------
+class SimpleOccupancyMap : public Map {
+public:
+    SimpleOccupancyMap(double res, uint32_t patch_size = 32) : Map(res, sizeof(int8_t), patch_size) {}
+    bool setFree(const V3u& c) { int8_t* cell = (int8_t*)get(c); if (*cell == -1) return false; *cell = -1; return true; }     // :53-61
+    bool setOccupied(const V3u& c) { int8_t* cell = (int8_t*)get(c); if (*cell == 1) return false; *cell = 1; return true; }   // :68-76
+    bool setUnknown(const V3u& c) { int8_t* cell = (int8_t*)get(c); if (*cell == 0) return false; *cell = 0; return true; }    // :83-91
+    bool isFree(const V3u& c) const { const int8_t* cell = (const int8_t*)get(c); return cell != 0 && *cell == -1; }           // :97-104
+    bool isFree(const V3d& p) const { return isFree(w2m(p)); }                                                                 // :92-95
+    bool isOccupied(const V3u& c) const { const int8_t* cell = (const int8_t*)get(c); return cell != 0 && *cell == 1; }        // :111-118
+};
+
+// lama::random (src/random.cpp:34-73): ONE process-wide std::mt19937; uniform() builds a fresh
+// std::uniform_real_distribution<double>(0,1) per call.  The reference seeds it from std::random_device unless
+// random::setSeed is called; tests always seed.
+namespace random {
+inline std::mt19937& gen() { static std::mt19937 g(5489u); return g; }
+inline void setSeed(uint32_t seed) { gen().seed(seed); }
+inline double uniform() { std::uniform_real_distribution<double> d(0.0, 1.0); return d(gen()); }
+}
+
 struct distance_t {            // dynamic_distance_map.h:48-53 (Vector3s = 3 x int16)
     int16_t obstacle[3];
     uint16_t sqdist;
@@ -1497,8 +1549,8 @@ private:
 
 // -------------------------------------------------------------------------------------
 // Loc2D  (include/lama/loc2d.h:47-165, src/loc2d.cpp:46-192): localisation on a fixed distance map.
-// Restated: Init, setPose, enoughMotion, update() incl. Solve(..., &cov) and RMSE.  globalLocalization (:249-286)
-// and addSamplingCovariance (:199-247, cov_blend = 0 by default) are out of scope.
+// Restated: Init, setPose, enoughMotion, update() incl. Solve(..., &cov) and RMSE, triggerGlobalLocalization /
+// globalLocalization (:194-197, :249-286) and addSamplingCovariance (:199-247).  Strategy "lm" is out of scope.
 // -------------------------------------------------------------------------------------
 // Solver::calculateCovariance (src/nlls/solver.cpp:133-150): rank of J by column-pivoted Householder QR
 // (Eigen ColPivHouseholderQR, threshold = epsilon * max(rows, cols) relative to the largest pivot); full rank ->
@@ -1548,16 +1600,34 @@ inline void inverse3(const double A[3][3], double out[9])
 struct LocOptions {                                     // src/loc2d.cpp:46-58
     double trans_thresh = 0.5, rot_thresh = 0.5, l2_max = 1.0, resolution = 0.05;
     uint32_t patch_size = 32, max_iter = 100;
+    uint32_t gloc_particles = 3000, gloc_iters = 10;
+    double gloc_thresh = 0.15, cov_blend = 0.0;
 };
 
 class Loc2D {
 public:
-    explicit Loc2D(const LocOptions& o) : opt_(o), dm_(o.resolution, o.patch_size)     // Init :61-108
+    explicit Loc2D(const LocOptions& o) : opt_(o), dm_(o.resolution, o.patch_size), occ_(o.resolution, o.patch_size)     // Init :61-108
     {
         dm_.setMaxDistance(o.l2_max);
         for (int k = 0; k < 9; ++k) cov_[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        cov_blend_ = std::max(std::min(o.cov_blend, 1.0), 0.0);                        // :90
+        const double sstep = dm_.resolution;                                            // :95-107
+        steps_.push_back({0.0, 0.0});
+        for (int i = 1; i <= 20; ++i) {
+            steps_.push_back({i * sstep, 0.0});   steps_.push_back({0.0, i * sstep});
+            steps_.push_back({-i * sstep, 0.0});  steps_.push_back({0.0, -i * sstep});
+            steps_.push_back({i * sstep, i * sstep});   steps_.push_back({-i * sstep, i * sstep});
+            steps_.push_back({i * sstep, -i * sstep});  steps_.push_back({-i * sstep, -i * sstep});
+        }
     }
     DynamicDistanceMap& dm() { return dm_; }
+    SimpleOccupancyMap& occ() { return occ_; }
+    void triggerGlobalLocalization() { do_gloc_ = true; }                              // :194-197
+    bool globalLocalizationIsActive() const { return do_gloc_; }
+    // instrumentation for the parity tests: the candidates of the last globalLocalization call
+    std::vector<SE2> gloc_poses;
+    std::vector<double> gloc_errors;
+    std::vector<double> sampling_l;
     void setPose(const SE2& p) { pose_ = p; has_first_scan = false; }                  // loc2d.h:136-137
     SE2 getPose() const { return pose_; }
     const double* getCovar() const { return cov_; }
@@ -1586,6 +1656,15 @@ public:
         if (!force_update && !enoughMotion(odometry)) return false;
         pose_ = ppose;
         odom_ = odometry;
+        if (do_gloc_) {                                                                 // :157-168
+            if (gloc_cur_iter_ < opt_.gloc_iters) {
+                ++gloc_cur_iter_;
+                globalLocalization(surface);
+            } else {
+                do_gloc_ = false;
+                gloc_cur_iter_ = 0;
+            }
+        }
         MatchSurface2D ms(&dm_, &surface, pose_);
         CauchyWeight cauchy(0.15);
         SolveStats st = solve_gn(ms, opt_.max_iter, cauchy);
@@ -1603,8 +1682,73 @@ public:
         rank_deficient_ = colpiv_qr_rank(J, r.size()) != 3;
         if (!rank_deficient_) inverse3(A, cov_);
         pose_ = ms.state_;
+        if (cov_blend_ > 0.0) addSamplingCovariance(surface);                           // :175-176
         rmse_ = rmse_at(surface, pose_);
+        if (do_gloc_ && rmse_ < opt_.gloc_thresh) { do_gloc_ = false; gloc_cur_iter_ = 0; }   // :182-189
         return true;
+    }
+
+    // :249-286.  The candidates come from the process-wide random::uniform() stream: x, y until the cell is free in
+    // the occupancy map, then the heading; the first candidate with the smallest squared residual norm wins.
+    void globalLocalization(const Scan& surface)
+    {
+        V3d mn, mx;
+        occ_.bounds(mn, mx);
+        const double diff0 = mx.x - mn.x, diff1 = mx.y - mn.y;
+        double best_error = std::numeric_limits<double>::max();
+        gloc_poses.clear(); gloc_errors.clear();
+        for (uint32_t i = 0; i < opt_.gloc_particles; ++i) {
+            double x, y, a;
+            for (;;) {
+                x = mn.x + random::uniform() * diff0;
+                y = mn.y + random::uniform() * diff1;
+                if (!occ_.isFree(V3d{x, y, 0.0})) continue;
+                a = random::uniform() * 2 * M_PI - M_PI;
+                break;
+            }
+            const SE2 p = se2_from_xyr(x, y, a);
+            MatchSurface2D ms(&dm_, &surface, p);
+            std::vector<double> r;
+            ms.eval(r, nullptr);
+            double error = 0;
+            for (double v : r) error += v * v;
+            gloc_poses.push_back(p); gloc_errors.push_back(error);
+            if (error < best_error) { best_error = error; pose_ = p; }
+        }
+    }
+
+    // :199-247  (Olson 2009 sampling covariance around the solution, blended into the xy block of cov_)
+    void addSamplingCovariance(const Scan& surface)
+    {
+        double K[2][2] = {{0, 0}, {0, 0}}, u[2] = {0, 0}, ssum = 0;
+        const Affine3 mtf = moving_tf(surface);
+        const size_t num_points = surface.points.size();
+        const size_t step = std::max(num_points / 100, size_t(1));
+        double Raa[3][3];
+        angle_axis_z(se2_rotation(pose_), Raa);
+        sampling_l.clear();
+        for (size_t k = 0; k < steps_.size(); ++k) {
+            const double x = pose_.tx + steps_[k][0], y = pose_.ty + steps_[k][1];
+            const double trans[3] = {x, y, 0.0};
+            const Affine3 tf = affine_mul(affine_from(trans, Raa), mtf);
+            double l = 0.0;
+            for (size_t i = 0; i < num_points; i += step) {
+                const V3d hit = affine_apply(tf, surface.points[i]);
+                const double dist = dm_.distance(dm_.w2m(hit));
+                const double e = std::exp(-(dist * dist) / 0.01);
+                l += e * e * e;
+            }
+            sampling_l.push_back(l);
+            K[0][0] = K[0][0] + x * x * l; K[0][1] = K[0][1] + x * y * l;               // trans.head<2>() * trans.head<2>()^T * l
+            K[1][0] = K[1][0] + y * x * l; K[1][1] = K[1][1] + y * y * l;
+            u[0] = u[0] + x * l; u[1] = u[1] + y * l;
+            ssum = ssum + l;
+        }
+        const double a1 = 1.0 / ssum, a2 = 1.0 / (ssum * ssum);
+        const double sc[2][2] = {{a1 * K[0][0] - a2 * u[0] * u[0], a1 * K[0][1] - a2 * u[0] * u[1]},
+                                 {a1 * K[1][0] - a2 * u[1] * u[0], a1 * K[1][1] - a2 * u[1] * u[1]}};
+        const double alpha = cov_blend_;
+        for (int r = 0; r < 2; ++r) for (int c = 0; c < 2; ++c) cov_[3 * r + c] = alpha * sc[r][c] + (1.0 - alpha) * cov_[3 * r + c];
     }
 
 private:
@@ -1619,6 +1763,11 @@ private:
     }
     LocOptions opt_;
     DynamicDistanceMap dm_;
+    SimpleOccupancyMap occ_;
+    std::vector<std::array<double, 2>> steps_;
+    double cov_blend_ = 0.0;
+    bool do_gloc_ = false;
+    uint32_t gloc_cur_iter_ = 0;
     SE2 odom_, pose_;
     double cov_[9];
     double rmse_ = 0.0;

@@ -373,5 +373,48 @@ int orc_loc_update(void* h, const double* pts, int n, const double* origin3, con
 void orc_loc_covar(void* h, double* out9) { std::memcpy(out9, ((LocBox*)h)->l->getCovar(), 72); }
 double orc_loc_rmse(void* h) { return ((LocBox*)h)->l->getRMSE(); }
 uint32_t orc_loc_iterations(void* h) { return ((LocBox*)h)->l->lastIterations(); }
+// global localisation / sampling covariance (src/loc2d.cpp:194-286)
+void* orc_loc_new2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t patch_size, uint32_t max_iter,
+                   uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend)
+{
+    LocOptions o;
+    o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.patch_size = patch_size; o.max_iter = max_iter;
+    o.gloc_particles = gloc_particles; o.gloc_iters = gloc_iters; o.gloc_thresh = gloc_thresh; o.cov_blend = cov_blend;
+    auto* b = new LocBox;
+    b->l.reset(new Loc2D(o));
+    return b;
+}
+void orc_random_set_seed(uint32_t seed) { orc::random::setSeed(seed); }
+double orc_random_uniform() { return orc::random::uniform(); }
+// cells: (x, y) map coordinates; state -1 free / 0 unknown / 1 occupied (SimpleOccupancyMap)
+void orc_loc_occ_set(void* h, const uint32_t* cells_xy, uint32_t n, int state)
+{
+    SimpleOccupancyMap& m = ((LocBox*)h)->l->occ();
+    for (uint32_t i = 0; i < n; ++i) {
+        const V3u c{cells_xy[2 * i], cells_xy[2 * i + 1], 0};
+        if (state < 0) m.setFree(c); else if (state > 0) m.setOccupied(c); else m.setUnknown(c);
+    }
+}
+void orc_loc_occ_bounds(void* h, double* out6)
+{
+    V3d a, b; ((LocBox*)h)->l->occ().bounds(a, b);
+    out6[0] = a.x; out6[1] = a.y; out6[2] = a.z; out6[3] = b.x; out6[4] = b.y; out6[5] = b.z;
+}
+void orc_loc_trigger_gloc(void* h) { ((LocBox*)h)->l->triggerGlobalLocalization(); }
+int orc_loc_gloc_active(void* h) { return ((LocBox*)h)->l->globalLocalizationIsActive() ? 1 : 0; }
+uint32_t orc_loc_gloc_candidates(void* h, double* poses4, double* errors, uint32_t cap)
+{
+    Loc2D& l = *((LocBox*)h)->l;
+    const uint32_t n = (uint32_t)l.gloc_poses.size();
+    for (uint32_t i = 0; i < n && i < cap; ++i) { se2_to(l.gloc_poses[i], poses4 + 4 * i); errors[i] = l.gloc_errors[i]; }
+    return n;
+}
+uint32_t orc_loc_sampling_l(void* h, double* out, uint32_t cap)
+{
+    Loc2D& l = *((LocBox*)h)->l;
+    const uint32_t n = (uint32_t)l.sampling_l.size();
+    for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = l.sampling_l[i];
+    return n;
+}
 
 } // extern "C"

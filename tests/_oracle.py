@@ -73,6 +73,10 @@ def lib():
             "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
             "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
             "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
+            "orc_loc_new2": (vp, [d, d, d, d, u32, u32, u32, u32, d, d]), "orc_random_set_seed": (None, [u32]),
+            "orc_random_uniform": (d, []), "orc_loc_occ_set": (None, [vp, vp, u32, i32]), "orc_loc_occ_bounds": (None, [vp, vp]),
+            "orc_loc_trigger_gloc": (None, [vp]), "orc_loc_gloc_active": (i32, [vp]),
+            "orc_loc_gloc_candidates": (u32, [vp, vp, vp, u32]), "orc_loc_sampling_l": (u32, [vp, vp, u32]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -382,10 +386,12 @@ class Slam:
 
 
 class Loc:
-    """Oracle Loc2D (src/loc2d.cpp) without global localisation."""
+    """Oracle Loc2D (src/loc2d.cpp) incl. global localisation and sampling covariance."""
 
-    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, patch_size=32, max_iter=100):
-        self.h = C.c_void_p(lib().orc_loc_new(trans_thresh, rot_thresh, l2_max, resolution, patch_size, max_iter))
+    def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, patch_size=32, max_iter=100,
+                 gloc_particles=3000, gloc_iters=10, gloc_thresh=0.15, cov_blend=0.0):
+        self.h = C.c_void_p(lib().orc_loc_new2(trans_thresh, rot_thresh, l2_max, resolution, patch_size, max_iter,
+                                               gloc_particles, gloc_iters, gloc_thresh, cov_blend))
 
     def __del__(self):
         if self.h:
@@ -417,3 +423,36 @@ class Loc:
 
     def iterations(self):
         return lib().orc_loc_iterations(self.h)
+
+    def occ_set_cells(self, cells_xy, state):
+        cells = np.ascontiguousarray(cells_xy, dtype=np.uint32).reshape(-1, 2)
+        lib().orc_loc_occ_set(self.h, _p(cells), len(cells), int(state))
+
+    def occ_bounds(self):
+        out = np.zeros(6)
+        lib().orc_loc_occ_bounds(self.h, _p(out))
+        return out[:3].copy(), out[3:].copy()
+
+    def trigger_global_localization(self):
+        lib().orc_loc_trigger_gloc(self.h)
+
+    def global_localization_active(self):
+        return bool(lib().orc_loc_gloc_active(self.h))
+
+    def gloc_candidates(self):
+        n = lib().orc_loc_gloc_candidates(self.h, None, None, 0)
+        poses, err = np.zeros((n, 4)), np.zeros(n)
+        if n:
+            lib().orc_loc_gloc_candidates(self.h, _p(poses), _p(err), n)
+        return poses, err
+
+    def sampling_likelihoods(self):
+        n = lib().orc_loc_sampling_l(self.h, None, 0)
+        out = np.zeros(n)
+        if n:
+            lib().orc_loc_sampling_l(self.h, _p(out), n)
+        return out
+
+
+def random_set_seed(seed):
+    lib().orc_random_set_seed(int(seed))

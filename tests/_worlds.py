@@ -20,3 +20,18 @@ def corridor_obstacles(res=0.05):
         cy = 0.8 if k % 2 == 0 else 3.2
         box(cx - 0.2, cy - 0.2, cx + 0.2, cy + 0.2)
     return np.array(pts)
+
+
+def corridor_free_cells(w2m, res=0.05):
+    """Map cells (x, y) of the corridor's interior (pillars excluded), for occupancy_map->setFree."""
+    cells = []
+    xs = np.arange(0.1, 27.9 + 1e-9, res)
+    ys = np.arange(0.1, 3.9 + 1e-9, res)
+    pillars = [(5.0 + 4.0 * k, 0.8 if k % 2 == 0 else 3.2) for k in range(6)]
+    for x in xs:
+        for y in ys:
+            if any(abs(x - cx) <= 0.3 and abs(y - cy) <= 0.3 for cx, cy in pillars):
+                continue
+            c = w2m([x, y, 0.0])
+            cells.append((int(c[0]), int(c[1])))
+    return np.array(sorted(set(cells)), dtype=np.uint32)

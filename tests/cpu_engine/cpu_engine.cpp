@@ -290,4 +290,52 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_eval_batch(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                            const double* poses, uint32_t B, double* sqnorm_out, double* loglik_out)
+{
+    Scan s = pts ? make_scan(pts, n, origin, quat) : c->last_scan;
+    c->last_scan = s;
+    if (loglik_out) c->tool->stage_set_scan(s);
+    for (uint32_t b = 0; b < B; ++b) {
+        if (sqnorm_out) {
+            MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(poses + 4 * b));
+            std::vector<double> r;
+            ms.eval(r, nullptr);
+            double e = 0;
+            for (double v : r) e += v * v;
+            sqnorm_out[b] = e;
+        }
+        if (loglik_out) {
+            Particle p;
+            p.pose = se2_of(poses + 4 * b); p.dm = c->dm[particle];
+            loglik_out[b] = c->tool->calculateLikelihood(p);
+        }
+    }
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin,
+                                       const double* quat, double yaw, const double* xy, uint32_t K, uint32_t point_step, double* l_out)
+{
+    Scan s = pts ? make_scan(pts, n, origin, quat) : c->last_scan;
+    c->last_scan = s;
+    const Affine3 mtf = moving_tf(s);
+    double Raa[3][3];
+    angle_axis_z(yaw, Raa);
+    const DynamicDistanceMap& dm = *c->dm[particle];
+    for (uint32_t k = 0; k < K; ++k) {
+        const double trans[3] = {xy[2 * k], xy[2 * k + 1], 0.0};
+        const Affine3 tf = affine_mul(affine_from(trans, Raa), mtf);
+        double l = 0.0;
+        for (size_t i = 0; i < s.points.size(); i += point_step) {
+            const V3d hit = affine_apply(tf, s.points[i]);
+            const double dist = dm.distance(dm.w2m(hit));
+            const double e = std::exp(-(dist * dist) / 0.01);
+            l += e * e * e;
+        }
+        l_out[k] = l;
+    }
+    return LAMA_HIP_OK;
+}
+
 } // extern "C"

@@ -386,3 +386,78 @@ def test_tiny_and_degenerate_scans(F):
         assert np.abs(g_poses - pf.poses()).max() < 1e-8
         ctx.set_poses(pf.poses())
     ctx.close()
+
+
+def test_loc2d_global_localization_and_sampling_covariance_gpu(F):
+    """SURVEY 8 f-1: Loc2D::globalLocalization (3000 candidates evaluated in one batch by lama_hip_eval_batch) and
+    addSamplingCovariance (lama_hip_map_sample_likelihood) on the device against the oracle: identical candidates (host
+    RNG), squared residual norms within 1e-11 relative, the same winner, localisation recovers the true pose."""
+    from _worlds import corridor_free_cells, corridor_obstacles
+    obst = corridor_obstacles()
+    free = corridor_free_cells(O.w2m)
+    steps = 5
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    kw = dict(gloc_particles=3000, gloc_iters=5, gloc_thresh=0.15, cov_blend=0.35)
+    o = O.Loc(**kw)
+    dm = o.dm()
+    ocells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in obst)], dtype=np.uint32)
+    for cx, cy in ocells:
+        dm.add(int(cx), int(cy))
+    dm.update()
+    o.occ_set_cells(free, -1)
+    o.occ_set_cells(ocells, 1)
+    h = F.Loc2D(**kw)
+    h.occ_set_cells(free, -1)
+    h.set_obstacles_world(obst)
+    assert h.engine_origin().endswith("liblama_hip.so")
+    O.random_set_seed(77)
+    F.random_set_seed(77)
+    start = np.array([20.0, 1.0, 2.0])
+    o.set_pose(O.se2(*start))
+    h.set_pose(*start)
+    o.trigger_global_localization()
+    h.trigger_global_localization()
+    ran = 0
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k), force=True) == h.update(pts[k], odom[k], float(k), force=True)
+        op, oe = o.gloc_candidates()
+        hp, he = h.gloc_candidates()
+        assert np.array_equal(op, hp), k
+        assert np.allclose(oe, he, rtol=1e-11, atol=0), (k, np.abs(oe - he).max())
+        assert int(np.argmin(oe)) == int(np.argmin(he))
+        ran += len(he) > 0
+        ol, hl = o.sampling_likelihoods(), h.sampling_likelihoods()
+        assert len(hl) == 161 and np.allclose(ol, hl, rtol=1e-12, atol=1e-300), (k, np.abs(ol - hl).max())
+        assert np.abs(o.pose() - h.pose()).max() < 1e-7, k
+        assert o.iterations() == h.iterations()
+        assert o.global_localization_active() == h.global_localization_active()
+        assert abs(o.rmse() - h.rmse()) < 1e-9
+        assert np.allclose(o.covar(), h.covar(), rtol=1e-6, atol=1e-12)
+    assert ran >= 1 and not h.global_localization_active()
+    g = h.pose()
+    assert np.hypot(g[2] - truth[steps][0], g[3] - truth[steps][1]) < 0.05
+    h.close()
+
+
+def test_eval_batch_matches_oracle_and_match_batch(F):
+    """lama_hip_eval_batch: squared residual norm and log-likelihood per pose on one particle's map."""
+    pts, odom, truth = F.corridor_log(2, 1080)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=1, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=1, profile=1))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(11)
+    B = 3000
+    poses = np.stack([O.se2(rng.uniform(0.5, 27.5), rng.uniform(0.5, 3.5), rng.uniform(-np.pi, np.pi)) for _ in range(B)])
+    ctx.reset_counters()
+    sq, ll = ctx.eval_batch(0, pts[1], poses)
+    ms = ctx.counters()["ms_eval_batch"]
+    ll2 = ctx.match_batch(0, pts[1], poses)
+    assert np.array_equal(ll, ll2)
+    dmo = pf.dm(0)
+    for b in range(0, B, 97):
+        r = O.eval_(dmo, pts[1], poses[b], jac=False)
+        assert abs(sq[b] - float(np.dot(r, r))) <= 1e-11 * max(1.0, sq[b])
+    print(f"eval_batch: {B} poses x 1080 beams in {ms:.3f} ms")

@@ -167,3 +167,57 @@ def test_loc2d_host_matches_oracle():
         g = h.pose()
         assert np.hypot(g[2] - truth[k][0], g[3] - truth[k][1]) < 0.05
     assert h.rmse() < 0.05
+
+
+def _loc_pair(obst, free, **kw):
+    o = O.Loc(**kw)
+    dm = o.dm()
+    ocells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in obst)], dtype=np.uint32)
+    for cx, cy in ocells:
+        dm.add(int(cx), int(cy))
+    dm.update()
+    o.occ_set_cells(free, -1)
+    o.occ_set_cells(ocells, 1)
+    h = F.Loc2D(**kw)
+    h.occ_set_cells(free, -1)
+    h.set_obstacles_world(obst)          # occupancy_map->setOccupied + distance_map->addObstacle + update
+    return o, h
+
+
+def test_loc2d_global_localization_and_sampling_covariance_host_matches_oracle():
+    """SURVEY 8 f-1: Loc2D::triggerGlobalLocalization / globalLocalization (src/loc2d.cpp:194-197, 249-286: candidates
+    from lama::random, first smallest squared residual norm wins) and addSamplingCovariance (:199-247) -- host logic
+    against the oracle with the oracle-backed engine double: everything must agree bit for bit."""
+    from _worlds import corridor_free_cells, corridor_obstacles
+    obst = corridor_obstacles()
+    free = corridor_free_cells(O.w2m)
+    steps = 6
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o, h = _loc_pair(obst, free, gloc_particles=300, gloc_iters=2, gloc_thresh=0.15, cov_blend=0.35)
+    lo, hi = o.occ_bounds()
+    hlo, hhi = h.occ_bounds()
+    assert np.array_equal(lo, hlo) and np.array_equal(hi, hhi)
+    assert lo[0] <= 0.1 and hi[0] >= 27.9 and hi[0] - lo[0] < 28.0 + 2 * 1.6 + 1e-9
+    O.random_set_seed(77)
+    F.random_set_seed(77)
+    start = np.array([20.0, 1.0, 2.0])                      # far from the truth: global localisation has to fix it
+    o.set_pose(O.se2(*start))
+    h.set_pose(*start)
+    o.trigger_global_localization()
+    h.trigger_global_localization()
+    assert h.global_localization_active()
+    for k in range(steps + 1):
+        ro = o.update(pts[k], O.se2(*odom[k]), float(k), force=True)
+        rh = h.update(pts[k], odom[k], float(k), force=True)
+        assert ro == rh
+        op, oe = o.gloc_candidates()
+        hp, he = h.gloc_candidates()
+        assert np.array_equal(op, hp) and np.array_equal(oe, he), k
+        assert np.array_equal(o.sampling_likelihoods(), h.sampling_likelihoods()), k
+        assert len(h.sampling_likelihoods()) == 161
+        assert np.array_equal(o.pose(), h.pose()), k
+        assert o.global_localization_active() == h.global_localization_active(), k
+        assert abs(o.rmse() - h.rmse()) <= 1e-15 * max(1.0, o.rmse())
+        assert np.allclose(o.covar(), h.covar(), rtol=1e-9, atol=1e-300), k
+    assert len(op) == 300
+    h.close()
