@@ -899,15 +899,21 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             bool over = nbok && new_sq < cmp;
             const bool tie = nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK);     // :311-317
             if (__ballot(tie)) {
-                uint16_t os = 0;
-                if (tie) {
-                    const int ox = x + obs_x(ob), oy = y + obs_y(ob);
-                    if ((uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) {
-                        const int oslot = dc.lookup(((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5));
-                        if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))];
+                // the neighbour's own obstacle cell: usually the very cell the popped cell points to (both were
+                // reached from the same obstacle), whose state lane 5 already holds -- no second load round then
+                const int ox = x + obs_x(ob), oy = y + obs_y(ob);
+                const bool same = ox == obx && oy == oby;
+                uint16_t os = cos_;
+                if (__ballot(tie && !same)) {
+                    if (tie && !same) {
+                        os = 0;
+                        if ((uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) {
+                            const int oslot = dc.lookup(((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5));
+                            if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))];
+                        }
                     }
-                    if (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
                 }
+                if (tie && (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0))) over = true;
             }
             if (over) {
                 sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
