@@ -18,6 +18,7 @@
 //     all-gather of the per-particle log-likelihoods in between (iris_lama_amd/distributed.py).
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <deque>
 #include <memory>
@@ -26,6 +27,7 @@
 #include <vector>
 
 #include "pose2d.h"
+#include "sdm_io.h"
 
 struct lama_hip_ctx;
 
@@ -103,6 +105,19 @@ public:
     // cells: 10240 B (distance_t) or 4096 B (frequency) per patch, masks: 16 x uint64 per patch.
     bool downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
     bool downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    // the same as lama::sdm::HostMap, ready for sdm::write (the reference's .sdm file) / sdm::export_to_png
+    bool downloadDistanceMap(sdm::HostMap& m) const
+    {
+        m.kind = sdm::kDistanceMap; m.resolution = options_.resolution;
+        const uint32_t r = (uint32_t)std::ceil(options_.l2_max * (1.0 / options_.resolution));    // DynamicDistanceMap::setMaxDistance :149-153
+        m.max_sqdist = r * r;
+        return downloadDistanceMap(m.ids, m.cells, m.masks);
+    }
+    bool downloadOccupancyMap(sdm::HostMap& m) const
+    {
+        m.kind = sdm::kFrequencyOccupancyMap; m.resolution = options_.resolution;
+        return downloadOccupancyMap(m.ids, m.cells, m.masks);
+    }
 
     // ------------------------------------------------------------------ step-wise API (sharded operation)
     enum Phase { kNoUpdate = 0, kFirstScan = 1, kMatched = 2 };

@@ -8,12 +8,14 @@
 // there is no CPU fallback.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <memory>
 #include <string>
 #include <vector>
 
 #include "pose2d.h"
+#include "sdm_io.h"
 
 struct lama_hip_ctx;
 
@@ -58,6 +60,19 @@ public:
 
     bool downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
     bool downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    // the same as lama::sdm::HostMap, ready for sdm::write (the reference's .sdm file) / sdm::export_to_png
+    bool downloadDistanceMap(sdm::HostMap& m) const
+    {
+        m.kind = sdm::kDistanceMap; m.resolution = resolution_;
+        const uint32_t r = (uint32_t)std::ceil(l2_max_ * (1.0 / resolution_));      // DynamicDistanceMap::setMaxDistance :149-153
+        m.max_sqdist = r * r;
+        return downloadDistanceMap(m.ids, m.cells, m.masks);
+    }
+    bool downloadOccupancyMap(sdm::HostMap& m) const
+    {
+        m.kind = sdm::kFrequencyOccupancyMap; m.resolution = resolution_;
+        return downloadOccupancyMap(m.ids, m.cells, m.masks);
+    }
     lama_hip_ctx* deviceContext() const { return ctx_; }
     const HipEngine* engine() const { return eng_.get(); }
 
@@ -67,6 +82,7 @@ private:
     lama_hip_ctx* ctx_ = nullptr;
     Pose2D odom_, pose_;
     double trans_thresh_, rot_thresh_;
+    double resolution_ = 0.05, l2_max_ = 0.5;
     bool has_first_scan = false;
     uint32_t number_of_proccessed_cells_ = 0;
     uint32_t last_iterations_ = 0;

@@ -138,6 +138,17 @@ void lama_loc_trigger_global_localization(lama_loc* l);
 int lama_loc_global_localization_active(const lama_loc* l);
 uint32_t lama_loc_gloc_candidates(const lama_loc* l, double* poses4, double* errors, uint32_t cap);
 uint32_t lama_loc_sampling_likelihoods(const lama_loc* l, double* out, uint32_t cap);
+/* ---- lama::sdm map formats (include/lama/sdm_io.h): the reference's `.sdm` file (Map::write/read, src/sdm/map.cpp:489-575)
+ * and the export images of src/sdm/export.cpp:46-110 for maps downloaded from the device.
+ * kind: 0 DynamicDistanceMap (10 B cells), 1 FrequencyOccupancyMap (4 B), 2 SimpleOccupancyMap (1 B). */
+int lama_sdm_write(const char* file, int kind, double resolution, uint32_t max_sqdist, uint32_t n,
+                   const uint64_t* ids, const uint8_t* cells, const uint64_t* masks);
+int lama_sdm_read(const char* file, int* kind, double* resolution, uint32_t* max_sqdist, uint32_t cap,
+                  uint64_t* ids, uint8_t* cells, uint64_t* masks, uint32_t* n);       /* cap = 0: query n */
+int lama_sdm_image(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                   const uint64_t* masks, uint32_t* width, uint32_t* height, uint8_t* out, uint64_t cap);
+int lama_sdm_export_png(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                        const uint64_t* masks, const char* file);
 /* lama::random (include/lama/random.h) */
 void lama_random_set_seed(uint32_t seed);
 double lama_random_uniform(void);

@@ -319,6 +319,7 @@ HOST_SYMBOLS = [
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
     "lama_loc_global_localization_active", "lama_loc_gloc_candidates", "lama_loc_sampling_likelihoods",
     "lama_random_set_seed", "lama_random_uniform",
+    "lama_sdm_write", "lama_sdm_read", "lama_sdm_image", "lama_sdm_export_png",
 ]
 
 
@@ -356,6 +357,10 @@ def _bind_host(L):
         "lama_loc_trigger_global_localization": (None, [vp]), "lama_loc_global_localization_active": (i32, [vp]),
         "lama_loc_gloc_candidates": (u32, [vp, vp, vp, u32]), "lama_loc_sampling_likelihoods": (u32, [vp, vp, u32]),
         "lama_random_set_seed": (None, [u32]), "lama_random_uniform": (d, []),
+        "lama_sdm_write": (i32, [C.c_char_p, i32, d, u32, u32, vp, vp, vp]),
+        "lama_sdm_read": (i32, [C.c_char_p, vp, vp, vp, u32, vp, vp, vp, vp]),
+        "lama_sdm_image": (i32, [i32, d, u32, u32, vp, vp, vp, vp, vp, vp, C.c_uint64]),
+        "lama_sdm_export_png": (i32, [i32, d, u32, u32, vp, vp, vp, C.c_char_p]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -708,3 +713,57 @@ class Loc2D:
 def random_set_seed(seed):
     """lama::random::setSeed (process-wide generator used by Loc2D::globalLocalization)."""
     _hostlib().lama_random_set_seed(int(seed))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# lama::sdm map formats (include/lama/sdm_io.h) on downloaded maps: {patch id: (cells, mask)} as HipContext.download_map returns
+# ---------------------------------------------------------------------------------------------------------------
+SDM_CELL_BYTES = {MAP_DISTANCE: 10, MAP_OCCUPANCY: 4, 2: 1}
+
+
+def _sdm_arrays(patches, kind):
+    ids = np.array(sorted(patches), dtype=np.uint64)
+    cb = SDM_CELL_BYTES[kind] * 1024
+    cells = np.zeros((len(ids), cb), dtype=np.uint8)
+    masks = np.zeros((len(ids), 16), dtype=np.uint64)
+    for k, i in enumerate(ids):
+        c, m = patches[int(i)]
+        cells[k] = np.ascontiguousarray(c).view(np.uint8).reshape(-1)
+        masks[k] = m
+    return ids, cells, masks
+
+
+def sdm_write(filename, patches, kind, resolution=0.05, max_sqdist=100):
+    ids, cells, masks = _sdm_arrays(patches, kind)
+    if _hostlib().lama_sdm_write(filename.encode(), kind, resolution, max_sqdist, len(ids), _p(ids), _p(cells), _p(masks)) != 0:
+        raise LamaError(f"cannot write {filename}")
+
+
+def sdm_read(filename):
+    """-> (kind, resolution, max_sqdist, {patch id: (cells bytes, mask)})"""
+    L = _hostlib()
+    kind, n, msq, res = C.c_int32(0), C.c_uint32(0), C.c_uint32(0), C.c_double(0)
+    if L.lama_sdm_read(filename.encode(), C.byref(kind), C.byref(res), C.byref(msq), 0, None, None, None, C.byref(n)) != 0:
+        raise LamaError(f"cannot read {filename}")
+    cb = SDM_CELL_BYTES[kind.value] * 1024
+    ids = np.zeros(n.value, dtype=np.uint64)
+    cells = np.zeros((n.value, cb), dtype=np.uint8)
+    masks = np.zeros((n.value, 16), dtype=np.uint64)
+    L.lama_sdm_read(filename.encode(), None, None, None, n.value, _p(ids), _p(cells), _p(masks), None)
+    return kind.value, res.value, msq.value, {int(ids[k]): (cells[k], masks[k]) for k in range(n.value)}
+
+
+def sdm_image(patches, kind, resolution=0.05, max_sqdist=100):
+    ids, cells, masks = _sdm_arrays(patches, kind)
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    L = _hostlib()
+    L.lama_sdm_image(kind, resolution, max_sqdist, len(ids), _p(ids), _p(cells), _p(masks), C.byref(w), C.byref(h), None, 0)
+    out = np.zeros((h.value, w.value), dtype=np.uint8)
+    L.lama_sdm_image(kind, resolution, max_sqdist, len(ids), _p(ids), _p(cells), _p(masks), C.byref(w), C.byref(h), _p(out), out.size)
+    return out
+
+
+def sdm_export_png(filename, patches, kind, resolution=0.05, max_sqdist=100):
+    ids, cells, masks = _sdm_arrays(patches, kind)
+    if _hostlib().lama_sdm_export_png(kind, resolution, max_sqdist, len(ids), _p(ids), _p(cells), _p(masks), filename.encode()) != 0:
+        raise LamaError(f"cannot write {filename}")

@@ -9,6 +9,7 @@
 #include "lama/pf_slam2d.h"
 #include "lama/loc2d.h"
 #include "lama/random.h"
+#include "lama/sdm_io.h"
 #include "lama/slam2d.h"
 
 using namespace lama;
@@ -404,6 +405,53 @@ uint32_t lama_loc_sampling_likelihoods(const lama_loc* h, double* out, uint32_t 
     const uint32_t n = (uint32_t)h->l.lastSamplingLikelihoods().size();
     for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = h->l.lastSamplingLikelihoods()[i];
     return n;
+}
+static lama::sdm::HostMap host_map(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                                    const uint64_t* masks)
+{
+    lama::sdm::HostMap m;
+    m.kind = (lama::sdm::MapKind)kind; m.resolution = resolution; m.max_sqdist = max_sqdist;
+    const size_t pb = (size_t)1024 * m.cellSize();
+    m.ids.assign(ids, ids + n);
+    m.cells.assign(cells, cells + (size_t)n * pb);
+    m.masks.assign(masks, masks + (size_t)n * 16);
+    return m;
+}
+int lama_sdm_write(const char* file, int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                   const uint64_t* masks)
+{
+    return lama::sdm::write(host_map(kind, resolution, max_sqdist, n, ids, cells, masks), file) ? 0 : -1;
+}
+int lama_sdm_read(const char* file, int* kind, double* resolution, uint32_t* max_sqdist, uint32_t cap, uint64_t* ids, uint8_t* cells,
+                  uint64_t* masks, uint32_t* n)
+{
+    lama::sdm::HostMap m;
+    if (!lama::sdm::read(m, file)) return -1;
+    if (kind) *kind = (int)m.kind;
+    if (resolution) *resolution = m.resolution;
+    if (max_sqdist) *max_sqdist = m.max_sqdist;
+    if (n) *n = (uint32_t)m.numPatches();
+    if (cap >= m.numPatches() && ids && cells && masks) {
+        std::memcpy(ids, m.ids.data(), m.ids.size() * 8);
+        std::memcpy(cells, m.cells.data(), m.cells.size());
+        std::memcpy(masks, m.masks.data(), m.masks.size() * 8);
+    }
+    return 0;
+}
+int lama_sdm_image(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                   const uint64_t* masks, uint32_t* width, uint32_t* height, uint8_t* out, uint64_t cap)
+{
+    lama::sdm::Image im;
+    lama::sdm::build_image(host_map(kind, resolution, max_sqdist, n, ids, cells, masks), im);
+    if (width) *width = im.width;
+    if (height) *height = im.height;
+    if (out && cap >= im.data.size()) std::memcpy(out, im.data.data(), im.data.size());
+    return 0;
+}
+int lama_sdm_export_png(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
+                        const uint64_t* masks, const char* file)
+{
+    return lama::sdm::export_to_png(host_map(kind, resolution, max_sqdist, n, ids, cells, masks), file) ? 0 : -1;
 }
 void lama_random_set_seed(uint32_t seed) { lama::random::setSeed(seed); }
 double lama_random_uniform(void) { return lama::random::uniform(); }

@@ -19,7 +19,7 @@ void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], 
 }
 } // namespace
 
-Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.rot_thresh)
+Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.rot_thresh), resolution_(o.resolution), l2_max_(o.l2_max)
 {
     if (o.strategy == "lm") throw std::runtime_error("lama::Slam2D: strategy \"lm\" is not available on the device path");   // src/slam2d.cpp:226-233
     if (o.use_compression || o.transient_map) throw std::runtime_error("lama::Slam2D: use_compression / transient_map are not supported on the device path");

@@ -40,6 +40,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <fstream>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -384,6 +385,70 @@ public:
         mn = m2w(a); mx = m2w(b);
     }
 
+    // map.cpp:489-575 Map::write / Map::read (uncompressed containers; IOHeader map.h:95-103 written as it lies in
+    // memory: 32 bytes on LP64) + Container::write/read (container.cpp:143-176: cells then the mask words)
+    struct IOHeader { uint32_t magic; uint16_t version; uint32_t cell_size; uint32_t patch_length; size_t num_patches; float resolution; bool is_3d; };
+    virtual void writeParameters(std::ofstream&) const {}
+    virtual void readParameters(std::ifstream&) {}
+    bool write(const std::string& filename) const
+    {
+        std::ofstream f(filename.c_str(), std::ios::out | std::ios::binary | std::ios::trunc);
+        if (!f.is_open()) return false;
+        IOHeader header;
+        std::memset(&header, 0, sizeof(header));
+        header.magic = 0x6d64732e; header.version = 0x0103; header.cell_size = (uint32_t)cell_memory_size;
+        header.patch_length = patch_length; header.num_patches = patches.size(); header.resolution = (float)resolution; header.is_3d = false;
+        f.write((char*)&header, sizeof(IOHeader));
+        if (!f) return false;
+        this->writeParameters(f);
+        for (auto it = patches.begin(); it != patches.end(); ++it) {
+            f.write((char*)&(it->first), sizeof(uint64_t));
+            f.write((const char*)it->second->data.data(), (std::streamsize)it->second->data.size());
+            f.write((const char*)it->second->mask.data(), (std::streamsize)(sizeof(uint64_t) * it->second->mask.size()));
+        }
+        f.close();
+        return true;
+    }
+    bool read(const std::string& filename)
+    {
+        std::ifstream f(filename.c_str(), std::ios::in | std::ios::binary);
+        if (!f.is_open()) return false;
+        IOHeader header;
+        f.read((char*)&header, sizeof(IOHeader));
+        if (!f) return false;
+        if (header.magic != 0x6d64732e || header.version != 0x0103) return false;
+        if ((header.cell_size != cell_memory_size) || header.is_3d) return false;
+        resolution = header.resolution;
+        scale = 1.0 / resolution;
+        patch_length = header.patch_length;
+        patch_volume = patch_length * patch_length;
+        log2dim = (int)std::log2((double)patch_length);
+        off = double(UNIVERSAL_CONSTANT >> 1) * double(patch_length);
+        this->readParameters(f);
+        for (size_t i = 0; i < header.num_patches; ++i) {
+            uint64_t idx;
+            f.read((char*)&idx, sizeof(idx));
+            if (!f) return false;
+            auto c = std::make_shared<Container>((uint32_t)log2dim, (uint32_t)cell_memory_size);
+            f.read((char*)c->data.data(), (std::streamsize)c->data.size());
+            f.read((char*)c->mask.data(), (std::streamsize)(sizeof(uint64_t) * c->mask.size()));
+            patches[idx] = c;
+        }
+        prev_patch_ = nullptr; prev_idx_ = ~uint64_t(0);
+        return true;
+    }
+    // map.cpp:352-359 visit_all_cells: every cell whose mask bit is on
+    template <typename F>
+    void visit_all_cells(F&& walker) const
+    {
+        for (auto& kv : patches) {
+            const V3u anchor = p2m(kv.first);
+            for (uint32_t c = 0; c < patch_volume; ++c)
+                if ((kv.second->mask[c >> 6] >> (c & 63)) & 1ull)
+                    walker(V3u{anchor.x + (c & (patch_length - 1)), anchor.y + (c >> log2dim), anchor.z});
+        }
+    }
+
     // map.cpp:371-412 (non-compressed branch) + COWPtr::operator-> detach (cow_ptr.h:86-114)
     uint8_t* get(const V3u& c)
     {
@@ -576,6 +641,8 @@ public:
         max_sqdist_ *= max_sqdist_;
     }
     double maxDistance() const { return std::sqrt((double)max_sqdist_) * resolution; } // :155-158
+    void writeParameters(std::ofstream& stream) const override { stream.write((char*)&max_sqdist_, sizeof(max_sqdist_)); }   // :200-203
+    void readParameters(std::ifstream& stream) override { stream.read((char*)&max_sqdist_, sizeof(max_sqdist_)); }          // :205-208
 
     double distance(const V3u& c) const                            // :140-147
     {
@@ -861,6 +928,35 @@ private:
 // -------------------------------------------------------------------------------------
 // nlls: CauchyWeight, GaussNewton, Solver  (src/nlls/*.cpp)
 // -------------------------------------------------------------------------------------
+// sdm::export_to_png's build_image (src/sdm/export.cpp:46-95), 2-D: the pixel array (rows = y, top row = min y)
+struct ExportImage { uint32_t width = 0, height = 0; std::vector<uint8_t> data; };
+template <typename OccMap>
+inline void build_image_occ(const OccMap& occ, ExportImage& image)
+{
+    V3u mn, mx;
+    occ.bounds(mn, mx);
+    image.width = mx.x - mn.x; image.height = mx.y - mn.y;
+    image.data.assign((size_t)image.width * image.height, 90);
+    occ.visit_all_cells([&](const V3u& coords) {
+        const uint32_t u = coords.x - mn.x, v = coords.y - mn.y;
+        uint8_t& px = image.data[u + (size_t)v * image.width];
+        if (occ.isFree(coords)) px = 255;
+        else if (occ.isOccupied(coords)) px = 0;
+        else px = 127;
+    });
+}
+inline void build_image_dm(const DynamicDistanceMap& dm, ExportImage& image)
+{
+    V3u mn, mx;
+    dm.bounds(mn, mx);
+    image.width = mx.x - mn.x; image.height = mx.y - mn.y;
+    image.data.assign((size_t)image.width * image.height, 127);
+    dm.visit_all_cells([&](const V3u& coords) {
+        const uint32_t u = coords.x - mn.x, v = coords.y - mn.y;
+        image.data[u + (size_t)v * image.width] = (uint8_t)(dm.distance(coords) * 255 / dm.maxDistance());
+    });
+}
+
 struct CauchyWeight {                                              // robust_cost.cpp:66-73
     double c_;
     explicit CauchyWeight(double param) : c_(1.0 / (param * param)) {}

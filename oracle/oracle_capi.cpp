@@ -384,6 +384,18 @@ void* orc_loc_new2(double trans_thresh, double rot_thresh, double l2_max, double
     b->l.reset(new Loc2D(o));
     return b;
 }
+// ---- map formats (src/sdm/map.cpp:489-575, src/sdm/export.cpp:46-95); kind 0 = DynamicDistanceMap, 1 = FrequencyOccupancyMap
+int orc_map_write(void* map, const char* file) { return ((Map*)map)->write(file) ? 1 : 0; }
+int orc_map_read(void* map, const char* file) { return ((Map*)map)->read(file) ? 1 : 0; }
+int orc_map_image(void* map, int kind, uint32_t* w, uint32_t* h, uint8_t* out, uint64_t cap)
+{
+    ExportImage im;
+    if (kind == 0) build_image_dm(*(DynamicDistanceMap*)map, im);
+    else build_image_occ(*(FrequencyOccupancyMap*)map, im);
+    *w = im.width; *h = im.height;
+    if (out && cap >= im.data.size()) std::memcpy(out, im.data.data(), im.data.size());
+    return 1;
+}
 void orc_random_set_seed(uint32_t seed) { orc::random::setSeed(seed); }
 double orc_random_uniform() { return orc::random::uniform(); }
 // cells: (x, y) map coordinates; state -1 free / 0 unknown / 1 occupied (SimpleOccupancyMap)

@@ -73,6 +73,8 @@ def lib():
             "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
             "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
             "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
+            "orc_map_write": (i32, [vp, C.c_char_p]), "orc_map_read": (i32, [vp, C.c_char_p]),
+            "orc_map_image": (i32, [vp, i32, vp, vp, vp, C.c_uint64]),
             "orc_loc_new2": (vp, [d, d, d, d, u32, u32, u32, u32, d, d]), "orc_random_set_seed": (None, [u32]),
             "orc_random_uniform": (d, []), "orc_loc_occ_set": (None, [vp, vp, u32, i32]), "orc_loc_occ_bounds": (None, [vp, vp]),
             "orc_loc_trigger_gloc": (None, [vp]), "orc_loc_gloc_active": (i32, [vp]),
@@ -150,6 +152,21 @@ class _MapBase:
     def dump(self):
         """{patch_id: (cells[1024], mask[16])}"""
         return {int(p): self.patch(p) for p in self.patch_ids()}
+
+    # Map::write / Map::read (src/sdm/map.cpp:489-575) and sdm::export_to_png's pixel array (src/sdm/export.cpp:46-95)
+    def write(self, filename):
+        assert lib().orc_map_write(self.h, filename.encode()) == 1
+
+    def read(self, filename):
+        return lib().orc_map_read(self.h, filename.encode()) == 1
+
+    def image(self):
+        kind = 0 if self._pre == "orc_dm" else 1
+        w, h = C.c_uint32(0), C.c_uint32(0)
+        lib().orc_map_image(self.h, kind, C.byref(w), C.byref(h), None, 0)
+        out = np.zeros((h.value, w.value), dtype=np.uint8)
+        lib().orc_map_image(self.h, kind, C.byref(w), C.byref(h), _p(out), out.size)
+        return out
 
 
 class DM(_MapBase):
