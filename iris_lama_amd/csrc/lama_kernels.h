@@ -593,7 +593,11 @@ struct BfLds {
     uint64_t lower[LQ];
     uint64_t raise[RQ];
     uint32_t dc[DC_SIZE];
-    uint32_t cmd;          // TW: heap length the helper wave has to pop, or BF_CMD_EXIT
+    // TW mailboxes (double buffered by iteration parity)
+    uint64_t pl_e[2][4];   // main -> helper: the entries lower() wants pushed, in neighbour order
+    uint32_t pl_n[2];      //                 and how many
+    uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
+    uint32_t cmd;          // heap length at the start of the lower wave, or BF_CMD_EXIT
 };
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
@@ -626,25 +630,25 @@ __device__ __forceinline__ uint64_t lds_pop_ancestors(int lane)
 __device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane, uint64_t anc)
 {
     if (!st.active) return;
-    const uint32_t lim = (uint32_t)__builtin_amdgcn_readfirstlane((int)((st.len - 1) / 2));
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
+    const uint32_t lim = (len - 1) / 2;
     const uint32_t H = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
     if (!(H < lim)) return;
-    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
     const int d = 31 - __clz(lane + 1);
     const uint32_t idx = (H << d) + (uint32_t)lane;                 // absolute heap index of my node
-    const bool have = lane >= 1 && lane < 63 && idx < len;
-    const bool cand = have && ((idx - 1) >> 1) < lim;               // my parent has both children
-    uint64_t v = 0; uint32_t psib = 0;
-    if (have) v = h[idx];
-    const bool is_left = (idx & 1u) != 0;
-    if (cand) psib = heap_prio(h[is_left ? idx + 1 : idx - 1]);
-    const uint32_t pme = heap_prio(v);
+    const bool is_left = (lane & 1) != 0;                           // H << d is even for d >= 1: odd index <=> odd lane
+    const uint32_t left = is_left ? idx : idx - 1;                  // my sibling pair: (left, left + 1), children of `parent`
+    const uint32_t parent = (left - 1) >> 1;
+    const bool cand = lane >= 1 && lane < 63 && parent < lim;       // my parent has both children (so both are < len)
+    const uint32_t la = cand ? left : 1u;                           // harmless address for idle lanes (len >= 3 here)
+    const uint64_t vl = h[la], vr = h[la + 1];                      // one ds_read2_b64
     // __adjust_heap: child = right; if (comp(right, left)) child = left   with comp(a, b) = prio(a) > prio(b)
-    const bool step_to_me = cand && (is_left ? psib > pme : !(pme > psib));
+    const bool take_left = heap_prio(vr) > heap_prio(vl);
+    const bool step_to_me = cand && (is_left == take_left);
     const unsigned long long okm = __ballot(step_to_me);
-    const bool onpath = have && (okm & anc) == anc;
+    const bool onpath = cand && (okm & anc) == anc;
     const unsigned long long pathm = __ballot(onpath);
-    if (onpath) h[(idx - 1) >> 1] = v;                               // first[hole] = first[child], all levels at once
+    if (onpath) h[parent] = is_left ? vl : vr;                       // first[hole] = first[child], all levels at once
     // new hole = deepest node of the path (the highest lane: lanes are numbered level by level)
     const int rel = pathm ? 63 - __clzll((long long)pathm) : 0;
     const uint32_t dd = 31 - __clz(rel + 1);
@@ -655,23 +659,27 @@ __device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int la
 {
     if (!st.active) return;
     const bool writer = lane == 0;
-    const uint32_t lim = (st.len - 1) / 2;
-    while (st.child < lim) lds_pop_chunk(h, st, lane, anc);
-    if ((st.len & 1) == 0 && st.child == (st.len - 2) / 2) {
-        st.child = 2 * (st.child + 1);
-        if (writer) h[st.hole] = h[st.child - 1];
-        st.hole = st.child - 1;
+    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
+    const uint32_t lim = (len - 1) / 2;
+    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)st.child) < lim) lds_pop_chunk(h, st, lane, anc);
+    uint32_t hole = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
+    if ((len & 1) == 0 && hole == (len - 2) / 2) {
+        const uint32_t child = 2 * (hole + 1);
+        if (writer) h[hole] = h[child - 1];
+        hole = child - 1;
     }
-    // __push_heap(first, hole, 0, value)
-    uint32_t hole = st.hole;
+    // __push_heap(first, hole, 0, value): wave-uniform, scalar control flow
+    const uint32_t vprio = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(st.value));
     while (hole > 0) {
         const uint32_t parent = (hole - 1) / 2;
         const uint64_t pv = h[parent];
-        if (!heap_comp(pv, st.value)) break;
+        const uint32_t pprio = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(pv));
+        if (!(pprio > vprio)) break;
         if (writer) h[hole] = pv;
         hole = parent;
     }
     if (writer) h[hole] = st.value;
+    st.hole = hole;
 }
 __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t value, bool writer)
 {
@@ -702,9 +710,16 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 // ------------------------------------------------------------------------------------------------
 //
 // TW ("two waves", used while the particle count leaves CUs idle): the kernel is bound by the instruction issue
-// rate of its single wave, so the lower wave's pop() -- a pure LDS heap sift-down, ~45 % of the instructions of
-// one iteration -- is handed to a helper wave on another SIMD of the CU and runs concurrently with the cell
-// loads and the lower() decision.  Two workgroup barriers per pop: "heap consistent, top taken" and "pop done".
+// rate of its single wave, so in the lower wave ALL heap work -- pop()'s sift-down and the push_heap calls, pure
+// LDS code, about half of the instructions of one iteration -- is done by a helper wave on another SIMD of the CU,
+// concurrently with the main wave's cell loads and lower() decision.  One workgroup barrier per pop:
+//   main  : [knows top e_k] loads, decision, map stores, writes the entries to push into a mailbox | barrier D_k |
+//           reads the root the helper saw after pop_k and derives e_{k+1} from it and its own pushes:
+//           push_heap moves a new entry above its parent only if the parent's priority is strictly greater, so
+//           after the pushes the root is the first pushed entry of the smallest priority if that priority is
+//           smaller than the old root's, else the old root -- no need to wait for the pushes themselves;
+//   helper: pop_k, publishes the new root | barrier D_k | pushes_k, then straight on to pop_{k+1}.
+// The sequence of heap operations is exactly the sequential one, so the result stays bit-identical.
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
@@ -732,16 +747,61 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     __syncthreads();
     const uint64_t anc = lds_pop_ancestors(lane);
     if (TW && tid >= UM_BLOCK) {
-        // helper wave: pop() of the lower queue on request
-        for (;;) {
-            __syncthreads();                                   // S: heap consistent, the main wave has taken top()
-            uint32_t n = sh.cmd;
-            if (n == BF_CMD_EXIT) return;
+        // helper wave: owns the lower queue during the lower wave
+        __syncthreads();                                       // S0: raise wave done, heap consistent
+        uint32_t n = sh.cmd;
+        if (n == BF_CMD_EXIT) return;
+#ifdef LAMA_PROFILE_BF
+        uint64_t hp[3] = {0, 0, 0};
+        uint64_t ht = __builtin_readcyclecounter();
+        #define HFT(k) do { const uint64_t t_ = __builtin_readcyclecounter(); hp[k] += t_ - ht; ht = t_; } while (0)
+#else
+        #define HFT(k) do {} while (0)
+#endif
+        for (uint32_t it = 0;; ++it) {
+            const uint32_t b = it & 1u;
             PopState ps_;
             lds_pop_begin(sh.lower, n, ps_);
             lds_pop_finish(sh.lower, ps_, lane, anc);
-            __syncthreads();                                   // D: pop done
+            if (lane == 0 && n > 0) sh.topq[b] = sh.lower[0];
+            HFT(0);
+            __syncthreads();                                   // D
+            HFT(1);
+            // count, entries and the would-be parents are read in ONE LDS round trip (speculatively for 4 entries)
+            const uint32_t l4 = (uint32_t)lane & 3u;
+            const uint32_t cnt_v = sh.pl_n[b];
+            const uint64_t entry = sh.pl_e[b][l4];
+            const uint32_t pos = n + l4;
+            const uint32_t pprio = heap_prio(sh.lower[n >= 4 ? (pos - 1) / 2 : 0]);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
+            if (cnt) {
+                // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries
+                // has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are
+                // simply appended, exactly what the sequential push_heap calls would have done.
+                bool done = false;
+                if (n >= 4) {
+                    const bool mine = (uint32_t)lane < cnt;
+                    const bool up = mine && pprio > heap_prio(entry);
+                    if (__ballot(up) == 0) {
+                        if (mine) sh.lower[pos] = entry;
+                        n += cnt;
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    #pragma unroll 1
+                    for (uint32_t i = 0; i < cnt; ++i) lds_push(sh.lower, n, sh.pl_e[b][i], lane == 0);
+                }
+            }
+            HFT(2);
+            if (n == 0 || n + 4 > (uint32_t)LQ_LDS) break;     // the main wave takes the same decision
         }
+#ifdef LAMA_PROFILE_BF
+        if (lane == 0) for (int k = 0; k < 3; ++k) prm.dbg[8 * p + 5 + k] = hp[k];
+#endif
+        #undef HFT
+        __syncthreads();                                       // F: last pushes applied
+        return;
     }
     const DirCache dc{sh.dc, dir, prm.W};
 
@@ -835,13 +895,19 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 
     // ---- lower wave ------------------------------------------------------------------------- :175-194
     BFT(7);
+    uint64_t e_next = 0;
+    uint32_t tw_it = 0;
+    bool tw_running = false;
+    if (TW) {
+        if (!spill && nl > 0 && nl + 4 > (uint32_t)LQ_LDS) spill = true;
+        tw_running = !spill && nl > 0;
+        if (lane == 0) sh.cmd = tw_running ? nl : BF_CMD_EXIT;
+        if (tw_running) e_next = sh.lower[0];
+        __syncthreads();                                       // S0: hands the lower queue to the helper wave
+    }
     while (!spill && nl > 0) {
-        if (nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
-        const uint64_t e = sh.lower[0];
-        if (TW) {
-            if (lane == 0) sh.cmd = nl;
-            __syncthreads();                                   // S
-        }
+        if (!TW && nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
+        const uint64_t e = TW ? e_next : sh.lower[0];
         const int rx = q_rx(e), ry = q_ry(e);
         ++processed;
         BFT(0);
@@ -856,6 +922,8 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;
         if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) { ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; } }
         BFT(1);
+        uint32_t tw_cnt = 0, tw_om = 0;
+        uint64_t tw_entry = 0;
         if (TW) {
             --nl;                                              // the helper wave pops
         } else {
@@ -921,13 +989,19 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             }
             if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
             BFT(4);
-            if (TW) __syncthreads();                           // D: the helper's pop is complete
             // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
             // to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply
             // appended, exactly what the sequential push_heap calls would have done.
             const unsigned long long om = __ballot(over);
             const int ocnt = __popcll(om);
             bool done = ocnt == 0;
+            if (TW) {                                          // the helper wave pushes: hand the entries over
+                tw_entry = q_entry(new_sq, x, y, obx - x, oby - y);
+                if (over) sh.pl_e[tw_it & 1u][__popcll(om & ((1ull << lane) - 1ull))] = tw_entry;
+                tw_cnt = (uint32_t)ocnt;
+                tw_om = (uint32_t)om & 15u;
+                done = true;
+            }
             if (!done && nl >= 4) {
                 const uint32_t pos = nl + (uint32_t)__popcll(om & ((1ull << lane) - 1ull));
                 bool stop = true;
@@ -949,16 +1023,30 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                 }
             }
             BFT(5);
-        } else if (TW) {
-            __syncthreads();                                   // D
+        }
+        if (TW) {
+            const uint32_t b = tw_it & 1u;
+            if (lane == 0) sh.pl_n[b] = tw_cnt;
+            __syncthreads();                                   // D: pop_k done, push list delivered
+            bool have = nl > 0;
+            const uint64_t tq = sh.topq[b];
+            uint64_t cand = have ? tq : 0;
+            #pragma unroll
+            for (int i = 0; i < 4; ++i) {                      // my own pushes, in neighbour (= lane) order
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tw_entry, i);
+                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tw_entry >> 32), i);
+                const uint64_t pe = ((uint64_t)hi << 32) | lo;
+                if (((tw_om >> i) & 1u) && (!have || heap_prio(pe) < heap_prio(cand))) { cand = pe; have = true; }
+            }
+            nl += tw_cnt;
+            e_next = cand;
+            ++tw_it;
+            if (nl > 0 && nl + 4 > (uint32_t)LQ_LDS) spill = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         BFT(6);
     }
-    if (TW) {
-        if (lane == 0) sh.cmd = BF_CMD_EXIT;
-        __syncthreads();                                       // S: releases the helper wave
-    }
+    if (TW && tw_running) __syncthreads();                     // F: the helper has applied the last pushes
     #undef BF_LOAD_A
     #undef BF_LOAD_B
     #undef BF_POP_WITH_LOADS
@@ -972,7 +1060,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         prm.stats[4 * p + 3] += processed;
         if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; prm.slow[p] = 1; }
 #ifdef LAMA_PROFILE_BF
-        for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];
+        for (int k = 0; k < (TW ? 5 : 8); ++k) prm.dbg[8 * p + k] = prof[k];
 #endif
     }
 }
