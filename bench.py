@@ -62,6 +62,53 @@ def cpu_baseline(pts, odom, P, updates, warm):
     return cores, res
 
 
+def next_rows(F):
+    """Informational timings of the SURVEY 8(f) rows that run on the device (never part of `value`)."""
+    import numpy as np
+    out = {}
+    try:
+        # f-1: Loc2D::globalLocalization's candidate evaluation, 3000 poses x 1080 beams on one static map
+        pts, odom, truth = F.corridor_log(1, 1080)
+        ctx = F.HipContext(F.default_cfg(particles=1, profile=1))
+        ctx.init(pts[0], F.pose_from_xyr(*odom[0]))
+        rng = np.random.default_rng(0)
+        th = rng.uniform(-np.pi, np.pi, 3000)
+        poses = np.stack([np.cos(th), np.sin(th), rng.uniform(0.5, 27.5, 3000), rng.uniform(0.5, 3.5, 3000)], axis=1)
+        ctx.eval_batch(0, pts[1], poses)
+        ctx.reset_counters()
+        for _ in range(10):
+            ctx.eval_batch(0, pts[1], poses)
+        c = ctx.counters()
+        out["loc2d_global_localization_eval"] = {"poses": 3000, "beams": 1080, "kernel_ms": c["ms_eval_batch"] / max(c["launches_eval_batch"], 1)}
+        # f-3: SE2 pose-graph linearisation, BASELINE config 5 size (10k poses / 50k factors)
+        N, Fc = 10000, 50000
+        thp = np.cumsum(rng.normal(0, 0.15, N))
+        xy = np.cumsum(np.stack([0.5 * np.cos(thp), 0.5 * np.sin(thp)], axis=1), axis=0)
+        x = np.stack([np.cos(thp), np.sin(thp), xy[:, 0], xy[:, 1]], axis=1)
+        fi = np.concatenate([[0], np.arange(N - 1), rng.integers(0, N - 200, Fc - N)]).astype(np.int32)
+        fj = np.concatenate([[-1], np.arange(1, N), np.zeros(Fc - N, dtype=np.int64)]).astype(np.int32)
+        fj[N:] = fi[N:] + rng.integers(2, 199, Fc - N)
+
+        def rel(a, b):          # a^-1 * b
+            c, s = a[:, 0], a[:, 1]
+            dx, dy = b[:, 2] - a[:, 2], b[:, 3] - a[:, 3]
+            return np.stack([c * b[:, 0] + s * b[:, 1], c * b[:, 1] - s * b[:, 0], c * dx + s * dy, -s * dx + c * dy], axis=1)
+        meas = np.zeros((Fc, 4))
+        meas[0] = x[0]
+        meas[1:] = rel(x[fi[1:]], x[fj[1:]])
+        sq = np.tile([2.0, 2.0, 10.0], (Fc, 1))
+        g = F.PoseGraph(N, fi, fj, meas, sq)
+        g.linearize(x, want_err=False, want_off=False)
+        ms = [g.linearize(x, want_err=False, want_off=False)["kernel_ms"] for _ in range(10)]
+        traffic = Fc * (128 + 288 + 192) + N * 96
+        out["pose_graph_linearize"] = {"poses": N, "factors": Fc, "kernel_ms": float(np.mean(ms)),
+                                       "algorithmic_GBps": traffic / (np.mean(ms) * 1e-3) / 1e9}
+        g.close()
+    except Exception as e:          # informational only: never let it break the headline line
+        out["error"] = str(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,7 +207,7 @@ def main():
         launches = max(c["launches_brushfire"], 1)
         dur_s = c["ms_brushfire"] / launches * 1e-3
         achieved = per_ps * args.particles / dur_s / 1e9          # GB/s on this rank's GPU
-        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire<1024,256>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire<1024,256,false,true> (+ its no-op resume stages)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                               "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
                               "mean_launch_ms": dur_s * 1e3}
@@ -185,6 +232,7 @@ def main():
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1)}
         result["canonical_brushfire_mode"] = canon
+        result["next_rows"] = next_rows(F)
     print(json.dumps(result))
 
 

@@ -169,6 +169,23 @@ int32_t lama_hip_match_solve(lama_hip_ctx* ctx, uint32_t particle, const double*
 int32_t lama_hip_pf_export_particle(lama_hip_ctx* ctx, uint32_t particle, void* device_buf, uint64_t cap, uint64_t* bytes);
 int32_t lama_hip_pf_import_particle(lama_hip_ctx* ctx, uint32_t particle, const void* device_buf, uint64_t bytes);
 
+/* SE2 pose-graph linearisation: the per-factor body and the accumulation of minisam's
+ * linearzationLowerHessian (vendor/minisam/minisam/nonlinear/linearization.cpp:150-272,290-341) for PriorFactor<SE2d> /
+ * BetweenFactor<SE2d> with DiagonalLoss, as built by SimplePGO::optimize (src/simple_pgo.cpp:48-105) and
+ * GraphSlam2D::optimizePoseGraph (src/graph_slam2d.cpp:394-430).  The graph structure and measurements are uploaded once
+ * (create), every Levenberg-Marquardt iteration calls linearize with the current poses {c, s, tx, ty}.  Outputs, dense 3x3
+ * blocks row-major (the caller scatters them into its sparse lower Hessian and runs the Cholesky on the host):
+ *   err   [F][3]  whitened error           Hoff [F][9]  J_i^T J_j of factor f (zero for a prior, fj = -1)
+ *   Hdiag [N][9]  sum of J_v^T J_v over the factors of v, in factor order     b [N][3]  Atb = -sum J_v^T err
+ * Any output may be NULL.  kernel_ms: device time of the two kernels (hipEvents on the graph's stream). */
+typedef struct lama_hip_pgo lama_hip_pgo;
+int32_t lama_hip_pgo_create(int32_t device, uint32_t num_poses, const int32_t* fi, const int32_t* fj, const double* meas4,
+                            const double* sqrt_info3, uint32_t num_factors, lama_hip_pgo** out);
+void lama_hip_pgo_destroy(lama_hip_pgo* g);
+const char* lama_hip_pgo_last_error(const lama_hip_pgo* g);
+int32_t lama_hip_pgo_linearize(lama_hip_pgo* g, const double* poses4, double* err, double* Hdiag, double* Hoff, double* b,
+                               double* chi2, double* kernel_ms);
+
 /* Accumulated per-kernel device time (hipEvent elapsed, on the stream the kernels run on) and work
  * counters since the last reset; valid when cfg.profile != 0. */
 typedef struct lama_hip_counters {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "lama_kernels.h"
+#include "lama_pgo.h"
 
 using namespace lama_dev;
 
@@ -673,6 +674,103 @@ int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* c, uint32_t particle, const
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(l_out, c->d_bout, sizeof(double) * K, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SE2 pose-graph linearisation (lama_pgo.h)
+// ------------------------------------------------------------------------------------------------
+struct lama_hip_pgo {
+    int32_t device = 0;
+    uint32_t N = 0, F = 0, blocksF = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_poses = nullptr, *d_meas = nullptr, *d_sqrt = nullptr, *d_err = nullptr, *d_hoff = nullptr, *d_fdi = nullptr, *d_fdj = nullptr,
+           *d_fg = nullptr, *d_hdiag = nullptr, *d_b = nullptr, *d_chi = nullptr;
+    int32_t *d_fi = nullptr, *d_fj = nullptr, *d_incptr = nullptr, *d_inc = nullptr;
+    std::vector<double> h_chi;
+    std::string error;
+};
+
+#define PGOCHK(g, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (g)->error = std::string(#call) + ": " + hipGetErrorString(e_); return LAMA_HIP_E_HIP; } } while (0)
+
+void lama_hip_pgo_destroy(lama_hip_pgo* g);
+#define PGOCHK_C(call) do { if ((call) != hipSuccess) { lama_hip_pgo_destroy(p); return LAMA_HIP_E_HIP; } } while (0)
+int32_t lama_hip_pgo_create(int32_t device, uint32_t N, const int32_t* fi, const int32_t* fj, const double* meas4, const double* sqrt_info3,
+                            uint32_t F, lama_hip_pgo** out)
+{
+    if (!out || !fi || !fj || !meas4 || !sqrt_info3 || N == 0 || F == 0) return LAMA_HIP_E_INVALID;
+    *out = nullptr;
+    for (uint32_t k = 0; k < F; ++k)
+        if (fi[k] < 0 || (uint32_t)fi[k] >= N || fj[k] >= (int32_t)N || fj[k] == fi[k]) return LAMA_HIP_E_INVALID;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= device || device < 0) return LAMA_HIP_E_HIP;
+    if (hipSetDevice(device) != hipSuccess) return LAMA_HIP_E_HIP;
+    lama_hip_pgo* p = new lama_hip_pgo;
+    p->device = device; p->N = N; p->F = F; p->blocksF = (F + PGO_BLOCK - 1) / PGO_BLOCK;
+    // incidence lists in factor order (counting sort): what the reference's sequential loop over the factors adds to a variable
+    std::vector<int32_t> ptr(N + 1, 0), inc;
+    for (uint32_t k = 0; k < F; ++k) { ++ptr[fi[k] + 1]; if (fj[k] >= 0) ++ptr[fj[k] + 1]; }
+    for (uint32_t v = 0; v < N; ++v) ptr[v + 1] += ptr[v];
+    inc.resize(ptr[N]);
+    std::vector<int32_t> fill(ptr.begin(), ptr.end() - 1);
+    for (uint32_t k = 0; k < F; ++k) { inc[fill[fi[k]]++] = (int32_t)(2 * k); if (fj[k] >= 0) inc[fill[fj[k]]++] = (int32_t)(2 * k + 1); }
+    PGOCHK_C(hipStreamCreate(&p->stream));
+    PGOCHK_C(hipEventCreate(&p->ev0)); PGOCHK_C(hipEventCreate(&p->ev1));
+    PGOCHK_C(hipMalloc(&p->d_poses, sizeof(double) * 4 * N)); PGOCHK_C(hipMalloc(&p->d_meas, sizeof(double) * 4 * F));
+    PGOCHK_C(hipMalloc(&p->d_sqrt, sizeof(double) * 3 * F)); PGOCHK_C(hipMalloc(&p->d_err, sizeof(double) * 3 * F));
+    PGOCHK_C(hipMalloc(&p->d_hoff, sizeof(double) * 9 * F)); PGOCHK_C(hipMalloc(&p->d_fdi, sizeof(double) * 9 * F));
+    PGOCHK_C(hipMalloc(&p->d_fdj, sizeof(double) * 9 * F)); PGOCHK_C(hipMalloc(&p->d_fg, sizeof(double) * 6 * F));
+    PGOCHK_C(hipMalloc(&p->d_hdiag, sizeof(double) * 9 * N)); PGOCHK_C(hipMalloc(&p->d_b, sizeof(double) * 3 * N));
+    PGOCHK_C(hipMalloc(&p->d_chi, sizeof(double) * p->blocksF));
+    PGOCHK_C(hipMalloc(&p->d_fi, sizeof(int32_t) * F)); PGOCHK_C(hipMalloc(&p->d_fj, sizeof(int32_t) * F));
+    PGOCHK_C(hipMalloc(&p->d_incptr, sizeof(int32_t) * (N + 1))); PGOCHK_C(hipMalloc(&p->d_inc, sizeof(int32_t) * std::max<size_t>(inc.size(), 1)));
+    PGOCHK_C(hipMemcpy(p->d_fi, fi, sizeof(int32_t) * F, hipMemcpyHostToDevice)); PGOCHK_C(hipMemcpy(p->d_fj, fj, sizeof(int32_t) * F, hipMemcpyHostToDevice));
+    PGOCHK_C(hipMemcpy(p->d_meas, meas4, sizeof(double) * 4 * F, hipMemcpyHostToDevice));
+    PGOCHK_C(hipMemcpy(p->d_sqrt, sqrt_info3, sizeof(double) * 3 * F, hipMemcpyHostToDevice));
+    PGOCHK_C(hipMemcpy(p->d_incptr, ptr.data(), sizeof(int32_t) * (N + 1), hipMemcpyHostToDevice));
+    PGOCHK_C(hipMemcpy(p->d_inc, inc.data(), sizeof(int32_t) * inc.size(), hipMemcpyHostToDevice));
+    p->h_chi.resize(p->blocksF);
+    *out = p;
+    return LAMA_HIP_OK;
+}
+
+void lama_hip_pgo_destroy(lama_hip_pgo* g)
+{
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    void* ptrs[] = {g->d_poses, g->d_meas, g->d_sqrt, g->d_err, g->d_hoff, g->d_fdi, g->d_fdj, g->d_fg, g->d_hdiag, g->d_b, g->d_chi,
+                    g->d_fi, g->d_fj, g->d_incptr, g->d_inc};
+    for (void* q : ptrs) if (q) (void)hipFree(q);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+}
+
+const char* lama_hip_pgo_last_error(const lama_hip_pgo* g) { return g ? g->error.c_str() : "null handle"; }
+
+int32_t lama_hip_pgo_linearize(lama_hip_pgo* g, const double* poses4, double* err, double* Hdiag, double* Hoff, double* b, double* chi2,
+                               double* kernel_ms)
+{
+    if (!g || !poses4) return LAMA_HIP_E_INVALID;
+    PGOCHK(g, hipSetDevice(g->device));
+    PGOCHK(g, hipMemcpyAsync(g->d_poses, poses4, sizeof(double) * 4 * g->N, hipMemcpyHostToDevice, g->stream));
+    PgoPtrs p{g->d_poses, g->d_fi, g->d_fj, g->d_meas, g->d_sqrt, g->d_err, g->d_hoff, g->d_fdi, g->d_fdj, g->d_fg, g->d_incptr, g->d_inc,
+              g->d_hdiag, g->d_b, g->d_chi};
+    PGOCHK(g, hipEventRecord(g->ev0, g->stream));
+    hipLaunchKernelGGL(k_pgo_factors, dim3(g->blocksF), dim3(PGO_BLOCK), 0, g->stream, p, g->F);
+    hipLaunchKernelGGL(k_pgo_reduce, dim3((g->N + PGO_BLOCK - 1) / PGO_BLOCK), dim3(PGO_BLOCK), 0, g->stream, p, g->N);
+    PGOCHK(g, hipEventRecord(g->ev1, g->stream));
+    PGOCHK(g, hipGetLastError());
+    if (err) PGOCHK(g, hipMemcpyAsync(err, g->d_err, sizeof(double) * 3 * g->F, hipMemcpyDeviceToHost, g->stream));
+    if (Hoff) PGOCHK(g, hipMemcpyAsync(Hoff, g->d_hoff, sizeof(double) * 9 * g->F, hipMemcpyDeviceToHost, g->stream));
+    if (Hdiag) PGOCHK(g, hipMemcpyAsync(Hdiag, g->d_hdiag, sizeof(double) * 9 * g->N, hipMemcpyDeviceToHost, g->stream));
+    if (b) PGOCHK(g, hipMemcpyAsync(b, g->d_b, sizeof(double) * 3 * g->N, hipMemcpyDeviceToHost, g->stream));
+    PGOCHK(g, hipMemcpyAsync(g->h_chi.data(), g->d_chi, sizeof(double) * g->blocksF, hipMemcpyDeviceToHost, g->stream));
+    PGOCHK(g, hipStreamSynchronize(g->stream));
+    if (chi2) { double t = 0; for (double x : g->h_chi) t += x; *chi2 = t; }
+    if (kernel_ms) { float ms = 0; PGOCHK(g, hipEventElapsedTime(&ms, g->ev0, g->ev1)); *kernel_ms = ms; }
     return LAMA_HIP_OK;
 }
 

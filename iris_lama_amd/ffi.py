@@ -50,6 +50,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_download_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
+    "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
 ]
 
 _hip = None
@@ -100,8 +101,19 @@ def _bind_hip(L):
         L.lama_hip_match_solve.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32]
         L.lama_hip_eval_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp, vp]
         L.lama_hip_map_sample_likelihood.argtypes = [vp, u32, vp, u32, vp, vp, C.c_double, vp, u32, u32, vp]
+        has_pgo = hasattr(L, "lama_hip_pgo_create")       # the engine test double (tests/cpu_engine) has no pose-graph part
+        if has_pgo:
+            L.lama_hip_pgo_create.argtypes = [i32, u32, vp, vp, vp, vp, u32, vp]
+            L.lama_hip_pgo_destroy.argtypes = [vp]
+            L.lama_hip_pgo_destroy.restype = None
+            L.lama_hip_pgo_last_error.argtypes = [vp]
+            L.lama_hip_pgo_last_error.restype = C.c_char_p
+            L.lama_hip_pgo_linearize.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         for s in HIP_SYMBOLS:
-            if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error"):
+            if s.startswith("lama_hip_pgo_") and not has_pgo:
+                continue
+            if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error", "lama_hip_pgo_destroy",
+                         "lama_hip_pgo_last_error"):
                 getattr(L, s).restype = i32
 
 
@@ -767,3 +779,44 @@ def sdm_export_png(filename, patches, kind, resolution=0.05, max_sqdist=100):
     ids, cells, masks = _sdm_arrays(patches, kind)
     if _hostlib().lama_sdm_export_png(kind, resolution, max_sqdist, len(ids), _p(ids), _p(cells), _p(masks), filename.encode()) != 0:
         raise LamaError(f"cannot write {filename}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SE2 pose-graph linearisation on the device (include/lama_hip.h, lama_hip_pgo_*)
+# ---------------------------------------------------------------------------------------------------------------
+class PoseGraph:
+    """Factors: fi, fj (fj = -1: prior on fi), meas [F,4] = {c, s, tx, ty}, sqrt_info [F,3] (DiagonalLoss: 1 / sigma)."""
+
+    def __init__(self, num_poses, fi, fj, meas, sqrt_info, device=0):
+        self.L = hip_lib()
+        self.N = int(num_poses)
+        self.fi = np.ascontiguousarray(fi, dtype=np.int32)
+        self.fj = np.ascontiguousarray(fj, dtype=np.int32)
+        self.meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 4)
+        self.sqrt_info = np.ascontiguousarray(sqrt_info, dtype=np.float64).reshape(-1, 3)
+        self.F = len(self.fi)
+        h = C.c_void_p()
+        rc = self.L.lama_hip_pgo_create(device, self.N, _p(self.fi), _p(self.fj), _p(self.meas), _p(self.sqrt_info), self.F, C.byref(h))
+        if rc != 0 or not h:
+            raise LamaError(f"lama_hip_pgo_create failed (status {rc}): no usable MI355X / HIP device or invalid graph; there is no CPU fallback")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lama_hip_pgo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def linearize(self, poses, want_err=True, want_off=True):
+        """-> dict(err [F,3], Hdiag [N,3,3], Hoff [F,3,3], b [N,3], chi2, kernel_ms)"""
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(self.N, 4)
+        err = np.zeros((self.F, 3)) if want_err else None
+        hoff = np.zeros((self.F, 3, 3)) if want_off else None
+        hd, b = np.zeros((self.N, 3, 3)), np.zeros((self.N, 3))
+        chi2, ms = C.c_double(0), C.c_double(0)
+        rc = self.L.lama_hip_pgo_linearize(self.h, _p(poses), _p(err), _p(hd), _p(hoff), _p(b), C.byref(chi2), C.byref(ms))
+        if rc != 0:
+            raise LamaError(self.L.lama_hip_pgo_last_error(self.h).decode())
+        return {"err": err, "Hdiag": hd, "Hoff": hoff, "b": b, "chi2": chi2.value, "kernel_ms": ms.value}

@@ -1871,4 +1871,84 @@ private:
     bool has_first_scan = false, rank_deficient_ = false;
 };
 
+// -------------------------------------------------------------------------------------
+// SE2 pose-graph linearisation: what minisam's linearzationLowerHessian
+// (vendor/minisam/minisam/nonlinear/linearization.cpp:150-272,290-341) accumulates for the factor graphs of
+// SimplePGO::optimize (src/simple_pgo.cpp:48-105) and GraphSlam2D::optimizePoseGraph (src/graph_slam2d.cpp:394-430):
+// PriorFactor<SE2d> (slam/PriorFactor.h:50-62) and BetweenFactor<SE2d> (slam/BetweenFactor.h:50-68) with
+// DiagonalLoss (core/LossFunction.cpp:95-113), Sophus traits (geometry/Sophus.h:45-74), SE2 log/Adj
+// (include/lama/sophus/se2.hpp:125-133,519-542).  Output as dense 3x3 blocks (the sparse scatter is the caller's):
+//   err[f]   : whitened error of factor f
+//   Hdiag[v] : sum over the factors touching v, in factor order, of J_v^T J_v   (row-major 3x3)
+//   Hoff[f]  : J_i^T J_j of a between factor (rows: columns of J_i; zero for a prior)
+//   b[v]     : Atb segment = - sum J_v^T err
+// -------------------------------------------------------------------------------------
+struct PgoFactor { int32_t i, j; SE2 meas; double sqrt_info[3]; };     // j < 0: prior on i
+
+inline void se2_log(const SE2& g, double out[3])                        // se2.hpp:519-542
+{
+    const double theta = std::atan2(g.s, g.c);
+    out[2] = theta;
+    const double halftheta = 0.5 * theta;
+    double h;
+    const double real_minus_one = g.c - 1.;
+    if (std::abs(real_minus_one) < 1e-10) h = 1. - (1. / 12) * theta * theta;
+    else h = -(halftheta * g.s) / (real_minus_one);
+    out[0] = h * g.tx + halftheta * g.ty;                                // V_inv * translation
+    out[1] = -halftheta * g.tx + h * g.ty;
+}
+inline void se2_adj(const SE2& g, double A[3][3])                       // se2.hpp:125-133
+{
+    A[0][0] = g.c; A[0][1] = -g.s; A[0][2] = g.ty;
+    A[1][0] = g.s; A[1][1] = g.c;  A[1][2] = -g.tx;
+    A[2][0] = 0;   A[2][1] = 0;    A[2][2] = 1;
+}
+inline void pgo_factor_terms(const PgoFactor& f, const std::vector<SE2>& x, double e[3], double Ji[3][3], double Jj[3][3])
+{
+    if (f.j < 0) {                                                       // PriorFactor: Local(prior, x), identity Jacobian
+        se2_log(se2_mul(se2_inverse(f.meas), x[f.i]), e);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { Ji[r][c] = r == c ? 1.0 : 0.0; Jj[r][c] = 0.0; }
+    } else {                                                             // BetweenFactor
+        const SE2& v1 = x[f.i]; const SE2& v2 = x[f.j];
+        const SE2 diff = se2_mul(se2_inverse(v1), v2);
+        se2_log(se2_mul(se2_inverse(f.meas), diff), e);
+        double Hinv[3][3], Hcmp1[3][3];
+        se2_adj(v1, Hinv);
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Hinv[r][c] = -Hinv[r][c];       // InverseJacobian: -Adj
+        se2_adj(se2_inverse(v2), Hcmp1);                                                        // ComposeJacobians: H1 = s2.inverse().Adj()
+        for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) {
+            Ji[r][c] = (Hcmp1[r][0] * Hinv[0][c] + Hcmp1[r][1] * Hinv[1][c]) + Hcmp1[r][2] * Hinv[2][c];
+            Jj[r][c] = r == c ? 1.0 : 0.0;
+        }
+    }
+    for (int r = 0; r < 3; ++r) {                                        // DiagonalLoss::weightInPlace
+        e[r] = e[r] * f.sqrt_info[r];
+        for (int c = 0; c < 3; ++c) { Ji[r][c] *= f.sqrt_info[r]; Jj[r][c] *= f.sqrt_info[r]; }
+    }
+}
+inline void pgo_linearize(const std::vector<SE2>& x, const std::vector<PgoFactor>& factors,
+                          std::vector<double>& err, std::vector<double>& Hdiag, std::vector<double>& Hoff, std::vector<double>& b, double& chi2)
+{
+    const size_t N = x.size(), F = factors.size();
+    err.assign(3 * F, 0.0); Hdiag.assign(9 * N, 0.0); Hoff.assign(9 * F, 0.0); b.assign(3 * N, 0.0);
+    chi2 = 0.0;
+    for (size_t k = 0; k < F; ++k) {
+        const PgoFactor& f = factors[k];
+        double e[3], Ji[3][3], Jj[3][3];
+        pgo_factor_terms(f, x, e, Ji, Jj);
+        for (int r = 0; r < 3; ++r) { err[3 * k + r] = e[r]; chi2 += e[r] * e[r]; }
+        auto JtJ = [](const double A[3][3], const double B[3][3], int a, int c) { return (A[0][a] * B[0][c] + A[1][a] * B[1][c]) + A[2][a] * B[2][c]; };
+        auto Jte = [&](const double A[3][3], int a) { return (A[0][a] * e[0] + A[1][a] * e[1]) + A[2][a] * e[2]; };
+        for (int a = 0; a < 3; ++a) {
+            b[3 * f.i + a] -= Jte(Ji, a);
+            for (int c = 0; c < 3; ++c) Hdiag[9 * f.i + 3 * a + c] += JtJ(Ji, Ji, a, c);
+        }
+        if (f.j >= 0)
+            for (int a = 0; a < 3; ++a) {
+                b[3 * f.j + a] -= Jte(Jj, a);
+                for (int c = 0; c < 3; ++c) { Hdiag[9 * f.j + 3 * a + c] += JtJ(Jj, Jj, a, c); Hoff[9 * k + 3 * a + c] = JtJ(Ji, Jj, a, c); }
+            }
+    }
+}
+
 } // namespace orc

@@ -396,6 +396,23 @@ int orc_map_image(void* map, int kind, uint32_t* w, uint32_t* h, uint8_t* out, u
     if (out && cap >= im.data.size()) std::memcpy(out, im.data.data(), im.data.size());
     return 1;
 }
+// ---- SE2 pose-graph linearisation (minisam linearzationLowerHessian restated, see lama_oracle.hpp)
+void orc_pgo_linearize(const double* poses4, uint32_t N, const int32_t* fi, const int32_t* fj, const double* meas4, const double* sqrt_info3,
+                       uint32_t F, double* err, double* Hdiag, double* Hoff, double* b, double* chi2)
+{
+    std::vector<SE2> x(N);
+    for (uint32_t i = 0; i < N; ++i) x[i] = se2_of(poses4 + 4 * i);
+    std::vector<PgoFactor> fs(F);
+    for (uint32_t k = 0; k < F; ++k) {
+        fs[k].i = fi[k]; fs[k].j = fj[k]; fs[k].meas = se2_of(meas4 + 4 * k);
+        for (int r = 0; r < 3; ++r) fs[k].sqrt_info[r] = sqrt_info3[3 * k + r];
+    }
+    std::vector<double> e, hd, ho, bb; double c2;
+    pgo_linearize(x, fs, e, hd, ho, bb, c2);
+    std::memcpy(err, e.data(), e.size() * 8); std::memcpy(Hdiag, hd.data(), hd.size() * 8);
+    std::memcpy(Hoff, ho.data(), ho.size() * 8); std::memcpy(b, bb.data(), bb.size() * 8);
+    *chi2 = c2;
+}
 void orc_random_set_seed(uint32_t seed) { orc::random::setSeed(seed); }
 double orc_random_uniform() { return orc::random::uniform(); }
 // cells: (x, y) map coordinates; state -1 free / 0 unknown / 1 occupied (SimpleOccupancyMap)

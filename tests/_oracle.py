@@ -73,6 +73,7 @@ def lib():
             "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
             "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
             "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
+            "orc_pgo_linearize": (None, [vp, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
             "orc_map_write": (i32, [vp, C.c_char_p]), "orc_map_read": (i32, [vp, C.c_char_p]),
             "orc_map_image": (i32, [vp, i32, vp, vp, vp, C.c_uint64]),
             "orc_loc_new2": (vp, [d, d, d, d, u32, u32, u32, u32, d, d]), "orc_random_set_seed": (None, [u32]),
@@ -112,6 +113,12 @@ def se2_exp(v):
 def se2_mul(a, b):
     out = np.zeros(4)
     lib().orc_se2_mul(_p(np.ascontiguousarray(a)), _p(np.ascontiguousarray(b)), _p(out))
+    return out
+
+
+def se2_inverse(a):
+    out = np.zeros(4)
+    lib().orc_se2_inverse(_p(np.ascontiguousarray(a)), _p(out))
     return out
 
 
@@ -473,3 +480,16 @@ class Loc:
 
 def random_set_seed(seed):
     lib().orc_random_set_seed(int(seed))
+
+
+def pgo_linearize(poses, fi, fj, meas, sqrt_info):
+    """Oracle restatement of minisam's linearzationLowerHessian for SE2 prior/between factors (dense blocks)."""
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+    fi = np.ascontiguousarray(fi, dtype=np.int32); fj = np.ascontiguousarray(fj, dtype=np.int32)
+    meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 4)
+    sq = np.ascontiguousarray(sqrt_info, dtype=np.float64).reshape(-1, 3)
+    N, F = len(poses), len(fi)
+    err, hd, ho, b = np.zeros((F, 3)), np.zeros((N, 3, 3)), np.zeros((F, 3, 3)), np.zeros((N, 3))
+    chi2 = C.c_double(0)
+    lib().orc_pgo_linearize(_p(poses), N, _p(fi), _p(fj), _p(meas), _p(sq), F, _p(err), _p(hd), _p(ho), _p(b), C.byref(chi2))
+    return {"err": err, "Hdiag": hd, "Hoff": ho, "b": b, "chi2": chi2.value}
