@@ -16,7 +16,8 @@ namespace sdm {
 enum MapKind : int32_t {
     kDistanceMap = 0,            // DynamicDistanceMap: distance_t, 10 B / cell (+ max_sqdist as map parameter)
     kFrequencyOccupancyMap = 1,  // FrequencyOccupancyMap: frequency {uint16 occupied, uint16 visited}, 4 B / cell
-    kSimpleOccupancyMap = 2      // SimpleOccupancyMap: int8 tri-state, 1 B / cell
+    kSimpleOccupancyMap = 2,     // SimpleOccupancyMap: int8 tri-state, 1 B / cell
+    kProbabilisticOccupancyMap = 3   // ProbabilisticOccupancyMap: prob_tag {float log-odds}, 4 B / cell (LidarOdometry2D)
 };
 
 struct HostMap {
@@ -28,12 +29,13 @@ struct HostMap {
     std::vector<uint8_t> cells;         // patch_volume * cell_size bytes per patch
     std::vector<uint64_t> masks;        // 16 words per patch (32 x 32 cells)
 
-    uint32_t cellSize() const { return kind == kDistanceMap ? 10u : (kind == kFrequencyOccupancyMap ? 4u : 1u); }
+    uint32_t cellSize() const { return kind == kDistanceMap ? 10u : (kind == kSimpleOccupancyMap ? 1u : 4u); }
     uint32_t patchVolume() const { return patch_length * patch_length; }
     size_t numPatches() const { return ids.size(); }
 };
 
-// Map::write / Map::read.  read() accepts any of the three cell sizes and sets `kind` from it.
+// Map::write / Map::read.  read() accepts any of the three cell sizes and sets `kind` from it (4-byte cells read as
+// kFrequencyOccupancyMap: the file does not say which of the two 4-byte policies wrote it -- set `kind` afterwards if needed).
 bool write(const HostMap& map, const std::string& filename);
 bool read(HostMap& map, const std::string& filename);
 

@@ -79,6 +79,11 @@ typedef struct lama_hip_cfg {
                                         the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */
     uint32_t brushfire_waves;    /* exact brushfire: 0 = auto (a helper wave per particle for the heap up to 768 particles per
                                     call), 1 = one wave per particle, 2 = always with the helper wave; all bit-identical */
+    uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}
+                                    (PFSlam2D, Slam2D); 1 = ProbabilisticOccupancyMap {float log-odds}
+                                    (src/sdm/probabilistic_occupancy_map.cpp:53-107; LidarOdometry2D) -- beam-sequential ray-cast */
+    uint32_t ray_rule;           /* where a ray starts: 0 = PFSlam2D/Slam2D (truncated_ray / truncated_range options),
+                                    1 = LidarOdometry2D::updateMaps (src/lidar_odometry_2d.cpp:108-114: the last metre before the hit) */
 } lama_hip_cfg;
 
 void lama_hip_default_cfg(lama_hip_cfg* cfg);
@@ -129,6 +134,13 @@ int32_t lama_hip_pf_update_maps(lama_hip_ctx* ctx, const double* pts_xyz, uint32
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t* num_patches);
 int32_t lama_hip_pf_download_map(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap,
                                  uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches);
+
+/* Patch bookkeeping for transient maps (LidarOdometry2D::updateMaps, src/lidar_odometry_2d.cpp:128-199):
+ *   lama_hip_pf_patch_ids     : Map::visit_all_patches -- the reference patch indices (Map::m2p) of the allocated patches;
+ *   lama_hip_pf_delete_patches: Map::deletePatchAt (src/sdm/map.cpp:465-488) on BOTH maps of the particle for every listed patch
+ *                               index (absent patches are skipped); the arenas stay dense.  *deleted = distance-map patches removed. */
+int32_t lama_hip_pf_patch_ids(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* patch_ids, uint32_t* num_patches);
+int32_t lama_hip_pf_delete_patches(lama_hip_ctx* ctx, uint32_t particle, const uint64_t* patch_ids, uint32_t n, uint32_t* deleted);
 
 /* Batched evaluation on ONE particle's distance map (Loc2D::globalLocalization-style):
  * B poses -> B log-likelihoods (calculateLikelihood) without changing any state. */

@@ -138,6 +138,18 @@ void lama_loc_trigger_global_localization(lama_loc* l);
 int lama_loc_global_localization_active(const lama_loc* l);
 uint32_t lama_loc_gloc_candidates(const lama_loc* l, double* poses4, double* errors, uint32_t cap);
 uint32_t lama_loc_sampling_likelihoods(const lama_loc* l, double* out, uint32_t cap);
+/* ---- lama::LidarOdometry2D (include/lama/lidar_odometry_2d.h), flattened ---- */
+typedef struct lama_lo lama_lo;
+lama_lo* lama_lo_create(double resolution, uint32_t max_iter, int32_t gpu_device, char* err, int errcap);
+void lama_lo_destroy(lama_lo* l);
+const char* lama_lo_last_error(const lama_lo* l);
+const char* lama_lo_engine_origin(const lama_lo* l);
+int lama_lo_update(lama_lo* l, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz, double timestamp);   /* 1 / <0 */
+int lama_lo_get_odom(const lama_lo* l, double* pose4);
+uint32_t lama_lo_iterations(const lama_lo* l);
+uint32_t lama_lo_deleted_patches(const lama_lo* l);
+void* lama_lo_device_context(const lama_lo* l);
+
 /* ---- lama::sdm map formats (include/lama/sdm_io.h): the reference's `.sdm` file (Map::write/read, src/sdm/map.cpp:489-575)
  * and the export images of src/sdm/export.cpp:46-110 for maps downloaded from the device.
  * kind: 0 DynamicDistanceMap (10 B cells), 1 FrequencyOccupancyMap (4 B), 2 SimpleOccupancyMap (1 B). */

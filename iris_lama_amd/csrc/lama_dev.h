@@ -74,6 +74,9 @@ struct DevParams {
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
     uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused
+    // occupancy cell policy / ray rule (cfg.occupancy_policy, cfg.ray_rule)
+    uint32_t occ_policy, ray_rule;
+    double lo_miss, lo_hit, lo_min, lo_max;   // ProbabilisticOccupancyMap parameters (float-rounded, as the reference stores them)
 };
 
 // ------------------------------------------------------------------------------------------------

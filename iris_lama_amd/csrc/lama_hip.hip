@@ -127,6 +127,11 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
+    p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule;
+    // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
+    // float argument, stored in double members
+    auto logods = [](float prob) { return (double)(float)std::log(prob / (1.0 - prob)); };
+    p.lo_miss = logods(0.4f); p.lo_hit = logods(0.7f); p.lo_min = logods(0.12f); p.lo_max = logods(0.97f);
     return p;
 }
 
@@ -234,7 +239,8 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        if (c->cfg.sequential_raycast == 1 || (c->cfg.sequential_raycast == 0 && count > 1024)) {
+        if (c->cfg.sequential_raycast == 1 || (c->cfg.sequential_raycast == 0 && count > 1024) || c->cfg.occupancy_policy == 1 ||
+            c->cfg.ray_rule == 1) {      // the parallel kernels implement the frequency counters and the PF ray rule only
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
@@ -517,6 +523,84 @@ int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* patch_ids, uint32_t* num_patches)
+{
+    if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const ParticleSet& s = c->set[c->cur];
+    const size_t WW = (size_t)c->W * c->W;
+    const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
+    std::vector<int16_t> dir(WW);
+    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + particle * WW, WW * 2, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> ids;
+    for (uint32_t wy = 0; wy < c->W; ++wy)
+        for (uint32_t wx = 0; wx < c->W; ++wx)
+            if (dir[wy * c->W + wx] >= 0) ids.push_back(((uint64_t)(c->wx0 >> 5) + wx) * 2642244ull + ((uint64_t)(c->wy0 >> 5) + wy));
+    std::sort(ids.begin(), ids.end());
+    if (num_patches) *num_patches = (uint32_t)ids.size();
+    if (patch_ids) for (size_t k = 0; k < ids.size() && k < cap; ++k) patch_ids[k] = ids[k];
+    return LAMA_HIP_OK;
+}
+
+// Map::deletePatchAt on both maps.  The arenas are bump allocated (slot = count++), so a deleted slot is refilled with the
+// last used slot and the directory entry of that patch is redirected: the arena stays dense.  Host driven (a handful of
+// patches per scan at most): device-to-device copies + memsets on the context's stream.
+int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uint64_t* patch_ids, uint32_t n, uint32_t* deleted)
+{
+    if (!c || particle >= c->P || (!patch_ids && n)) return LAMA_HIP_E_INVALID;
+    if (deleted) *deleted = 0;
+    if (n == 0) return LAMA_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    ParticleSet& s = c->set[c->cur];
+    const size_t WW = (size_t)c->W * c->W;
+    for (int kind = 0; kind < 2; ++kind) {
+        const bool dm = kind == 0;
+        const size_t cap = dm ? c->cfg.dm_patch_capacity : c->cfg.occ_patch_capacity;
+        int16_t* d_dir = (dm ? s.dm_dir : s.occ_dir) + particle * WW;
+        std::vector<int16_t> dir(WW);
+        HIPCHK(c, hipMemcpy(dir.data(), d_dir, WW * 2, hipMemcpyDeviceToHost));
+        int count = c->h_counts[2 * particle + (dm ? 0 : 1)];
+        bool touched = false;
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint64_t px = patch_ids[k] / 2642244ull, py = patch_ids[k] % 2642244ull;
+            const int64_t wx = (int64_t)px - (int64_t)(c->wx0 >> 5), wy = (int64_t)py - (int64_t)(c->wy0 >> 5);
+            if (wx < 0 || wy < 0 || wx >= (int64_t)c->W || wy >= (int64_t)c->W) continue;
+            const size_t pidx = (size_t)wy * c->W + (size_t)wx;
+            const int slot = dir[pidx];
+            if (slot < 0) continue;
+            const int last = count - 1;
+            auto plane_move = [&](void* base, size_t bytes_per_slot) -> hipError_t {
+                char* b = (char*)base + (size_t)particle * cap * bytes_per_slot;
+                if (slot != last) {
+                    hipError_t e = hipMemcpyAsync(b + (size_t)slot * bytes_per_slot, b + (size_t)last * bytes_per_slot, bytes_per_slot, hipMemcpyDeviceToDevice, c->stream);
+                    if (e != hipSuccess) return e;
+                }
+                return hipMemsetAsync(b + (size_t)last * bytes_per_slot, 0, bytes_per_slot, c->stream);
+            };
+            if (dm) {
+                HIPCHK(c, plane_move(s.dm_sv, 2048)); HIPCHK(c, plane_move(s.dm_obs, 4096)); HIPCHK(c, plane_move(s.dm_mask, 128));
+            } else {
+                HIPCHK(c, plane_move(s.occ, 4096)); HIPCHK(c, plane_move(s.occ_mask, 128));
+                if (c->d_occ_hit) HIPCHK(c, plane_move(c->d_occ_hit, 128));
+            }
+            if (slot != last)
+                for (size_t q = 0; q < WW; ++q) if (dir[q] == last) { dir[q] = (int16_t)slot; break; }
+            dir[pidx] = -1;
+            --count;
+            touched = true;
+            if (dm && deleted) ++*deleted;
+        }
+        if (touched) {
+            HIPCHK(c, hipMemcpyAsync(d_dir, dir.data(), WW * 2, hipMemcpyHostToDevice, c->stream));
+            c->h_counts[2 * particle + (dm ? 0 : 1)] = count;
+            HIPCHK(c, hipMemcpyAsync(s.counts + 2 * particle + (dm ? 0 : 1), &c->h_counts[2 * particle + (dm ? 0 : 1)], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));          // `dir` and h_counts are read by the copies above
+        }
+    }
+    return LAMA_HIP_OK;
+}
+
 int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap,
                                  uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches)
 {
@@ -573,7 +657,7 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
             }
         } else {
             std::memcpy(cells + (size_t)k * 4096, &hocc[(size_t)slot * 1024], 4096);   // {u16 occupied, u16 visited} little endian
-            if (masks) {   // Container mask of an occupancy cell = "visited != 0" (plus the plane bits set on uint16 wrap)
+            if (masks && c->cfg.occupancy_policy == 0) {   // Container mask of a frequency cell = "visited != 0" (plus the plane bits set on uint16 wrap)
                 uint64_t* mk = masks + (size_t)k * 16;
                 for (int ci = 0; ci < 1024; ++ci)
                     if (hocc[(size_t)slot * 1024 + ci] >> 16) mk[ci >> 6] |= 1ull << (ci & 63);

@@ -458,7 +458,11 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
                 mark_hit = false;
             }
         }
-        if (mark_hit && prm.trunc_ray > 0.0) {                              // :481-491
+        if (prm.ray_rule == 1) {                                            // LidarOdometry2D::updateMaps, lidar_odometry_2d.cpp:108-114
+            abx = hx - sx; aby = hy - sy; abz = hz - sz;
+            ray_length = sqrt((abx * abx + aby * aby) + abz * abz);
+            if (ray_length >= 1.0) { sx = hx - abx / ray_length; sy = hy - aby / ray_length; sz = hz - abz / ray_length; }
+        } else if (mark_hit && prm.trunc_ray > 0.0) {                       // :481-491
             if (prm.trunc_range == 0.0) {
                 abx = hx - sx; aby = hy - sy; abz = hz - sz;
                 ray_length = sqrt((abx * abx + aby * aby) + abz * abz);
@@ -508,6 +512,23 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
                 uint32_t* cell = occ + (size_t)slot * 1024 + ci;
                 const uint32_t v = *cell;
                 uint32_t o = v & 0xFFFFu, vis = v >> 16;
+                if (prm.occ_policy == 1) {
+                    // ProbabilisticOccupancyMap (probabilistic_occupancy_map.cpp:82-107): float log-odds cell, double parameters,
+                    // occ_thresh = 0; every get() turns the mask bit on
+                    const float lp = __uint_as_float(v);
+                    float np_;
+                    if (is_hit) {
+                        const bool occupied = (double)lp > 0.0;
+                        np_ = (float)fmin((double)lp + prm.lo_hit, prm.lo_max);
+                        changed = !occupied && ((double)np_ > 0.0);
+                    } else {
+                        const bool was_free = (double)lp < 0.0;
+                        np_ = (float)fmax((double)lp + prm.lo_miss, prm.lo_min);
+                        changed = !was_free && ((double)np_ < 0.0);
+                    }
+                    *cell = __float_as_uint(np_);
+                    atomicOr((unsigned long long*)(occ_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
+                } else {
                 if (is_hit) {                                               // setOccupied (frequency_occupancy_map.cpp:81-91)
                     const bool occupied = vis != 0 && 4u * o > vis;         // prob > 0.25
                     o = (o + 1) & 0xFFFFu; vis = (vis + 1) & 0xFFFFu;
@@ -520,6 +541,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
                 *cell = o | (vis << 16);
                 // Container mask bit of an occupancy cell == "visited != 0"; only a uint16 wrap needs the plane
                 if (vis == 0) atomicOr((unsigned long long*)(occ_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
+                }
             }
             const int dslot = coop_slot(dm_dc, dm_dir, dm_count, (int)prm.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
             bool push = false;

@@ -26,7 +26,7 @@ class HipCfg(C.Structure):
                 ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32),
                 ("occ_patch_capacity", C.c_uint32), ("queue_capacity", C.c_uint32), ("profile", C.c_uint32),
                 ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32), ("brushfire_mode", C.c_uint32),
-                ("brushfire_waves", C.c_uint32)]
+                ("brushfire_waves", C.c_uint32), ("occupancy_policy", C.c_uint32), ("ray_rule", C.c_uint32)]
 
 
 class HipCounters(C.Structure):
@@ -51,6 +51,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
+    "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches",
 ]
 
 _hip = None
@@ -100,6 +101,8 @@ def _bind_hip(L):
         L.lama_hip_map_add_obstacles.argtypes = [vp, u32, vp, u32]
         L.lama_hip_match_solve.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32]
         L.lama_hip_eval_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp, vp]
+        L.lama_hip_pf_patch_ids.argtypes = [vp, u32, i32, u32, vp, vp]
+        L.lama_hip_pf_delete_patches.argtypes = [vp, u32, vp, u32, vp]
         L.lama_hip_map_sample_likelihood.argtypes = [vp, u32, vp, u32, vp, vp, C.c_double, vp, u32, u32, vp]
         has_pgo = hasattr(L, "lama_hip_pgo_create")       # the engine test double (tests/cpu_engine) has no pose-graph part
         if has_pgo:
@@ -224,6 +227,19 @@ class HipContext:
         self._chk(self.L.lama_hip_match_batch(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(poses), len(poses), _p(out)))
         return out
 
+    def patch_ids(self, particle, kind):
+        n = C.c_uint32(0)
+        self._chk(self.L.lama_hip_pf_patch_ids(self.h, particle, kind, 0, None, C.byref(n)))
+        ids = np.zeros(n.value, dtype=np.uint64)
+        self._chk(self.L.lama_hip_pf_patch_ids(self.h, particle, kind, n.value, _p(ids), C.byref(n)))
+        return ids
+
+    def delete_patches(self, particle, ids):
+        ids = np.ascontiguousarray(ids, dtype=np.uint64)
+        d = C.c_uint32(0)
+        self._chk(self.L.lama_hip_pf_delete_patches(self.h, particle, _p(ids), len(ids), C.byref(d)))
+        return d.value
+
     def eval_batch(self, particle, pts, poses, origin=None, quat=None):
         """-> (squared residual norm, log-likelihood) per pose (Loc2D::globalLocalization's candidate evaluation)"""
         pts, origin, quat = self._scan(pts, origin, quat)
@@ -332,6 +348,8 @@ HOST_SYMBOLS = [
     "lama_loc_global_localization_active", "lama_loc_gloc_candidates", "lama_loc_sampling_likelihoods",
     "lama_random_set_seed", "lama_random_uniform",
     "lama_sdm_write", "lama_sdm_read", "lama_sdm_image", "lama_sdm_export_png",
+    "lama_lo_create", "lama_lo_destroy", "lama_lo_last_error", "lama_lo_engine_origin", "lama_lo_update", "lama_lo_get_odom",
+    "lama_lo_iterations", "lama_lo_deleted_patches", "lama_lo_device_context",
 ]
 
 
@@ -369,6 +387,10 @@ def _bind_host(L):
         "lama_loc_trigger_global_localization": (None, [vp]), "lama_loc_global_localization_active": (i32, [vp]),
         "lama_loc_gloc_candidates": (u32, [vp, vp, vp, u32]), "lama_loc_sampling_likelihoods": (u32, [vp, vp, u32]),
         "lama_random_set_seed": (None, [u32]), "lama_random_uniform": (d, []),
+        "lama_lo_create": (vp, [d, u32, i32, vp, i32]), "lama_lo_destroy": (None, [vp]), "lama_lo_last_error": (C.c_char_p, [vp]),
+        "lama_lo_engine_origin": (C.c_char_p, [vp]), "lama_lo_update": (i32, [vp, vp, u32, vp, vp, d]),
+        "lama_lo_get_odom": (i32, [vp, vp]), "lama_lo_iterations": (u32, [vp]), "lama_lo_deleted_patches": (u32, [vp]),
+        "lama_lo_device_context": (vp, [vp]),
         "lama_sdm_write": (i32, [C.c_char_p, i32, d, u32, u32, vp, vp, vp]),
         "lama_sdm_read": (i32, [C.c_char_p, vp, vp, vp, u32, vp, vp, vp, vp]),
         "lama_sdm_image": (i32, [i32, d, u32, u32, vp, vp, vp, vp, vp, vp, C.c_uint64]),
@@ -730,7 +752,7 @@ def random_set_seed(seed):
 # ---------------------------------------------------------------------------------------------------------------
 # lama::sdm map formats (include/lama/sdm_io.h) on downloaded maps: {patch id: (cells, mask)} as HipContext.download_map returns
 # ---------------------------------------------------------------------------------------------------------------
-SDM_CELL_BYTES = {MAP_DISTANCE: 10, MAP_OCCUPANCY: 4, 2: 1}
+SDM_CELL_BYTES = {MAP_DISTANCE: 10, MAP_OCCUPANCY: 4, 2: 1, 3: 4}      # 3 = ProbabilisticOccupancyMap (float log-odds)
 
 
 def _sdm_arrays(patches, kind):
@@ -820,3 +842,58 @@ class PoseGraph:
         if rc != 0:
             raise LamaError(self.L.lama_hip_pgo_last_error(self.h).decode())
         return {"err": err, "Hdiag": hd, "Hoff": hoff, "b": b, "chi2": chi2.value, "kernel_ms": ms.value}
+
+
+class LidarOdometry2D:
+    """ctypes view of the host-side lama::LidarOdometry2D (include/lama/lidar_odometry_2d.h)."""
+
+    def __init__(self, resolution=0.05, max_iter=100, gpu_device=0):
+        self.L = _hostlib()
+        err = C.create_string_buffer(512)
+        h = self.L.lama_lo_create(resolution, max_iter, gpu_device, err, 512)
+        if not h:
+            raise LamaError(err.value.decode())
+        self.h = C.c_void_p(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.lama_lo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def engine_origin(self):
+        return self.L.lama_lo_engine_origin(self.h).decode()
+
+    def update(self, pts, ts=0.0, origin=None, quat=None):
+        pts, origin, quat = PFSlam2D._scan(pts, origin, quat)
+        rc = self.L.lama_lo_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), float(ts))
+        if rc < 0:
+            raise LamaError(self.L.lama_lo_last_error(self.h).decode())
+        return bool(rc)
+
+    def odom(self):
+        out = np.zeros(4)
+        self.L.lama_lo_get_odom(self.h, _p(out))
+        return out
+
+    def iterations(self):
+        return self.L.lama_lo_iterations(self.h)
+
+    def deleted_patches(self):
+        return self.L.lama_lo_deleted_patches(self.h)
+
+    def hip_context(self):
+        """Borrowed HipContext view of the device context (map downloads in tests)."""
+        ctx = HipContext.__new__(HipContext)
+        if self.engine_origin().endswith("liblama_hip.so"):
+            ctx.L = hip_lib()
+        else:
+            ctx.L = C.CDLL(self.engine_origin())
+            _bind_hip(ctx.L)
+        ctx.cfg = None
+        ctx.P = 1
+        ctx.h = C.c_void_p(self.L.lama_lo_device_context(self.h))
+        ctx._is_borrowed = True
+        return ctx

@@ -60,6 +60,8 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(map_add_obstacles, lama_hip_map_add_obstacles)
     BIND(match_solve, lama_hip_match_solve)
     BIND(eval_batch, lama_hip_eval_batch)
+    BIND(pf_patch_ids, lama_hip_pf_patch_ids)
+    BIND(pf_delete_patches, lama_hip_pf_delete_patches)
     BIND(map_sample_likelihood, lama_hip_map_sample_likelihood)
 #undef BIND
     return e;

@@ -34,6 +34,8 @@ struct HipEngine {
     decltype(&lama_hip_map_add_obstacles) map_add_obstacles = nullptr;
     decltype(&lama_hip_match_solve) match_solve = nullptr;
     decltype(&lama_hip_eval_batch) eval_batch = nullptr;
+    decltype(&lama_hip_pf_patch_ids) pf_patch_ids = nullptr;
+    decltype(&lama_hip_pf_delete_patches) pf_delete_patches = nullptr;
     decltype(&lama_hip_map_sample_likelihood) map_sample_likelihood = nullptr;
     ~HipEngine();
 };

@@ -7,6 +7,7 @@
 
 #include "hip_engine.hpp"
 #include "lama/pf_slam2d.h"
+#include "lama/lidar_odometry_2d.h"
 #include "lama/loc2d.h"
 #include "lama/random.h"
 #include "lama/sdm_io.h"
@@ -406,6 +407,39 @@ uint32_t lama_loc_sampling_likelihoods(const lama_loc* h, double* out, uint32_t 
     for (uint32_t i = 0; i < n && i < cap; ++i) out[i] = h->l.lastSamplingLikelihoods()[i];
     return n;
 }
+// ------------------------------------------------------------------ LidarOdometry2D
+struct lama_lo {
+    std::unique_ptr<LidarOdometry2D> l;
+    std::string error;
+};
+lama_lo* lama_lo_create(double resolution, uint32_t max_iter, int32_t gpu_device, char* err, int errcap)
+{
+    auto* h = new lama_lo;
+    try {
+        LidarOdometry2D::Options o;
+        o.resolution = resolution; o.max_iter = max_iter; o.gpu_device = gpu_device;
+        h->l.reset(new LidarOdometry2D(o));
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+void lama_lo_destroy(lama_lo* h) { delete h; }
+const char* lama_lo_last_error(const lama_lo* h) { return h ? h->error.c_str() : "null handle"; }
+const char* lama_lo_engine_origin(const lama_lo* h) { return (h && h->l->engine()) ? h->l->engine()->origin.c_str() : ""; }
+int lama_lo_update(lama_lo* h, const double* pts, uint32_t n, const double* origin3, const double* quat, double ts)
+{
+    try {
+        return h->l->update(make_cloud(pts, n, origin3, quat), ts) ? 1 : 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
+int lama_lo_get_odom(const lama_lo* h, double* pose4) { h->l->odom.state.toArray(pose4); return 0; }
+uint32_t lama_lo_iterations(const lama_lo* h) { return h->l->getLastIterations(); }
+uint32_t lama_lo_deleted_patches(const lama_lo* h) { return h->l->getLastDeletedPatches(); }
+void* lama_lo_device_context(const lama_lo* h) { return h->l->deviceContext(); }
+
 static lama::sdm::HostMap host_map(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
                                     const uint64_t* masks)
 {

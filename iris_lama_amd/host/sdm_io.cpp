@@ -116,6 +116,10 @@ void build_image(const HostMap& m, Image& image)                         // src/
                 // FrequencyOccupancyMap::prob / isFree / isOccupied (src/sdm/frequency_occupancy_map.cpp:38-45,119-138)
                 const double p = vis == 0 ? 0.25 : ((double)occ) / ((double)vis);
                 px = p < 0.25 ? 255 : (p > 0.25 ? 0 : 127);
+            } else if (m.kind == kProbabilisticOccupancyMap) {
+                float lp; std::memcpy(&lp, cell, 4);
+                // ProbabilisticOccupancyMap::isFree / isOccupied (src/sdm/probabilistic_occupancy_map.cpp:131-150), occ_thresh = 0
+                px = (double)lp < 0.0 ? 255 : ((double)lp > 0.0 ? 0 : 127);
             } else {
                 const int8_t s = (int8_t)cell[0];
                 px = s == -1 ? 255 : (s == 1 ? 0 : 127);

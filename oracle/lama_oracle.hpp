@@ -437,6 +437,17 @@ public:
         prev_patch_ = nullptr; prev_idx_ = ~uint64_t(0);
         return true;
     }
+    // map.cpp:465-488 deletePatchAt (no LRU here), map.cpp:361-367 visit_all_patches
+    bool deletePatchAt(const V3u& c)
+    {
+        auto it = patches.find(m2p(c));
+        if (it == patches.end()) return false;
+        patches.erase(it);
+        prev_patch_ = nullptr; prev_idx_ = ~uint64_t(0);
+        return true;
+    }
+    template <typename F>
+    void visit_all_patches(F&& walker) const { for (auto& kv : patches) walker(p2m(kv.first)); }
     // map.cpp:352-359 visit_all_cells: every cell whose mask bit is on
     template <typename F>
     void visit_all_cells(F&& walker) const
@@ -598,6 +609,41 @@ public:
     bool isFree(const V3u& c) const { const int8_t* cell = (const int8_t*)get(c); return cell != 0 && *cell == -1; }           // :97-104
     bool isFree(const V3d& p) const { return isFree(w2m(p)); }                                                                 // :92-95
     bool isOccupied(const V3u& c) const { const int8_t* cell = (const int8_t*)get(c); return cell != 0 && *cell == 1; }        // :111-118
+};
+
+// -------------------------------------------------------------------------------------
+// ProbabilisticOccupancyMap  (include/lama/sdm/probabilistic_occupancy_map.h:40-100, src/sdm/probabilistic_occupancy_map.cpp:36-195)
+// log-odds cell {float prob}; the parameters are doubles holding float-rounded values (logods() returns float).
+// -------------------------------------------------------------------------------------
+class ProbabilisticOccupancyMap : public Map {
+public:
+    static float logods(const float& prob) { return (float)std::log(prob / (1.0 - prob)); }      // :43-46
+    static float prob_of(const float& l) { return (float)(1.0 - 1.0 / (1.0 + std::exp(l))); }      // :38-41 (std::exp(float))
+    ProbabilisticOccupancyMap(double res, uint32_t patch_size = 32) : Map(res, sizeof(float), patch_size)
+    {
+        miss_ = logods(0.4); hit_ = logods(0.7);                        // :53-59
+        clamp_min_ = logods(0.12); clamp_max_ = logods(0.97);
+        occ_thresh_ = 0.0 * logods(0.5);
+    }
+    bool setFree(const V3u& c)                                          // :82-91
+    {
+        float* cell = (float*)get(c);
+        bool free = *cell < occ_thresh_;
+        *cell = (float)std::max(*cell + miss_, clamp_min_);
+        if (free) return false;
+        return (*cell < occ_thresh_);
+    }
+    bool setOccupied(const V3u& c)                                      // :98-107
+    {
+        float* cell = (float*)get(c);
+        bool occupied = *cell > occ_thresh_;
+        *cell = (float)std::min(*cell + hit_, clamp_max_);
+        if (occupied) return false;
+        return (*cell > occ_thresh_);
+    }
+    bool isFree(const V3u& c) const { const float* cell = (const float*)get(c); return cell != 0 && *cell < occ_thresh_; }       // :131-137
+    bool isOccupied(const V3u& c) const { const float* cell = (const float*)get(c); return cell != 0 && *cell > occ_thresh_; }   // :144-150
+    double miss_, hit_, clamp_min_, clamp_max_, occ_thresh_;
 };
 
 // lama::random (src/random.cpp:34-73): ONE process-wide std::mt19937; uniform() builds a fresh
@@ -1641,6 +1687,118 @@ private:
     SE2 odom_, pose_;
     bool has_first_scan = false;
     uint32_t processed_ = 0;
+};
+
+// -------------------------------------------------------------------------------------
+// LidarOdometry2D  (include/lama/lidar_odometry_2d.h:45-80, src/lidar_odometry_2d.cpp:42-200): scan-to-map odometry on a
+// log-odds occupancy map + distance map (max distance 1 m) that keeps only the patches near the latest scan.
+// -------------------------------------------------------------------------------------
+struct AABB {                                                           // include/lama/aabb.h:41-74
+    double center[3], hwidth[3];
+    AABB(const double mn[3], const double mx[3])
+    {
+        for (int k = 0; k < 3; ++k) { const double local = mx[k] - mn[k]; hwidth[k] = local * 0.5; center[k] = mn[k] + hwidth[k]; }
+    }
+    bool testIntersection(const AABB& o) const
+    {
+        bool r = true;
+        for (int k = 0; k < 3; ++k) r = r && (std::abs(center[k] - o.center[k]) <= (hwidth[k] + o.hwidth[k]));
+        return r;
+    }
+};
+
+// LidarOdometry2D::updateMaps, ray-cast part (src/lidar_odometry_2d.cpp:85-126): hit -> setOccupied/addObstacle, the
+// last metre of the ray -> setFree/removeObstacle, then distance_map->update().  mn/mx: bounding box of the hits.
+inline uint32_t lidar_update_maps_body(DynamicDistanceMap& dm_, ProbabilisticOccupancyMap& occ_, const Scan& surface, const SE2& odom,
+                                       double mn[3], double mx[3])
+{
+    const Affine3 mtf = moving_tf(surface);
+    const Affine3 ftf = fixed_tf(odom);
+    const Affine3 tf = affine_mul(ftf, mtf);
+    const V3d wso{tf.t[0], tf.t[1], tf.t[2]};
+    for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<double>::max(); mx[k] = -std::numeric_limits<double>::max(); }
+    for (size_t i = 0; i < surface.points.size(); ++i) {
+        V3d start = wso;
+        const V3d hit = affine_apply(tf, surface.points[i]);
+        const V3d AB{hit.x - start.x, hit.y - start.y, hit.z - start.z};
+        const double ray_length = std::sqrt((AB.x * AB.x + AB.y * AB.y) + AB.z * AB.z);
+        if (ray_length >= 1.0) start = V3d{hit.x - AB.x / ray_length, hit.y - AB.y / ray_length, hit.z - AB.z / ray_length};
+        const V3u mhit = occ_.w2m(hit);
+        mn[0] = std::min(mn[0], hit.x); mn[1] = std::min(mn[1], hit.y); mn[2] = std::min(mn[2], hit.z);
+        mx[0] = std::max(mx[0], hit.x); mx[1] = std::max(mx[1], hit.y); mx[2] = std::max(mx[2], hit.z);
+        if (occ_.setOccupied(mhit)) dm_.addObstacle(mhit);
+        occ_.computeRay(occ_.w2m(start), mhit, [&](const V3u& coord) {
+            if (occ_.setFree(coord)) dm_.removeObstacle(coord);
+        });
+    }
+    return dm_.update();
+}
+
+class LidarOdometry2D {
+public:
+    explicit LidarOdometry2D(double resolution = 0.05, uint32_t max_iter = 100)      // :42-52
+        : dm_(resolution), occ_(resolution), max_iter_(max_iter)
+    {
+        dm_.setMaxDistance(1.0);
+    }
+    DynamicDistanceMap& dm() { return dm_; }
+    ProbabilisticOccupancyMap& occ() { return occ_; }
+    SE2 odom, map_update_odom;
+    SolveStats last_solve;
+    uint32_t deleted_last = 0, map_updates = 0;
+
+    bool update(const Scan& surface, double /*timestamp*/)               // :60-83
+    {
+        if (!has_first_scan) {
+            updateMaps(surface);
+            has_first_scan = true;
+            return true;
+        }
+        MatchSurface2D ms(&dm_, &surface, odom);
+        CauchyWeight cauchy(0.15);
+        last_solve = solve_gn(ms, max_iter_, cauchy);
+        odom = ms.state_;
+        SE2 odelta = pose_minus(map_update_odom, odom);
+        if (std::sqrt(odelta.tx * odelta.tx + odelta.ty * odelta.ty) > 0.1 || std::abs(se2_rotation(odelta)) > 0.5) {
+            updateMaps(surface);
+            map_update_odom = odom;
+        }
+        return true;
+    }
+
+    void updateMaps(const Scan& surface)                                 // :85-200
+    {
+        ++map_updates;
+        double mn[3], mx[3];
+        lidar_update_maps_body(dm_, occ_, surface, odom, mn, mx);
+        // transient map: drop the patches whose box does not meet the (symmetrised, expanded) box of the scan  :128-199
+        mn[2] = mx[2] = 0;
+        const double xdist = std::max(odom.tx - mn[0], mx[0] - odom.tx);
+        const double ydist = std::max(odom.ty - mn[1], mx[1] - odom.ty);
+        mn[0] = odom.tx - xdist; mn[1] = odom.ty - ydist;
+        mx[0] = odom.tx + xdist; mx[1] = odom.ty + ydist;
+        AABB a(mn, mx);
+        for (int k = 0; k < 3; ++k) a.hwidth[k] += 2.0 * dm_.maxDistance();
+        std::vector<V3u> to_remove;
+        dm_.visit_all_patches([&](const V3u& origin) {
+            const uint32_t length = occ_.patch_length;
+            V3d ws = occ_.m2w(origin);
+            V3d we = occ_.m2w(V3u{origin.x + length, origin.y + length, origin.z + 0});
+            ws.z = we.z = 0.0;
+            const double b0[3] = {ws.x, ws.y, ws.z}, b1[3] = {we.x, we.y, we.z};
+            AABB b(b0, b1);
+            if (a.testIntersection(b)) return;
+            to_remove.push_back(origin);
+        });
+        deleted_last = 0;
+        for (auto& coord : to_remove) { occ_.deletePatchAt(coord); if (dm_.deletePatchAt(coord)) ++deleted_last; }
+    }
+
+private:
+    DynamicDistanceMap dm_;
+    ProbabilisticOccupancyMap occ_;
+    uint32_t max_iter_;
+    bool has_first_scan = false;
 };
 
 // -------------------------------------------------------------------------------------

@@ -396,6 +396,32 @@ int orc_map_image(void* map, int kind, uint32_t* w, uint32_t* h, uint8_t* out, u
     if (out && cap >= im.data.size()) std::memcpy(out, im.data.data(), im.data.size());
     return 1;
 }
+// ---- LidarOdometry2D (src/lidar_odometry_2d.cpp) on a ProbabilisticOccupancyMap
+struct LoBox { std::unique_ptr<LidarOdometry2D> l; Scan scan; };
+void* orc_lo_new(double resolution, uint32_t max_iter) { auto* b = new LoBox; b->l.reset(new LidarOdometry2D(resolution, max_iter)); return b; }
+void orc_lo_free(void* h) { delete (LoBox*)h; }
+int orc_lo_update(void* h, const double* pts, int n, const double* origin3, const double* quat4, double ts)
+{
+    LoBox* b = (LoBox*)h;
+    b->scan = make_scan(pts, n, origin3, quat4);
+    return b->l->update(b->scan, ts) ? 1 : 0;
+}
+void orc_lo_get_odom(void* h, double* pose4) { se2_to(((LoBox*)h)->l->odom, pose4); }
+void orc_lo_set_odom(void* h, const double* pose4) { ((LoBox*)h)->l->odom = se2_of(pose4); }
+void* orc_lo_dm(void* h) { return &((LoBox*)h)->l->dm(); }
+void* orc_lo_occ(void* h) { return &((LoBox*)h)->l->occ(); }
+uint32_t orc_lo_deleted_last(void* h) { return ((LoBox*)h)->l->deleted_last; }
+uint32_t orc_lo_map_updates(void* h) { return ((LoBox*)h)->l->map_updates; }
+uint32_t orc_lo_iterations(void* h) { return ((LoBox*)h)->l->last_solve.iterations; }
+int orc_pocc_patch_ids(void* h, uint64_t* ids, int cap) { return patch_ids((const ProbabilisticOccupancyMap*)h, ids, cap); }
+int orc_pocc_patch_read(void* h, uint64_t id, uint8_t* cells, uint64_t* mask) { return patch_read((const ProbabilisticOccupancyMap*)h, id, cells, mask); }
+void orc_pocc_free(void*) {}
+void orc_pocc_params(double* out5)
+{
+    ProbabilisticOccupancyMap m(0.05);
+    out5[0] = m.miss_; out5[1] = m.hit_; out5[2] = m.clamp_min_; out5[3] = m.clamp_max_; out5[4] = m.occ_thresh_;
+}
+
 // ---- SE2 pose-graph linearisation (minisam linearzationLowerHessian restated, see lama_oracle.hpp)
 void orc_pgo_linearize(const double* poses4, uint32_t N, const int32_t* fi, const int32_t* fj, const double* meas4, const double* sqrt_info3,
                        uint32_t F, double* err, double* Hdiag, double* Hoff, double* b, double* chi2)

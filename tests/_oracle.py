@@ -73,6 +73,11 @@ def lib():
             "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
             "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
             "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
+            "orc_lo_new": (vp, [d, u32]), "orc_lo_free": (None, [vp]), "orc_lo_update": (i32, [vp, vp, i32, vp, vp, d]),
+            "orc_lo_get_odom": (None, [vp, vp]), "orc_lo_set_odom": (None, [vp, vp]), "orc_lo_dm": (vp, [vp]), "orc_lo_occ": (vp, [vp]),
+            "orc_lo_deleted_last": (u32, [vp]), "orc_lo_map_updates": (u32, [vp]), "orc_lo_iterations": (u32, [vp]),
+            "orc_pocc_patch_ids": (i32, [vp, vp, i32]), "orc_pocc_patch_read": (i32, [vp, u64, vp, vp]), "orc_pocc_free": (None, [vp]),
+            "orc_pocc_params": (None, [vp]),
             "orc_pgo_linearize": (None, [vp, u32, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp]),
             "orc_map_write": (i32, [vp, C.c_char_p]), "orc_map_read": (i32, [vp, C.c_char_p]),
             "orc_map_image": (i32, [vp, i32, vp, vp, vp, C.c_uint64]),
@@ -230,6 +235,61 @@ class Occ(_MapBase):
 
     def probability(self, x, y, z=0):
         return lib().orc_occ_probability(self.h, x, y, z)
+
+
+PROB_T = np.dtype([("prob", "<f4")])
+
+
+class POcc(_MapBase):
+    """ProbabilisticOccupancyMap (log-odds float cells)."""
+    _pre = "orc_pocc"
+    _dtype = PROB_T
+
+
+def pocc_params():
+    """miss, hit, clamp_min, clamp_max, occ_thresh of ProbabilisticOccupancyMap (float-rounded doubles)"""
+    out = np.zeros(5)
+    lib().orc_pocc_params(_p(out))
+    return out
+
+
+class LidarOdometry:
+    """Oracle LidarOdometry2D (src/lidar_odometry_2d.cpp)."""
+
+    def __init__(self, resolution=0.05, max_iter=100):
+        self.h = C.c_void_p(lib().orc_lo_new(resolution, max_iter))
+
+    def __del__(self):
+        if self.h:
+            lib().orc_lo_free(self.h)
+            self.h = None
+
+    def update(self, pts, ts=0.0, origin=ZERO3, quat=IDENT_Q):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        return bool(lib().orc_lo_update(self.h, _p(pts), len(pts), _p(origin), _p(quat), ts))
+
+    def odom(self):
+        out = np.zeros(4)
+        lib().orc_lo_get_odom(self.h, _p(out))
+        return out
+
+    def set_odom(self, pose4):
+        lib().orc_lo_set_odom(self.h, _p(np.ascontiguousarray(pose4, dtype=np.float64)))
+
+    def dm(self):
+        return DM(lib().orc_lo_dm(self.h), owned=False)
+
+    def occ(self):
+        return POcc(lib().orc_lo_occ(self.h), owned=False)
+
+    def deleted_last(self):
+        return lib().orc_lo_deleted_last(self.h)
+
+    def map_updates(self):
+        return lib().orc_lo_map_updates(self.h)
+
+    def iterations(self):
+        return lib().orc_lo_iterations(self.h)
 
 
 def compute_ray(frm, to):

@@ -22,6 +22,7 @@ struct lama_hip_ctx {
     std::vector<SE2> poses;
     std::vector<std::shared_ptr<DynamicDistanceMap>> dm;
     std::vector<std::shared_ptr<FrequencyOccupancyMap>> occ;
+    std::vector<std::shared_ptr<ProbabilisticOccupancyMap>> pocc;     // cfg.occupancy_policy == 1 (LidarOdometry2D)
     std::unique_ptr<PFSlam2D> tool;   // borrowed for scanMatch / updateParticleMaps bodies
     Scan last_scan;
     lama_hip_counters ctr;
@@ -82,6 +83,17 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c) { delete c; }
 int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat, const double* pose0)
 {
     Scan s = make_scan(pts, n, origin, quat);
+    if (c->cfg.occupancy_policy == 1) {          // one-"particle" log-odds context (LidarOdometry2D)
+        c->last_scan = s;
+        c->pocc.assign(1, std::make_shared<ProbabilisticOccupancyMap>(c->cfg.resolution, c->cfg.patch_size));
+        c->dm[0] = std::make_shared<DynamicDistanceMap>(c->cfg.resolution, c->cfg.patch_size);
+        c->dm[0]->setMaxDistance(c->cfg.l2_max);
+        c->poses[0] = se2_of(pose0);
+        double mn[3], mx[3];
+        lidar_update_maps_body(*c->dm[0], *c->pocc[0], s, c->poses[0], mn, mx);
+        c->init = true;
+        return LAMA_HIP_OK;
+    }
     c->tool->stage_set_scan(s);
     Particle p0;
     p0.pose = se2_of(pose0);
@@ -146,6 +158,11 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* idx)
 int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
 {
     Scan s = pts ? make_scan(pts, n, origin, quat) : c->last_scan;
+    if (c->cfg.occupancy_policy == 1) {
+        double mn[3], mx[3];
+        lidar_update_maps_body(*c->dm[0], *c->pocc[0], s, c->poses[0], mn, mx);
+        return LAMA_HIP_OK;
+    }
     c->tool->stage_set_scan(s);
     for (uint32_t i = 0; i < c->cfg.particles; ++i) {
         Particle p;
@@ -157,14 +174,16 @@ int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, 
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
 {
-    *num = (uint32_t)(kind == LAMA_HIP_MAP_DISTANCE ? c->dm[particle]->patches.size() : c->occ[particle]->patches.size());
+    *num = (uint32_t)(kind == LAMA_HIP_MAP_DISTANCE ? c->dm[particle]->patches.size()
+                      : (c->cfg.occupancy_policy == 1 ? c->pocc[particle]->patches.size() : c->occ[particle]->patches.size()));
     return LAMA_HIP_OK;
 }
 
 int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* ids, uint8_t* cells,
                                  uint64_t* masks, uint32_t* num)
 {
-    const Map& m = kind == LAMA_HIP_MAP_DISTANCE ? (const Map&)*c->dm[particle] : (const Map&)*c->occ[particle];
+    const Map& m = kind == LAMA_HIP_MAP_DISTANCE ? (const Map&)*c->dm[particle]
+                   : (c->cfg.occupancy_policy == 1 ? (const Map&)*c->pocc[particle] : (const Map&)*c->occ[particle]);
     std::vector<uint64_t> v = sorted_ids(m);
     if (num) *num = (uint32_t)v.size();
     const size_t cb = (kind == LAMA_HIP_MAP_DISTANCE ? 10 : 4) * 1024;
@@ -287,6 +306,27 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
     se2_to(ms.state_, pose);
     if (out7) { out7[0] = A[0][0]; out7[1] = A[1][0]; out7[2] = A[1][1]; out7[3] = A[2][0]; out7[4] = A[2][1]; out7[5] = A[2][2]; out7[6] = s2; }
     if (iters) *iters = (int32_t)st.iterations;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* ids, uint32_t* num)
+{
+    const Map& m = kind == LAMA_HIP_MAP_DISTANCE ? (const Map&)*c->dm[particle]
+                   : (c->cfg.occupancy_policy == 1 ? (const Map&)*c->pocc[particle] : (const Map&)*c->occ[particle]);
+    std::vector<uint64_t> v = sorted_ids(m);
+    if (num) *num = (uint32_t)v.size();
+    if (ids) for (size_t k = 0; k < v.size() && k < cap; ++k) ids[k] = v[k];
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uint64_t* ids, uint32_t n, uint32_t* deleted)
+{
+    if (deleted) *deleted = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        const V3u origin = c->dm[particle]->p2m(ids[k]);
+        if (c->cfg.occupancy_policy == 1) c->pocc[particle]->deletePatchAt(origin); else c->occ[particle]->deletePatchAt(origin);
+        if (c->dm[particle]->deletePatchAt(origin) && deleted) ++*deleted;
+    }
     return LAMA_HIP_OK;
 }
 

@@ -461,3 +461,31 @@ def test_eval_batch_matches_oracle_and_match_batch(F):
         r = O.eval_(dmo, pts[1], poses[b], jac=False)
         assert abs(sq[b] - float(np.dot(r, r))) <= 1e-11 * max(1.0, sq[b])
     print(f"eval_batch: {B} poses x 1080 beams in {ms:.3f} ms")
+
+
+def test_lidar_odometry_gpu_vs_oracle(F):
+    """SURVEY 8 f-4: lama::LidarOdometry2D on the device -- ProbabilisticOccupancyMap log-odds cells (float, bit-exact), the
+    last-metre ray rule, distance map with 1 m range, transient-map patch deletion -- against the oracle, free running."""
+    steps = 26
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    o = O.LidarOdometry()
+    h = F.LidarOdometry2D()
+    assert h.engine_origin().endswith("liblama_hip.so")
+    deleted = 0
+    for k in range(steps + 1):
+        p = pts[k][np.hypot(pts[k][:, 0], pts[k][:, 1]) < 4.0]
+        assert o.update(p, float(k)) == h.update(p, float(k))
+        assert np.abs(o.odom() - h.odom()).max() < 1e-7, (k, o.odom(), h.odom())
+        assert o.iterations() == h.iterations(), k
+        deleted += h.deleted_patches()
+        assert h.deleted_patches() == o.deleted_last(), k
+        if k % 5 == 0 or k == steps:
+            ctx = h.hip_context()
+            assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, f"lo dm {k}")
+            got, ref = ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump()
+            assert sorted(got) == sorted(ref), k
+            for pid in ref:
+                assert np.array_equal(np.ascontiguousarray(got[pid][0]).view(np.float32).reshape(-1), ref[pid][0]["prob"]), (k, pid)
+                assert np.array_equal(got[pid][1], ref[pid][1]), (k, pid)
+    assert deleted > 0
+    h.close()

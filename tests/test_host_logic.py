@@ -221,3 +221,38 @@ def test_loc2d_global_localization_and_sampling_covariance_host_matches_oracle()
         assert np.allclose(o.covar(), h.covar(), rtol=1e-9, atol=1e-300), k
     assert len(op) == 300
     h.close()
+
+
+def _limited(p, rng=4.0):
+    return p[np.hypot(p[:, 0], p[:, 1]) < rng]
+
+
+def test_lidar_odometry_host_matches_oracle():
+    """SURVEY 8 f-4: lama::LidarOdometry2D (src/lidar_odometry_2d.cpp:60-200: GN scan-to-map, log-odds occupancy map, last-metre
+    ray rule, transient map with patch deletion) -- host logic against the oracle over the oracle-backed engine double: poses
+    bit for bit, maps identical incl. the set of surviving patches."""
+    from _cmp import DM_FIELDS, assert_maps_equal
+    steps = 24
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o = O.LidarOdometry()
+    h = F.LidarOdometry2D()
+    assert h.engine_origin().endswith("liblama_cpu_engine.so")
+    deleted = 0
+    for k in range(steps + 1):
+        p = _limited(pts[k])
+        assert o.update(p, float(k)) == h.update(p, float(k))
+        assert np.array_equal(o.odom(), h.odom()), k
+        assert o.iterations() == h.iterations()
+        deleted += h.deleted_patches()
+        ctx = h.hip_context()
+        assert np.array_equal(ctx.patch_ids(0, F.MAP_DISTANCE), o.dm().patch_ids()), k
+        assert np.array_equal(ctx.patch_ids(0, F.MAP_OCCUPANCY), o.occ().patch_ids()), k
+    assert deleted > 0                                   # the transient-map step really removed patches
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "lo dm")
+    got = ctx.download_map(0, F.MAP_OCCUPANCY)
+    ref = o.occ().dump()
+    assert sorted(got) == sorted(ref)
+    for pid in ref:
+        assert np.array_equal(np.ascontiguousarray(got[pid][0]).view(np.float32).reshape(-1), ref[pid][0]["prob"]), pid
+        assert np.array_equal(got[pid][1], ref[pid][1])
+    h.close()
