@@ -59,6 +59,25 @@ def cpu_baseline(pts, odom, P, updates, warm):
         if threads <= 1 and n:
             res["bytes"] = dict(maps=b_maps / (P * n), match=b_match / (P * n), total=b_all / (P * n),
                                 brushfire=b_bf / (P * n), raycast=b_ray / (P * n))
+    # the thread pool only fills the host at larger particle counts: time it there too (bounded: 8 updates each)
+    res["pool_other"] = {}
+    for Pk in (300, 3000):
+        try:
+            pf = O.PF(O.default_options(particles=Pk, seed=42, threads=cores))
+            pf.set_prior(O.se2(*odom[0]))
+            pf.update(pts[0], O.se2(*odom[0]), 0.0)
+            t_tot, n = 0.0, 0
+            for k in range(1, min(2 + 8, len(pts) - 1) + 1):
+                t0 = time.perf_counter()
+                ok = pf.update(pts[k], O.se2(*odom[k]), float(k))
+                dt = time.perf_counter() - t0
+                if k > 2 and ok:
+                    t_tot += dt
+                    n += 1
+            res["pool_other"][str(Pk)] = dict(value=Pk * n / t_tot, seconds=t_tot, updates=n)
+            del pf
+        except Exception as e:
+            res["pool_other"][str(Pk)] = dict(error=str(e))
     return cores, res
 
 
@@ -191,7 +210,11 @@ def main():
         cores, base = cpu_baseline(pts, odom, args.particles, K, W)
         result["cpu_baseline"] = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
                                   "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
-                                            f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s"}
+                                            f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s; "
+                                            f"pool at P=300/3000 (8 updates each): "
+                                            + "/".join(f"{v.get('value', float('nan')):.0f}" for v in base["pool_other"].values()) + "/s",
+                                  "serial_value": base["serial"]["value"],
+                                  "pool_other_particle_counts": base["pool_other"]}
     # roofline of the dominant kernel (k_brushfire): algorithmic bytes per launch / mean launch duration.
     # Algorithmic bytes (reference record sizes): every DM patch the brushfire touches is read
     # and written once = 2 x 10,368 B x n(S_bf) per particle-scan, n(S_bf) counted by the oracle on the same log.
