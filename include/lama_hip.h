@@ -72,8 +72,7 @@ typedef struct lama_hip_cfg {
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
     uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */
     uint32_t active_capacity;    /* parallel ray-cast: max. order-sensitive cell visits per particle and scan (default 8192) */
-    uint32_t sequential_raycast; /* ray-cast kernel: 0 = auto (parallel up to 1024 particles per call, beam-sequential above),
-                                    1 = always beam-sequential, 2 = always parallel; all bit-identical */
+    uint32_t sequential_raycast; /* ray-cast kernels: 0 / 2 = parallel form (default), 1 = beam-sequential form; bit-identical */
     uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
                                     1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
                                         the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -239,7 +240,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        if (c->cfg.sequential_raycast == 1 || (c->cfg.sequential_raycast == 0 && count > 1024) || c->cfg.occupancy_policy == 1 ||
+        if (c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
             c->cfg.ray_rule == 1) {      // the parallel kernels implement the frequency counters and the PF ray rule only
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
@@ -316,6 +317,9 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
     if (cfg.active_capacity == 0) cfg.active_capacity = 8192;
     if (cfg.active_capacity > 8192) cfg.active_capacity = 8192;      // largest k_ray_replay stage
+    // tuning overrides for contexts created by the host classes (all variants are bit-identical)
+    if (cfg.sequential_raycast == 0) if (const char* e = std::getenv("LAMA_HIP_SEQUENTIAL_RAYCAST")) cfg.sequential_raycast = (uint32_t)std::atoi(e);
+    if (cfg.brushfire_waves == 0) if (const char* e = std::getenv("LAMA_HIP_BRUSHFIRE_WAVES")) cfg.brushfire_waves = (uint32_t)std::atoi(e);
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)

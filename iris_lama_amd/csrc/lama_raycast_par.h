@@ -28,7 +28,8 @@
 
 namespace lama_dev {
 
-constexpr int RAY_BEAMS_PER_BLOCK = 16;      // k_ray_visits: 4 waves x 4 beams
+constexpr int RAY_BEAMS_PER_BLOCK = 64;      // k_ray_visits: 4 waves x 16 beams
+constexpr int RV_TABLE = 2048;               // LDS aggregation table of k_ray_visits (entries); 16 KB -> ~10 workgroups per CU
 constexpr int RP_BLOCK = 256;
 
 // ---- directory entry (int16 inside an aligned 32-bit word) with lock-free allocation ----------------------
@@ -152,9 +153,18 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     act_append(prm, p, act_key(rx, ry, (uint32_t)i, 0u));
 }
 
+// Neighbouring beams share most of their cells near the sensor (0.25 deg apart: one cell at 11 m), and agent-scope
+// atomics are executed memory-side (the line leaves the L2 every time, ~45 B of HBM traffic per atomic).  The plain
+// "visited++" of an already-free cell -- the overwhelming majority of the visits -- is therefore first counted per
+// workgroup (64 adjacent beams) in an LDS hash table keyed by the cell's arena index and flushed as ONE atomicAdd per
+// distinct cell.  The counters commute, so the result is unchanged.
 __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double* __restrict__ pts, int n,
                                                      const double* __restrict__ tfs, int first_particle)
 {
+    __shared__ uint32_t tkey[RV_TABLE];      // window-relative cell (ry << 13 | rx), 0xFFFFFFFF = empty
+    __shared__ uint32_t tval[RV_TABLE];      // visits counted so far
+    for (int k = threadIdx.x; k < RV_TABLE; k += 256) { tkey[k] = 0xFFFFFFFFu; tval[k] = 0; }
+    __syncthreads();
     const int p = first_particle + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t WW = (size_t)prm.W * prm.W;
@@ -165,10 +175,24 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
     const int b0 = blockIdx.y * RAY_BEAMS_PER_BLOCK + wave * (RAY_BEAMS_PER_BLOCK / 4);
+    // the geometry of this wave's 16 beams (fp64 transform, one 64-bit division each) is computed by 16 lanes at once and
+    // broadcast beam by beam
+    BeamGeom mine;
+    {
+        const int ib = b0 + (lane < RAY_BEAMS_PER_BLOCK / 4 ? lane : 0);
+        const int ic = ib < n ? ib : (n - 1);
+        mine = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
+    }
     for (int bi = 0; bi < RAY_BEAMS_PER_BLOCK / 4; ++bi) {
         const int i = b0 + bi;
         if (i >= n) break;
-        const BeamGeom g = beam_geometry(prm, T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+        BeamGeom g;
+        g.msx = (uint32_t)__shfl((int)mine.msx, bi, 64); g.msy = (uint32_t)__shfl((int)mine.msy, bi, 64);
+        g.a0 = (uint32_t)__shfl((int)mine.a0, bi, 64); g.a1 = (uint32_t)__shfl((int)mine.a1, bi, 64);
+        g.nn = (uint32_t)__shfl((int)mine.nn, bi, 64);
+        g.s0 = __shfl(mine.s0, bi, 64); g.s1 = __shfl(mine.s1, bi, 64);
+        g.steps = __shfl(mine.steps, bi, 64);
+        g.magic = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(mine.magic >> 32), bi, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)mine.magic, bi, 64);
         for (int base = 0; base < g.steps; base += 64) {
             const int t = base + lane + 1;
             if (t > g.steps) continue;
@@ -177,6 +201,18 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
             const uint32_t cx = g.msx + (uint32_t)(g.s0 * (int)st0), cy = g.msy + (uint32_t)(g.s1 * (int)st1);
             const uint32_t rx = cx - prm.wx0, ry = cy - prm.wy0;
             if (rx >= prm.WC || ry >= prm.WC) { atomicOr(prm.err, ERR_WINDOW); continue; }
+            // a cell this workgroup has already classified as "plain visited++" needs no global access at all
+            const uint32_t key = (ry << 13) | rx;
+            const uint32_t h0 = (key * 2654435761u) >> 21;                   // 11 bits
+            {
+                bool found = false;
+#pragma unroll
+                for (int tr = 0; tr < 4 && !found; ++tr) {
+                    const uint32_t hh = (h0 + (uint32_t)tr) & (RV_TABLE - 1);
+                    if (tkey[hh] == key) { atomicAdd(&tval[hh], 1u); found = true; }
+                }
+                if (found) continue;
+            }
             const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
             const int slot = dir_get_or_alloc(occ_dir, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
             if (slot < 0) continue;
@@ -187,7 +223,16 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
             const uint32_t o0 = v & 0xFFFFu, v0 = v >> 16;
             const bool inert = !hitcell && (v0 == 0 ? o0 == 0 : 4u * o0 < v0);
             if (inert && v0 != 0 && v0 < 0xF000u) {
-                atomicAdd(cell, 0x10000u);                                   // visited++ (setFree): no event, no wrap possible
+                // visited++ (setFree): no event, no wrap possible -> count it in the LDS table (linear probing, 4 tries)
+                uint32_t h = h0;
+                bool done = false;
+#pragma unroll
+                for (int tr = 0; tr < 4 && !done; ++tr) {
+                    const uint32_t old = atomicCAS(&tkey[h], 0xFFFFFFFFu, key);
+                    if (old == 0xFFFFFFFFu || old == key) { atomicAdd(&tval[h], 1u); done = true; }
+                    h = (h + 1) & (RV_TABLE - 1);
+                }
+                if (!done) atomicAdd(cell, 0x10000u);
             } else if (inert) {
                 const uint32_t old = atomicAdd(cell, 0x10000u);              // visited++ (setFree, no event possible ...)
                 if (old == 0) {                                              // ... except the first miss of a new cell:
@@ -200,6 +245,17 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
             } else {
                 act_append(prm, p, act_key(rx, ry, (uint32_t)i, (uint32_t)t));
             }
+        }
+    }
+    // flush: one atomicAdd per distinct cell of this workgroup
+    __syncthreads();
+    uint32_t* occ_base = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    for (int k = threadIdx.x; k < RV_TABLE; k += 256) {
+        const uint32_t cnt = tval[k];
+        if (cnt) {      // the patch exists (the cell was classified through it): plain directory read
+            const uint32_t key = tkey[k], rx = key & 0x1FFFu, ry = key >> 13;
+            const int slot = occ_dir[(ry >> 5) * prm.W + (rx >> 5)];
+            atomicAdd(occ_base + (uint32_t)slot * 1024u + ((rx & 31u) | ((ry & 31u) << 5)), cnt << 16);
         }
     }
 }
