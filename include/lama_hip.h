@@ -76,8 +76,8 @@ typedef struct lama_hip_cfg {
     uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
                                     1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
                                         the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */
-    uint32_t brushfire_waves;    /* exact brushfire: 0 = auto (a helper wave per particle for the heap up to 768 particles per
-                                    call), 1 = one wave per particle, 2 = always with the helper wave; all bit-identical */
+    uint32_t brushfire_waves;    /* exact brushfire: 0 / 2 = a helper wave per particle owns the heap (default), 1 = one wave per
+                                    particle; bit-identical */
     uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}
                                     (PFSlam2D, Slam2D); 1 = ProbabilisticOccupancyMap {float log-odds}
                                     (src/sdm/probabilistic_occupancy_map.cpp:53-107; LidarOdometry2D) -- beam-sequential ray-cast */

@@ -19,7 +19,7 @@ constexpr int UM_BLOCK = 64;        // update-maps workgroup: 1 wave
 // brushfire queue windows in LDS (entries): a small one for throughput (many waves per CU) and a big resume stage
 constexpr int LQ_SMALL = 1024, RQ_SMALL = 256;     // 8 + 2 KiB
 constexpr int LQ_BIG = 8192, RQ_BIG = 2048;        // 64 + 16 KiB
-constexpr uint32_t BF_TW_MAX_PARTICLES = 768;     // up to 3 two-wave workgroups per CU; beyond that the waves of other particles hide the latency
+constexpr uint32_t BF_TW_MAX_PARTICLES = 1u << 30;     // the helper-wave form wins at every measured particle count (30 .. 3000); cfg.brushfire_waves = 1 forces one wave
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (fixed shape => results do not depend on how particles are sharded)
