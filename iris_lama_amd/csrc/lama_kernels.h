@@ -616,10 +616,13 @@ struct BfLds {
     uint64_t raise[RQ];
     uint32_t dc[DC_SIZE];
     // TW mailboxes (double buffered by iteration parity)
-    uint64_t pl_e[2][4];   // main -> helper: the entries lower() wants pushed, in neighbour order
+    uint64_t pl_e[2][4];   // main -> helper: the entries to push into the LOWER queue, in neighbour order
     uint32_t pl_n[2];      //                 and how many
+    uint64_t pr_e[2][4];   // main -> helper: the entries raise() pushes into the RAISE queue
+    uint32_t pr_n[2];
+    uint32_t cmd_r;        // raise-queue length at the hand-over
     uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
-    uint32_t cmd;          // heap length at the start of the lower wave, or BF_CMD_EXIT
+    uint32_t cmd;          // lower-queue length at the hand-over, or BF_CMD_EXIT
 };
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
@@ -731,10 +734,10 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 //     mask update is applied once the decision is known.
 // ------------------------------------------------------------------------------------------------
 //
-// TW ("two waves", used while the particle count leaves CUs idle): the kernel is bound by the instruction issue
-// rate of its single wave, so in the lower wave ALL heap work -- pop()'s sift-down and the push_heap calls, pure
-// LDS code, about half of the instructions of one iteration -- is done by a helper wave on another SIMD of the CU,
-// concurrently with the main wave's cell loads and lower() decision.  One workgroup barrier per pop:
+// TW ("two waves"): the kernel is bound by the instruction issue rate of its single wave, so ALL heap work of both
+// queues -- pop()'s sift-down and the push_heap calls, pure LDS code, about half of the instructions of one
+// iteration -- is done by a helper wave on another SIMD of the CU, concurrently with the main wave's cell loads and
+// raise() / lower() decision.  One workgroup barrier per pop:
 //   main  : [knows top e_k] loads, decision, map stores, writes the entries to push into a mailbox | barrier D_k |
 //           reads the root the helper saw after pop_k and derives e_{k+1} from it and its own pushes:
 //           push_heap moves a new entry above its parent only if the parent's priority is strictly greater, so
@@ -769,10 +772,11 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     __syncthreads();
     const uint64_t anc = lds_pop_ancestors(lane);
     if (TW && tid >= UM_BLOCK) {
-        // helper wave: owns the lower queue during the lower wave
-        __syncthreads();                                       // S0: raise wave done, heap consistent
-        uint32_t n = sh.cmd;
-        if (n == BF_CMD_EXIT) return;
+        // helper wave: owns both queues from the hand-over on.  While the raise queue is not empty it is the one popped
+        // (dynamic_distance_map.cpp:162-173), then the lower queue (:175-194).
+        __syncthreads();                                       // S0: heaps consistent
+        uint32_t hnl = sh.cmd, hnr = sh.cmd_r;
+        if (hnl == BF_CMD_EXIT) return;
 #ifdef LAMA_PROFILE_BF
         uint64_t hp[3] = {0, 0, 0};
         uint64_t ht = __builtin_readcyclecounter();
@@ -780,43 +784,54 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #else
         #define HFT(k) do {} while (0)
 #endif
+        // push_heap of `cnt` (<= 4) mailbox entries.  Fast path: one gather of all parents; if none of the new entries
+        // has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply appended,
+        // exactly what the sequential push_heap calls would have done.
+        auto pushes = [&](uint64_t* heap, uint32_t& n, const uint64_t* ent, uint32_t cnt_v) {
+            const uint32_t l4 = (uint32_t)lane & 3u;
+            const uint64_t entry = ent[l4];                    // count, entries and would-be parents: ONE LDS round trip
+            const uint32_t pos = n + l4;
+            const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
+            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
+            if (!cnt) return;
+            bool done = false;
+            if (n >= 4) {
+                const bool mine = (uint32_t)lane < cnt;
+                const bool up = mine && pprio > heap_prio(entry);
+                if (__ballot(up) == 0) {
+                    if (mine) heap[pos] = entry;
+                    n += cnt;
+                    done = true;
+                }
+            }
+            if (!done) {
+                #pragma unroll 1
+                for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
+            }
+        };
         for (uint32_t it = 0;; ++it) {
             const uint32_t b = it & 1u;
+            const bool ph_r = hnr > 0;
             PopState ps_;
-            lds_pop_begin(sh.lower, n, ps_);
-            lds_pop_finish(sh.lower, ps_, lane, anc);
-            if (lane == 0 && n > 0) sh.topq[b] = sh.lower[0];
+            if (ph_r) {
+                lds_pop_begin(sh.raise, hnr, ps_);
+                lds_pop_finish(sh.raise, ps_, lane, anc);
+                if (lane == 0 && hnr > 0) sh.topq[b] = sh.raise[0];
+            } else {
+                lds_pop_begin(sh.lower, hnl, ps_);
+                lds_pop_finish(sh.lower, ps_, lane, anc);
+                if (lane == 0 && hnl > 0) sh.topq[b] = sh.lower[0];
+            }
             HFT(0);
             __syncthreads();                                   // D
             HFT(1);
-            // count, entries and the would-be parents are read in ONE LDS round trip (speculatively for 4 entries)
-            const uint32_t l4 = (uint32_t)lane & 3u;
-            const uint32_t cnt_v = sh.pl_n[b];
-            const uint64_t entry = sh.pl_e[b][l4];
-            const uint32_t pos = n + l4;
-            const uint32_t pprio = heap_prio(sh.lower[n >= 4 ? (pos - 1) / 2 : 0]);
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
-            if (cnt) {
-                // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries
-                // has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are
-                // simply appended, exactly what the sequential push_heap calls would have done.
-                bool done = false;
-                if (n >= 4) {
-                    const bool mine = (uint32_t)lane < cnt;
-                    const bool up = mine && pprio > heap_prio(entry);
-                    if (__ballot(up) == 0) {
-                        if (mine) sh.lower[pos] = entry;
-                        n += cnt;
-                        done = true;
-                    }
-                }
-                if (!done) {
-                    #pragma unroll 1
-                    for (uint32_t i = 0; i < cnt; ++i) lds_push(sh.lower, n, sh.pl_e[b][i], lane == 0);
-                }
-            }
+            const uint32_t cr = sh.pr_n[b], cl = sh.pl_n[b];
+            pushes(sh.raise, hnr, sh.pr_e[b], cr);
+            pushes(sh.lower, hnl, sh.pl_e[b], cl);
             HFT(2);
-            if (n == 0 || n + 4 > (uint32_t)LQ_LDS) break;     // the main wave takes the same decision
+            const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
+            if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
+            if (ph_r && hnr == 0) __syncthreads();             // X: phase switch, the main wave reads lower[0] after the pushes
         }
 #ifdef LAMA_PROFILE_BF
         if (lane == 0) for (int k = 0; k < 3; ++k) prm.dbg[8 * p + 5 + k] = hp[k];
@@ -861,16 +876,54 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         BF_LOAD_A()                                                                                         \
         BFT(1);                                                                                             \
         PopState ps_;                                                                                       \
-        lds_pop_begin(H, N, ps_);                                                                           \
-        lds_pop_chunk(H, ps_, lane, anc);                                                                   \
+        if (TW) { --N; /* the helper wave pops */ } else { lds_pop_begin(H, N, ps_); lds_pop_chunk(H, ps_, lane, anc); } \
         BF_LOAD_B()                                                                                         \
-        lds_pop_finish(H, ps_, lane, anc);                                                                  \
+        if (!TW) lds_pop_finish(H, ps_, lane, anc);                                                         \
         BFT(2);
 
+    // TW: hand both queues to the helper wave; from here on the main wave derives every next top itself
+    uint64_t e_next = 0;
+    uint32_t tw_it = 0;
+    bool tw_running = false, tw_go = false;
+    if (TW) {
+        spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
+        tw_running = tw_go = !spill && (nr > 0 || nl > 0);
+        if (lane == 0) { sh.cmd = tw_go ? nl : BF_CMD_EXIT; sh.cmd_r = nr; }
+        if (tw_go) e_next = nr > 0 ? sh.raise[0] : sh.lower[0];
+        __syncthreads();                                       // S0
+    }
+    // end of a TW iteration: deliver the push lists, meet the helper (its pop is done), derive the next top from the root it
+    // published and my own pushes into the queue that was popped (push_heap lifts an entry above its parent only if the
+    // parent's priority is strictly greater; a pushed entry therefore becomes the root iff its priority is smaller than the
+    // root's, the first of the smallest ones).  On the raise -> lower switch the lower queue's root is read after the pushes.
+    #define BF_TW_TAIL(WAS_RAISE, NPOP, CNT_R, CNT_L, OWN_ENTRY, OWN_MASK)                                  \
+        {                                                                                                   \
+            const uint32_t b_ = tw_it & 1u;                                                                 \
+            if (lane == 0) { sh.pr_n[b_] = (CNT_R); sh.pl_n[b_] = (CNT_L); }                                \
+            __syncthreads();                                   /* D */                                      \
+            bool have_ = (NPOP) > 0;                                                                        \
+            uint64_t cand_ = have_ ? sh.topq[b_] : 0;                                                       \
+            _Pragma("unroll")                                                                               \
+            for (int i_ = 0; i_ < 4; ++i_) {                                                                \
+                const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(OWN_ENTRY), i_);   \
+                const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((OWN_ENTRY) >> 32), i_); \
+                const uint64_t pe_ = ((uint64_t)hi_ << 32) | lo_;                                           \
+                if ((((OWN_MASK) >> i_) & 1u) && (!have_ || heap_prio(pe_) < heap_prio(cand_))) { cand_ = pe_; have_ = true; } \
+            }                                                                                               \
+            nr += (CNT_R); nl += (CNT_L);                                                                   \
+            spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);                      \
+            tw_running = !spill && (nr > 0 || nl > 0);                                                      \
+            if (tw_running) {                                                                               \
+                if ((WAS_RAISE) && nr == 0) { __syncthreads(); /* X */ e_next = sh.lower[0]; }              \
+                else e_next = cand_;                                                                        \
+            }                                                                                               \
+            ++tw_it;                                                                                        \
+        }
+
     // ---- raise wave ------------------------------------------------------------------------- :162-173
-    while (nr > 0) {
-        if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { spill = true; break; }
-        const uint64_t e = sh.raise[0];                  // priority_queue::top(); the cell loads below are in
+    while (TW ? (tw_running && nr > 0) : (nr > 0)) {
+        if (!TW && (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS)) { spill = true; break; }
+        const uint64_t e = TW ? e_next : sh.raise[0];    // priority_queue::top(); the cell loads below are in
         const int rx = q_rx(e), ry = q_ry(e);            // flight while pop() sifts the heap in LDS
         ++processed;
         BF_POP_WITH_LOADS(sh.raise, nr)
@@ -898,8 +951,18 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         }
         const bool to_raise = cand && !ovalid;           // :262-268
         const bool to_lower = cand && ovalid;            // :269-272
+        uint32_t rw_cnt_r = 0, rw_cnt_l = 0, rw_rm = 0;
+        uint64_t rw_entry_r = 0;
+        if (TW) {                                        // pushes in neighbour order: the helper wave applies them
+            const uint32_t rm = (uint32_t)__ballot(to_raise) & 15u, lm = (uint32_t)__ballot(to_lower) & 15u;
+            const uint32_t below = (1u << lane) - 1u;
+            rw_entry_r = q_entry((uint32_t)(s & SV_SQMASK), x, y);
+            if (to_raise) sh.pr_e[tw_it & 1u][__popc(rm & below)] = rw_entry_r;
+            if (to_lower) sh.pl_e[tw_it & 1u][__popc(lm & below)] = q_entry((uint32_t)(s & SV_SQMASK), x, y, obs_x(ob), obs_y(ob));
+            rw_cnt_r = (uint32_t)__popc(rm); rw_cnt_l = (uint32_t)__popc(lm); rw_rm = rm;
+        }
         #pragma unroll 1
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; !TW && i < 4; ++i) {
             const bool r_i = __builtin_amdgcn_readlane((int)to_raise, i) != 0, l_i = __builtin_amdgcn_readlane((int)to_lower, i) != 0;
             if (r_i || l_i) {
                 const uint32_t prio = (uint32_t)__builtin_amdgcn_readlane((int)(s & SV_SQMASK), i);
@@ -912,22 +975,13 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0; }
         if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
         if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
+        if (TW) BF_TW_TAIL(true, nr, rw_cnt_r, rw_cnt_l, rw_entry_r, rw_rm)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
 
     // ---- lower wave ------------------------------------------------------------------------- :175-194
     BFT(7);
-    uint64_t e_next = 0;
-    uint32_t tw_it = 0;
-    bool tw_running = false;
-    if (TW) {
-        if (!spill && nl > 0 && nl + 4 > (uint32_t)LQ_LDS) spill = true;
-        tw_running = !spill && nl > 0;
-        if (lane == 0) sh.cmd = tw_running ? nl : BF_CMD_EXIT;
-        if (tw_running) e_next = sh.lower[0];
-        __syncthreads();                                       // S0: hands the lower queue to the helper wave
-    }
-    while (!spill && nl > 0) {
+    while (TW ? (tw_running && nl > 0) : (!spill && nl > 0)) {
         if (!TW && nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
         const uint64_t e = TW ? e_next : sh.lower[0];
         const int rx = q_rx(e), ry = q_ry(e);
@@ -1046,29 +1100,12 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             }
             BFT(5);
         }
-        if (TW) {
-            const uint32_t b = tw_it & 1u;
-            if (lane == 0) sh.pl_n[b] = tw_cnt;
-            __syncthreads();                                   // D: pop_k done, push list delivered
-            bool have = nl > 0;
-            const uint64_t tq = sh.topq[b];
-            uint64_t cand = have ? tq : 0;
-            #pragma unroll
-            for (int i = 0; i < 4; ++i) {                      // my own pushes, in neighbour (= lane) order
-                const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)tw_entry, i);
-                const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(tw_entry >> 32), i);
-                const uint64_t pe = ((uint64_t)hi << 32) | lo;
-                if (((tw_om >> i) & 1u) && (!have || heap_prio(pe) < heap_prio(cand))) { cand = pe; have = true; }
-            }
-            nl += tw_cnt;
-            e_next = cand;
-            ++tw_it;
-            if (nl > 0 && nl + 4 > (uint32_t)LQ_LDS) spill = true;
-        }
+        if (TW) BF_TW_TAIL(false, nl, 0u, tw_cnt, tw_entry, tw_om)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         BFT(6);
     }
-    if (TW && tw_running) __syncthreads();                     // F: the helper has applied the last pushes
+    if (TW && tw_go) __syncthreads();                          // F: the helper has applied the last pushes
+    #undef BF_TW_TAIL
     #undef BF_LOAD_A
     #undef BF_LOAD_B
     #undef BF_POP_WITH_LOADS
