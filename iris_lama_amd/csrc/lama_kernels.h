@@ -745,6 +745,10 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 //           smaller than the old root's, else the old root -- no need to wait for the pushes themselves;
 //   helper: pop_k, publishes the new root | barrier D_k | pushes_k, then straight on to pop_{k+1}.
 // The sequence of heap operations is exactly the sequential one, so the result stays bit-identical.
+// Workgroup barrier that orders LDS traffic only: the main wave's global stores / atomics of the iteration need not be
+// acknowledged before it meets the helper wave (which never touches global memory); __syncthreads() would drain vmcnt.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
@@ -823,15 +827,15 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                 if (lane == 0 && hnl > 0) sh.topq[b] = sh.lower[0];
             }
             HFT(0);
-            __syncthreads();                                   // D
+            lds_barrier();                                     // D
             HFT(1);
             const uint32_t cr = sh.pr_n[b], cl = sh.pl_n[b];
-            pushes(sh.raise, hnr, sh.pr_e[b], cr);
+            if (ph_r) pushes(sh.raise, hnr, sh.pr_e[b], cr);   // raise() is the only producer of raise entries
             pushes(sh.lower, hnl, sh.pl_e[b], cl);
             HFT(2);
             const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
             if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
-            if (ph_r && hnr == 0) __syncthreads();             // X: phase switch, the main wave reads lower[0] after the pushes
+            if (ph_r && hnr == 0) lds_barrier();               // X: phase switch, the main wave reads lower[0] after the pushes
         }
 #ifdef LAMA_PROFILE_BF
         if (lane == 0) for (int k = 0; k < 3; ++k) prm.dbg[8 * p + 5 + k] = hp[k];
@@ -900,21 +904,26 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         {                                                                                                   \
             const uint32_t b_ = tw_it & 1u;                                                                 \
             if (lane == 0) { sh.pr_n[b_] = (CNT_R); sh.pl_n[b_] = (CNT_L); }                                \
-            __syncthreads();                                   /* D */                                      \
-            bool have_ = (NPOP) > 0;                                                                        \
-            uint64_t cand_ = have_ ? sh.topq[b_] : 0;                                                       \
-            _Pragma("unroll")                                                                               \
-            for (int i_ = 0; i_ < 4; ++i_) {                                                                \
-                const uint32_t lo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(OWN_ENTRY), i_);   \
-                const uint32_t hi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((OWN_ENTRY) >> 32), i_); \
-                const uint64_t pe_ = ((uint64_t)hi_ << 32) | lo_;                                           \
-                if ((((OWN_MASK) >> i_) & 1u) && (!have_ || heap_prio(pe_) < heap_prio(cand_))) { cand_ = pe_; have_ = true; } \
-            }                                                                                               \
+            /* my own best push: smallest (priority, neighbour index); scalar min over the 4 neighbour lanes */ \
+            const uint32_t key_ = (((OWN_MASK) >> (lane & 3)) & 1u) ? ((heap_prio(OWN_ENTRY) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu; \
+            const uint32_t k0_ = (uint32_t)__builtin_amdgcn_readlane((int)key_, 0), k1_ = (uint32_t)__builtin_amdgcn_readlane((int)key_, 1); \
+            const uint32_t k2_ = (uint32_t)__builtin_amdgcn_readlane((int)key_, 2), k3_ = (uint32_t)__builtin_amdgcn_readlane((int)key_, 3); \
+            const uint32_t k01_ = k0_ < k1_ ? k0_ : k1_, k23_ = k2_ < k3_ ? k2_ : k3_;                      \
+            const uint32_t kb_ = k01_ < k23_ ? k01_ : k23_;                                                 \
+            const int bl_ = (int)(kb_ & 3u);                                                                \
+            const uint32_t olo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(OWN_ENTRY), bl_);     \
+            const uint32_t ohi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((OWN_ENTRY) >> 32), bl_); \
+            const bool have_own_ = kb_ != 0xFFFFFFFFu;                                                      \
+            lds_barrier();                                     /* D */                                      \
+            const bool have_root_ = (NPOP) > 0;                                                             \
+            const uint64_t root_ = sh.topq[b_];                                                             \
+            const bool own_wins_ = have_own_ && (!have_root_ || (kb_ >> 2) < heap_prio(root_));             \
+            const uint64_t cand_ = own_wins_ ? (((uint64_t)ohi_ << 32) | olo_) : root_;                     \
             nr += (CNT_R); nl += (CNT_L);                                                                   \
             spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);                      \
             tw_running = !spill && (nr > 0 || nl > 0);                                                      \
             if (tw_running) {                                                                               \
-                if ((WAS_RAISE) && nr == 0) { __syncthreads(); /* X */ e_next = sh.lower[0]; }              \
+                if ((WAS_RAISE) && nr == 0) { lds_barrier(); /* X */ e_next = sh.lower[0]; }                \
                 else e_next = cand_;                                                                        \
             }                                                                                               \
             ++tw_it;                                                                                        \
