@@ -28,6 +28,34 @@ struct ParticleSet {
 
 } // namespace
 
+// Page-locked host array with the part of std::vector's interface the context uses: the per-call transfers (poses, counts,
+// statistics, transforms, scan points) then are real DMA transfers that overlap with kernel launches instead of staged,
+// blocking pageable copies.
+template <class T>
+struct PinVec {
+    T* p = nullptr; size_t n = 0, cap = 0;
+    PinVec() {}
+    PinVec(const PinVec&) = delete;
+    PinVec& operator=(const PinVec&) = delete;
+    ~PinVec() { if (p) (void)hipHostFree(p); }
+    void reserve(size_t m)
+    {
+        if (m <= cap) return;
+        T* q = nullptr;
+        if (hipHostMalloc((void**)&q, m * sizeof(T), hipHostMallocDefault) != hipSuccess || !q) throw std::bad_alloc();
+        if (p) { std::memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); }
+        p = q; cap = m;
+    }
+    void resize(size_t m) { reserve(m); if (m > n) std::memset(p + n, 0, (m - n) * sizeof(T)); n = m; }
+    void assign(size_t m, T v) { reserve(m); n = m; for (size_t i = 0; i < m; ++i) p[i] = v; }
+    void swap(PinVec& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 struct lama_hip_ctx {
     lama_hip_cfg cfg;
     std::string error;
@@ -54,14 +82,17 @@ struct lama_hip_ctx {
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
-    std::vector<uint64_t> h_stats;
+    PinVec<uint64_t> h_stats;
+    PinVec<double> h_tfs, h_pts, h_ll;
+    PinVec<int32_t> h_it;
+    PinVec<int32_t> h_err;
     double* d_tfs = nullptr;
     double* d_loglik = nullptr; int32_t* d_iters = nullptr;
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
-    std::vector<double> h_poses;      // host mirror of the particle poses (source of truth between calls)
-    std::vector<int32_t> h_counts;    // host mirror of counts of the current set (refreshed after map updates)
+    PinVec<double> h_poses;           // host mirror of the particle poses (source of truth between calls)
+    PinVec<int32_t> h_counts;         // host mirror of counts of the current set (refreshed after map updates)
     lama_hip_counters ctr;
 };
 
@@ -154,7 +185,9 @@ int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
         c->pts_cap = std::max<uint32_t>(n, 2048);
         HIPCHK(c, hipMalloc(&c->d_pts, sizeof(double) * 3 * c->pts_cap));
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
+    c->h_pts.resize((size_t)3 * n);                       // the caller's buffer is only borrowed for the call
+    std::memcpy(c->h_pts.data(), pts, sizeof(double) * 3 * n);
+    HIPCHK(c, hipMemcpyAsync(c->d_pts, c->h_pts.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     return LAMA_HIP_OK;
 }
 
@@ -164,7 +197,9 @@ void resolve_timers(lama_hip_ctx* c);
 // per-particle patch counts and statistics (a single host round trip per call).
 int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false)
 {
-    int32_t e = 0;
+    c->h_err.resize(1);
+    int32_t& e = c->h_err[0];
+    e = 0;
     const bool stats = maps || match;
     if (stats) {
         c->h_stats.resize((size_t)c->P * 4);
@@ -183,7 +218,7 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
         return fail(c, LAMA_HIP_E_NUMERIC, "unit complex number is (near) zero (SophusException in the reference)");
     }
     if (stats) {
-        const std::vector<uint64_t>& st = c->h_stats;
+        const PinVec<uint64_t>& st = c->h_stats;
         uint64_t dm = 0, oc = 0;
         for (uint32_t p = 0; p < c->P; ++p) {
             if (match) { c->ctr.gn_iterations += st[4 * p]; c->ctr.gn_evals += st[4 * p + 1]; }
@@ -232,7 +267,8 @@ void resolve_timers(lama_hip_ctx* c)      // call after the stream has been sync
 
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
 {
-    std::vector<double> tfs((size_t)c->P * 12);
+    PinVec<double>& tfs = c->h_tfs;
+    tfs.resize((size_t)c->P * 12);
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
     HIPCHK(c, hipMemcpyAsync(c->d_tfs, tfs.data(), sizeof(double) * tfs.size(), hipMemcpyHostToDevice, c->stream));
     DevParams prm = make_params(c, c->cur);
@@ -468,11 +504,14 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_poses.data(), c->d_poses, sizeof(double) * 4 * c->P, hipMemcpyDeviceToHost, c->stream));
-    if (loglik_out) HIPCHK(c, hipMemcpyAsync(loglik_out, c->d_loglik, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
-    if (iters_out) HIPCHK(c, hipMemcpyAsync(iters_out, c->d_iters, sizeof(int32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
+    c->h_ll.resize(c->P); c->h_it.resize(c->P);
+    if (loglik_out) HIPCHK(c, hipMemcpyAsync(c->h_ll.data(), c->d_loglik, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
+    if (iters_out) HIPCHK(c, hipMemcpyAsync(c->h_it.data(), c->d_iters, sizeof(int32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
     rc = check_device_errors(c, false, c->cfg.profile != 0);   // synchronises
     if (rc) return rc;
     if (poses_out) std::memcpy(poses_out, c->h_poses.data(), sizeof(double) * 4 * c->P);
+    if (loglik_out) std::memcpy(loglik_out, c->h_ll.data(), sizeof(double) * c->P);
+    if (iters_out) std::memcpy(iters_out, c->h_it.data(), sizeof(int32_t) * c->P);
     return LAMA_HIP_OK;
 }
 
@@ -499,8 +538,8 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
         std::memcpy(&np[4 * i], &c->h_poses[4 * sample_idx[i]], sizeof(double) * 4);
         nc[2 * i] = c->h_counts[2 * sample_idx[i]]; nc[2 * i + 1] = c->h_counts[2 * sample_idx[i] + 1];
     }
-    c->h_poses.swap(np);
-    c->h_counts.swap(nc);
+    std::memcpy(c->h_poses.data(), np.data(), np.size() * sizeof(double));
+    std::memcpy(c->h_counts.data(), nc.data(), nc.size() * sizeof(int32_t));
     HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->cur = dst;
