@@ -489,3 +489,48 @@ def test_lidar_odometry_gpu_vs_oracle(F):
                 assert np.array_equal(got[pid][1], ref[pid][1]), (k, pid)
     assert deleted > 0
     h.close()
+
+
+def test_full_size_3000_particles_properties(F):
+    """BASELINE config 2 size (3000 particles on one GPU), size-independent properties: particles driven with identical
+    poses must end with identical maps (each equal to the oracle's single particle), the patch counters add up, a scan-match
+    from identical start poses gives identical results for all 3000, and resampling is a pure gather of whole particles."""
+    P = 3000
+    pts, odom, truth = F.corridor_log(3, 1080)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=1, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    ctx.init(pts[0], pose0)
+    for k in (1, 2):
+        start = np.tile(O.se2(*truth[k]), (P, 1))
+        pf.set_poses(start[:1])
+        pf.set_weights(w=np.zeros(1), ws=np.zeros(1))
+        pf.stage_set_scan(pts[k])
+        pf.stage_scan_match()
+        ctx.set_poses(start)
+        g_poses, g_ll, g_it = ctx.scan_match(pts[k])
+        assert (g_poses == g_poses[0]).all() and (g_ll == g_ll[0]).all() and (g_it == g_it[0]).all()     # same input -> same bits
+        assert np.abs(g_poses[0] - pf.poses()[0]).max() < 1e-8
+        ctx.set_poses(np.tile(pf.poses()[0], (P, 1)))
+        pf.stage_update_maps()
+        ctx.update_maps(pts[k])
+    c = ctx.counters()
+    ref_dm, ref_occ = pf.dm(0).dump(), pf.occ(0).dump()
+    assert c["dm_patches"] == P * len(ref_dm) and c["occ_patches"] == P * len(ref_occ)
+    for i in (0, 1, 511, 1499, 2998, 2999):
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), ref_dm, DM_FIELDS, f"dm p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), ref_occ, OCC_FIELDS, f"occ p{i}")
+    # make particle 7 different, then resample everything from it and from particle 8 alternately
+    poses = np.tile(pf.poses()[0], (P, 1))
+    poses[7] = O.se2_mul(poses[7], O.se2(0.1, -0.05, 0.02))
+    ctx.set_poses(poses)
+    ctx.update_maps(pts[3])
+    d7, d8 = ctx.download_map(7, F.MAP_DISTANCE), ctx.download_map(8, F.MAP_DISTANCE)
+    idx = np.where(np.arange(P) % 2 == 0, 7, 8).astype(np.int32)
+    ctx.resample(idx)
+    for i in (0, 1, 1000, 2999):
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), d7 if i % 2 == 0 else d8, DM_FIELDS, f"resampled dm p{i}")
+    assert np.array_equal(ctx.get_poses()[::2], np.tile(poses[7], (P // 2, 1)))
+    ctx.close()
