@@ -157,9 +157,10 @@ def main():
     P_total = args.particles * world
     pts, odom, truth = F.corridor_log(W + K, 1080)
 
-    def run(P, updates, warm, profile=True, brushfire_mode=0):
+    def run(P, updates, warm, profile=True, brushfire_mode=0, gain=None):
+        kw = {} if gain is None else {"meas_sigma_gain": gain}
         opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
-                            create_summary=1, profile=1 if profile else 0, brushfire_mode=brushfire_mode)
+                            create_summary=1, profile=1 if profile else 0, brushfire_mode=brushfire_mode, **kw)
         pf = ShardedPF(opts)
         assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
         pf.set_prior(*odom[0])
@@ -173,20 +174,31 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         done = 0
+        buckets = np.zeros(5)
         for k in range(warm + 1, warm + updates + 1):
             done += 1 if pf.update(pts[k], odom[k], float(k)) else 0
+            if world == 1:                                   # PFSlam2D::Summary sub-buckets of this update (host clocks)
+                t = pf.pf.last_times()
+                buckets += (t["total"], t["solving"], t["normalizing"], t["resampling"], t["mapping"])
         torch.cuda.synchronize()
         pf.barrier()
         dt = pf.max_over_ranks(time.perf_counter() - t0)
         c = ctx.counters()
         err = float(np.linalg.norm(pf.pf.best_pose_xyr()[:2] - truth[warm + updates][:2])) if pf.owns_best() else None
         out = dict(P=P, seconds=dt, updates=done, value=P * done / dt, ms_per_step=1e3 * dt / max(done, 1), counters=c,
-                   resamples=pf.pf.num_resamples() - r0, pose_err_m=err)
+                   resamples=pf.pf.num_resamples() - r0, pose_err_m=err,
+                   shipped_particles=pf.shipped_particles, shipped_bytes=pf.shipped_bytes,
+                   buckets_ms=dict(zip(("total", "solving", "normalizing", "resampling", "mapping"), (1e3 * buckets / max(done, 1)).tolist())))
         pf.close()
         return out
 
     main_run = run(P_total, K, W)
     assert main_run["updates"] == K, "every scan of the log must pass the motion gate"
+    # with the default gain resampling is rare; a variant with meas_sigma_gain = 0.01 makes the filter resample
+    # (and, sharded, ship particles between GPUs).  Single GPU by default; LAMA_BENCH_RESAMPLE_VARIANT=1 also runs it sharded.
+    resample_run = None
+    if world == 1 or os.environ.get("LAMA_BENCH_RESAMPLE_VARIANT") == "1":
+        resample_run = run(P_total, K, W, gain=0.01)
 
     if rank != 0:
         return
@@ -205,6 +217,13 @@ def main():
                                "brushfire": c["ms_brushfire"] / max(c["launches_brushfire"], 1),
                                "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0},
     }
+    if world == 1:
+        result["summary_buckets_ms_per_update"] = main_run["buckets_ms"]
+    if resample_run is not None:
+        result["forced_resample_variant"] = {"meas_sigma_gain": 0.01, "value": resample_run["value"], "ms_per_step": resample_run["ms_per_step"],
+                                             "resamples": resample_run["resamples"], "shipped_particles": resample_run["shipped_particles"],
+                                             "shipped_bytes": resample_run["shipped_bytes"],
+                                             "resample_kernel_ms": resample_run["counters"]["ms_resample"] / max(resample_run["counters"]["launches_resample"], 1)}
     cores, base = (None, None)
     if not args.no_cpu:
         cores, base = cpu_baseline(pts, odom, args.particles, K, W)
