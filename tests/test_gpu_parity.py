@@ -534,3 +534,40 @@ def test_full_size_3000_particles_properties(F):
         assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), d7 if i % 2 == 0 else d8, DM_FIELDS, f"resampled dm p{i}")
     assert np.array_equal(ctx.get_poses()[::2], np.tile(poses[7], (P // 2, 1)))
     ctx.close()
+
+
+def test_limits_fail_loudly_with_status_codes(F):
+    """A cell outside the device window, a full patch arena, too many order-sensitive visits and an invalid configuration are
+    errors with a status code and a message -- never silent truncation (include/lama_hip.h status codes)."""
+    pts, odom, truth = F.corridor_log(1, 1080)
+    pose0 = O.se2(*odom[0])
+    # window of 8 patches = 12.8 m: the 28 m corridor does not fit
+    ctx = F.HipContext(F.default_cfg(particles=2, window_patches=8))
+    with pytest.raises(F.LamaError, match=r"status -\d+: .*window"):
+        ctx.init(pts[0], pose0)
+    ctx.close()
+    # 4 distance-map patches per particle
+    ctx = F.HipContext(F.default_cfg(particles=2, dm_patch_capacity=4))
+    with pytest.raises(F.LamaError, match=r"status -\d+: .*(arena|capacity)"):
+        ctx.init(pts[0], pose0)
+    ctx.close()
+    ctx = F.HipContext(F.default_cfg(particles=2, occ_patch_capacity=4))
+    with pytest.raises(F.LamaError, match=r"status -\d+: .*(arena|capacity)"):
+        ctx.init(pts[0], pose0)
+    ctx.close()
+    # the parallel ray-cast keeps order-sensitive visits in a list of active_capacity entries (1080 hits alone exceed 64)
+    ctx = F.HipContext(F.default_cfg(particles=2, active_capacity=64, sequential_raycast=2))
+    with pytest.raises(F.LamaError, match=r"status -\d+"):
+        ctx.init(pts[0], pose0)
+    ctx.close()
+    for bad in (dict(patch_size=16), dict(window_patches=252), dict(resolution=0.0), dict(l2_max=10.0)):
+        with pytest.raises(F.LamaError, match="lama_hip_ctx_create failed"):
+            F.HipContext(F.default_cfg(particles=2, **bad))
+    # calls before init / with bad arguments
+    ctx = F.HipContext(F.default_cfg(particles=2))
+    with pytest.raises(F.LamaError, match="before"):
+        ctx.scan_match(pts[0])
+    ctx.init(pts[0], pose0)
+    with pytest.raises(F.LamaError):
+        ctx.download_map(5, F.MAP_DISTANCE)          # particle out of range
+    ctx.close()
