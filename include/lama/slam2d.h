@@ -4,7 +4,7 @@
 // update() follows src/slam2d.cpp:143-198.  Scan matching (MatchSurface2D + Solve, :172-175) and updateMaps()
 // (:247-321) run on the device through the C-ABI of include/lama_hip.h with a one-particle context -- the same
 // kernels as PFSlam2D.  Differences: getOccupancyMap()/getDistanceMap() become downloadOccupancyMap()/
-// downloadDistanceMap(); strategy "lm" and transient_map are not supported on the device (constructor throws);
+// downloadDistanceMap(); strategy "lm" is not supported on the device (constructor throws);
 // there is no CPU fallback.
 #pragma once
 
@@ -54,6 +54,7 @@ public:
     uint64_t getMemoryUsage() const;
     uint32_t getNumberOfProcessedCells() const { return number_of_proccessed_cells_; }
     uint32_t getLastIterations() const { return last_iterations_; }
+    uint32_t getLastDeletedPatches() const { return last_deleted_; }   // transient_map: patches removed by the last update
 
     void setPose(const Pose2D& pose) { pose_ = pose; }
     Pose2D getPose() const { return pose_; }
@@ -82,7 +83,9 @@ private:
     lama_hip_ctx* ctx_ = nullptr;
     Pose2D odom_, pose_;
     double trans_thresh_, rot_thresh_;
-    double resolution_ = 0.05, l2_max_ = 0.5;
+    double resolution_ = 0.05, l2_max_ = 0.5, truncated_range_ = 0.0;
+    bool transient_map_ = false;
+    uint32_t last_deleted_ = 0;
     bool has_first_scan = false;
     uint32_t number_of_proccessed_cells_ = 0;
     uint32_t last_iterations_ = 0;

@@ -95,6 +95,7 @@ typedef struct lama_slam_options {
     double trans_thresh, rot_thresh, l2_max, truncated_ray, truncated_range, resolution;
     uint32_t patch_size, max_iter;
     int32_t gpu_device;
+    int32_t transient_map;      /* Slam2D::Options::transient_map (src/slam2d.cpp:322-379) */
 } lama_slam_options;
 void lama_slam_default_options(lama_slam_options* o);
 lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap);
@@ -108,6 +109,7 @@ int lama_slam_update(lama_slam* s, const double* pts_xyz, uint32_t n, const doub
 int lama_slam_enough_motion(lama_slam* s, const double* odom_xyr);
 uint32_t lama_slam_processed_cells(const lama_slam* s);
 uint32_t lama_slam_iterations(const lama_slam* s);
+uint32_t lama_slam_deleted_patches(const lama_slam* s);
 void* lama_slam_device_context(const lama_slam* s);
 const char* lama_slam_engine_origin(const lama_slam* s);
 

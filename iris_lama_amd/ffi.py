@@ -341,7 +341,7 @@ HOST_SYMBOLS = [
     "lama_pose_minus", "lama_pose_from_xyr",
     "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
     "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
-    "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin",
+    "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin", "lama_slam_deleted_patches",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
@@ -375,7 +375,7 @@ def _bind_host(L):
         "lama_slam_last_error": (C.c_char_p, [vp]), "lama_slam_set_pose": (None, [vp, d, d, d]),
         "lama_slam_get_pose": (i32, [vp, vp]), "lama_slam_update": (i32, [vp, vp, u32, vp, vp, vp, d]),
         "lama_slam_enough_motion": (i32, [vp, vp]), "lama_slam_processed_cells": (u32, [vp]),
-        "lama_slam_iterations": (u32, [vp]), "lama_slam_device_context": (vp, [vp]),
+        "lama_slam_iterations": (u32, [vp]), "lama_slam_device_context": (vp, [vp]), "lama_slam_deleted_patches": (u32, [vp]),
         "lama_slam_engine_origin": (C.c_char_p, [vp]),
         "lama_loc_create": (vp, [d, d, d, d, u32, i32, vp, i32]), "lama_loc_destroy": (None, [vp]),
         "lama_loc_last_error": (C.c_char_p, [vp]), "lama_loc_engine_origin": (C.c_char_p, [vp]),
@@ -587,7 +587,7 @@ class PFSlam2D:
 class SlamOptions(C.Structure):
     _fields_ = [("trans_thresh", C.c_double), ("rot_thresh", C.c_double), ("l2_max", C.c_double),
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
-                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("gpu_device", C.c_int32)]
+                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("gpu_device", C.c_int32), ("transient_map", C.c_int32)]
 
 
 class Slam2D:
@@ -612,6 +612,9 @@ class Slam2D:
 
     def __del__(self):
         self.close()
+
+    def deleted_patches(self):
+        return self.L.lama_slam_deleted_patches(self.h)
 
     def engine_origin(self):
         return self.L.lama_slam_engine_origin(self.h).decode()

@@ -272,6 +272,7 @@ void lama_slam_default_options(lama_slam_options* o)
     o->trans_thresh = d.trans_thresh; o->rot_thresh = d.rot_thresh; o->l2_max = d.l2_max; o->truncated_ray = d.truncated_ray;
     o->truncated_range = d.truncated_range; o->resolution = d.resolution; o->patch_size = d.patch_size; o->max_iter = d.max_iter;
     o->gpu_device = 0;
+    o->transient_map = d.transient_map ? 1 : 0;
 }
 
 lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap)
@@ -282,6 +283,7 @@ lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap)
         p.trans_thresh = o->trans_thresh; p.rot_thresh = o->rot_thresh; p.l2_max = o->l2_max; p.truncated_ray = o->truncated_ray;
         p.truncated_range = o->truncated_range; p.resolution = o->resolution; p.patch_size = o->patch_size; p.max_iter = o->max_iter;
         p.gpu_device = o->gpu_device;
+        p.transient_map = o->transient_map != 0;
         h->s.reset(new Slam2D(p));
         h->origin = h->s->engine()->origin;
         return h;
@@ -304,6 +306,7 @@ int lama_slam_update(lama_slam* h, const double* pts, uint32_t n, const double* 
 }
 int lama_slam_enough_motion(lama_slam* h, const double* odom_xyr) { return h->s->enoughMotion(Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2])) ? 1 : 0; }
 uint32_t lama_slam_processed_cells(const lama_slam* h) { return h->s->getNumberOfProcessedCells(); }
+uint32_t lama_slam_deleted_patches(const lama_slam* h) { return h->s->getLastDeletedPatches(); }
 uint32_t lama_slam_iterations(const lama_slam* h) { return h->s->getLastIterations(); }
 void* lama_slam_device_context(const lama_slam* h) { return (void*)h->s->deviceContext(); }
 

@@ -6,6 +6,7 @@
 #include <stdexcept>
 
 #include "hip_engine.hpp"
+#include "transient_map.hpp"
 
 namespace lama {
 
@@ -22,7 +23,8 @@ void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], 
 Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.rot_thresh), resolution_(o.resolution), l2_max_(o.l2_max)
 {
     if (o.strategy == "lm") throw std::runtime_error("lama::Slam2D: strategy \"lm\" is not available on the device path");   // src/slam2d.cpp:226-233
-    if (o.use_compression || o.transient_map) throw std::runtime_error("lama::Slam2D: use_compression / transient_map are not supported on the device path");
+    if (o.use_compression) throw std::runtime_error("lama::Slam2D: use_compression is not supported on the device path");
+    transient_map_ = o.transient_map; truncated_range_ = o.truncated_range;
     eng_ = engineOverride() ? engineOverride() : loadHipEngine();
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
@@ -70,6 +72,10 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
         int32_t rc = eng_->pf_init(ctx_, pts.data(), n, o, q, p); // updateMaps(surface) at pose_
         if (rc) fail(rc, "lama_hip_pf_init");
         if (eng_->get_counters(ctx_, &c1) == 0) number_of_proccessed_cells_ = (uint32_t)c1.bf_cells;
+        if (transient_map_) {                                      // :322-379
+            rc = transient::prune(eng_.get(), ctx_, *surface, pose_, resolution_, l2_max_, truncated_range_, 2.0, &last_deleted_);
+            if (rc) fail(rc, "transient map");
+        }
         has_first_scan = true;
         return true;
     }
@@ -93,6 +99,10 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
     rc = eng_->pf_update_maps(ctx_, pts.data(), n, o, q);
     if (rc) fail(rc, "lama_hip_pf_update_maps");
     if (eng_->get_counters(ctx_, &c1) == 0) number_of_proccessed_cells_ = (uint32_t)(c1.bf_cells - c0.bf_cells);
+    if (transient_map_) {                                          // :322-379
+        rc = transient::prune(eng_.get(), ctx_, *surface, pose_, resolution_, l2_max_, truncated_range_, 2.0, &last_deleted_);
+        if (rc) fail(rc, "transient map");
+    }
     return true;
 }
 

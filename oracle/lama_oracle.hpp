@@ -1623,6 +1623,20 @@ private:
 // Strategy "gn" only (GaussNewton + CauchyWeight(0.15), src/slam2d.cpp:103-106); transient_map pruning
 // (:322-373) is out of scope.
 // -------------------------------------------------------------------------------------
+struct AABB {                                                           // include/lama/aabb.h:41-74
+    double center[3], hwidth[3];
+    AABB(const double mn[3], const double mx[3])
+    {
+        for (int k = 0; k < 3; ++k) { const double local = mx[k] - mn[k]; hwidth[k] = local * 0.5; center[k] = mn[k] + hwidth[k]; }
+    }
+    bool testIntersection(const AABB& o) const
+    {
+        bool r = true;
+        for (int k = 0; k < 3; ++k) r = r && (std::abs(center[k] - o.center[k]) <= (hwidth[k] + o.hwidth[k]));
+        return r;
+    }
+};
+
 struct SlamOptions {                                    // slam2d.h:91-125
     double trans_thresh = 0.5, rot_thresh = 0.5;
     double l2_max = 0.5;
@@ -1630,6 +1644,7 @@ struct SlamOptions {                                    // slam2d.h:91-125
     double resolution = 0.05;
     uint32_t patch_size = 32;
     uint32_t max_iter = 100;
+    bool transient_map = false;
 };
 
 class Slam2D {
@@ -1677,10 +1692,50 @@ public:
     }
 
 private:
-    void updateMaps(const Scan& surface)                                // :247-321
+    void updateMaps(const Scan& surface)                                // :247-379
     {
         processed_ = update_maps_body(dm_, occ_, surface, pose_, opt_.truncated_ray, opt_.truncated_range);
+        deleted_last = 0;
+        if (!opt_.transient_map) return;
+        // 4. transient map (:322-379): box of the (range-truncated) hits, symmetric about the pose at TWICE the largest
+        // offset, expanded by twice the distance map's range; patches that do not meet it are deleted from both maps
+        const Affine3 tf = affine_mul(fixed_tf(pose_), moving_tf(surface));
+        double mn[3], mx[3];
+        for (int k = 0; k < 3; ++k) { mn[k] = std::numeric_limits<double>::max(); mx[k] = -std::numeric_limits<double>::max(); }
+        for (size_t i = 0; i < surface.points.size(); ++i) {
+            V3d hit = affine_apply(tf, surface.points[i]);
+            if (opt_.truncated_range > 0.0) {
+                const V3d AB{hit.x - tf.t[0], hit.y - tf.t[1], hit.z - tf.t[2]};
+                const double ray_length = std::sqrt((AB.x * AB.x + AB.y * AB.y) + AB.z * AB.z);
+                if (opt_.truncated_range < ray_length)
+                    hit = V3d{tf.t[0] + AB.x / ray_length * opt_.truncated_range, tf.t[1] + AB.y / ray_length * opt_.truncated_range,
+                              tf.t[2] + AB.z / ray_length * opt_.truncated_range};
+            }
+            mn[0] = std::min(mn[0], hit.x); mn[1] = std::min(mn[1], hit.y); mn[2] = std::min(mn[2], hit.z);
+            mx[0] = std::max(mx[0], hit.x); mx[1] = std::max(mx[1], hit.y); mx[2] = std::max(mx[2], hit.z);
+        }
+        mn[2] = mx[2] = 0;
+        const double xdist = std::max(pose_.tx - mn[0], mx[0] - pose_.tx) * 2.0;
+        const double ydist = std::max(pose_.ty - mn[1], mx[1] - pose_.ty) * 2.0;
+        mn[0] = pose_.tx - xdist; mn[1] = pose_.ty - ydist;
+        mx[0] = pose_.tx + xdist; mx[1] = pose_.ty + ydist;
+        AABB a(mn, mx);
+        for (int k = 0; k < 3; ++k) a.hwidth[k] += 2.0 * dm_.maxDistance();
+        std::vector<V3u> to_remove;
+        dm_.visit_all_patches([&](const V3u& origin) {
+            const uint32_t length = occ_.patch_length;
+            V3d ws = occ_.m2w(origin);
+            V3d we = occ_.m2w(V3u{origin.x + length, origin.y + length, origin.z + 0});
+            ws.z = we.z = 0.0;
+            const double b0[3] = {ws.x, ws.y, ws.z}, b1[3] = {we.x, we.y, we.z};
+            if (a.testIntersection(AABB(b0, b1))) return;
+            to_remove.push_back(origin);
+        });
+        for (auto& coord : to_remove) { occ_.deletePatchAt(coord); if (dm_.deletePatchAt(coord)) ++deleted_last; }
     }
+public:
+    uint32_t deleted_last = 0;
+private:
     SlamOptions opt_;
     DynamicDistanceMap dm_;
     FrequencyOccupancyMap occ_;
@@ -1693,20 +1748,6 @@ private:
 // LidarOdometry2D  (include/lama/lidar_odometry_2d.h:45-80, src/lidar_odometry_2d.cpp:42-200): scan-to-map odometry on a
 // log-odds occupancy map + distance map (max distance 1 m) that keeps only the patches near the latest scan.
 // -------------------------------------------------------------------------------------
-struct AABB {                                                           // include/lama/aabb.h:41-74
-    double center[3], hwidth[3];
-    AABB(const double mn[3], const double mx[3])
-    {
-        for (int k = 0; k < 3; ++k) { const double local = mx[k] - mn[k]; hwidth[k] = local * 0.5; center[k] = mn[k] + hwidth[k]; }
-    }
-    bool testIntersection(const AABB& o) const
-    {
-        bool r = true;
-        for (int k = 0; k < 3; ++k) r = r && (std::abs(center[k] - o.center[k]) <= (hwidth[k] + o.hwidth[k]));
-        return r;
-    }
-};
-
 // LidarOdometry2D::updateMaps, ray-cast part (src/lidar_odometry_2d.cpp:85-126): hit -> setOccupied/addObstacle, the
 // last metre of the ray -> setFree/removeObstacle, then distance_map->update().  mn/mx: bounding box of the hits.
 inline uint32_t lidar_update_maps_body(DynamicDistanceMap& dm_, ProbabilisticOccupancyMap& occ_, const Scan& surface, const SE2& odom,

@@ -334,6 +334,18 @@ void* orc_slam_new(double trans_thresh, double rot_thresh, double l2_max, double
     b->s.reset(new Slam2D(o));
     return b;
 }
+void* orc_slam_new2(double trans_thresh, double rot_thresh, double l2_max, double truncated_ray, double truncated_range,
+                    double resolution, uint32_t patch_size, uint32_t max_iter, int transient_map)
+{
+    SlamOptions o;
+    o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.truncated_ray = truncated_ray;
+    o.truncated_range = truncated_range; o.resolution = resolution; o.patch_size = patch_size; o.max_iter = max_iter;
+    o.transient_map = transient_map != 0;
+    auto* b = new SlamBox;
+    b->s.reset(new Slam2D(o));
+    return b;
+}
+uint32_t orc_slam_deleted_last(void* h) { return ((SlamBox*)h)->s->deleted_last; }
 void orc_slam_free(void* h) { delete (SlamBox*)h; }
 void orc_slam_set_pose(void* h, const double* pose4) { ((SlamBox*)h)->s->setPose(se2_of(pose4)); }
 void orc_slam_get_pose(void* h, double* pose4) { se2_to(((SlamBox*)h)->s->getPose(), pose4); }

@@ -64,7 +64,8 @@ def lib():
             "orc_scan_tf": (None, [vp, vp, vp, vp]), "orc_ldlt3_solve": (None, [vp, vp, vp]),
             "orc_se2_exp": (None, [vp, vp]), "orc_se2_mul": (None, [vp, vp, vp]), "orc_se2_inverse": (None, [vp, vp]),
             "orc_pose_minus": (None, [vp, vp, vp]),
-            "orc_slam_new": (vp, [d, d, d, d, d, d, u32, u32]), "orc_slam_free": (None, [vp]),
+            "orc_slam_new": (vp, [d, d, d, d, d, d, u32, u32]), "orc_slam_new2": (vp, [d, d, d, d, d, d, u32, u32, i32]),
+            "orc_slam_deleted_last": (u32, [vp]), "orc_slam_free": (None, [vp]),
             "orc_slam_set_pose": (None, [vp, vp]), "orc_slam_get_pose": (None, [vp, vp]),
             "orc_slam_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "orc_slam_enough_motion": (i32, [vp, vp]),
             "orc_slam_processed_cells": (u32, [vp]), "orc_slam_iterations": (u32, [vp]),
@@ -432,9 +433,12 @@ class Slam:
     """Oracle Slam2D (src/slam2d.cpp)."""
 
     def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=0.5, truncated_ray=0.0, truncated_range=0.0,
-                 resolution=0.05, patch_size=32, max_iter=100):
-        self.h = C.c_void_p(lib().orc_slam_new(trans_thresh, rot_thresh, l2_max, truncated_ray, truncated_range,
-                                               resolution, patch_size, max_iter))
+                 resolution=0.05, patch_size=32, max_iter=100, transient_map=False):
+        self.h = C.c_void_p(lib().orc_slam_new2(trans_thresh, rot_thresh, l2_max, truncated_ray, truncated_range,
+                                                resolution, patch_size, max_iter, 1 if transient_map else 0))
+
+    def deleted_last(self):
+        return lib().orc_slam_deleted_last(self.h)
 
     def __del__(self):
         if self.h:

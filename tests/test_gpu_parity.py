@@ -571,3 +571,27 @@ def test_limits_fail_loudly_with_status_codes(F):
     with pytest.raises(F.LamaError):
         ctx.download_map(5, F.MAP_DISTANCE)          # particle out of range
     ctx.close()
+
+
+def test_slam2d_transient_map_gpu_vs_oracle(F):
+    """Slam2D with transient_map (src/slam2d.cpp:322-379) on the device: patch deletion keeps both maps bit-exact."""
+    steps = 30
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    kw = dict(transient_map=True, truncated_range=3.5)
+    o = O.Slam(**kw)
+    h = F.Slam2D(**kw)
+    assert h.engine_origin().endswith("liblama_hip.so")
+    o.set_pose(O.se2(*odom[0]))
+    h.set_pose(*odom[0])
+    deleted = 0
+    for k in range(steps + 1):
+        p = pts[k][np.hypot(pts[k][:, 0], pts[k][:, 1]) < 4.0]
+        assert o.update(p, O.se2(*odom[k]), float(k)) == h.update(p, odom[k], float(k))
+        assert np.abs(o.pose() - h.pose()).max() < 1e-7, k
+        assert o.deleted_last() == h.deleted_patches(), k
+        deleted += h.deleted_patches()
+    assert deleted > 0
+    ctx = h.hip_context()
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "transient occ")
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "transient dm")
+    h.close()

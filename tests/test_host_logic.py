@@ -256,3 +256,27 @@ def test_lidar_odometry_host_matches_oracle():
         assert np.array_equal(np.ascontiguousarray(got[pid][0]).view(np.float32).reshape(-1), ref[pid][0]["prob"]), pid
         assert np.array_equal(got[pid][1], ref[pid][1])
     h.close()
+
+
+def test_slam2d_transient_map_host_matches_oracle():
+    """Slam2D::Options::transient_map (src/slam2d.cpp:322-379: only the patches near the latest scan survive), with
+    range-limited scans so that patches really fall out of the box."""
+    from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+    steps = 30
+    pts, odom, truth = F.corridor_log(steps, 360)
+    kw = dict(transient_map=True, truncated_range=3.5)
+    o = O.Slam(**kw)
+    h = F.Slam2D(**kw)
+    o.set_pose(O.se2(*odom[0]))
+    h.set_pose(*odom[0])
+    deleted = 0
+    for k in range(steps + 1):
+        p = _limited(pts[k], 4.0)
+        assert o.update(p, O.se2(*odom[k]), float(k)) == h.update(p, odom[k], float(k))
+        assert np.array_equal(o.pose(), h.pose()), k
+        assert o.deleted_last() == h.deleted_patches(), k
+        deleted += h.deleted_patches()
+    assert deleted > 0
+    ctx = h.hip_context()
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "dm")
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "occ")
