@@ -8,7 +8,8 @@
 // the device when distance_map->update() is called.  On the device: scan matching with covariance
 // (Solve(..., &cov)) and the RMSE (lama_hip_match_solve), the candidate evaluation of globalLocalization (:249-286,
 // lama_hip_eval_batch; the candidates are drawn on the host from lama::random like the reference) and the likelihood
-// samples of addSamplingCovariance (:199-247, lama_hip_map_sample_likelihood).  Not available: strategy "lm" (throws).
+// samples of addSamplingCovariance (:199-247, lama_hip_map_sample_likelihood); strategy "lm" = Levenberg-Marquardt in the
+// same kernel (cfg.solver_strategy).
 #pragma once
 
 #include <cstdint>

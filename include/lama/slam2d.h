@@ -4,7 +4,7 @@
 // update() follows src/slam2d.cpp:143-198.  Scan matching (MatchSurface2D + Solve, :172-175) and updateMaps()
 // (:247-321) run on the device through the C-ABI of include/lama_hip.h with a one-particle context -- the same
 // kernels as PFSlam2D.  Differences: getOccupancyMap()/getDistanceMap() become downloadOccupancyMap()/
-// downloadDistanceMap(); strategy "lm" is not supported on the device (constructor throws);
+// downloadDistanceMap(); strategy "lm" runs Levenberg-Marquardt on the device (cfg.solver_strategy);
 // there is no CPU fallback.
 #pragma once
 

@@ -83,6 +83,8 @@ typedef struct lama_hip_cfg {
                                     (src/sdm/probabilistic_occupancy_map.cpp:53-107; LidarOdometry2D) -- beam-sequential ray-cast */
     uint32_t ray_rule;           /* where a ray starts: 0 = PFSlam2D/Slam2D (truncated_ray / truncated_range options),
                                     1 = LidarOdometry2D::updateMaps (src/lidar_odometry_2d.cpp:108-114: the last metre before the hit) */
+    uint32_t solver_strategy;    /* nlls strategy of the scan matcher: 0 = GaussNewton (src/nlls/gauss_newton.cpp; PFSlam2D always),
+                                    1 = LevenbergMarquard (src/nlls/levenberg_marquardt.cpp; Slam2D / Loc2D with strategy "lm") */
 } lama_hip_cfg;
 
 void lama_hip_default_cfg(lama_hip_cfg* cfg);

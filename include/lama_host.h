@@ -96,6 +96,7 @@ typedef struct lama_slam_options {
     uint32_t patch_size, max_iter;
     int32_t gpu_device;
     int32_t transient_map;      /* Slam2D::Options::transient_map (src/slam2d.cpp:322-379) */
+    int32_t lm;                 /* Slam2D::Options::strategy == "lm" (Levenberg-Marquardt instead of Gauss-Newton) */
 } lama_slam_options;
 void lama_slam_default_options(lama_slam_options* o);
 lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap);
@@ -133,6 +134,9 @@ uint32_t lama_loc_iterations(const lama_loc* l);
 lama_loc* lama_loc_create2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
                            uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend,
                            int32_t gpu_device, char* err, int errcap);
+lama_loc* lama_loc_create3(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                           uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend,
+                           const char* strategy /* "gn" | "lm" */, int32_t gpu_device, char* err, int errcap);
 /* occupancy_map->setFree / setUnknown / setOccupied on map cells (x, y pairs); state -1 / 0 / 1 */
 int lama_loc_occ_set_cells(lama_loc* l, const uint32_t* cells_xy, uint32_t n, int state);
 int lama_loc_occ_bounds(const lama_loc* l, double* out6);

@@ -76,6 +76,7 @@ struct DevParams {
     uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused
     // occupancy cell policy / ray rule (cfg.occupancy_policy, cfg.ray_rule)
     uint32_t occ_policy, ray_rule;
+    uint32_t strategy;     // 0 = GaussNewton, 1 = LevenbergMarquard (cfg.solver_strategy; Slam2D / Loc2D "lm")
     double lo_miss, lo_hit, lo_min, lo_max;   // ProbabilisticOccupancyMap parameters (float-rounded, as the reference stores them)
 };
 
@@ -192,6 +193,23 @@ __device__ inline void ldlt3_solve(const double A[3][3], const double b[3], doub
     for (int k = 2; k >= 0; --k)
         if (tr[k] != k) { double t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
     x[0] = d[0]; x[1] = d[1]; x[2] = d[2];
+}
+
+// Eigen LLT on selfadjointView<Upper> + solve for a 3x3 (LevenbergMarquard::step, src/nlls/levenberg_marquardt.cpp:76-77;
+// published algorithm: llt_inplace::unblocked and the two triangular solves)
+__device__ inline void llt3_solve(const double A[3][3] /*upper used*/, const double b[3], double x[3])
+{
+    const double l00 = sqrt(A[0][0]);
+    const double l10 = A[0][1] / l00, l20 = A[0][2] / l00;
+    const double l11 = sqrt(A[1][1] - l10 * l10);
+    const double l21 = (A[1][2] - l20 * l10) / l11;
+    const double l22 = sqrt(A[2][2] - (l20 * l20 + l21 * l21));
+    const double y0 = b[0] / l00;
+    const double y1 = (b[1] - l10 * y0) / l11;
+    const double y2 = (b[2] - (l20 * y0 + l21 * y1)) / l22;
+    x[2] = y2 / l22;
+    x[1] = (y1 - l21 * x[2]) / l11;
+    x[0] = (y0 - (l10 * x[1] + l20 * x[2])) / l00;
 }
 
 // ------------------------------------------------------------------------------------------------

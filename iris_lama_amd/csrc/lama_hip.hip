@@ -159,7 +159,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
-    p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule;
+    p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
     // float argument, stored in double members
     auto logods = [](float prob) { return (double)(float)std::log(prob / (1.0 - prob)); };

@@ -100,6 +100,9 @@ struct SMShared {
     SE2 state;
     double h[3];
     int ctl;      // 0 = continue, 1 = stop
+    // LevenbergMarquard state (src/nlls/levenberg_marquardt.cpp:49-54) and the sums of the last accepted linearisation
+    double mu, v, keep[10];
+    int reuse;    // 1 = the last step was rejected: step again from `keep` without re-evaluating (solver.cpp:69)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -110,29 +113,44 @@ struct SMShared {
 __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, const uint16_t* sv, const double* __restrict__ pts, int n,
                                     const Affine& mtf, SMShared& sh, uint32_t& evals)
 {
-    const double eps1 = 1e-4, eps2 = 1e-4;
+    const double eps1 = 1e-4, eps2 = 1e-4, tau = 1e-4;
+    const bool lm = prm.strategy == 1;
     uint32_t iter = 0;
+    if (threadIdx.x == 0) { sh.mu = -1.0; sh.v = 2.0; sh.reuse = 0; }      // strategy->reset()
+    __syncthreads();
     while (iter < prm.max_iter) {
-        // 1. residuals + Jacobian at the current state, weighted, reduced
-        double acc[10];
-        {
-            const Affine tf = sh.tf;
-            eval_beams_jac(prm, dir, sv, pts, n, tf, acc);
+        // 1. residuals + Jacobian at the current state, weighted, reduced (skipped after a rejected LM step)
+        if (!sh.reuse) {
+            double acc[10];
+            {
+                const Affine tf = sh.tf;
+                eval_beams_jac(prm, dir, sv, pts, n, tf, acc);
+            }
+            block_sum<10>(acc, sh.red, sh.tot);
+            ++evals;
+        } else {
+            __syncthreads();
+            if (threadIdx.x < 10) sh.tot[threadIdx.x] = sh.keep[threadIdx.x];
+            __syncthreads();
         }
-        block_sum<10>(acc, sh.red, sh.tot);
-        ++evals;
-        // 2. Gauss-Newton step (one thread; 3x3)
+        // 2. Gauss-Newton / Levenberg-Marquardt step (one thread; 3x3)
         if (threadIdx.x == 0) {
             const double* t = sh.tot;
             const double g[3] = {t[6], t[7], t[8]};
             const double max_abs_g = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
             int stop = 0;
+            if (lm) for (int k = 0; k < 10; ++k) sh.keep[k] = t[k];
             if (max_abs_g < eps1) {
                 stop = 1;                                   // h = 0, not applied
             } else {
                 const double A[3][3] = {{t[0], 0, 0}, {t[1], t[2], 0}, {t[3], t[4], t[5]}};
                 const double mg[3] = {-g[0], -g[1], -g[2]};
                 double h[3];
+                if (lm) {                                   // levenberg_marquardt.cpp:69-77
+                    if (sh.mu < 0) sh.mu = tau * fmax(t[0], fmax(t[2], t[5]));
+                    const double Au[3][3] = {{t[0] + sh.mu, t[1], t[3]}, {0, t[2] + sh.mu, t[4]}, {0, 0, t[5] + sh.mu}};
+                    llt3_solve(Au, mg, h);
+                } else
                 ldlt3_solve(A, mg, h);
                 const double max_abs_h = fmax(fabs(h[0]), fmax(fabs(h[1]), fabs(h[2])));
                 if (max_abs_h < eps2) stop = 1;             // returned but NOT applied (solver.cpp:84-86)
@@ -159,8 +177,24 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
         if (threadIdx.x == 0) {
             const double dF = sh.tot[9] - sh.tot[0];
             int stop = 0;
-            if (!(dF > 0)) {
-                stop = 1;                                   // invalid: revert (solver.cpp:99-102)
+            bool invalid = !(dF > 0);
+            if (lm) {                                       // LevenbergMarquard::valid, levenberg_marquardt.cpp:86-101
+                const double* h = sh.h;
+                const double* gk = sh.keep + 6;
+                const double dL = 0.5 * ((h[0] * (sh.mu * h[0] - gk[0]) + h[1] * (sh.mu * h[1] - gk[1])) + h[2] * (sh.mu * h[2] - gk[2]));
+                if (dL > 0.0 && dF > 0.0) {
+                    const double q = 2 * (dF / dL) - 1;
+                    sh.mu = sh.mu * fmax(1.0 / 3.0, 1 - q * q * q);
+                    sh.v = 2.0;
+                    invalid = false;
+                } else {
+                    sh.mu = sh.mu * sh.v; sh.v = 2 * sh.v;
+                    invalid = true;
+                }
+                sh.reuse = invalid ? 1 : 0;
+            }
+            if (invalid) {
+                stop = lm ? 0 : 1;                          // invalid: revert (solver.cpp:99-102); GaussNewton also stops
                 const double mh[3] = {-sh.h[0], -sh.h[1], -sh.h[2]};
                 bool ok = true;
                 sh.state = se2_exp_mul(mh, sh.state, ok);

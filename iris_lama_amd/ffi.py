@@ -26,7 +26,8 @@ class HipCfg(C.Structure):
                 ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32),
                 ("occ_patch_capacity", C.c_uint32), ("queue_capacity", C.c_uint32), ("profile", C.c_uint32),
                 ("active_capacity", C.c_uint32), ("sequential_raycast", C.c_uint32), ("brushfire_mode", C.c_uint32),
-                ("brushfire_waves", C.c_uint32), ("occupancy_policy", C.c_uint32), ("ray_rule", C.c_uint32)]
+                ("brushfire_waves", C.c_uint32), ("occupancy_policy", C.c_uint32), ("ray_rule", C.c_uint32),
+                ("solver_strategy", C.c_uint32)]
 
 
 class HipCounters(C.Structure):
@@ -341,7 +342,7 @@ HOST_SYMBOLS = [
     "lama_pose_minus", "lama_pose_from_xyr",
     "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
     "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
-    "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin", "lama_slam_deleted_patches",
+    "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin", "lama_slam_deleted_patches", "lama_loc_create3",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
@@ -383,6 +384,7 @@ def _bind_host(L):
         "lama_loc_get_pose": (i32, [vp, vp]), "lama_loc_update": (i32, [vp, vp, u32, vp, vp, vp, d, i32]),
         "lama_loc_covar": (i32, [vp, vp]), "lama_loc_rmse": (d, [vp]), "lama_loc_iterations": (u32, [vp]),
         "lama_loc_create2": (vp, [d, d, d, d, u32, u32, u32, d, d, i32, vp, i32]),
+        "lama_loc_create3": (vp, [d, d, d, d, u32, u32, u32, d, d, C.c_char_p, i32, vp, i32]),
         "lama_loc_occ_set_cells": (i32, [vp, vp, u32, i32]), "lama_loc_occ_bounds": (i32, [vp, vp]),
         "lama_loc_trigger_global_localization": (None, [vp]), "lama_loc_global_localization_active": (i32, [vp]),
         "lama_loc_gloc_candidates": (u32, [vp, vp, vp, u32]), "lama_loc_sampling_likelihoods": (u32, [vp, vp, u32]),
@@ -587,7 +589,8 @@ class PFSlam2D:
 class SlamOptions(C.Structure):
     _fields_ = [("trans_thresh", C.c_double), ("rot_thresh", C.c_double), ("l2_max", C.c_double),
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
-                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("gpu_device", C.c_int32), ("transient_map", C.c_int32)]
+                ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("gpu_device", C.c_int32), ("transient_map", C.c_int32),
+                ("lm", C.c_int32)]
 
 
 class Slam2D:
@@ -662,11 +665,11 @@ class Loc2D:
     """ctypes view of the host-side lama::Loc2D (include/lama/loc2d.h): localisation on a fixed distance map."""
 
     def __init__(self, trans_thresh=0.5, rot_thresh=0.5, l2_max=1.0, resolution=0.05, max_iter=100, gpu_device=0,
-                 gloc_particles=3000, gloc_iters=10, gloc_thresh=0.15, cov_blend=0.0):
+                 gloc_particles=3000, gloc_iters=10, gloc_thresh=0.15, cov_blend=0.0, strategy="gn"):
         self.L = _hostlib()
         err = C.create_string_buffer(512)
-        h = self.L.lama_loc_create2(trans_thresh, rot_thresh, l2_max, resolution, max_iter, gloc_particles, gloc_iters,
-                                    gloc_thresh, cov_blend, gpu_device, err, 512)
+        h = self.L.lama_loc_create3(trans_thresh, rot_thresh, l2_max, resolution, max_iter, gloc_particles, gloc_iters,
+                                    gloc_thresh, cov_blend, strategy.encode(), gpu_device, err, 512)
         if not h:
             raise LamaError(err.value.decode())
         self.h = C.c_void_p(h)

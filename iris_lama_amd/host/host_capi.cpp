@@ -273,6 +273,7 @@ void lama_slam_default_options(lama_slam_options* o)
     o->truncated_range = d.truncated_range; o->resolution = d.resolution; o->patch_size = d.patch_size; o->max_iter = d.max_iter;
     o->gpu_device = 0;
     o->transient_map = d.transient_map ? 1 : 0;
+    o->lm = 0;
 }
 
 lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap)
@@ -284,6 +285,7 @@ lama_slam* lama_slam_create(const lama_slam_options* o, char* err, int errcap)
         p.truncated_range = o->truncated_range; p.resolution = o->resolution; p.patch_size = o->patch_size; p.max_iter = o->max_iter;
         p.gpu_device = o->gpu_device;
         p.transient_map = o->transient_map != 0;
+        if (o->lm) p.strategy = "lm";
         h->s.reset(new Slam2D(p));
         h->origin = h->s->engine()->origin;
         return h;
@@ -369,6 +371,25 @@ lama_loc* lama_loc_create2(double trans_thresh, double rot_thresh, double l2_max
         Loc2D::Options o;
         o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.max_iter = max_iter;
         o.gloc_particles = gloc_particles; o.gloc_iters = gloc_iters; o.gloc_thresh = gloc_thresh; o.cov_blend = cov_blend;
+        o.gpu_device = gpu_device;
+        h->l.Init(o);
+        return h;
+    } catch (const std::exception& e) {
+        if (err && errcap > 0) { std::strncpy(err, e.what(), (size_t)errcap - 1); err[errcap - 1] = 0; }
+        delete h;
+        return nullptr;
+    }
+}
+lama_loc* lama_loc_create3(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t max_iter,
+                           uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend,
+                           const char* strategy, int32_t gpu_device, char* err, int errcap)
+{
+    auto* h = new lama_loc;
+    try {
+        Loc2D::Options o;
+        o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.max_iter = max_iter;
+        o.gloc_particles = gloc_particles; o.gloc_iters = gloc_iters; o.gloc_thresh = gloc_thresh; o.cov_blend = cov_blend;
+        o.strategy = strategy ? strategy : "gn";
         o.gpu_device = gpu_device;
         h->l.Init(o);
         return h;

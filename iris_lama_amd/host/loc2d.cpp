@@ -34,7 +34,6 @@ bool Loc2D::OccupancyMapProxy::isOccupied(const Vector3ui& c) const { auto it = 
 
 void Loc2D::Init(const Options& o)
 {
-    if (o.strategy == "lm") throw std::runtime_error("lama::Loc2D: strategy \"lm\" is not available on the device path");
     opt_ = o;
     delete occupancy_map; delete distance_map;
     occupancy_map = new OccupancyMapProxy;
@@ -102,6 +101,7 @@ void Loc2D::ensureContext()
     cfg.particles = 1;
     cfg.resolution = opt_.resolution; cfg.patch_size = opt_.patch_size; cfg.l2_max = distance_map->l2_max; cfg.max_iter = opt_.max_iter;
     cfg.device = opt_.gpu_device;
+    cfg.solver_strategy = opt_.strategy == "lm" ? 1u : 0u;       // makeStrategy, src/loc2d.cpp:288-294
     cfg.dm_patch_capacity = 4096;            // a static building-scale map; occupancy is not kept on the device
     cfg.occ_patch_capacity = 8;
     cfg.queue_capacity = 1u << 20;

@@ -22,7 +22,6 @@ void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], 
 
 Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.rot_thresh), resolution_(o.resolution), l2_max_(o.l2_max)
 {
-    if (o.strategy == "lm") throw std::runtime_error("lama::Slam2D: strategy \"lm\" is not available on the device path");   // src/slam2d.cpp:226-233
     if (o.use_compression) throw std::runtime_error("lama::Slam2D: use_compression is not supported on the device path");
     transient_map_ = o.transient_map; truncated_range_ = o.truncated_range;
     eng_ = engineOverride() ? engineOverride() : loadHipEngine();
@@ -32,6 +31,7 @@ Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.
     cfg.resolution = o.resolution; cfg.patch_size = o.patch_size; cfg.l2_max = o.l2_max; cfg.max_iter = o.max_iter;
     cfg.truncated_ray = o.truncated_ray; cfg.truncated_range = o.truncated_range; cfg.device = o.gpu_device;
     cfg.meas_sigma = 0.05;                       // unused by Slam2D (no likelihood)
+    cfg.solver_strategy = o.strategy == "lm" ? 1u : 0u;           // makeStrategy, src/slam2d.cpp:226-233
     const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
     if (rc != 0 || !ctx_) {
         char msg[200];

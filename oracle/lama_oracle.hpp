@@ -1177,6 +1177,91 @@ inline SolveStats solve_gn(MatchSurface2D& problem, uint32_t max_iterations, con
     return st;
 }
 
+// Eigen LLT on selfadjointView<Upper> + solve for a 3x3 (published algorithm, Eigen 3.3 Cholesky/LLT.h llt_inplace::unblocked
+// and the triangular solves): L L^T = A, L y = b, L^T x = y.
+inline void llt3_solve(const double A[3][3] /*upper used*/, const double b[3], double x[3])
+{
+    const double l00 = std::sqrt(A[0][0]);
+    const double l10 = A[0][1] / l00, l20 = A[0][2] / l00;
+    const double l11 = std::sqrt(A[1][1] - l10 * l10);
+    const double l21 = (A[1][2] - l20 * l10) / l11;
+    const double l22 = std::sqrt(A[2][2] - (l20 * l20 + l21 * l21));
+    const double y0 = b[0] / l00;
+    const double y1 = (b[1] - l10 * y0) / l11;
+    const double y2 = (b[2] - (l20 * y0 + l21 * y1)) / l22;
+    x[2] = y2 / l22;
+    x[1] = (y1 - l21 * x[2]) / l11;
+    x[0] = (y0 - (l10 * x[1] + l20 * x[2])) / l00;
+}
+
+// Solver::solve (src/nlls/solver.cpp:53-107) with the LevenbergMarquard strategy (src/nlls/levenberg_marquardt.cpp:38-107,
+// eps1 = eps2 = tau = 1e-4) and CauchyWeight -- what Slam2D / Loc2D run with Options::strategy = "lm".
+inline SolveStats solve_lm(MatchSurface2D& problem, uint32_t max_iterations, const CauchyWeight& robust)
+{
+    const double eps1 = 1e-4, eps2 = 1e-4, tau = 1e-4;
+    SolveStats st;
+    std::vector<double> r, ur, J;
+    double h[3] = {0, 0, 0}, g[3] = {0, 0, 0};
+    double mu_ = -1, v_ = 2.0, chi2_ = 0.0;             // reset() :49-54
+    bool stop_ = false, valid = true;
+    uint32_t iter = 0;
+    while (!stop_ && iter < max_iterations) {
+        if (valid) {
+            problem.eval(r, &J); ++st.evals;
+            for (size_t i = 0; i < r.size(); ++i) {
+                double w = std::sqrt(robust.value(r[i]));
+                r[i] *= w;
+                J[3 * i + 0] *= w; J[3 * i + 1] *= w; J[3 * i + 2] *= w;
+            }
+        }
+        {                                               // step() :56-84
+            const size_t rows = r.size();
+            chi2_ = 0.0;
+            for (size_t i = 0; i < rows; ++i) chi2_ += r[i] * r[i];
+            g[0] = g[1] = g[2] = 0;
+            for (size_t i = 0; i < rows; ++i) { g[0] += J[3 * i] * r[i]; g[1] += J[3 * i + 1] * r[i]; g[2] += J[3 * i + 2] * r[i]; }
+            const double max_abs_g = std::max(std::fabs(g[0]), std::max(std::fabs(g[1]), std::fabs(g[2])));
+            if (max_abs_g < eps1) {
+                stop_ = true;
+                h[0] = h[1] = h[2] = 0.0;
+            } else {
+                double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+                for (size_t i = 0; i < rows; ++i)
+                    for (int a = 0; a < 3; ++a)
+                        for (int b = 0; b < 3; ++b) A[a][b] += J[3 * i + a] * J[3 * i + b];
+                if (mu_ < 0) mu_ = tau * std::max(A[0][0], std::max(A[1][1], A[2][2]));
+                A[0][0] += mu_; A[1][1] += mu_; A[2][2] += mu_;
+                const double mg[3] = {-g[0], -g[1], -g[2]};
+                llt3_solve(A, mg, h);
+                const double max_abs_h = std::max(std::fabs(h[0]), std::max(std::fabs(h[1]), std::fabs(h[2])));
+                if (max_abs_h < eps2) stop_ = true;
+            }
+        }
+        if (stop_) break;
+        problem.update(h);
+        problem.eval(ur, nullptr); ++st.evals;
+        double ur2 = 0.0;
+        for (size_t i = 0; i < ur.size(); ++i) { double w = std::sqrt(robust.value(ur[i])); ur[i] *= w; }
+        for (size_t i = 0; i < ur.size(); ++i) ur2 += ur[i] * ur[i];
+        {                                               // valid() :86-101
+            const double dF = chi2_ - ur2;
+            const double dL = 0.5 * ((h[0] * (mu_ * h[0] - g[0]) + h[1] * (mu_ * h[1] - g[1])) + h[2] * (mu_ * h[2] - g[2]));
+            if (dL > 0.0 && dF > 0.0) {
+                mu_ = mu_ * std::max(1.0 / 3.0, 1 - std::pow(2 * (dF / dL) - 1, 3));
+                v_ = 2.0;
+                valid = true;
+            } else {
+                mu_ = mu_ * v_; v_ = 2 * v_;
+                valid = false;
+            }
+        }
+        if (!valid) { const double mh[3] = {-h[0], -h[1], -h[2]}; problem.update(mh); }
+        ++iter;
+    }
+    st.iterations = iter;
+    return st;
+}
+
 // -------------------------------------------------------------------------------------
 // Map update shared by PFSlam2D::updateParticleMaps (src/pf_slam2d.cpp:439-509) and Slam2D::updateMaps
 // (src/slam2d.cpp:247-321, identical statement for statement except the transient-map pruning): ray-cast the scan
@@ -1645,6 +1730,7 @@ struct SlamOptions {                                    // slam2d.h:91-125
     uint32_t patch_size = 32;
     uint32_t max_iter = 100;
     bool transient_map = false;
+    bool lm = false;                                     // Options::strategy == "lm" (src/slam2d.cpp:226-233)
 };
 
 class Slam2D {
@@ -1654,6 +1740,7 @@ public:
         dm_.setMaxDistance(o.l2_max);                                   // src/slam2d.cpp:94-95
     }
     void setPose(const SE2& p) { pose_ = p; }
+    void set_lm(bool on) { opt_.lm = on; }
     SE2 getPose() const { return pose_; }
     uint32_t getNumberOfProcessedCells() const { return processed_; }
     DynamicDistanceMap& dm() { return dm_; }
@@ -1685,7 +1772,7 @@ public:
         odom_ = odometry;
         MatchSurface2D ms(&dm_, &surface, pose_);
         CauchyWeight cauchy(0.15);
-        last_solve = solve_gn(ms, opt_.max_iter, cauchy);
+        last_solve = opt_.lm ? solve_lm(ms, opt_.max_iter, cauchy) : solve_gn(ms, opt_.max_iter, cauchy);
         pose_ = ms.state_;
         updateMaps(surface);
         return true;
@@ -1897,6 +1984,7 @@ struct LocOptions {                                     // src/loc2d.cpp:46-58
     uint32_t patch_size = 32, max_iter = 100;
     uint32_t gloc_particles = 3000, gloc_iters = 10;
     double gloc_thresh = 0.15, cov_blend = 0.0;
+    bool lm = false;                                     // Options::strategy == "lm" (src/loc2d.cpp:288-294)
 };
 
 class Loc2D {
@@ -1917,6 +2005,7 @@ public:
     }
     DynamicDistanceMap& dm() { return dm_; }
     SimpleOccupancyMap& occ() { return occ_; }
+    void set_lm(bool on) { opt_.lm = on; }
     void triggerGlobalLocalization() { do_gloc_ = true; }                              // :194-197
     bool globalLocalizationIsActive() const { return do_gloc_; }
     // instrumentation for the parity tests: the candidates of the last globalLocalization call
@@ -1962,7 +2051,7 @@ public:
         }
         MatchSurface2D ms(&dm_, &surface, pose_);
         CauchyWeight cauchy(0.15);
-        SolveStats st = solve_gn(ms, opt_.max_iter, cauchy);
+        SolveStats st = opt_.lm ? solve_lm(ms, opt_.max_iter, cauchy) : solve_gn(ms, opt_.max_iter, cauchy);
         iters_ = st.iterations;
         // covariance branch of Solver::solve (src/nlls/solver.cpp:109-116)
         std::vector<double> r, J;

