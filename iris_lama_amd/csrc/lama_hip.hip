@@ -33,22 +33,25 @@ struct ParticleSet {
 // blocking pageable copies.
 template <class T>
 struct PinVec {
-    T* p = nullptr; size_t n = 0, cap = 0;
+    T* p = nullptr; size_t n = 0, cap = 0; bool pinned = false;
     PinVec() {}
     PinVec(const PinVec&) = delete;
     PinVec& operator=(const PinVec&) = delete;
-    ~PinVec() { if (p) (void)hipHostFree(p); }
+    ~PinVec() { release(); }
+    void release() { if (p) { if (pinned) (void)hipHostFree(p); else std::free(p); } p = nullptr; }
     void reserve(size_t m)
     {
         if (m <= cap) return;
         T* q = nullptr;
-        if (hipHostMalloc((void**)&q, m * sizeof(T), hipHostMallocDefault) != hipSuccess || !q) throw std::bad_alloc();
-        if (p) { std::memcpy(q, p, n * sizeof(T)); (void)hipHostFree(p); }
-        p = q; cap = m;
+        bool pin = hipHostMalloc((void**)&q, m * sizeof(T), hipHostMallocDefault) == hipSuccess && q;
+        if (!pin) { (void)hipGetLastError(); q = (T*)std::malloc(m * sizeof(T)); }       // pageable memory still works, only slower
+        if (!q) std::abort();                                                           // out of host memory
+        if (p) std::memcpy(q, p, n * sizeof(T));
+        release();
+        p = q; cap = m; pinned = pin;
     }
     void resize(size_t m) { reserve(m); if (m > n) std::memset(p + n, 0, (m - n) * sizeof(T)); n = m; }
     void assign(size_t m, T v) { reserve(m); n = m; for (size_t i = 0; i < m; ++i) p[i] = v; }
-    void swap(PinVec& o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     T* data() { return p; }
     const T* data() const { return p; }
     size_t size() const { return n; }
