@@ -256,7 +256,7 @@ def main():
     if world == 1 and args.sweep:
         extra = {}
         for P in [int(x) for x in args.sweep.split(",") if x]:
-            r = run(P, min(K, 10), 2, profile=True)
+            r = run(P, K, W, profile=True)
             cc = r["counters"]
             extra[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
                              "update_maps_ms": cc["ms_update_maps"] / max(cc["launches_update_maps"], 1),
@@ -268,7 +268,7 @@ def main():
         # offsets of tie cells) -- reported for information, never as `value`
         canon = {}
         for P in [args.particles] + [int(x) for x in args.sweep.split(",") if x]:
-            r = run(P, min(K, 10) if P != args.particles else K, W if P == args.particles else 2, profile=True, brushfire_mode=1)
+            r = run(P, K, W, profile=True, brushfire_mode=1)
             cc = r["counters"]
             canon[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
