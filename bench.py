@@ -157,10 +157,12 @@ def main():
     P_total = args.particles * world
     pts, odom, truth = F.corridor_log(W + K, 1080)
 
-    def run(P, updates, warm, profile=True, brushfire_mode=0, gain=None):
+    def run(P, updates, warm, profile=True, brushfire_mode=0, gain=None, summary=False):
+        # summary=True: PFSlam2D::Summary buckets (each update then waits for its map kernels); False: the map update of scan t
+        # overlaps with the host part (motion sampling) of scan t+1, the default of the host class
         kw = {} if gain is None else {"meas_sigma_gain": gain}
         opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
-                            create_summary=1, profile=1 if profile else 0, brushfire_mode=brushfire_mode, **kw)
+                            create_summary=1 if summary else 0, profile=1 if profile else 0, brushfire_mode=brushfire_mode, **kw)
         pf = ShardedPF(opts)
         assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
         pf.set_prior(*odom[0])
@@ -177,7 +179,7 @@ def main():
         buckets = np.zeros(5)
         for k in range(warm + 1, warm + updates + 1):
             done += 1 if pf.update(pts[k], odom[k], float(k)) else 0
-            if world == 1:                                   # PFSlam2D::Summary sub-buckets of this update (host clocks)
+            if summary:                                      # PFSlam2D::Summary sub-buckets of this update (host clocks)
                 t = pf.pf.last_times()
                 buckets += (t["total"], t["solving"], t["normalizing"], t["resampling"], t["mapping"])
         torch.cuda.synchronize()
@@ -218,7 +220,7 @@ def main():
                                "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0},
     }
     if world == 1:
-        result["summary_buckets_ms_per_update"] = main_run["buckets_ms"]
+        result["summary_buckets_ms_per_update"] = run(P_total, K, W, summary=True)["buckets_ms"]
     if resample_run is not None:
         result["forced_resample_variant"] = {"meas_sigma_gain": 0.01, "value": resample_run["value"], "ms_per_step": resample_run["ms_per_step"],
                                              "resamples": resample_run["resamples"], "shipped_particles": resample_run["shipped_particles"],

@@ -136,6 +136,15 @@ int32_t lama_hip_pf_map_patches(lama_hip_ctx* ctx, uint32_t particle, int32_t ki
 int32_t lama_hip_pf_download_map(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap,
                                  uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches);
 
+/* The same map update split in two, so that the host work of the NEXT scan (odometry prediction, motion sampling) overlaps
+ * with the kernels: _begin queues the work on the context's stream and returns; its status (window / capacity errors) and
+ * counters are collected by lama_hip_sync, or implicitly at the start of the next call on the context, whichever comes
+ * first -- a deferred error is then returned by THAT call (message prefixed "deferred from ...").
+ * lama_hip_pf_update_maps == _begin followed by lama_hip_sync. */
+int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
+                                      const double* sensor_origin3, const double* sensor_quat_wxyz);
+int32_t lama_hip_sync(lama_hip_ctx* ctx);
+
 /* Patch bookkeeping for transient maps (LidarOdometry2D::updateMaps, src/lidar_odometry_2d.cpp:128-199):
  *   lama_hip_pf_patch_ids     : Map::visit_all_patches -- the reference patch indices (Map::m2p) of the allocated patches;
  *   lama_hip_pf_delete_patches: Map::deletePatchAt (src/sdm/map.cpp:465-488) on BOTH maps of the particle for every listed patch

@@ -94,6 +94,7 @@ struct lama_hip_ctx {
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
+    bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
     PinVec<double> h_poses;           // host mirror of the particle poses (source of truth between calls)
     PinVec<int32_t> h_counts;         // host mirror of counts of the current set (refreshed after map updates)
     lama_hip_counters ctr;
@@ -232,6 +233,19 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
     }
     return LAMA_HIP_OK;
 }
+
+// Collects the status of a map update queued by lama_hip_pf_update_maps_begin (one synchronisation); called at the start of
+// every other entry point, so a deferred error surfaces in the next call on the context.
+int32_t finish_pending(lama_hip_ctx* c)
+{
+    if (!c->pending_maps) return LAMA_HIP_OK;
+    c->pending_maps = false;
+    (void)hipSetDevice(c->cfg.device);
+    const int32_t rc = check_device_errors(c, true, false);
+    if (rc) c->error = "deferred from lama_hip_pf_update_maps_begin: " + c->error;
+    return rc;
+}
+#define ENTER(c) do { const int32_t rc_enter_ = finish_pending(c); if (rc_enter_) return rc_enter_; } while (0)
 
 // hipEvent bracket around a kernel group; resolved (elapsed time read) by resolve_timers() after the API call's final
 // stream synchronisation, so profiling adds no host round trips.
@@ -442,6 +456,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
 int32_t lama_hip_pf_set_poses(lama_hip_ctx* c, const double* poses)
 {
     if (!c || !poses) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     std::memcpy(c->h_poses.data(), poses, sizeof(double) * 4 * c->P);
     // asynchronous: the source is the context's own host mirror, which stays valid; later calls are stream ordered
@@ -452,6 +467,7 @@ int32_t lama_hip_pf_set_poses(lama_hip_ctx* c, const double* poses)
 int32_t lama_hip_pf_get_poses(lama_hip_ctx* c, double* poses)
 {
     if (!c || !poses) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     std::memcpy(poses, c->h_poses.data(), sizeof(double) * 4 * c->P);
     return LAMA_HIP_OK;
 }
@@ -460,6 +476,7 @@ int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const d
                          const double* pose0)
 {
     if (!c || !pts || !pose0 || n == 0) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_init called twice");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     // centre the map window on the first pose (patch aligned)
@@ -494,6 +511,7 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
                                double* poses_out, double* loglik_out, int32_t* iters_out)
 {
     if (!c || !pts || n == 0) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_scan_match before lama_hip_pf_init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -521,6 +539,7 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
 int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
 {
     if (!c || !sample_idx) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_resample before lama_hip_pf_init");
     for (uint32_t i = 0; i < c->P; ++i)
         if (sample_idx[i] < 0 || (uint32_t)sample_idx[i] >= c->P) return fail(c, LAMA_HIP_E_INVALID, "sample_idx out of range");
@@ -549,9 +568,10 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
     return LAMA_HIP_OK;
 }
 
-int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
+int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
 {
     if (!c || n == 0) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_pf_update_maps before lama_hip_pf_init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -559,12 +579,28 @@ int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, 
     const Affine mtf = moving_tf(origin3, quat);
     rc = run_update_maps(c, n, mtf, 0, c->P);
     if (rc) return rc;
-    return check_device_errors(c, true, false);
+    c->pending_maps = true;
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_sync(lama_hip_ctx* c)
+{
+    if (!c) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return finish_pending(c);
+}
+
+int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
+{
+    const int32_t rc = lama_hip_pf_update_maps_begin(c, pts, n, origin3, quat);
+    if (rc) return rc;
+    return lama_hip_sync(c);
 }
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
 {
     if (!c || !num || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     *num = (uint32_t)c->h_counts[2 * particle + (kind == LAMA_HIP_MAP_OCCUPANCY ? 1 : 0)];
     return LAMA_HIP_OK;
 }
@@ -572,6 +608,7 @@ int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind
 int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* patch_ids, uint32_t* num_patches)
 {
     if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const ParticleSet& s = c->set[c->cur];
     const size_t WW = (size_t)c->W * c->W;
@@ -594,6 +631,7 @@ int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, 
 int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uint64_t* patch_ids, uint32_t n, uint32_t* deleted)
 {
     if (!c || particle >= c->P || (!patch_ids && n)) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (deleted) *deleted = 0;
     if (n == 0) return LAMA_HIP_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -651,6 +689,7 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
                                  uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches)
 {
     if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const ParticleSet& s = c->set[c->cur];
     const size_t WW = (size_t)c->W * c->W;
@@ -717,6 +756,7 @@ int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* p
                              const double* quat, const double* poses, uint32_t B, double* out)
 {
     if (!c || !pts || !poses || !out || n == 0 || B == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_match_batch before lama_hip_pf_init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -742,6 +782,7 @@ int32_t lama_hip_eval_batch(lama_hip_ctx* c, uint32_t particle, const double* pt
                             const double* quat, const double* poses, uint32_t B, double* sqnorm_out, double* loglik_out)
 {
     if (!c || !poses || (!sqnorm_out && !loglik_out) || n == 0 || B == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_eval_batch before the map exists");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -774,6 +815,7 @@ int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* c, uint32_t particle, const
                                        const double* quat, double yaw, const double* xy, uint32_t K, uint32_t point_step, double* l_out)
 {
     if (!c || !xy || !l_out || n == 0 || K == 0 || point_step == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_map_sample_likelihood before the map exists");
     if ((n + point_step - 1) / point_step > (uint32_t)SL_MAX_TERMS) return fail(c, LAMA_HIP_E_INVALID, "more than 128 sampled points per pose");
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -907,6 +949,7 @@ int32_t lama_hip_pgo_linearize(lama_hip_pgo* g, const double* poses4, double* er
 int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uint32_t* cells_xy, uint32_t n)
 {
     if (!c || !cells_xy || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (!c->initialised) {
         c->wx0 = ((cells_xy[0] >> 5) - c->W / 2) * 32;
@@ -937,6 +980,7 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
                              double* pose_inout, double* out7, int32_t* iters_out, int32_t do_solve)
 {
     if (!c || !pts || !pose_inout || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_match_solve before a map exists");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int32_t rc = upload_scan(c, pts, n);
@@ -975,6 +1019,7 @@ static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
 int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* buf, uint64_t cap, uint64_t* bytes)
 {
     if (!c || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "export before init");
     const int dmc = c->h_counts[2 * particle], occ = c->h_counts[2 * particle + 1];
     const uint64_t need = blob_bytes(c, dmc, occ);
@@ -1008,6 +1053,7 @@ int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* bu
 int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const void* buf, uint64_t bytes)
 {
     if (!c || !buf || particle >= c->P || bytes < 48) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "import before init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint8_t* in = (const uint8_t*)buf;
@@ -1058,6 +1104,7 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
 int32_t lama_hip_debug_cycles(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
 {
     if (!c || !out) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     HIPCHK(c, hipMemcpy(out, c->d_dbg, sizeof(uint64_t) * 8 * c->P, hipMemcpyDeviceToHost));
     return LAMA_HIP_OK;
 }
@@ -1065,6 +1112,7 @@ int32_t lama_hip_debug_cycles(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
 int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
 {
     if (!c || !out) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     *out = c->ctr;
     return LAMA_HIP_OK;
 }
@@ -1072,6 +1120,7 @@ int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
 int32_t lama_hip_reset_counters(lama_hip_ctx* c)
 {
     if (!c) return LAMA_HIP_E_INVALID;
+    ENTER(c);
     const uint64_t dm = c->ctr.dm_patches, oc = c->ctr.occ_patches;
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;

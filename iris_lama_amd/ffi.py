@@ -52,7 +52,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
-    "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches",
+    "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
 ]
 
 _hip = None
@@ -92,6 +92,8 @@ def _bind_hip(L):
         L.lama_hip_pf_scan_match.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp]
         L.lama_hip_pf_resample.argtypes = [vp, vp]
         L.lama_hip_pf_update_maps.argtypes = [vp, vp, u32, vp, vp]
+        L.lama_hip_pf_update_maps_begin.argtypes = [vp, vp, u32, vp, vp]
+        L.lama_hip_sync.argtypes = [vp]
         L.lama_hip_pf_map_patches.argtypes = [vp, u32, i32, vp]
         L.lama_hip_pf_download_map.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
         L.lama_hip_match_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp]
@@ -227,6 +229,14 @@ class HipContext:
         out = np.zeros(len(poses))
         self._chk(self.L.lama_hip_match_batch(self.h, particle, _p(pts), len(pts), _p(origin), _p(quat), _p(poses), len(poses), _p(out)))
         return out
+
+    def update_maps_begin(self, pts, origin=None, quat=None):
+        """Queues the map update and returns; status and counters are collected by sync() or the next call."""
+        pts, origin, quat = self._scan(pts, origin, quat)
+        self._chk(self.L.lama_hip_pf_update_maps_begin(self.h, _p(pts), len(pts), _p(origin), _p(quat)))
+
+    def sync(self):
+        self._chk(self.L.lama_hip_sync(self.h))
 
     def patch_ids(self, particle, kind):
         n = C.c_uint32(0)

@@ -50,6 +50,8 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(pf_scan_match, lama_hip_pf_scan_match)
     BIND(pf_resample, lama_hip_pf_resample)
     BIND(pf_update_maps, lama_hip_pf_update_maps)
+    BIND(pf_update_maps_begin, lama_hip_pf_update_maps_begin)
+    BIND(sync, lama_hip_sync)
     BIND(pf_map_patches, lama_hip_pf_map_patches)
     BIND(pf_download_map, lama_hip_pf_download_map)
     BIND(match_batch, lama_hip_match_batch)

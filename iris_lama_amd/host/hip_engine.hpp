@@ -24,6 +24,8 @@ struct HipEngine {
     decltype(&lama_hip_pf_scan_match) pf_scan_match = nullptr;
     decltype(&lama_hip_pf_resample) pf_resample = nullptr;
     decltype(&lama_hip_pf_update_maps) pf_update_maps = nullptr;
+    decltype(&lama_hip_pf_update_maps_begin) pf_update_maps_begin = nullptr;
+    decltype(&lama_hip_sync) sync = nullptr;
     decltype(&lama_hip_pf_map_patches) pf_map_patches = nullptr;
     decltype(&lama_hip_pf_download_map) pf_download_map = nullptr;
     decltype(&lama_hip_match_batch) match_batch = nullptr;

@@ -263,9 +263,14 @@ void PFSlam2D::updateMaps()
     const double t0 = now_s();
     const uint32_t n = (uint32_t)(pts_.size() / 3);
     // the scan is already resident on the device (uploaded by scan_match of this update)
-    const int32_t rc = eng_->pf_update_maps(ctx_, scan_resident_ ? nullptr : pts_.data(), n, origin_, quat_);      // :289-302
+    // queued, not awaited: the host part of the next scan overlaps with the kernels; the status is collected by the next call
+    // on the context (a deferred device error makes THAT call fail)
+    const int32_t rc = eng_->pf_update_maps_begin(ctx_, scan_resident_ ? nullptr : pts_.data(), n, origin_, quat_);      // :289-302
     if (rc) fail(rc, "lama_hip_pf_update_maps");
     if (summary) {
+        // the Summary's per-update buckets need the real duration: wait for the kernels here
+        const int32_t rs = eng_->sync(ctx_);
+        if (rs) fail(rs, "lama_hip_sync");
         summary->time_mapping.push_back(now_s() - t0);
         summary->time.push_back(now_s() - t_begin_);
         summary->timestamp.push_back(timestamps_.empty() ? 0.0 : timestamps_.back());

@@ -163,7 +163,9 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* idx)
     return LAMA_HIP_OK;
 }
 
-int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
+// (internal linkage: the exported names also exist in the real liblama_hip.so, which may be loaded in the same process;
+// a call through the PLT could bind to that one)
+static int32_t update_maps_impl(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
 {
     Scan s = pts ? make_scan(pts, n, origin, quat) : c->last_scan;
     if (c->cfg.occupancy_policy == 1) {
@@ -179,6 +181,16 @@ int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, 
     }
     return LAMA_HIP_OK;
 }
+
+int32_t lama_hip_pf_update_maps(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
+{
+    return update_maps_impl(c, pts, n, origin, quat);
+}
+int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin, const double* quat)
+{
+    return update_maps_impl(c, pts, n, origin, quat);
+}
+int32_t lama_hip_sync(lama_hip_ctx*) { return LAMA_HIP_OK; }
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
 {

@@ -570,7 +570,20 @@ def test_limits_fail_loudly_with_status_codes(F):
     ctx.init(pts[0], pose0)
     with pytest.raises(F.LamaError):
         ctx.download_map(5, F.MAP_DISTANCE)          # particle out of range
+    # a map update that was only queued reports its error at the next synchronising call
+    far = np.tile(O.se2(500.0, 2.0, 0.0), (2, 1))    # 500 m away: outside the 204.8 m window
+    ctx.set_poses(far)
+    ctx.update_maps_begin(pts[0])                    # returns before the kernels have run
+    with pytest.raises(F.LamaError, match=r"deferred from lama_hip_pf_update_maps_begin.*window"):
+        ctx.sync()
     ctx.close()
+    # ... and begin + sync is the same as the synchronous call
+    a, b = F.HipContext(F.default_cfg(particles=2)), F.HipContext(F.default_cfg(particles=2))
+    a.init(pts[0], pose0); b.init(pts[0], pose0)
+    a.update_maps(pts[1])
+    b.update_maps_begin(pts[1])
+    assert_maps_equal(b.download_map(1, F.MAP_DISTANCE), a.download_map(1, F.MAP_DISTANCE), DM_FIELDS, "begin/sync")   # download collects the status
+    a.close(); b.close()
 
 
 def test_slam2d_transient_map_gpu_vs_oracle(F):
