@@ -53,19 +53,24 @@ __device__ inline void block_sum(double (&acc)[NV], double* sh /*[SM_BLOCK/64][N
 // MatchSurface2D::eval (src/match_surface_2d.cpp:42-90) fused with the robust weighting of
 // Solver::solve (src/nlls/solver.cpp:74-79, 92-96) and the J^T J / J^T r / chi2 products of
 // GaussNewton::step (src/nlls/gauss_newton.cpp:55-56, 64).
-//   acc[0..5] = lower triangle of A (00,10,11,20,21,22), acc[6..8] = g, acc[9] = chi2
+//   acc[0..5] = lower triangle of A (00,10,11,20,21,22), acc[6..8] = g, acc[9] = chi2,
+//   acc[10]   = sum -(d*d)/meas_sigma of the UNWEIGHTED distances (calculateLikelihood, pf_slam2d.cpp:393-414)
+// The same pass therefore serves as the validation of a step (chi2), as the linearisation of the next iteration (the
+// reference evaluates the problem twice at that state, solver.cpp:90 and :71) and as the likelihood at the solution.
 // ------------------------------------------------------------------------------------------------
+constexpr int NJ = 11;
 __device__ inline void eval_beams_jac(const DevParams& prm, const int16_t* dir, const uint16_t* sv,
-                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[10])
+                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[NJ])
 {
 #pragma unroll
-    for (int k = 0; k < 10; ++k) acc[k] = 0.0;
+    for (int k = 0; k < NJ; ++k) acc[k] = 0.0;
     for (int i = threadIdx.x; i < n; i += SM_BLOCK) {
         const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
         const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
         const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
         double gx, gy;
         double r = dm_distance(prm, dir, sv, hx, hy, &gx, &gy);
+        acc[10] += -(r * r) / prm.meas_sigma;
         const double w = sqrt(cauchy015(r));
         r *= w;
         const double j0 = gx * w, j1 = gy * w, j2 = (gy * hx - gx * hy) * w;
@@ -94,14 +99,17 @@ __device__ inline void eval_beams_res(const DevParams& prm, const int16_t* dir, 
 }
 
 struct SMShared {
-    double red[(SM_BLOCK / 64) * 10];
-    double tot[10];
+    double red[(SM_BLOCK / 64) * NJ];
+    double tot[NJ];        // sums of the linearisation at the current state
+    double tot2[NJ];       // sums at the trial state of the step being validated
+    int have_lin;          // tot already holds the linearisation at the current state (taken over from the validation)
+    int lin_is_final;      // on return: sh.tot was evaluated at exactly the returned state
     Affine tf;
     SE2 state;
     double h[3];
     int ctl;      // 0 = continue, 1 = stop
     // LevenbergMarquard state (src/nlls/levenberg_marquardt.cpp:49-54) and the sums of the last accepted linearisation
-    double mu, v, keep[10];
+    double mu, v, keep[NJ];
     int reuse;    // 1 = the last step was rejected: step again from `keep` without re-evaluating (solver.cpp:69)
 };
 
@@ -116,21 +124,24 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
     const double eps1 = 1e-4, eps2 = 1e-4, tau = 1e-4;
     const bool lm = prm.strategy == 1;
     uint32_t iter = 0;
-    if (threadIdx.x == 0) { sh.mu = -1.0; sh.v = 2.0; sh.reuse = 0; }      // strategy->reset()
+    if (threadIdx.x == 0) { sh.mu = -1.0; sh.v = 2.0; sh.reuse = 0; sh.have_lin = 0; sh.lin_is_final = 0; }      // strategy->reset()
     __syncthreads();
     while (iter < prm.max_iter) {
-        // 1. residuals + Jacobian at the current state, weighted, reduced (skipped after a rejected LM step)
-        if (!sh.reuse) {
-            double acc[10];
+        // 1. residuals + Jacobian at the current state, weighted, reduced: taken over from the validation pass of the
+        //    previous (accepted) step, or restored after a rejected LM step, or evaluated
+        if (sh.have_lin) {
+            ++evals;
+        } else if (!sh.reuse) {
+            double acc[NJ];
             {
                 const Affine tf = sh.tf;
                 eval_beams_jac(prm, dir, sv, pts, n, tf, acc);
             }
-            block_sum<10>(acc, sh.red, sh.tot);
+            block_sum<NJ>(acc, sh.red, sh.tot);
             ++evals;
         } else {
             __syncthreads();
-            if (threadIdx.x < 10) sh.tot[threadIdx.x] = sh.keep[threadIdx.x];
+            if (threadIdx.x < NJ) sh.tot[threadIdx.x] = sh.keep[threadIdx.x];
             __syncthreads();
         }
         // 2. Gauss-Newton / Levenberg-Marquardt step (one thread; 3x3)
@@ -139,7 +150,8 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
             const double g[3] = {t[6], t[7], t[8]};
             const double max_abs_g = fmax(fabs(g[0]), fmax(fabs(g[1]), fabs(g[2])));
             int stop = 0;
-            if (lm) for (int k = 0; k < 10; ++k) sh.keep[k] = t[k];
+            sh.lin_is_final = 1;                            // unless a step is applied below
+            if (lm) for (int k = 0; k < NJ; ++k) sh.keep[k] = t[k];
             if (max_abs_g < eps1) {
                 stop = 1;                                   // h = 0, not applied
             } else {
@@ -160,22 +172,23 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
                     sh.state = se2_exp_mul(h, sh.state, ok);    // problem.update(h)
                     if (!ok) atomicOr(prm.err, ERR_NUMERIC);
                     sh.tf = scan_tf(sh.state, mtf);
+                    sh.lin_is_final = 0;
                 }
             }
             sh.ctl = stop;
         }
         __syncthreads();
         if (sh.ctl) break;
-        // 3. validation: residuals at the updated state
-        double a2[2];
+        // 3. validation: the problem at the updated state (chi2 decides; the other sums are next iteration's linearisation)
+        double acc2[NJ];
         {
             const Affine tf = sh.tf;
-            eval_beams_res(prm, dir, sv, pts, n, tf, a2);
+            eval_beams_jac(prm, dir, sv, pts, n, tf, acc2);
         }
-        block_sum<2>(a2, sh.red, sh.tot);        // writes tot[0..1]; chi2 of step 1 stays in tot[9]
+        block_sum<NJ>(acc2, sh.red, sh.tot2);
         ++evals;
         if (threadIdx.x == 0) {
-            const double dF = sh.tot[9] - sh.tot[0];
+            const double dF = sh.tot[9] - sh.tot2[9];
             int stop = 0;
             bool invalid = !(dF > 0);
             if (lm) {                                       // LevenbergMarquard::valid, levenberg_marquardt.cpp:86-101
@@ -197,9 +210,14 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
                 stop = lm ? 0 : 1;                          // invalid: revert (solver.cpp:99-102); GaussNewton also stops
                 const double mh[3] = {-sh.h[0], -sh.h[1], -sh.h[2]};
                 bool ok = true;
-                sh.state = se2_exp_mul(mh, sh.state, ok);
+                sh.state = se2_exp_mul(mh, sh.state, ok);   // NOT bitwise the state of sh.tot: lin_is_final stays 0
                 if (!ok) atomicOr(prm.err, ERR_NUMERIC);
                 sh.tf = scan_tf(sh.state, mtf);
+                sh.have_lin = 0;
+            } else {
+                for (int k = 0; k < NJ; ++k) sh.tot[k] = sh.tot2[k];
+                sh.have_lin = 1;
+                sh.lin_is_final = 1;                        // if the loop ends here (max_iter), tot is at the returned state
             }
             sh.ctl = stop;
         }
@@ -229,18 +247,25 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
     __syncthreads();
     uint32_t evals = 0;
     const uint32_t iter = gn_solve(prm, dir, sv, pts, n, mtf, sh, evals);
-    // likelihood at the final state (pf_slam2d.cpp:433-436)
-    double a2[2];
-    {
-        const Affine tf = sh.tf;
-        eval_beams_res(prm, dir, sv, pts, n, tf, a2);
+    // likelihood at the final state (pf_slam2d.cpp:433-436): already summed by the last linearisation when that was taken
+    // at exactly the returned state; after a reverted step the state differs in the last bits, so it is evaluated
+    double loglik;
+    if (sh.lin_is_final) {
+        loglik = sh.tot[10];
+    } else {
+        double a2[2];
+        {
+            const Affine tf = sh.tf;
+            eval_beams_res(prm, dir, sv, pts, n, tf, a2);
+        }
+        block_sum<2>(a2, sh.red, sh.tot2);
+        loglik = sh.tot2[1];
     }
-    block_sum<2>(a2, sh.red, sh.tot);
     ++evals;
     if (threadIdx.x == 0) {
         double* q = prm.poses + 4 * p;
         q[0] = sh.state.c; q[1] = sh.state.s; q[2] = sh.state.tx; q[3] = sh.state.ty;
-        loglik_out[p] = sh.tot[1];
+        loglik_out[p] = loglik;
         iters_out[p] = (int32_t)iter;
         prm.stats[4 * p + 0] = iter;
         prm.stats[4 * p + 1] = evals;
