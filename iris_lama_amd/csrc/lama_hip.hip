@@ -298,8 +298,9 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
-            hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + RAY_BEAMS_PER_BLOCK - 1) / RAY_BEAMS_PER_BLOCK), dim3(256), 0, c->stream, prm,
-                               c->d_pts, (int)n, c->d_tfs, (int)first);
+            const int bpw = count <= 64 ? 4 : 16;                            // see k_ray_visits
+            hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + 4 * bpw - 1) / (4 * bpw)), dim3(256), 0, c->stream, prm,
+                               c->d_pts, (int)n, c->d_tfs, (int)first, bpw);
             hipLaunchKernelGGL((k_ray_replay<2048, 2048, false>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_ray_replay<8192, 8192, true>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
         }

@@ -28,7 +28,7 @@
 
 namespace lama_dev {
 
-constexpr int RAY_BEAMS_PER_BLOCK = 64;      // k_ray_visits: 4 waves x 16 beams
+
 constexpr int RV_TABLE = 2048;               // LDS aggregation table of k_ray_visits (entries); 16 KB -> ~10 workgroups per CU
 constexpr int RP_BLOCK = 256;
 
@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
 // "visited++" of an already-free cell -- the overwhelming majority of the visits -- is therefore first counted per
 // workgroup (64 adjacent beams) in an LDS hash table keyed by the cell's arena index and flushed as ONE atomicAdd per
 // distinct cell.  The counters commute, so the result is unchanged.
+// `bpw` = beams per wave (<= 16; a workgroup takes 4 * bpw adjacent beams): many beams per workgroup aggregate better (fewer
+// flush atomics: what counts when the chip is full), few beams per wave give short dependent chains (what counts when it is not).
 __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double* __restrict__ pts, int n,
-                                                     const double* __restrict__ tfs, int first_particle)
+                                                     const double* __restrict__ tfs, int first_particle, int bpw)
 {
     __shared__ uint32_t tkey[RV_TABLE];      // window-relative cell (ry << 13 | rx), 0xFFFFFFFF = empty
     __shared__ uint32_t tval[RV_TABLE];      // visits counted so far
@@ -174,16 +176,16 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
-    const int b0 = blockIdx.y * RAY_BEAMS_PER_BLOCK + wave * (RAY_BEAMS_PER_BLOCK / 4);
+    const int b0 = (blockIdx.y * 4 + wave) * bpw;
     // the geometry of this wave's 16 beams (fp64 transform, one 64-bit division each) is computed by 16 lanes at once and
     // broadcast beam by beam
     BeamGeom mine;
     {
-        const int ib = b0 + (lane < RAY_BEAMS_PER_BLOCK / 4 ? lane : 0);
+        const int ib = b0 + (lane < bpw ? lane : 0);
         const int ic = ib < n ? ib : (n - 1);
         mine = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
     }
-    for (int bi = 0; bi < RAY_BEAMS_PER_BLOCK / 4; ++bi) {
+    for (int bi = 0; bi < bpw; ++bi) {
         const int i = b0 + bi;
         if (i >= n) break;
         BeamGeom g;
