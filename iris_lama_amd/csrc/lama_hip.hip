@@ -301,8 +301,13 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             const int bpw = count <= 64 ? 4 : 16;                            // see k_ray_visits
             hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + 4 * bpw - 1) / (4 * bpw)), dim3(256), 0, c->stream, prm,
                                c->d_pts, (int)n, c->d_tfs, (int)first, bpw);
-            hipLaunchKernelGGL((k_ray_replay<2048, 2048, false>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
-            hipLaunchKernelGGL((k_ray_replay<8192, 8192, true>), dim3(count), dim3(RP_BLOCK), 0, c->stream, prm, (int)first);
+            if (count <= 512) {
+                hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
+            } else {
+                hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_SMALL>), dim3(count), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_SMALL>), dim3(count), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
+            }
         }
         t.stop();
     }

@@ -30,7 +30,7 @@ namespace lama_dev {
 
 
 constexpr int RV_TABLE = 2048;               // LDS aggregation table of k_ray_visits (entries); 16 KB -> ~10 workgroups per CU
-constexpr int RP_BLOCK = 256;
+constexpr int RP_BLOCK_SMALL = 256, RP_BLOCK_LARGE = 1024;   // k_ray_replay workgroup: 1024 threads while the chip is not full
 
 // ---- directory entry (int16 inside an aligned 32-bit word) with lock-free allocation ----------------------
 // -1 = absent, -2 = being allocated, -3 = allocation failed (arena full), >= 0 = slot (never changes afterwards)
@@ -262,7 +262,8 @@ __global__ __launch_bounds__(256) void k_ray_visits(DevParams prm, const double*
     }
 }
 
-// ---- in-LDS bitonic sort (ascending) of m = 2^k keys by RP_BLOCK threads ---------------------------------
+// ---- in-LDS bitonic sort (ascending) of m = 2^k keys by the RP_BLOCK threads of the workgroup ---------------------------------
+template <int RP_BLOCK>
 __device__ inline void bitonic_sort(uint64_t* a, uint32_t m)
 {
     for (uint32_t k = 2; k <= m; k <<= 1) {
@@ -289,7 +290,7 @@ struct ReplayLds {
 };
 
 // event: (seq << 32) | (is_add << 31) | cellkey
-template <int SORT_CAP, int EV_CAP, bool RESUME>
+template <int SORT_CAP, int EV_CAP, bool RESUME, int RP_BLOCK>
 __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int first_particle)
 {
     __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
     for (uint32_t i = threadIdx.x; i < m; i += RP_BLOCK) sh.keys[i] = i < n ? src[i] : ~0ull;
     if (threadIdx.x == 0) { sh.ev_n = 0; sh.nadd = 0; sh.nrem = 0; }
     __syncthreads();
-    if (m > 1) bitonic_sort(sh.keys, m);
+    if (m > 1) bitonic_sort<RP_BLOCK>(sh.keys, m);
 
     // ---- per-cell replay in the reference's visit order (one thread per active cell) ----
     for (uint32_t i = threadIdx.x; i < n; i += RP_BLOCK) {
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
     while (me < ne) me <<= 1;
     for (uint32_t i = ne + threadIdx.x; i < me; i += RP_BLOCK) sh.ev[i] = ~0ull;
     __syncthreads();
-    if (me > 1) bitonic_sort(sh.ev, me);
+    if (me > 1) bitonic_sort<RP_BLOCK>(sh.ev, me);
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         uint32_t nadd = 0, nrem = 0;
