@@ -922,8 +922,8 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);                              \
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);                               \
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;                                                  \
-        uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;                                                   \
-        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; }
+        uint16_t s = 0; uint32_t ob = 0;                                                                    \
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; ob = obs[slot * 1024 + (int)ci]; }
     // round B: the cell my offset points to (obstacle cell); offset 0 -> myself
     #define BF_LOAD_B()                                                                                     \
         const int ox = x + obs_x(ob), oy = y + obs_y(ob);                                                   \
@@ -1003,7 +1003,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         const bool nbok = nb && slot >= 0;
         if (nbok) {
             const uint64_t bit = 1ull << (ci & 63);
-            if (fresh || !(mw & bit)) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
+            // the Container mask bit of a cell with a flag set is on already (every writer get()s the cell first): only
+            // flag-less cells need the OR (idempotent for those that were touched before) -- no mask word is loaded
+            if (fresh || !(s & (SV_VALID | SV_QUEUED))) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
         }
         // :253  skip queued or invalid neighbours
         const bool cand = nbok && !(s & SV_QUEUED) && (s & SV_VALID);
@@ -1063,8 +1065,8 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;
-        uint16_t s = 0; uint32_t ob = 0; uint64_t mw = 0;
-        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) { ob = obs[slot * 1024 + (int)ci]; mw = mask[(size_t)slot * 16 + (ci >> 6)]; } }
+        uint16_t s = 0; uint32_t ob = 0;
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) ob = obs[slot * 1024 + (int)ci]; }
         BFT(1);
         uint32_t tw_cnt = 0, tw_om = 0;
         uint64_t tw_entry = 0;
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const bool nbok = nb && slot >= 0;
             if (nbok) {
                 const uint64_t bit = 1ull << (ci & 63);
-                if (fresh || !(mw & bit)) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
+                if (fresh || !(s & (SV_VALID | SV_QUEUED))) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);   // see raise()
             }
             const int qx = x - obx, qy = y - oby;
             const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
