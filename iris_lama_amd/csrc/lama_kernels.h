@@ -668,6 +668,11 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 #else
 #define BFT(k) do {} while (0)
 #endif
+#ifdef LAMA_PROFILE_BF_MAIN
+#define BFT_MAIN(k) BFT(k)
+#else
+#define BFT_MAIN(k) do {} while (0)
+#endif
 
 template <int LQ, int RQ>
 struct BfLds {
@@ -738,6 +743,65 @@ __device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lan
     const uint32_t dd = 31 - __clz(rel + 1);
     st.hole = (H << dd) + (uint32_t)rel;
     st.child = st.hole;
+}
+// pop() as the helper wave of the two-wave brushfire runs it: the same final heap array as __adjust_heap +
+// __push_heap, computed top-down.  __adjust_heap moves every entry n_1 .. n_k of the hole's path (the preferred
+// children down to a leaf) up one slot, then __push_heap walks the re-inserted last entry v back up, moving entries
+// with prio(n_i) > prio(v) down again -- into the very slots they came from.  Priorities are non-decreasing along
+// the path, so the net effect is: the entries with prio(n_i) <= prio(v), a prefix of the path, move up one slot, v
+// takes the slot of the last of them, everything below stays.  The descent can therefore stop at the first entry
+// that stays; nothing is read back, and the entry that ends up at the root is known from registers (returned;
+// meaningful when size > 0 afterwards).
+__device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size, int lane, uint64_t anc)
+{
+    --size;
+    const uint32_t len = size;
+    if (len == 0) return 0;
+    const uint64_t value = h[len];
+    const uint32_t vprio = heap_prio(value);
+    const uint32_t lim = (len - 1) / 2;                              // nodes below `lim` have both children
+    const int d = 31 - __clz(lane + 1);
+    const bool is_left = (lane & 1) != 0;
+    uint32_t H = 0;
+    uint32_t root_lo = (uint32_t)value, root_hi = (uint32_t)(value >> 32);
+    bool stopped = false;
+    while (H < lim) {
+        const uint32_t idx = (H << d) + (uint32_t)lane;              // lane L: the node at relative position L below H
+        const uint32_t left = is_left ? idx : idx - 1;
+        const uint32_t parent = (left - 1) >> 1;
+        const bool cand = lane >= 1 && lane < 63 && parent < lim;
+        const uint32_t la = cand ? left : 1u;
+        const uint64_t vl = h[la], vr = h[la + 1];                   // one ds_read2_b64
+        const bool take_left = heap_prio(vr) > heap_prio(vl);        // __adjust_heap: right unless comp(right, left)
+        const bool step_to_me = cand && (is_left == take_left);
+        const unsigned long long okm = __ballot(step_to_me);
+        const bool onpath = cand && (okm & anc) == anc;
+        const uint64_t mine = is_left ? vl : vr;
+        const bool moves = onpath && !(heap_prio(mine) > vprio);
+        const unsigned long long pathm = __ballot(onpath), mvm = __ballot(moves);
+        if (moves) h[parent] = mine;
+        if (mvm) {
+            if (H == 0) {
+                const int r1 = (mvm & 2ull) ? 1 : 2;
+                root_hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), r1);
+                root_lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, r1);
+            }
+            const int rel = 63 - __clzll((long long)mvm);            // deepest moved entry: its old slot is the new hole
+            H = (H << (31 - __clz(rel + 1))) + (uint32_t)rel;
+        }
+        if (mvm != pathm) { stopped = true; break; }
+    }
+    if (!stopped && (len & 1) == 0 && H == (len - 2) / 2) {          // the hole has a lone left child, the array's last entry
+        const uint64_t c = h[len - 1];
+        const bool up = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(c)) <= (uint32_t)__builtin_amdgcn_readfirstlane((int)vprio);
+        if (up) {
+            if (lane == 0) h[H] = c;
+            if (H == 0) { root_lo = (uint32_t)c; root_hi = (uint32_t)(c >> 32); }
+            H = len - 1;
+        }
+    }
+    if (lane == 0) h[H] = value;
+    return ((uint64_t)root_hi << 32) | root_lo;
 }
 __device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane, uint64_t anc)
 {
@@ -875,15 +939,12 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         for (uint32_t it = 0;; ++it) {
             const uint32_t b = it & 1u;
             const bool ph_r = hnr > 0;
-            PopState ps_;
             if (ph_r) {
-                lds_pop_begin(sh.raise, hnr, ps_);
-                lds_pop_finish(sh.raise, ps_, lane, anc);
-                if (lane == 0 && hnr > 0) sh.topq[b] = sh.raise[0];
+                const uint64_t root_ = lds_pop_topdown(sh.raise, hnr, lane, anc);
+                if (lane == 0 && hnr > 0) sh.topq[b] = root_;
             } else {
-                lds_pop_begin(sh.lower, hnl, ps_);
-                lds_pop_finish(sh.lower, ps_, lane, anc);
-                if (lane == 0 && hnl > 0) sh.topq[b] = sh.lower[0];
+                const uint64_t root_ = lds_pop_topdown(sh.lower, hnl, lane, anc);
+                if (lane == 0 && hnl > 0) sh.topq[b] = root_;
             }
             HFT(0);
             lds_barrier();                                     // D
@@ -897,7 +958,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             if (ph_r && hnr == 0) lds_barrier();               // X: phase switch, the main wave reads lower[0] after the pushes
         }
 #ifdef LAMA_PROFILE_BF
+#ifndef LAMA_PROFILE_BF_MAIN
         if (lane == 0) for (int k = 0; k < 3; ++k) prm.dbg[8 * p + 5 + k] = hp[k];
+#endif
 #endif
         #undef HFT
         __syncthreads();                                       // F: last pushes applied
@@ -973,7 +1036,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const uint32_t olo_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(OWN_ENTRY), bl_);     \
             const uint32_t ohi_ = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((OWN_ENTRY) >> 32), bl_); \
             const bool have_own_ = kb_ != 0xFFFFFFFFu;                                                      \
+            BFT_MAIN(5);                                                                                    \
             lds_barrier();                                     /* D */                                      \
+            BFT_MAIN(7);                                                                                    \
             const bool have_root_ = (NPOP) > 0;                                                             \
             const uint64_t root_ = sh.topq[b_];                                                             \
             const bool own_wins_ = have_own_ && (!have_root_ || (kb_ >> 2) < heap_prio(root_));             \
@@ -1050,7 +1115,11 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     }
 
     // ---- lower wave ------------------------------------------------------------------------- :175-194
+#ifdef LAMA_PROFILE_BF_MAIN
+    BFT(0);
+#else
     BFT(7);
+#endif
     while (TW ? (tw_running && nl > 0) : (!spill && nl > 0)) {
         if (!TW && nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
         const uint64_t e = TW ? e_next : sh.lower[0];
@@ -1189,7 +1258,11 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         prm.stats[4 * p + 3] += processed;
         if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; prm.slow[p] = 1; }
 #ifdef LAMA_PROFILE_BF
+#ifdef LAMA_PROFILE_BF_MAIN
+        for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];
+#else
         for (int k = 0; k < (TW ? 5 : 8); ++k) prm.dbg[8 * p + k] = prof[k];
+#endif
 #endif
     }
 }

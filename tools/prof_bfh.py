@@ -1,4 +1,4 @@
-"""Developer tool: per-phase cycle breakdown of k_brushfire (needs the -DLAMA_PROFILE_BF build of the HIP library)."""
+"""Developer tool: cycle breakdown of the brushfire HELPER wave (needs a -DLAMA_PROFILE_BF -DLAMA_PROFILE_BFH build)."""
 import ctypes as C, sys, os
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,9 +10,7 @@ ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
 ctx.init(pts[0], F.pose_from_xyr(*odom[0]))
 L = F.hip_lib()
 L.lama_hip_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
-names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "H:pop", "H:wait_D", "H:pushes"]
-if os.environ.get("LAMA_PROF_MAIN"):   # -DLAMA_PROFILE_BF_MAIN build: all eight buckets belong to the main wave
-    names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "handover+pre_D", "post_D", "wait_D"]
+names = ["-", "wait_D", "pushes", "begin", "chunks", "finish", "topq", "n_chunks"]
 for k in range(1, 13):
     poses = np.tile(F.pose_from_xyr(*truth[k]), (P, 1))
     ctx.set_poses(poses)
@@ -22,6 +20,5 @@ for k in range(1, 13):
     d = np.zeros((P, 8), dtype=np.uint64)
     L.lama_hip_debug_cycles(ctx.h, d.ctypes.data_as(C.c_void_p))
     pops = c["bf_cells"] / P
-    tot = d[0][:5].sum()
-    print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms raycast {c['ms_raycast']:.3f} ms  cycles/pop {tot / max(pops,1):.0f} :: " +
-          " ".join(f"{n}={d[0][i] / max(pops,1):.0f}" for i, n in enumerate(names)))
+    print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms :: " +
+          " ".join(f"{n}={d[0][i] / max(pops,1):.2f}" for i, n in enumerate(names)))
