@@ -1935,8 +1935,9 @@ private:
 // globalLocalization (:194-197, :249-286) and addSamplingCovariance (:199-247).  Strategy "lm" is out of scope.
 // -------------------------------------------------------------------------------------
 // Solver::calculateCovariance (src/nlls/solver.cpp:133-150): rank of J by column-pivoted Householder QR
-// (Eigen ColPivHouseholderQR, threshold = epsilon * max(rows, cols) relative to the largest pivot); full rank ->
-// (J^T J)^-1, else V diag(sv > 1e-3 ? 1/sv^2 : 3.0) V^T from the SVD of J.
+// (Eigen ColPivHouseholderQR::rank(): pivots above epsilon * diagonalSize() = 3 eps relative to the largest pivot --
+// Eigen 3.3 is not in this image, the threshold is restated from its published source); full rank -> (J^T J)^-1,
+// else V diag(|sv| > 1e-3 ? 1/sv^2 : 3.0) V^T from the thin SVD of J (svd_cov3 below).
 inline int colpiv_qr_rank(std::vector<double> J /*n x 3 row-major, copied*/, size_t n)
 {
     double r[3];
@@ -1964,10 +1965,47 @@ inline int colpiv_qr_rank(std::vector<double> J /*n x 3 row-major, copied*/, siz
         r[k] = std::fabs(alpha);
     }
     const double maxp = std::max(r[0], std::max(r[1], r[2]));
-    const double thr = 2.220446049250313e-16 * (double)std::max<size_t>(n, 3) * maxp;
+    const double thr = 2.220446049250313e-16 * 3.0 * maxp;
     int rank = 0;
     for (int k = 0; k < 3; ++k) if (r[k] > thr) ++rank;
     return rank;
+}
+
+// The rank-deficient branch (src/nlls/solver.cpp:143-149): singular values and right singular vectors of the n x 3
+// Jacobian by one-sided (Hestenes) Jacobi rotations -- the same decomposition Eigen::JacobiSVD returns, up to the signs /
+// order of the columns of V, which V D V^T does not depend on.
+inline void svd_cov3(std::vector<double> U /*n x 3 row-major, copied*/, size_t n, double cov[9])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        bool rotated = false;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (size_t i = 0; i < n; ++i) { alpha += U[3 * i + p] * U[3 * i + p]; beta += U[3 * i + q] * U[3 * i + q]; gamma += U[3 * i + p] * U[3 * i + q]; }
+                if (gamma == 0.0 || std::fabs(gamma) <= 1e-300 + 2.220446049250313e-16 * std::sqrt(alpha * beta)) continue;
+                rotated = true;
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (size_t i = 0; i < n; ++i) {
+                    const double up = U[3 * i + p], uq = U[3 * i + q];
+                    U[3 * i + p] = c * up - sn * uq; U[3 * i + q] = sn * up + c * uq;
+                }
+                for (int i = 0; i < 3; ++i) {
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (!rotated) break;
+    }
+    double d[3];
+    for (int j = 0; j < 3; ++j) {
+        double s2 = 0; for (size_t i = 0; i < n; ++i) s2 += U[3 * i + j] * U[3 * i + j];
+        const double sv = std::sqrt(s2);
+        d[j] = sv > 1.e-3 ? 1.0 / (sv * sv) : 3.0;                                      // :147-148
+    }
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cov[3 * a + b] = V[a][0] * d[0] * V[b][0] + V[a][1] * d[1] * V[b][1] + V[a][2] * d[2] * V[b][2];
 }
 
 inline void inverse3(const double A[3][3], double out[9])
@@ -2064,7 +2102,7 @@ public:
         for (size_t i = 0; i < r.size(); ++i)
             for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] += J[3 * i + a] * J[3 * i + b];
         rank_deficient_ = colpiv_qr_rank(J, r.size()) != 3;
-        if (!rank_deficient_) inverse3(A, cov_);
+        if (!rank_deficient_) inverse3(A, cov_); else svd_cov3(J, r.size(), cov_);
         pose_ = ms.state_;
         if (cov_blend_ > 0.0) addSamplingCovariance(surface);                           // :175-176
         rmse_ = rmse_at(surface, pose_);

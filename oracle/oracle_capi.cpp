@@ -387,6 +387,7 @@ int orc_loc_update(void* h, const double* pts, int n, const double* origin3, con
 void orc_loc_covar(void* h, double* out9) { std::memcpy(out9, ((LocBox*)h)->l->getCovar(), 72); }
 double orc_loc_rmse(void* h) { return ((LocBox*)h)->l->getRMSE(); }
 uint32_t orc_loc_iterations(void* h) { return ((LocBox*)h)->l->lastIterations(); }
+int32_t orc_loc_rank_deficient(void* h) { return ((LocBox*)h)->l->rankDeficient() ? 1 : 0; }
 // global localisation / sampling covariance (src/loc2d.cpp:194-286)
 void* orc_loc_new2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t patch_size, uint32_t max_iter,
                    uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend)

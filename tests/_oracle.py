@@ -73,7 +73,7 @@ def lib():
             "orc_loc_new": (vp, [d, d, d, d, u32, u32]), "orc_loc_free": (None, [vp]), "orc_loc_dm": (vp, [vp]),
             "orc_loc_set_pose": (None, [vp, vp]), "orc_loc_get_pose": (None, [vp, vp]),
             "orc_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "orc_loc_covar": (None, [vp, vp]),
-            "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]),
+            "orc_loc_rmse": (d, [vp]), "orc_loc_iterations": (u32, [vp]), "orc_loc_rank_deficient": (i32, [vp]),
             "orc_lo_new": (vp, [d, u32]), "orc_lo_free": (None, [vp]), "orc_lo_update": (i32, [vp, vp, i32, vp, vp, d]),
             "orc_lo_get_odom": (None, [vp, vp]), "orc_lo_set_odom": (None, [vp, vp]), "orc_lo_dm": (vp, [vp]), "orc_lo_occ": (vp, [vp]),
             "orc_lo_deleted_last": (u32, [vp]), "orc_lo_map_updates": (u32, [vp]), "orc_lo_iterations": (u32, [vp]),
@@ -515,6 +515,9 @@ class Loc:
 
     def iterations(self):
         return lib().orc_loc_iterations(self.h)
+
+    def rank_deficient(self):
+        return bool(lib().orc_loc_rank_deficient(self.h))
 
     def occ_set_cells(self, cells_xy, state):
         cells = np.ascontiguousarray(cells_xy, dtype=np.uint32).reshape(-1, 2)

@@ -35,3 +35,26 @@ def corridor_free_cells(w2m, res=0.05):
             c = w2m([x, y, 0.0])
             cells.append((int(c[0]), int(c[1])))
     return np.array(sorted(set(cells)), dtype=np.uint32)
+
+
+def open_corridor(res=0.05, half_len=40.0, width=4.0):
+    """Two parallel walls y = 0 and y = width, x in [-half_len, half_len]: a corridor whose ends are out of sight, so
+    the along-corridor direction is unobservable (exactly rank-deficient scan-matching Jacobian)."""
+    n = int(round(2 * half_len / res)) + 1
+    xs = -half_len + res * np.arange(n)
+    return np.concatenate([np.stack([xs, np.zeros(n)], 1), np.stack([xs, np.full(n, width)], 1)])
+
+
+def open_corridor_scan(x, y, yaw, beams=360, fov=np.deg2rad(270.0), max_range=12.0, width=4.0):
+    """Sensor-frame points (n, 3) of the beams of a scanner at (x, y, yaw) that reach one of the two walls of
+    open_corridor() within max_range (the others have no return and are dropped)."""
+    out = []
+    for k in range(beams):
+        phi = -fov / 2 + fov * k / (beams - 1)
+        d = np.sin(yaw + phi)
+        if abs(d) < 1e-9:
+            continue
+        r = (width - y) / d if d > 0 else (0.0 - y) / d
+        if 0.2 < r <= max_range:
+            out.append((r * np.cos(phi), r * np.sin(phi), 0.0))
+    return np.array(out)

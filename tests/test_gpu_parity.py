@@ -269,6 +269,34 @@ def test_loc2d_gpu_vs_oracle(F):
     h.close()
 
 
+def test_loc2d_rank_deficient_covariance_gpu(F):
+    """Rank-deficient branch of Solver::calculateCovariance (src/nlls/solver.cpp:143-149) on the device path: corridor
+    with its ends out of sight, x unobservable -> variance 3.0 along x, (J^T J)-eigen pairs elsewhere."""
+    from _worlds import open_corridor, open_corridor_scan
+    obst = open_corridor()
+    o = O.Loc()
+    dm = o.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    h = F.Loc2D()
+    h.set_obstacles_world(obst)
+    assert h.engine_origin().endswith("liblama_hip.so")
+    truth = np.array([1.3, 1.7, 0.12])
+    scan = open_corridor_scan(*truth, beams=1080)
+    start = truth + np.array([0.0, 0.06, -0.02])
+    o.set_pose(O.se2(*start)); h.set_pose(*start)
+    assert o.update(scan, O.se2(*start), 0.0, force=True) == h.update(scan, start, 0.0, force=True)
+    assert o.rank_deficient()
+    assert np.abs(o.pose() - h.pose()).max() < 1e-8
+    assert o.iterations() == h.iterations()
+    co, ch = o.covar().reshape(3, 3), h.covar().reshape(3, 3)
+    assert np.allclose(co, ch, rtol=1e-6, atol=1e-10)
+    assert abs(ch[0, 0] - 3.0) < 1e-9 and abs(ch[0, 1]) < 1e-9 and abs(ch[0, 2]) < 1e-9
+    h.close()
+
+
 def test_canonical_brushfire_mode(F):
     """cfg.brushfire_mode = 1 (level-synchronous, canonical tie rule): bit-exact against the oracle's update_canonical(),
     and -- against the FAITHFUL oracle -- identical in everything but the obstacle offsets of tie cells."""

@@ -169,6 +169,37 @@ def test_loc2d_host_matches_oracle():
     assert h.rmse() < 0.05
 
 
+def test_loc2d_rank_deficient_covariance_host_matches_oracle():
+    """Solver::calculateCovariance's rank-deficient branch (src/nlls/solver.cpp:143-149): in a corridor whose ends are
+    out of sight the x column of the Jacobian is exactly zero; the reference then returns V diag(1/sv^2 | 3.0) V^T.
+    The oracle works on J (pivoted QR rank + one-sided Jacobi SVD), the host on the J^T J the engine returns."""
+    from _worlds import open_corridor, open_corridor_scan
+    obst = open_corridor()
+    o = O.Loc()
+    dm = o.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    h = F.Loc2D()
+    h.set_obstacles_world(obst)
+    truth = np.array([1.3, 1.7, 0.12])
+    scan = open_corridor_scan(*truth)
+    assert len(scan) > 200
+    start = truth + np.array([0.0, 0.06, -0.02])
+    o.set_pose(O.se2(*start)); h.set_pose(*start)
+    assert o.update(scan, O.se2(*start), 0.0, force=True) == h.update(scan, start, 0.0, force=True)
+    assert o.rank_deficient()
+    assert np.array_equal(o.pose(), h.pose())
+    co, ch = o.covar().reshape(3, 3), h.covar().reshape(3, 3)
+    assert np.allclose(co, ch, rtol=1e-9, atol=1e-12)
+    assert abs(ch[0, 0] - 3.0) < 1e-12 and abs(ch[0, 1]) < 1e-12 and abs(ch[0, 2]) < 1e-12     # unobservable direction: 3.0
+    assert 0 < ch[1, 1] < 1e-2 and 0 < ch[2, 2] < 1e-2
+    g = h.pose()
+    assert abs(g[3] - truth[1]) < 0.02 and abs(np.arctan2(g[1], g[0]) - truth[2]) < 0.01
+    h.close()
+
+
 def _loc_pair(obst, free, **kw):
     o = O.Loc(**kw)
     dm = o.dm()
