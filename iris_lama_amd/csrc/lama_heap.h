@@ -83,4 +83,37 @@ LAMA_HD uint64_t heap_pop(Store& st, uint32_t& size)
     return top;
 }
 
+// The same pop, computed top-down (scalar statement of lds_pop_topdown in lama_kernels.h, which the helper wave of
+// k_brushfire runs 63 nodes at a time).  __adjust_heap moves every entry n_1 .. n_k of the hole's path up one slot,
+// __push_heap then moves the entries with prio(n_i) > prio(value) down again, into the slots they came from.  Priorities
+// do not decrease along the path, so the net effect is: the prefix of the path with prio(n_i) <= prio(value) moves up,
+// `value` takes the slot of its last entry.  Same final array as heap_pop(); also returns the new root through `root`.
+template <class Store>
+LAMA_HD uint64_t heap_pop_topdown(Store& st, uint32_t& size, uint64_t* root)
+{
+    const uint64_t top = st.get(0);
+    --size;
+    if (size == 0) { if (root) *root = 0; return top; }
+    const uint64_t value = st.get(size);
+    const uint32_t len = size, lim = (len - 1) / 2;
+    uint32_t hole = 0;
+    bool stopped = false;
+    while (hole < lim) {
+        const uint32_t right = 2 * hole + 2;
+        const uint64_t r = st.get(right), l = st.get(right - 1);
+        const uint32_t child = heap_comp(r, l) ? right - 1 : right;
+        const uint64_t cv = heap_comp(r, l) ? l : r;
+        if (heap_prio(cv) > heap_prio(value)) { stopped = true; break; }
+        st.set(hole, cv);
+        hole = child;
+    }
+    if (!stopped && (len & 1) == 0 && hole == (len - 2) / 2) {      // lone left child at the end of the array
+        const uint64_t cv = st.get(len - 1);
+        if (!(heap_prio(cv) > heap_prio(value))) { st.set(hole, cv); hole = len - 1; }
+    }
+    st.set(hole, value);
+    if (root) *root = st.get(0);
+    return top;
+}
+
 } // namespace lama_dev

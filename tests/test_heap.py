@@ -30,3 +30,22 @@ def test_heap_matches_libstdcxx_priority_queue_with_ties():
         b = np.zeros(len(ops), dtype=np.uint32)
         k = L.heap_replay(ops.ctypes.data_as(C.c_void_p), len(ops), a.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p))
         assert k > 0 and np.array_equal(a[:k], b[:k]), trial
+
+
+def test_topdown_pop_leaves_the_array_of_libstdcxx_pop_heap():
+    """lds_pop_topdown (helper wave of k_brushfire; scalar statement: heap_pop_topdown in lama_heap.h) stops the descent
+    where __push_heap would stop moving the re-inserted entry back up: the resulting ARRAY must equal the one
+    std::pop_heap produces after every single operation (ties in later pops depend on the layout)."""
+    L = _lib()
+    rng = np.random.default_rng(1)
+    for trial in range(40):
+        n = int(rng.integers(20, 1500))
+        span = int(rng.choice([1, 2, 5, 20, 200]))
+        ops = np.where(rng.random(n) < 0.55, rng.integers(0, span, size=n), -1).astype(np.int32)
+        if trial % 4 == 0:                                # brushfire-like: zeros first, then a slowly growing front
+            ops[: n // 5] = 0
+            front = np.cumsum(rng.random(n) < 0.02)
+            ops = np.where(ops >= 0, np.minimum(ops, 3) + front.astype(np.int32), -1).astype(np.int32)
+            ops[: n // 5] = 0
+        ops = np.concatenate([ops, np.full(n, -1, dtype=np.int32)])
+        assert L.heap_replay_layout(ops.ctypes.data_as(C.c_void_p), len(ops)) == len(ops), trial
