@@ -526,7 +526,8 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     DevParams prm = make_params(c, c->cur);
     {
         Timer t(c, &c->ctr.ms_scan_match, &c->ctr.launches_scan_match);
-        hipLaunchKernelGGL(k_scan_match, dim3(c->P), dim3(SM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, mtf, c->d_loglik, c->d_iters);
+        if (c->max_sqdist > (uint32_t)SM_LUT) hipLaunchKernelGGL(k_scan_match<true>, dim3(c->P), dim3(SM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, mtf, c->d_loglik, c->d_iters);
+        else hipLaunchKernelGGL(k_scan_match<false>, dim3(c->P), dim3(SM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, mtf, c->d_loglik, c->d_iters);
         t.stop();
     }
     HIPCHK(c, hipGetLastError());
@@ -777,7 +778,8 @@ int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* p
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, poses, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
     DevParams prm = make_params(c, c->cur);
-    hipLaunchKernelGGL(k_loglik_batch, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
+    if (c->max_sqdist > (uint32_t)SM_LUT) hipLaunchKernelGGL(k_loglik_batch<true>, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
+    else hipLaunchKernelGGL(k_loglik_batch<false>, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(out, c->d_bout, sizeof(double) * B, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1001,8 +1003,12 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, pose_inout, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
     DevParams prm = make_params(c, c->cur);
-    hipLaunchKernelGGL(k_match_solve, dim3(1), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout,
-                       c->d_iters, (int)do_solve);
+    if (c->max_sqdist > (uint32_t)SM_LUT)
+        hipLaunchKernelGGL(k_match_solve<true>, dim3(1), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout,
+                           c->d_iters, (int)do_solve);
+    else
+        hipLaunchKernelGGL(k_match_solve<false>, dim3(1), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout,
+                           c->d_iters, (int)do_solve);
     HIPCHK(c, hipGetLastError());
     double o7[7]; int32_t it = 0;
     HIPCHK(c, hipMemcpyAsync(pose_inout, c->d_bposes, sizeof(double) * 4, hipMemcpyDeviceToHost, c->stream));

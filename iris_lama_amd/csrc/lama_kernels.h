@@ -24,21 +24,40 @@ constexpr uint32_t BF_TW_MAX_PARTICLES = 1u << 30;     // the helper-wave form w
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (fixed shape => results do not depend on how particles are sharded)
 // ------------------------------------------------------------------------------------------------
-__device__ inline double wave_sum(double v)
+// One DPP step of a wave reduction on a double: v + (v of the lane the DPP control selects); rows not in `row_mask` add 0.0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    const uint64_t u = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, ROW_MASK, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, ROW_MASK, 0xF, false);
+    return v + __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 
+// Block sum of NV per-thread values with a FIXED tree (=> the result does not depend on how particles are sharded):
+// within a wave pairs, quads, half rows, rows (quad_perm / row_half_mirror / row_mirror: both partners add the same two
+// operands), then (row3 + row2) + (row1 + row0) through row_bcast15 / row_bcast31 into lane 63; the four waves are added in
+// order by thread k.  All register-to-register (DPP), no LDS round trips: a __shfl_xor butterfly costs two ds_bpermute
+// per step and value -- 3,800 cycles for the 11 sums of an evaluation pass.
 template <int NV>
 __device__ inline void block_sum(double (&acc)[NV], double* sh /*[SM_BLOCK/64][NV]*/, double* out /*[NV]*/)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double v = wave_sum(acc[k]);
-        if (lane == 0) sh[wave * NV + k] = v;
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0xB1, 0xF>(acc[k]);        // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0x4E, 0xF>(acc[k]);        // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0x141, 0xF>(acc[k]);       // row_half_mirror
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0x140, 0xF>(acc[k]);       // row_mirror: every lane holds its row's sum
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0x142, 0xA>(acc[k]);       // row_bcast15 into rows 1, 3
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = dpp_add<0x143, 0xC>(acc[k]);       // row_bcast31 into rows 2, 3: lane 63 = total
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) sh[wave * NV + k] = acc[k];
     }
     __syncthreads();
     if (threadIdx.x < NV) {
@@ -59,46 +78,160 @@ __device__ inline void block_sum(double (&acc)[NV], double* sh /*[SM_BLOCK/64][N
 // reference evaluates the problem twice at that state, solver.cpp:90 and :71) and as the likelihood at the solution.
 // ------------------------------------------------------------------------------------------------
 constexpr int NJ = 11;
+
+// The gathers of an evaluation pass, batched: a thread owns the beams t, t + 256, ... (SM_NB of them per batch).  Written
+// beam by beam, every bilinear corner is a chain of two dependent loads (directory entry, then the cell) behind early-out
+// branches -- with one wave per SIMD that is 8 round trips per beam.  Here the directory entries of ALL corners of ALL the
+// thread's beams are requested first, then all cells, then the arithmetic runs in the original beam order (same
+// operations, same summation order => bit-identical sums).  sqrt(sqdist) * resolution of the few hundred possible sqdist
+// values comes from an LDS table built with the same expression (DynamicDistanceMap::distance(Vector3ui),
+// src/sdm/dynamic_distance_map.cpp:140-147).
+constexpr int SM_NB = 5;            // beams per thread and batch (1080 beams / 256 threads = 4.2)
+constexpr int SM_LUT = 512;         // sqdist values with a table entry (max_sqdist is 100 / 400 in the reference's configurations;
+                                    // contexts with a larger max_sqdist run the BIGSQ instantiations, which take the square root)
+
+__device__ inline void sm_build_lut(const DevParams& prm, double* lut)
+{
+    for (int k = threadIdx.x; k < SM_LUT; k += SM_BLOCK) lut[k] = sqrt((double)k) * prm.resolution;
+}
+
+struct BeamCorners {
+    double hx, hy, mu0, mu1;
+    uint32_t off[4];                // directory index, then cell offset (slot * 1024 + cell), of the four corners
+    uint32_t okm;                   // bit c: corner c is inside the window (stage 1) / has a patch (stage 2)
+    uint32_t ci[4];
+};
+
+__device__ inline void sm_corners_begin(const DevParams& prm, const Affine& tf, double px, double py, double pz, BeamCorners& b)
+{
+    b.hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
+    b.hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
+    const double mx = w2m_nocast(prm, b.hx), my = w2m_nocast(prm, b.hy);
+    const uint32_t dx = (uint32_t)mx, dy = (uint32_t)my;
+    b.mu0 = mx - (double)dx; b.mu1 = my - (double)dy;
+    b.okm = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t rx = dx + (uint32_t)(c & 1) - prm.wx0, ry = dy + (uint32_t)(c >> 1) - prm.wy0;
+        const bool in = rx < prm.WC && ry < prm.WC;
+        b.off[c] = in ? (ry >> 5) * prm.W + (rx >> 5) : 0u;
+        b.ci[c] = (rx & 31u) | ((ry & 31u) << 5);
+        b.okm |= in ? (1u << c) : 0u;
+    }
+}
+
+// value + gradient of DynamicDistanceMap::distance(Vector3d, Vector3d*) (src/sdm/dynamic_distance_map.cpp:66-91) from the
+// four fetched cells
+template <bool BIGSQ>
+__device__ inline double sm_corners_finish(const DevParams& prm, const double* lut, const BeamCorners& b, const uint16_t (&v)[4],
+                                           double* gx, double* gy)
+{
+    double d[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t sq = v[c] & SV_SQMASK;
+        const bool valid = ((b.okm >> c) & 1u) && (v[c] & SV_VALID);
+        const double t = BIGSQ ? sqrt((double)sq) * prm.resolution : lut[sq & (uint32_t)(SM_LUT - 1)];   // valid => sq < max_sqdist
+        d[c] = valid ? t : prm.maxdist;
+    }
+    const double mu0 = b.mu0, mu1 = b.mu1, muinv0 = 1.0 - mu0, muinv1 = 1.0 - mu1;
+    const double dist = d[0] * muinv0 * muinv1 + d[1] * muinv1 * mu0 + d[2] * muinv0 * mu1 + d[3] * mu0 * mu1;
+    if (gx) {
+        *gx = -((d[0] - d[1]) * muinv1 + (d[2] - d[3]) * mu1) * prm.scale;
+        *gy = -((d[0] - d[2]) * muinv0 + (d[1] - d[3]) * mu0) * prm.scale;
+    }
+    return dist;
+}
+
+// stages 1 + 2 for the thread's beams of the batch starting at `base`; returns the number of beams it owns there
+__device__ inline int sm_gather(const DevParams& prm, const int16_t* __restrict__ dir, const uint16_t* __restrict__ sv,
+                                const double* __restrict__ pts, int n, int base, const Affine& tf, BeamCorners (&bc)[SM_NB],
+                                uint16_t (&cv)[SM_NB][4])
+{
+    int nb = 0;
+#pragma unroll
+    for (int b = 0; b < SM_NB; ++b) {
+        const int i = base + b * SM_BLOCK + (int)threadIdx.x;
+        const int ic = i < n ? i : n - 1;
+        if (i < n) nb = b + 1;
+        sm_corners_begin(prm, tf, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2], bc[b]);
+    }
+    int16_t sl[SM_NB][4];
+#pragma unroll
+    for (int b = 0; b < SM_NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sl[b][c] = dir[bc[b].off[c]];
+#pragma unroll
+    for (int b = 0; b < SM_NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bool have = ((bc[b].okm >> c) & 1u) && sl[b][c] >= 0;
+            bc[b].off[c] = have ? (uint32_t)sl[b][c] * 1024u + bc[b].ci[c] : 0u;
+            if (!have) bc[b].okm &= ~(1u << c);
+        }
+#pragma unroll
+    for (int b = 0; b < SM_NB; ++b)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) cv[b][c] = sv[bc[b].off[c]];
+    return nb;
+}
+
+template <bool BIGSQ>
 __device__ inline void eval_beams_jac(const DevParams& prm, const int16_t* dir, const uint16_t* sv,
-                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[NJ])
+                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[NJ], const double* lut)
 {
 #pragma unroll
     for (int k = 0; k < NJ; ++k) acc[k] = 0.0;
-    for (int i = threadIdx.x; i < n; i += SM_BLOCK) {
-        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
-        const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
-        const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
+    for (int base = 0; base < n; base += SM_NB * SM_BLOCK) {
+        BeamCorners bc[SM_NB];
+        uint16_t cv[SM_NB][4];
+        const int nb = sm_gather(prm, dir, sv, pts, n, base, tf, bc, cv);
+#pragma unroll
+        for (int b = 0; b < SM_NB; ++b) {
+        {
+        // no branch around a beam the thread does not own (its inputs are those of beam n - 1): the five chains can then be
+        // interleaved by the scheduler; what is added for it is +0.0, which leaves every sum (never -0.0) unchanged
+        const bool own = b < nb;
+        const double hx = bc[b].hx, hy = bc[b].hy;
         double gx, gy;
-        double r = dm_distance(prm, dir, sv, hx, hy, &gx, &gy);
-        acc[10] += -(r * r) / prm.meas_sigma;
+        double r = sm_corners_finish<BIGSQ>(prm, lut, bc[b], cv[b], &gx, &gy);
+        acc[10] += own ? -(r * r) / prm.meas_sigma : 0.0;
         const double w = sqrt(cauchy015(r));
         r *= w;
         const double j0 = gx * w, j1 = gy * w, j2 = (gy * hx - gx * hy) * w;
-        acc[0] += j0 * j0; acc[1] += j1 * j0; acc[2] += j1 * j1;
-        acc[3] += j2 * j0; acc[4] += j2 * j1; acc[5] += j2 * j2;
-        acc[6] += j0 * r;  acc[7] += j1 * r;  acc[8] += j2 * r;
-        acc[9] += r * r;
+        acc[0] += own ? j0 * j0 : 0.0; acc[1] += own ? j1 * j0 : 0.0; acc[2] += own ? j1 * j1 : 0.0;
+        acc[3] += own ? j2 * j0 : 0.0; acc[4] += own ? j2 * j1 : 0.0; acc[5] += own ? j2 * j2 : 0.0;
+        acc[6] += own ? j0 * r : 0.0;  acc[7] += own ? j1 * r : 0.0;  acc[8] += own ? j2 * r : 0.0;
+        acc[9] += own ? r * r : 0.0;
+        }
+        }
     }
 }
 
 // residual-only evaluation: acc[0] = sum (w r)^2 (validation, solver.cpp:90-96),
 //                           acc[1] = sum -(d*d)/meas_sigma (calculateLikelihood, pf_slam2d.cpp:393-414)
+template <bool BIGSQ>
 __device__ inline void eval_beams_res(const DevParams& prm, const int16_t* dir, const uint16_t* sv,
-                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[2])
+                                      const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[2], const double* lut)
 {
     acc[0] = 0.0; acc[1] = 0.0;
-    for (int i = threadIdx.x; i < n; i += SM_BLOCK) {
-        const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
-        const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
-        const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
-        const double d = dm_distance(prm, dir, sv, hx, hy, nullptr, nullptr);
-        const double wr = d * sqrt(cauchy015(d));
-        acc[0] += wr * wr;
-        acc[1] += -(d * d) / prm.meas_sigma;
+    for (int base = 0; base < n; base += SM_NB * SM_BLOCK) {
+        BeamCorners bc[SM_NB];
+        uint16_t cv[SM_NB][4];
+        const int nb = sm_gather(prm, dir, sv, pts, n, base, tf, bc, cv);
+#pragma unroll
+        for (int b = 0; b < SM_NB; ++b) {
+            const bool own = b < nb;               // see eval_beams_jac
+            const double d = sm_corners_finish<BIGSQ>(prm, lut, bc[b], cv[b], nullptr, nullptr);
+            const double wr = d * sqrt(cauchy015(d));
+            acc[0] += own ? wr * wr : 0.0;
+            acc[1] += own ? -(d * d) / prm.meas_sigma : 0.0;
+        }
     }
 }
 
 struct SMShared {
+    double lut[SM_LUT];    // sqrt(sqdist) * resolution (sm_build_lut)
     double red[(SM_BLOCK / 64) * NJ];
     double tot[NJ];        // sums of the linearisation at the current state
     double tot2[NJ];       // sums at the trial state of the step being validated
@@ -118,9 +251,19 @@ struct SMShared {
 // CauchyWeight(0.15), executed by one workgroup on the problem (dir, sv, pts, state in sh.state).
 // On return sh.state / sh.tf hold the solution; returns the iteration count (applied + reverted steps).
 // ------------------------------------------------------------------------------------------------
+#ifdef LAMA_PROFILE_SM                 // developer build: cycles per phase of the solver loop -> prm.dbg (tools/prof_sm.py)
+#define SMT(k) do { const uint64_t t_ = __builtin_readcyclecounter(); smp[k] += t_ - smt; smt = t_; } while (0)
+#else
+#define SMT(k) do {} while (0)
+#endif
+template <bool BIGSQ>
 __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, const uint16_t* sv, const double* __restrict__ pts, int n,
                                     const Affine& mtf, SMShared& sh, uint32_t& evals)
 {
+#ifdef LAMA_PROFILE_SM
+    uint64_t smp[4] = {0, 0, 0, 0};
+    uint64_t smt = __builtin_readcyclecounter();
+#endif
     const double eps1 = 1e-4, eps2 = 1e-4, tau = 1e-4;
     const bool lm = prm.strategy == 1;
     uint32_t iter = 0;
@@ -135,9 +278,11 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
             double acc[NJ];
             {
                 const Affine tf = sh.tf;
-                eval_beams_jac(prm, dir, sv, pts, n, tf, acc);
+                eval_beams_jac<BIGSQ>(prm, dir, sv, pts, n, tf, acc, sh.lut);
             }
+            SMT(0);
             block_sum<NJ>(acc, sh.red, sh.tot);
+            SMT(1);
             ++evals;
         } else {
             __syncthreads();
@@ -178,14 +323,17 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
             sh.ctl = stop;
         }
         __syncthreads();
+        SMT(2);
         if (sh.ctl) break;
         // 3. validation: the problem at the updated state (chi2 decides; the other sums are next iteration's linearisation)
         double acc2[NJ];
         {
             const Affine tf = sh.tf;
-            eval_beams_jac(prm, dir, sv, pts, n, tf, acc2);
+            eval_beams_jac<BIGSQ>(prm, dir, sv, pts, n, tf, acc2, sh.lut);
         }
+        SMT(0);
         block_sum<NJ>(acc2, sh.red, sh.tot2);
+        SMT(1);
         ++evals;
         if (threadIdx.x == 0) {
             const double dF = sh.tot[9] - sh.tot2[9];
@@ -223,14 +371,20 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
         }
         ++iter;
         __syncthreads();
+        SMT(3);
         if (sh.ctl) break;
     }
+#ifdef LAMA_PROFILE_SM
+    if (threadIdx.x == 0) for (int k = 0; k < 4; ++k) prm.dbg[8 * blockIdx.x + k] = smp[k];
+#endif
     return iter;
 }
+#undef SMT
 
 // ------------------------------------------------------------------------------------------------
 // k_scan_match: PFSlam2D::scanMatch (src/pf_slam2d.cpp:416-437) for every particle of the shard.
 // ------------------------------------------------------------------------------------------------
+template <bool BIGSQ>
 __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const double* __restrict__ pts, int n, Affine mtf,
                                                           double* __restrict__ loglik_out, int32_t* __restrict__ iters_out)
 {
@@ -244,9 +398,10 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
         sh.tf = scan_tf(sh.state, mtf);
         sh.ctl = 0;
     }
+    sm_build_lut(prm, sh.lut);
     __syncthreads();
     uint32_t evals = 0;
-    const uint32_t iter = gn_solve(prm, dir, sv, pts, n, mtf, sh, evals);
+    const uint32_t iter = gn_solve<BIGSQ>(prm, dir, sv, pts, n, mtf, sh, evals);
     // likelihood at the final state (pf_slam2d.cpp:433-436): already summed by the last linearisation when that was taken
     // at exactly the returned state; after a reverted step the state differs in the last bits, so it is evaluated
     double loglik;
@@ -256,7 +411,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
         double a2[2];
         {
             const Affine tf = sh.tf;
-            eval_beams_res(prm, dir, sv, pts, n, tf, a2);
+            eval_beams_res<BIGSQ>(prm, dir, sv, pts, n, tf, a2, sh.lut);
         }
         block_sum<2>(a2, sh.red, sh.tot2);
         loglik = sh.tot2[1];
@@ -278,6 +433,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const do
 //   out[0..5] lower triangle of J^T J with J weighted (Solver::solve cov branch, src/nlls/solver.cpp:109-116)
 //   out[6]    sum of squared UNWEIGHTED residuals (RMSE, src/loc2d.cpp:178-180)
 // ------------------------------------------------------------------------------------------------
+template <bool BIGSQ>
 __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int particle, const double* __restrict__ pts, int n, Affine mtf,
                                                            double* __restrict__ pose_io, double* __restrict__ out7, int32_t* __restrict__ iters_out,
                                                            int do_solve)
@@ -290,9 +446,10 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
         sh.tf = scan_tf(sh.state, mtf);
         sh.ctl = 0;
     }
+    sm_build_lut(prm, sh.lut);
     __syncthreads();
     uint32_t evals = 0;
-    const uint32_t iter = do_solve ? gn_solve(prm, dir, sv, pts, n, mtf, sh, evals) : 0u;
+    const uint32_t iter = do_solve ? gn_solve<BIGSQ>(prm, dir, sv, pts, n, mtf, sh, evals) : 0u;
     double acc[10];
     const Affine tf = sh.tf;
 #pragma unroll
@@ -318,11 +475,13 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
 }
 
 // calculateLikelihood for B poses against particle `particle`'s distance map
+template <bool BIGSQ>
 __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int particle, const double* __restrict__ pts, int n,
                                                             Affine mtf, const double* __restrict__ poses, double* __restrict__ out)
 {
     __shared__ double red[(SM_BLOCK / 64) * 2];
     __shared__ double tot[2];
+    __shared__ double lut[SM_LUT];
     __shared__ Affine tfs;
     const int b = blockIdx.x;
     const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
@@ -331,10 +490,11 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
         const double* q = poses + 4 * b;
         tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
     }
+    sm_build_lut(prm, lut);
     __syncthreads();
     double a2[2];
     const Affine tf = tfs;
-    eval_beams_res(prm, dir, sv, pts, n, tf, a2);
+    eval_beams_res<BIGSQ>(prm, dir, sv, pts, n, tf, a2, lut);
     block_sum<2>(a2, red, tot);
     if (threadIdx.x == 0) out[b] = tot[1];
 }
