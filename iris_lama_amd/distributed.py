@@ -27,12 +27,15 @@ def owner_of(i, P, G):
 
 
 class ShardedPF:
-    def __init__(self, opts, device=None):
+    def __init__(self, opts, device=None, force_collectives=False):
         self.pf = F.PFSlam2D(opts)
         self.world = opts.shard_world
         self.rank = opts.shard_rank
         self.P = opts.particles
-        if self.world > 1:
+        # force_collectives: take the multi-rank code path (all-gather, resample planning, P2P bookkeeping) even with one
+        # rank -- lets a single-GPU box exercise the RCCL path end to end
+        self.collective = self.world > 1 or force_collectives
+        if self.collective:
             assert dist.is_initialized() and dist.get_world_size() == self.world and dist.get_rank() == self.rank
             self.backend = dist.get_backend()
         else:
@@ -58,11 +61,11 @@ class ShardedPF:
 
     # ------------------------------------------------------------------ collectives
     def barrier(self):
-        if self.world > 1:
+        if self.collective:
             dist.barrier()
 
     def max_over_ranks(self, x):
-        if self.world == 1:
+        if not self.collective:
             return float(x)
         t = torch.tensor([float(x)], dtype=torch.float64, device=self.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -72,13 +75,22 @@ class ShardedPF:
         return self.pf.lo <= self.pf.best() < self.pf.hi
 
     def _all_gather_loglik(self, local):
-        send = torch.zeros(self.maxblk, dtype=torch.float64, device=self.device)
-        send[: len(local)] = torch.from_numpy(local).to(self.device)
-        out = [torch.empty(self.maxblk, dtype=torch.float64, device=self.device) for _ in range(self.world)]
-        dist.all_gather(out, send)
+        # buffers are allocated once: per scan this is one small H2D copy, the collective and one D2H copy
+        if not hasattr(self, "_ag_send"):
+            pin = self.device.type == "cuda"
+            self._ag_host_in = torch.zeros(self.maxblk, dtype=torch.float64, pin_memory=pin)
+            self._ag_send = torch.zeros(self.maxblk, dtype=torch.float64, device=self.device)
+            self._ag_flat = torch.empty(self.world * self.maxblk, dtype=torch.float64, device=self.device)
+            self._ag_out = [self._ag_flat[r * self.maxblk:(r + 1) * self.maxblk] for r in range(self.world)]
+            self._ag_host_out = torch.empty(self.world * self.maxblk, dtype=torch.float64, pin_memory=pin)
+        self._ag_host_in[: len(local)] = torch.from_numpy(local)
+        self._ag_send.copy_(self._ag_host_in, non_blocking=True)
+        dist.all_gather(self._ag_out, self._ag_send)
+        self._ag_host_out.copy_(self._ag_flat)               # blocking D2H (orders after the collective on the same stream)
+        flat = self._ag_host_out.numpy()
         allv = np.empty(self.P)
         for r, (lo, hi) in enumerate(self.blocks):
-            allv[lo:hi] = out[r][: hi - lo].cpu().numpy()
+            allv[lo:hi] = flat[r * self.maxblk: r * self.maxblk + (hi - lo)]
         return allv
 
     # ------------------------------------------------------------------ resample with cross-shard clones
@@ -125,7 +137,7 @@ class ShardedPF:
 
     # ------------------------------------------------------------------ PFSlam2D::update, sharded
     def update(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
-        if self.world == 1:
+        if not self.collective:
             return self.pf.update(pts, odom_xyr, ts, origin, quat)
         phase = self.pf.update_begin(pts, odom_xyr, ts, origin, quat)
         if phase == 0:

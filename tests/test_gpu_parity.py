@@ -297,6 +297,43 @@ def test_loc2d_rank_deficient_covariance_gpu(F):
     h.close()
 
 
+def test_sharded_collective_path_on_rccl(F):
+    """The multi-rank code path of ShardedPF (device all-gather of the log-likelihoods over RCCL, resample planning, barrier /
+    max-over-ranks) forced on a world of ONE rank: must reproduce the plain PFSlam2D run bit for bit.  (More ranks need more
+    GPUs; the sharding logic itself is covered with gloo, world_size 2, in test_distributed_cpu.py.)"""
+    import os
+    import torch
+    import torch.distributed as dist
+    from iris_lama_amd.distributed import ShardedPF
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        P, steps = 12, 8
+        pts, odom, truth = F.corridor_log(steps, 1080)
+        kw = dict(particles=P, seed=11, gpu_device=0, meas_sigma_gain=0.01)       # small gain: resampling happens
+        a = ShardedPF(F.pf_options(**kw), force_collectives=True)
+        b = F.PFSlam2D(F.pf_options(**kw))
+        assert a.backend == "nccl" and a.device.type == "cuda"
+        a.set_prior(*odom[0]); b.set_prior(*odom[0])
+        for k in range(steps + 1):
+            assert a.update(pts[k], odom[k], float(k)) == b.update(pts[k], odom[k], float(k))
+            assert np.array_equal(a.pf.poses(), b.poses()), k
+            assert a.pf.best() == b.best()
+        assert a.max_over_ranks(1.25) == 1.25
+        a.barrier()
+        assert b.num_resamples() > 0 and a.pf.num_resamples() == b.num_resamples()
+        a.close(); b.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_canonical_brushfire_mode(F):
     """cfg.brushfire_mode = 1 (level-synchronous, canonical tie rule): bit-exact against the oracle's update_canonical(),
     and -- against the FAITHFUL oracle -- identical in everything but the obstacle offsets of tie cells."""
