@@ -824,7 +824,11 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 //     mask update is applied once the decision is known.
 // ------------------------------------------------------------------------------------------------
 #ifdef LAMA_PROFILE_BF
+#ifdef LAMA_PROFILE_BF_COUNT           // event counts instead of cycles (tools/prof_bf.py, LAMA_PROF_COUNT=1)
+#define BFT(k) do { (void)tprev; } while (0)
+#else
 #define BFT(k) do { const uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
+#endif
 #else
 #define BFT(k) do {} while (0)
 #endif
@@ -1323,6 +1327,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         // :183-192  valid, its obstacle still has sqdist 0 (valid NOT tested), and lower() :283 still queued
         const bool fire = (cs & SV_VALID) && (cos_ & SV_SQMASK) == 0 && (cs & SV_QUEUED);
         BFT(3);
+#ifdef LAMA_PROFILE_BF_COUNT
+        prof[0] += 1; prof[1] += fire ? 1 : 0; prof[2] += (obs_x(cob) != q_ox(e) || obs_y(cob) != q_oy(e)) ? 1 : 0;
+#endif
         if (fire) {
             const int cox = obs_x(cob), coy = obs_y(cob);
             const int obx = rx + cox, oby = ry + coy;
@@ -1341,12 +1348,18 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const uint32_t cmp = (s & SV_VALID) ? (uint32_t)(s & SV_SQMASK) : prm.max_sqdist;
             bool over = nbok && new_sq < cmp;
             const bool tie = nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK);     // :311-317
+#ifdef LAMA_PROFILE_BF_COUNT
+            prof[3] += __ballot(tie) ? 1 : 0;
+#endif
             if (__ballot(tie)) {
                 // the neighbour's own obstacle cell: usually the very cell the popped cell points to (both were
                 // reached from the same obstacle), whose state lane 5 already holds -- no second load round then
                 const int ox = x + obs_x(ob), oy = y + obs_y(ob);
                 const bool same = ox == obx && oy == oby;
                 uint16_t os = cos_;
+#ifdef LAMA_PROFILE_BF_COUNT
+                prof[4] += __ballot(tie && !same) ? 1 : 0;
+#endif
                 if (__ballot(tie && !same)) {
                     if (tie && !same) {
                         os = 0;
@@ -1369,6 +1382,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             // appended, exactly what the sequential push_heap calls would have done.
             const unsigned long long om = __ballot(over);
             const int ocnt = __popcll(om);
+#ifdef LAMA_PROFILE_BF_COUNT
+            prof[5] += ocnt;
+#endif
             bool done = ocnt == 0;
             if (TW) {                                          // the helper wave pushes: hand the entries over
                 tw_entry = q_entry(new_sq, x, y, obx - x, oby - y);

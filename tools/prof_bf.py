@@ -13,6 +13,8 @@ L.lama_hip_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
 names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "H:pop", "H:wait_D", "H:pushes"]
 if os.environ.get("LAMA_PROF_MAIN"):   # -DLAMA_PROFILE_BF_MAIN build: all eight buckets belong to the main wave
     names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "handover+pre_D", "post_D", "wait_D"]
+if os.environ.get("LAMA_PROF_COUNT"):  # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_COUNT build: event counts of the lower wave
+    names = ["lower_pops", "fire", "stale_entry", "tie", "tie_other_obstacle", "pushes", "-", "-"]
 for k in range(1, 13):
     poses = np.tile(F.pose_from_xyr(*truth[k]), (P, 1))
     ctx.set_poses(poses)
@@ -22,6 +24,10 @@ for k in range(1, 13):
     d = np.zeros((P, 8), dtype=np.uint64)
     L.lama_hip_debug_cycles(ctx.h, d.ctypes.data_as(C.c_void_p))
     pops = c["bf_cells"] / P
+    if os.environ.get("LAMA_PROF_COUNT"):
+        j = int(np.argmax(d[:, 0]))
+        print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:6])))
+        continue
     tot = d[0][:5].sum()
     print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms raycast {c['ms_raycast']:.3f} ms  cycles/pop {tot / max(pops,1):.0f} :: " +
           " ".join(f"{n}={d[0][i] / max(pops,1):.0f}" for i, n in enumerate(names)))
