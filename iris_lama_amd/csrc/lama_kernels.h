@@ -855,61 +855,22 @@ struct BfLds {
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
 // ---- LDS-resident libstdc++ heap (same algorithm as lama_heap.h).  All heap state is wave-uniform: every lane
-// executes the code, lane 0 stores.  The sift-down of pop() is resumable so that the two global load rounds of a
-// brushfire pop can be issued in between and complete underneath it.
-struct PopState { uint32_t hole, child, len; uint64_t value; bool active; };
-
-__device__ inline void lds_pop_begin(const uint64_t* h, uint32_t& size, PopState& st)
-{
-    --size;
-    st.active = size > 0;
-    st.len = size; st.hole = 0; st.child = 0;
-    st.value = st.active ? h[size] : 0;
-}
-// One "gather chunk" of __adjust_heap's first loop.  All heap state is wave-uniform, so instead of a chain of
-// dependent LDS reads (one per level) the wave looks at the whole 6-level subtree below the hole at once: lane L
-// holds the node at relative heap position L (children of L are 2L+1 and 2L+2; absolute index
-// hole * 2^depth(L) + L) and the priority of its sibling.  Every lane decides locally whether __adjust_heap,
-// standing on its parent, would step to it (`comp(right, left)` -> left, else right; the parent must have both
-// children); a ballot turns that into a mask and a lane is on the hole's path iff the bits of ALL its ancestors
-// are set -- one AND/compare against a per-lane constant (`anc`), no serial chase.  The moved entries are written
-// with a single ds_write: each node on the path stores itself into its parent's slot.
+// executes the code, lane 0 stores.
+// pop() looks at the whole 6-level subtree below the hole at once instead of chasing one dependent LDS read per
+// level: lane L holds the node at relative heap position L (children of L are 2L+1 and 2L+2; absolute index
+// hole * 2^depth(L) + L) and its sibling.  Every lane decides locally whether __adjust_heap, standing on its parent,
+// would step to it (`comp(right, left)` -> left, else right; the parent must have both children); a ballot turns that
+// into a mask and a lane is on the hole's path iff the bits of ALL its ancestors are set -- one AND/compare against a
+// per-lane constant (`anc`), no serial chase.  The moved entries are written with a single ds_write: each node on the
+// path stores itself into its parent's slot.
 __device__ __forceinline__ uint64_t lds_pop_ancestors(int lane)
 {
     uint64_t anc = 0;
     if (lane < 63) for (int a = lane; a > 0; a = (a - 1) >> 1) anc |= 1ull << a;
     return anc;
 }
-__device__ __forceinline__ void lds_pop_chunk(uint64_t* h, PopState& st, int lane, uint64_t anc)
-{
-    if (!st.active) return;
-    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
-    const uint32_t lim = (len - 1) / 2;
-    const uint32_t H = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
-    if (!(H < lim)) return;
-    const int d = 31 - __clz(lane + 1);
-    const uint32_t idx = (H << d) + (uint32_t)lane;                 // absolute heap index of my node
-    const bool is_left = (lane & 1) != 0;                           // H << d is even for d >= 1: odd index <=> odd lane
-    const uint32_t left = is_left ? idx : idx - 1;                  // my sibling pair: (left, left + 1), children of `parent`
-    const uint32_t parent = (left - 1) >> 1;
-    const bool cand = lane >= 1 && lane < 63 && parent < lim;       // my parent has both children (so both are < len)
-    const uint32_t la = cand ? left : 1u;                           // harmless address for idle lanes (len >= 3 here)
-    const uint64_t vl = h[la], vr = h[la + 1];                      // one ds_read2_b64
-    // __adjust_heap: child = right; if (comp(right, left)) child = left   with comp(a, b) = prio(a) > prio(b)
-    const bool take_left = heap_prio(vr) > heap_prio(vl);
-    const bool step_to_me = cand && (is_left == take_left);
-    const unsigned long long okm = __ballot(step_to_me);
-    const bool onpath = cand && (okm & anc) == anc;
-    const unsigned long long pathm = __ballot(onpath);
-    if (onpath) h[parent] = is_left ? vl : vr;                       // first[hole] = first[child], all levels at once
-    // new hole = deepest node of the path (the highest lane: lanes are numbered level by level)
-    const int rel = pathm ? 63 - __clzll((long long)pathm) : 0;
-    const uint32_t dd = 31 - __clz(rel + 1);
-    st.hole = (H << dd) + (uint32_t)rel;
-    st.child = st.hole;
-}
-// pop() as the helper wave of the two-wave brushfire runs it: the same final heap array as __adjust_heap +
-// __push_heap, computed top-down.  __adjust_heap moves every entry n_1 .. n_k of the hole's path (the preferred
+// The pop itself (run by the helper wave of the two-wave brushfire, or by the only wave): the same final heap array as
+// __adjust_heap + __push_heap, computed top-down.  __adjust_heap moves every entry n_1 .. n_k of the hole's path (the preferred
 // children down to a leaf) up one slot, then __push_heap walks the re-inserted last entry v back up, moving entries
 // with prio(n_i) > prio(v) down again -- into the very slots they came from.  Priorities are non-decreasing along
 // the path, so the net effect is: the entries with prio(n_i) <= prio(v), a prefix of the path, move up one slot, v
@@ -966,32 +927,6 @@ __device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size,
     }
     if (lane == 0) h[H] = value;
     return ((uint64_t)root_hi << 32) | root_lo;
-}
-__device__ __forceinline__ void lds_pop_finish(uint64_t* h, PopState& st, int lane, uint64_t anc)
-{
-    if (!st.active) return;
-    const bool writer = lane == 0;
-    const uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.len);
-    const uint32_t lim = (len - 1) / 2;
-    while ((uint32_t)__builtin_amdgcn_readfirstlane((int)st.child) < lim) lds_pop_chunk(h, st, lane, anc);
-    uint32_t hole = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.hole);
-    if ((len & 1) == 0 && hole == (len - 2) / 2) {
-        const uint32_t child = 2 * (hole + 1);
-        if (writer) h[hole] = h[child - 1];
-        hole = child - 1;
-    }
-    // __push_heap(first, hole, 0, value): wave-uniform, scalar control flow
-    const uint32_t vprio = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(st.value));
-    while (hole > 0) {
-        const uint32_t parent = (hole - 1) / 2;
-        const uint64_t pv = h[parent];
-        const uint32_t pprio = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(pv));
-        if (!(pprio > vprio)) break;
-        if (writer) h[hole] = pv;
-        hole = parent;
-    }
-    if (writer) h[hole] = st.value;
-    st.hole = hole;
 }
 __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t value, bool writer)
 {
@@ -1165,10 +1100,8 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     #define BF_POP_WITH_LOADS(H, N)                                                                         \
         BF_LOAD_A()                                                                                         \
         BFT(1);                                                                                             \
-        PopState ps_;                                                                                       \
-        if (TW) { --N; /* the helper wave pops */ } else { lds_pop_begin(H, N, ps_); lds_pop_chunk(H, ps_, lane, anc); } \
+        if (TW) { --N; /* the helper wave pops */ } else { (void)lds_pop_topdown(H, N, lane, anc); }        \
         BF_LOAD_B()                                                                                         \
-        if (!TW) lds_pop_finish(H, ps_, lane, anc);                                                         \
         BFT(2);
 
     // TW: hand both queues to the helper wave; from here on the main wave derives every next top itself
@@ -1306,9 +1239,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         if (TW) {
             --nl;                                              // the helper wave pops
         } else {
-            PopState ps_;
-            lds_pop_begin(sh.lower, nl, ps_);
-            lds_pop_finish(sh.lower, ps_, lane, anc);
+            (void)lds_pop_topdown(sh.lower, nl, lane, anc);
         }
         BFT(2);
         const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
