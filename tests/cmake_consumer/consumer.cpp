@@ -1,0 +1,40 @@
+// Compiles against the mirrored class API the way a node of iris_lama_ros does (pf_slam2d_ros.cpp: fills
+// lama::PFSlam2D::Options from parameters, builds a PointCloudXYZ per scan, calls update(cloud, odom, stamp)).
+// Without a GPU the constructor must fail loudly (no CPU fallback); that is what this program checks when it runs.
+#include <cstdio>
+#include <stdexcept>
+
+#include <lama/loc2d.h>
+#include <lama/pf_slam2d.h>
+#include <lama/slam2d.h>
+
+int main()
+{
+    lama::PFSlam2D::Options options;
+    options.particles = 4;
+    options.resolution = 0.05;
+    options.l2_max = 0.5;
+    options.seed = 7;
+    lama::Pose2D prior(1.0, 2.0, 0.25), step(0.5, 0.0, 0.1);
+    const lama::Pose2D next = prior + step;                     // SE2 composition, src/pose2d.cpp:76-96
+    if (std::fabs(next.rotation() - 0.35) > 1e-12) return 2;
+    lama::PointCloudXYZ::Ptr cloud(new lama::PointCloudXYZ);     // a room seen from its middle: 360 returns on a 3 m circle
+    for (int k = 0; k < 360; ++k) {
+        const double a = k * 3.14159265358979323846 / 180.0;
+        cloud->points.push_back(lama::Vector3d(3.0 * std::cos(a), 3.0 * std::sin(a), 0.0));
+    }
+    try {
+        lama::PFSlam2D slam(options);
+        slam.setPrior(prior);
+        const bool first = slam.update(cloud, prior, 0.0);
+        const bool second = slam.update(cloud, prior + lama::Pose2D(0.0, 0.0, 0.6), 1.0);   // past rot_thresh: a full update
+        const lama::Pose2D p = slam.getPose();
+        std::printf("device path ran: updates %d %d, %zu particles, pose %.3f %.3f %.3f\n", (int)first, (int)second,
+                    slam.getParticles().size(), p.x(), p.y(), p.rotation());
+        if (!second || std::fabs(p.x() - 1.0) > 0.2 || std::fabs(p.y() - 2.0) > 0.2) return 3;
+    } catch (const std::runtime_error& e) {
+        std::printf("no device: %s\n", e.what());                // expected on a box without an MI355X
+        return 0;
+    }
+    return 0;
+}
