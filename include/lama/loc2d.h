@@ -26,16 +26,6 @@ namespace lama {
 
 struct HipEngine;
 
-struct Vector3ui {
-    uint32_t v[3] = {0, 0, 0};
-    Vector3ui() {}
-    Vector3ui(uint32_t a, uint32_t b, uint32_t c) { v[0] = a; v[1] = b; v[2] = c; }
-    uint32_t& operator()(int i) { return v[i]; }
-    uint32_t operator()(int i) const { return v[i]; }
-    uint32_t& operator[](int i) { return v[i]; }
-    uint32_t operator[](int i) const { return v[i]; }
-};
-
 struct Matrix3d_ {      // 3x3 row-major stand-in for Eigen::Matrix3d (getCovar)
     double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     double operator()(int r, int c) const { return m[3 * r + c]; }

@@ -28,6 +28,7 @@
 
 #include "pose2d.h"
 #include "sdm_io.h"
+#include "sdm_maps.h"
 
 struct lama_hip_ctx;
 
@@ -119,6 +120,29 @@ public:
         return downloadOccupancyMap(m.ids, m.cells, m.masks);
     }
 
+    // The reference's accessors (include/lama/pf_slam2d.h:211-225): the best particle's occupancy / distance map, with the
+    // const query API consumers use (lama/sdm_maps.h: bounds, visit_all_cells, isFree / isOccupied / getProbability,
+    // distance, ...).  The maps live in HBM: what is returned is a host SNAPSHOT, downloaded on first use after an update and
+    // kept until the next update() call.  nullptr before the first scan or when the best particle lives on another shard.
+    const FrequencyOccupancyMap* getOccupancyMap() const
+    {
+        if (!occ_view_) {
+            sdm::HostMap m;
+            if (!downloadOccupancyMap(m)) return nullptr;
+            occ_view_.reset(new FrequencyOccupancyMap(std::move(m)));
+        }
+        return occ_view_.get();
+    }
+    const DynamicDistanceMap* getDistanceMap() const
+    {
+        if (!dm_view_) {
+            sdm::HostMap m;
+            if (!downloadDistanceMap(m)) return nullptr;
+            dm_view_.reset(new DynamicDistanceMap(std::move(m)));
+        }
+        return dm_view_.get();
+    }
+
     // ------------------------------------------------------------------ step-wise API (sharded operation)
     enum Phase { kNoUpdate = 0, kFirstScan = 1, kMatched = 2 };
     uint32_t localBegin() const { return lo_; }
@@ -169,6 +193,9 @@ private:
     // summary bookkeeping
     double t_begin_ = 0, t_solve_ = 0;
     bool scan_resident_ = false;
+    mutable std::unique_ptr<FrequencyOccupancyMap> occ_view_;     // snapshots handed out by getOccupancyMap / getDistanceMap
+    mutable std::unique_ptr<DynamicDistanceMap> dm_view_;
+    void dropMapViews() { occ_view_.reset(); dm_view_.reset(); }
 };
 
 } // namespace lama

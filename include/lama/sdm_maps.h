@@ -1,0 +1,213 @@
+// lama/sdm_maps.h -- read-only host views of maps downloaded from the device, with the const query API of the
+// reference's map classes, so that consumer code written against `const lama::FrequencyOccupancyMap*` /
+// `const lama::DynamicDistanceMap*` (iris_lama_ros builds its nav_msgs/OccupancyGrid and distance images from
+// getOccupancyMap() / getDistanceMap() this way) keeps compiling:
+//   lama::Map                     include/lama/sdm/map.h:109-296   w2m / m2w / bounds / visit_all_cells / visit_all_patches /
+//                                                                  resolution / patch_length / patches / memory / write
+//   lama::FrequencyOccupancyMap   src/sdm/frequency_occupancy_map.cpp:38-45,113-172   isFree / isOccupied / isUnknown / getProbability
+//   lama::ProbabilisticOccupancyMap src/sdm/probabilistic_occupancy_map.cpp:38-46,126-175   (LidarOdometry2D's log-odds map)
+//   lama::DynamicDistanceMap      src/sdm/dynamic_distance_map.cpp:66-91,140-158   distance(cell) / distance(point, gradient) / maxDistance
+// The views own a snapshot (lama::sdm::HostMap: the reference's record formats + Container masks); they are not the
+// live maps -- those stay in HBM -- and have no mutating members.  Header only.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <utility>
+
+#include "sdm_io.h"
+#include "types.h"
+
+namespace lama {
+
+class Map {
+public:
+    explicit Map(sdm::HostMap m) : host_(std::move(m))
+    {
+        resolution = host_.resolution;
+        scale = 1.0 / resolution;
+        patch_length = host_.patch_length;
+        patch_volume = patch_length * patch_length;
+        log2dim_ = 0;
+        while ((1u << log2dim_) < patch_length) ++log2dim_;
+        off_ = double(UNIVERSAL_CONSTANT >> 1) * double(patch_length);                 // src/sdm/map.cpp:42-59
+        index_.reserve(host_.ids.size() * 2);
+        for (size_t i = 0; i < host_.ids.size(); ++i) index_[host_.ids[i]] = i;
+    }
+    virtual ~Map() {}
+
+    static constexpr uint64_t UNIVERSAL_CONSTANT = 2642244;                            // include/lama/sdm/map.h:88
+    double resolution = 0.05, scale = 20.0;
+    uint32_t patch_length = 32, patch_volume = 1024;
+
+    // include/lama/sdm/map.h:125-126, 137-138, 147-148
+    Vector3ui w2m(const Vector3d& p) const
+    {
+        return Vector3ui((uint32_t)(scale * p[0] + off_ + 0.5), (uint32_t)(scale * p[1] + off_ + 0.5), (uint32_t)(scale * p[2] + off_ + 0.5));
+    }
+    Vector3d w2m_nocast(const Vector3d& p) const { return Vector3d(scale * p[0] + off_, scale * p[1] + off_, scale * p[2] + off_); }
+    Vector3d m2w(const Vector3ui& c) const
+    {
+        // tf_inv_ = (Translation(off) * Scaling(scale)).inverse(): linear = (s*s) * (1 / ((s*s)*s)), translation = -(linear * off)
+        const double l = (scale * scale) * (1.0 / ((scale * scale) * scale)), t = -(l * off_);
+        return Vector3d(l * (double)c(0) + t, l * (double)c(1) + t, l * (double)c(2) + t);
+    }
+    // src/sdm/map.cpp:139-157 (cells) and include/lama/sdm/map.h:221-225 (world): extent of the allocated patches
+    void bounds(Vector3ui& min, Vector3ui& max) const
+    {
+        min = Vector3ui(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        max = Vector3ui(0, 0, 0);
+        for (uint64_t id : host_.ids) {
+            const Vector3ui a = p2m(id);
+            for (int k = 0; k < 3; ++k) { min[k] = std::min(min(k), a(k)); max[k] = std::max(max(k), a(k)); }
+        }
+        for (int k = 0; k < 3; ++k) max[k] += patch_length;
+    }
+    void bounds(Vector3d& min, Vector3d& max) const
+    {
+        Vector3ui a, b;
+        bounds(a, b);
+        min = m2w(a); max = m2w(b);
+    }
+    // src/sdm/map.cpp:352-367: every cell whose Container mask bit is on / the anchor of every patch
+    template <typename F>
+    void visit_all_cells(F&& walker) const
+    {
+        for (size_t i = 0; i < host_.ids.size(); ++i) {
+            const Vector3ui anchor = p2m(host_.ids[i]);
+            const uint64_t* mask = &host_.masks[i * (patch_volume / 64)];
+            for (uint32_t c = 0; c < patch_volume; ++c)
+                if ((mask[c >> 6] >> (c & 63)) & 1ull)
+                    walker(Vector3ui(anchor(0) + (c & (patch_length - 1)), anchor(1) + (c >> log2dim_), anchor(2)));
+        }
+    }
+    template <typename F>
+    void visit_all_patches(F&& walker) const { for (uint64_t id : host_.ids) walker(p2m(id)); }
+
+    size_t patches() const { return host_.ids.size(); }                                  // number of allocated patches
+    size_t memory() const { return host_.cells.size() + host_.masks.size() * sizeof(uint64_t); }
+    bool write(const std::string& filename) const { return sdm::write(host_, filename); }   // the reference's .sdm format
+    const sdm::HostMap& snapshot() const { return host_; }
+
+protected:
+    // const Map::get (src/sdm/map.cpp:414-455): nullptr for an absent patch or a cell whose mask bit is off
+    const uint8_t* get(const Vector3ui& c) const
+    {
+        const uint64_t id = uint64_t(c(0) >> log2dim_) * UNIVERSAL_CONSTANT + uint64_t(c(1) >> log2dim_);   // m2p, map.h:153-161
+        const auto it = index_.find(id);
+        if (it == index_.end()) return nullptr;
+        const uint32_t m = patch_length - 1;
+        const uint32_t cell = (c(0) & m) | ((c(1) & m) << log2dim_);                                            // m2c, map.h:182-189
+        if (!((host_.masks[it->second * (patch_volume / 64) + (cell >> 6)] >> (cell & 63)) & 1ull)) return nullptr;
+        return &host_.cells[(it->second * (size_t)patch_volume + cell) * host_.cellSize()];
+    }
+    Vector3ui p2m(uint64_t id) const                                                                            // map.h:166-177
+    {
+        return Vector3ui(uint32_t((id / UNIVERSAL_CONSTANT) << log2dim_), uint32_t((id % UNIVERSAL_CONSTANT) << log2dim_), 0);
+    }
+
+    sdm::HostMap host_;
+    std::unordered_map<uint64_t, size_t> index_;
+    uint32_t log2dim_ = 5;
+    double off_ = 0.0;
+};
+
+class OccupancyMap : public Map {                     // include/lama/sdm/occupancy_map.h:66-76 (the const part)
+public:
+    using Map::Map;
+    virtual bool isFree(const Vector3ui& coordinates) const = 0;
+    virtual bool isOccupied(const Vector3ui& coordinates) const = 0;
+    virtual bool isUnknown(const Vector3ui& coordinates) const = 0;
+    virtual double getProbability(const Vector3ui& coordinates) const = 0;
+    bool isFree(const Vector3d& p) const { return isFree(w2m(p)); }
+    bool isOccupied(const Vector3d& p) const { return isOccupied(w2m(p)); }
+    bool isUnknown(const Vector3d& p) const { return isUnknown(w2m(p)); }
+    double getProbability(const Vector3d& p) const { return getProbability(w2m(p)); }
+};
+
+class FrequencyOccupancyMap : public OccupancyMap {
+public:
+    struct frequency { uint16_t occupied, visited; };                                   // frequency_occupancy_map.h:43-46
+    explicit FrequencyOccupancyMap(sdm::HostMap m) : OccupancyMap(std::move(m)) {}
+    using OccupancyMap::isFree; using OccupancyMap::isOccupied; using OccupancyMap::isUnknown; using OccupancyMap::getProbability;
+    bool isFree(const Vector3ui& c) const override { frequency f; return cell(c, f) && prob(f) < 0.25; }          // :119-125
+    bool isOccupied(const Vector3ui& c) const override { frequency f; return cell(c, f) && prob(f) > 0.25; }      // :132-138
+    bool isUnknown(const Vector3ui& c) const override { frequency f; return !cell(c, f) || f.visited == 0; }      // :145-151
+    double getProbability(const Vector3ui& c) const override { frequency f; return cell(c, f) ? prob(f) : 0.25; } // :166-172
+    bool counters(const Vector3ui& c, frequency& f) const { return cell(c, f); }
+
+private:
+    static double prob(const frequency& f) { return f.visited == 0 ? 0.25 : ((double)f.occupied) / ((double)f.visited); }   // :38-45
+    bool cell(const Vector3ui& c, frequency& f) const
+    {
+        const uint8_t* p = get(c);
+        if (!p) return false;
+        std::memcpy(&f, p, sizeof(f));
+        return true;
+    }
+};
+
+class ProbabilisticOccupancyMap : public OccupancyMap {
+public:
+    explicit ProbabilisticOccupancyMap(sdm::HostMap m) : OccupancyMap(std::move(m)) {}
+    using OccupancyMap::isFree; using OccupancyMap::isOccupied; using OccupancyMap::isUnknown; using OccupancyMap::getProbability;
+    bool isFree(const Vector3ui& c) const override { float l; return cell(c, l) && l < 0.0f; }                     // :131-137 (occ_thresh_ = 0)
+    bool isOccupied(const Vector3ui& c) const override { float l; return cell(c, l) && l > 0.0f; }                 // :144-150
+    bool isUnknown(const Vector3ui& c) const override { float l; return !cell(c, l) || l == 0.0f; }                // :157-163
+    double getProbability(const Vector3ui& c) const override { float l; return cell(c, l) ? prob(l) : prob(0.0f); }   // :169-175
+    bool logOdds(const Vector3ui& c, float& l) const { return cell(c, l); }
+
+private:
+    static float prob(const float& logods) { return 1.0 - 1.0 / (1.0 + std::exp(logods)); }                      // :38-41
+    bool cell(const Vector3ui& c, float& l) const
+    {
+        const uint8_t* p = get(c);
+        if (!p) return false;
+        std::memcpy(&l, p, sizeof(l));
+        return true;
+    }
+};
+
+class DynamicDistanceMap : public Map {
+public:
+#pragma pack(push, 1)
+    struct distance_t { int16_t obstacle[3]; uint16_t sqdist; bool valid_obstacle; bool is_queued; };   // dynamic_distance_map.h:48-53 (10 bytes)
+#pragma pack(pop)
+    explicit DynamicDistanceMap(sdm::HostMap m) : Map(std::move(m)) {}
+
+    double maxDistance() const { return std::sqrt((double)host_.max_sqdist) * resolution; }                      // :149-152
+    // :140-147
+    double distance(const Vector3ui& coordinates) const
+    {
+        distance_t d;
+        if (!cell(coordinates, d) || !d.valid_obstacle) return maxDistance();
+        return std::sqrt((double)d.sqdist) * resolution;
+    }
+    // :66-91 (2-D branch): bilinear value and gradient
+    double distance(const Vector3d& coordinates, Vector3d* gradient = nullptr) const
+    {
+        const Vector3d m = w2m_nocast(coordinates);
+        const uint32_t dx = (uint32_t)m[0], dy = (uint32_t)m[1];
+        const double mu0 = m[0] - (double)dx, mu1 = m[1] - (double)dy, muinv0 = 1.0 - mu0, muinv1 = 1.0 - mu1;
+        const double v0 = distance(Vector3ui(dx, dy, 0)), v1 = distance(Vector3ui(dx + 1, dy, 0));
+        const double v2 = distance(Vector3ui(dx, dy + 1, 0)), v3 = distance(Vector3ui(dx + 1, dy + 1, 0));
+        if (gradient) {
+            (*gradient)[0] = -((v0 - v1) * muinv1 + (v2 - v3) * mu1) * scale;
+            (*gradient)[1] = -((v0 - v2) * muinv0 + (v1 - v3) * mu0) * scale;
+            (*gradient)[2] = 0.0;
+        }
+        return v0 * muinv0 * muinv1 + v1 * muinv1 * mu0 + v2 * muinv0 * mu1 + v3 * mu0 * mu1;
+    }
+    bool cell(const Vector3ui& c, distance_t& d) const
+    {
+        const uint8_t* p = get(c);
+        if (!p) return false;
+        std::memcpy(&d, p, sizeof(d));
+        return true;
+    }
+};
+
+} // namespace lama

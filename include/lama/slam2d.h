@@ -16,6 +16,7 @@
 
 #include "pose2d.h"
 #include "sdm_io.h"
+#include "sdm_maps.h"
 
 struct lama_hip_ctx;
 
@@ -74,11 +75,33 @@ public:
         m.kind = sdm::kFrequencyOccupancyMap; m.resolution = resolution_;
         return downloadOccupancyMap(m.ids, m.cells, m.masks);
     }
+    // The reference's accessors (include/lama/slam2d.h:150-156) as host snapshots with the const query API (lama/sdm_maps.h);
+    // downloaded on first use after an update, kept until the next update() call; nullptr before the first scan.
+    const FrequencyOccupancyMap* getOccupancyMap() const
+    {
+        if (!occ_view_) {
+            sdm::HostMap m;
+            if (!downloadOccupancyMap(m)) return nullptr;
+            occ_view_.reset(new FrequencyOccupancyMap(std::move(m)));
+        }
+        return occ_view_.get();
+    }
+    const DynamicDistanceMap* getDistanceMap() const
+    {
+        if (!dm_view_) {
+            sdm::HostMap m;
+            if (!downloadDistanceMap(m)) return nullptr;
+            dm_view_.reset(new DynamicDistanceMap(std::move(m)));
+        }
+        return dm_view_.get();
+    }
     lama_hip_ctx* deviceContext() const { return ctx_; }
     const HipEngine* engine() const { return eng_.get(); }
 
 private:
     void fail(int32_t rc, const char* what) const;
+    mutable std::unique_ptr<FrequencyOccupancyMap> occ_view_;
+    mutable std::unique_ptr<DynamicDistanceMap> dm_view_;
     std::shared_ptr<HipEngine> eng_;
     lama_hip_ctx* ctx_ = nullptr;
     Pose2D odom_, pose_;

@@ -22,6 +22,7 @@ namespace lama {
 using Eigen::Quaterniond;
 using Eigen::Vector2d;
 using Eigen::Vector3d;
+typedef Eigen::Matrix<uint32_t, 3, 1> Vector3ui;      // include/lama/types.h of the reference
 }
 #else
 namespace lama {
@@ -52,6 +53,16 @@ struct Vector3d {
     double& operator[](int i) { return v[i]; }
     double operator[](int i) const { return v[i]; }
     static Vector3d Zero() { return Vector3d(); }
+};
+
+struct Vector3ui {
+    uint32_t v[3] = {0, 0, 0};
+    Vector3ui() {}
+    Vector3ui(uint32_t a, uint32_t b, uint32_t c) { v[0] = a; v[1] = b; v[2] = c; }
+    uint32_t& operator()(int i) { return v[i]; }
+    uint32_t operator()(int i) const { return v[i]; }
+    uint32_t& operator[](int i) { return v[i]; }
+    uint32_t operator[](int i) const { return v[i]; }
 };
 
 struct Quaterniond {

@@ -112,6 +112,14 @@ uint32_t lama_slam_processed_cells(const lama_slam* s);
 uint32_t lama_slam_iterations(const lama_slam* s);
 uint32_t lama_slam_deleted_patches(const lama_slam* s);
 void* lama_slam_device_context(const lama_slam* s);
+/* Queries on the snapshots returned by Slam2D::getOccupancyMap() / getDistanceMap() (include/lama/sdm_maps.h: the const
+ * query API of the reference's map classes).  which: 0 = occupancy, 1 = distance.  All return < 0 when no map is available. */
+int lama_slam_view_bounds(lama_slam* s, int which, uint32_t* min3, uint32_t* max3, double* wmin3, double* wmax3);
+int64_t lama_slam_view_cells(lama_slam* s, int which, uint32_t* xy_out, uint64_t cap);      /* visit_all_cells; returns the count */
+int lama_slam_view_occupancy(lama_slam* s, uint64_t n, const uint32_t* xy, uint8_t* is_free, uint8_t* is_occupied,
+                             uint8_t* is_unknown, double* probability);
+int lama_slam_view_distance_cells(lama_slam* s, uint64_t n, const uint32_t* xy, double* distance);
+int lama_slam_view_distance_points(lama_slam* s, uint64_t n, const double* xy, double* dist_gx_gy);   /* n x 3 out */
 const char* lama_slam_engine_origin(const lama_slam* s);
 
 /* ---- lama::Loc2D (include/lama/loc2d.h), flattened ---- */

@@ -353,6 +353,7 @@ HOST_SYMBOLS = [
     "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
     "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
     "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin", "lama_slam_deleted_patches", "lama_loc_create3",
+    "lama_slam_view_bounds", "lama_slam_view_cells", "lama_slam_view_occupancy", "lama_slam_view_distance_cells", "lama_slam_view_distance_points",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
@@ -388,6 +389,9 @@ def _bind_host(L):
         "lama_slam_enough_motion": (i32, [vp, vp]), "lama_slam_processed_cells": (u32, [vp]),
         "lama_slam_iterations": (u32, [vp]), "lama_slam_device_context": (vp, [vp]), "lama_slam_deleted_patches": (u32, [vp]),
         "lama_slam_engine_origin": (C.c_char_p, [vp]),
+        "lama_slam_view_bounds": (i32, [vp, i32, vp, vp, vp, vp]), "lama_slam_view_cells": (C.c_int64, [vp, i32, vp, C.c_uint64]),
+        "lama_slam_view_occupancy": (i32, [vp, C.c_uint64, vp, vp, vp, vp, vp]),
+        "lama_slam_view_distance_cells": (i32, [vp, C.c_uint64, vp, vp]), "lama_slam_view_distance_points": (i32, [vp, C.c_uint64, vp, vp]),
         "lama_loc_create": (vp, [d, d, d, d, u32, i32, vp, i32]), "lama_loc_destroy": (None, [vp]),
         "lama_loc_last_error": (C.c_char_p, [vp]), "lama_loc_engine_origin": (C.c_char_p, [vp]),
         "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_set_pose": (None, [vp, d, d, d]),
@@ -656,6 +660,41 @@ class Slam2D:
 
     def iterations(self):
         return self.L.lama_slam_iterations(self.h)
+
+    # ---- Slam2D::getOccupancyMap() / getDistanceMap(): host snapshots with the reference's const map API (lama/sdm_maps.h)
+    def view_bounds(self, which):
+        mn, mx = np.zeros(3, dtype=np.uint32), np.zeros(3, dtype=np.uint32)
+        wmn, wmx = np.zeros(3), np.zeros(3)
+        if self.L.lama_slam_view_bounds(self.h, int(which), _p(mn), _p(mx), _p(wmn), _p(wmx)) < 0:
+            return None
+        return mn, mx, wmn, wmx
+
+    def view_cells(self, which):
+        n = self.L.lama_slam_view_cells(self.h, int(which), None, 0)
+        if n < 0:
+            return None
+        out = np.zeros((n, 2), dtype=np.uint32)
+        self.L.lama_slam_view_cells(self.h, int(which), _p(out), n)
+        return out
+
+    def view_occupancy(self, cells_xy):
+        c = np.ascontiguousarray(cells_xy, dtype=np.uint32)
+        n = len(c)
+        fr, oc, un = (np.zeros(n, dtype=np.uint8) for _ in range(3))
+        pr = np.zeros(n)
+        if self.L.lama_slam_view_occupancy(self.h, n, _p(c), _p(fr), _p(oc), _p(un), _p(pr)) < 0:
+            return None
+        return fr.astype(bool), oc.astype(bool), un.astype(bool), pr
+
+    def view_distance_cells(self, cells_xy):
+        c = np.ascontiguousarray(cells_xy, dtype=np.uint32)
+        out = np.zeros(len(c))
+        return out if self.L.lama_slam_view_distance_cells(self.h, len(c), _p(c), _p(out)) >= 0 else None
+
+    def view_distance_points(self, pts_xy):
+        q = np.ascontiguousarray(pts_xy, dtype=np.float64)
+        out = np.zeros((len(q), 3))
+        return out if self.L.lama_slam_view_distance_points(self.h, len(q), _p(q), _p(out)) >= 0 else None
 
     def hip_context(self):
         ctx = HipContext.__new__(HipContext)

@@ -312,6 +312,80 @@ uint32_t lama_slam_deleted_patches(const lama_slam* h) { return h->s->getLastDel
 uint32_t lama_slam_iterations(const lama_slam* h) { return h->s->getLastIterations(); }
 void* lama_slam_device_context(const lama_slam* h) { return (void*)h->s->deviceContext(); }
 
+}   // extern "C"
+namespace {
+template <class M>
+int view_bounds(const M* m, uint32_t* min3, uint32_t* max3, double* wmin3, double* wmax3)
+{
+    if (!m) return -1;
+    Vector3ui a, b;
+    Vector3d wa, wb;
+    m->bounds(a, b);
+    m->bounds(wa, wb);
+    for (int k = 0; k < 3; ++k) { min3[k] = a(k); max3[k] = b(k); wmin3[k] = wa[k]; wmax3[k] = wb[k]; }
+    return 0;
+}
+template <class M>
+int64_t view_cells(const M* m, uint32_t* xy_out, uint64_t cap)
+{
+    if (!m) return -1;
+    uint64_t n = 0;
+    m->visit_all_cells([&](const Vector3ui& c) {
+        if (n < cap) { xy_out[2 * n] = c(0); xy_out[2 * n + 1] = c(1); }
+        ++n;
+    });
+    return (int64_t)n;
+}
+}
+extern "C" {
+
+int lama_slam_view_bounds(lama_slam* h, int which, uint32_t* min3, uint32_t* max3, double* wmin3, double* wmax3)
+{
+    try {
+        return which == 0 ? view_bounds(h->s->getOccupancyMap(), min3, max3, wmin3, wmax3) : view_bounds(h->s->getDistanceMap(), min3, max3, wmin3, wmax3);
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+int64_t lama_slam_view_cells(lama_slam* h, int which, uint32_t* xy_out, uint64_t cap)
+{
+    try {
+        return which == 0 ? view_cells(h->s->getOccupancyMap(), xy_out, cap) : view_cells(h->s->getDistanceMap(), xy_out, cap);
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+int lama_slam_view_occupancy(lama_slam* h, uint64_t n, const uint32_t* xy, uint8_t* is_free, uint8_t* is_occupied, uint8_t* is_unknown, double* probability)
+{
+    try {
+        const FrequencyOccupancyMap* m = h->s->getOccupancyMap();
+        if (!m) return -1;
+        for (uint64_t i = 0; i < n; ++i) {
+            const Vector3ui c(xy[2 * i], xy[2 * i + 1], 0);
+            is_free[i] = m->isFree(c); is_occupied[i] = m->isOccupied(c); is_unknown[i] = m->isUnknown(c); probability[i] = m->getProbability(c);
+        }
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+int lama_slam_view_distance_cells(lama_slam* h, uint64_t n, const uint32_t* xy, double* distance)
+{
+    try {
+        const DynamicDistanceMap* m = h->s->getDistanceMap();
+        if (!m) return -1;
+        for (uint64_t i = 0; i < n; ++i) distance[i] = m->distance(Vector3ui(xy[2 * i], xy[2 * i + 1], 0));
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+int lama_slam_view_distance_points(lama_slam* h, uint64_t n, const double* xy, double* out)
+{
+    try {
+        const DynamicDistanceMap* m = h->s->getDistanceMap();
+        if (!m) return -1;
+        for (uint64_t i = 0; i < n; ++i) {
+            Vector3d g;
+            out[3 * i] = m->distance(Vector3d(xy[2 * i], xy[2 * i + 1], 0.0), &g);
+            out[3 * i + 1] = g[0]; out[3 * i + 2] = g[1];
+        }
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+
 
 // ------------------------------------------------------------------ Loc2D
 struct lama_loc {

@@ -162,6 +162,7 @@ PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const P
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::PFSlam2D::update: empty scan");
     t_begin_ = now_s();
     scan_resident_ = false;
+    dropMapViews();
     current_surface_ = surface;
     scanToArrays(*surface);
     const uint32_t n = (uint32_t)surface->points.size();
@@ -261,6 +262,7 @@ void PFSlam2D::applyResample(const std::vector<int32_t>& sample_idx)
 void PFSlam2D::updateMaps()
 {
     const double t0 = now_s();
+    dropMapViews();
     const uint32_t n = (uint32_t)(pts_.size() / 3);
     // the scan is already resident on the device (uploaded by scan_match of this update)
     // queued, not awaited: the host part of the next scan overlaps with the kernels; the status is collected by the next call

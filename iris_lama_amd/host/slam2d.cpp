@@ -60,6 +60,7 @@ bool Slam2D::enoughMotion(const Pose2D& odometry)                 // src/slam2d.
 bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double /*timestamp*/)
 {
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::Slam2D::update: empty scan");
+    occ_view_.reset(); dm_view_.reset();
     std::vector<double> pts;
     double o[3], q[4], p[4];
     scan_arrays(*surface, pts, o, q);

@@ -584,6 +584,12 @@ public:
         if (cell == 0) return false;
         return prob(*cell) > 0.25;
     }
+    bool isUnknown(const V3u& c) const                  // :145-151
+    {
+        const frequency* cell = (const frequency*)get(c);
+        if (cell == 0) return true;
+        return cell->visited == 0;
+    }
     double getProbability(const V3u& c) const           // :166-172
     {
         const frequency* cell = (const frequency*)get(c);

@@ -151,6 +151,30 @@ void orc_occ_free(void* h) { delete (FrequencyOccupancyMap*)h; }
 int orc_occ_set_free(void* h, uint32_t x, uint32_t y, uint32_t z) { return ((FrequencyOccupancyMap*)h)->setFree(V3u{x, y, z}) ? 1 : 0; }
 int orc_occ_set_occupied(void* h, uint32_t x, uint32_t y, uint32_t z) { return ((FrequencyOccupancyMap*)h)->setOccupied(V3u{x, y, z}) ? 1 : 0; }
 double orc_occ_probability(void* h, uint32_t x, uint32_t y, uint32_t z) { return ((const FrequencyOccupancyMap*)h)->getProbability(V3u{x, y, z}); }
+// bit 0 isFree, bit 1 isOccupied, bit 2 isUnknown
+int orc_occ_state(void* h, uint32_t x, uint32_t y, uint32_t z)
+{
+    const FrequencyOccupancyMap* m = (const FrequencyOccupancyMap*)h;
+    return (m->isFree(V3u{x, y, z}) ? 1 : 0) | (m->isOccupied(V3u{x, y, z}) ? 2 : 0) | (m->isUnknown(V3u{x, y, z}) ? 4 : 0);
+}
+// Map::bounds (cells and world) and Map::visit_all_cells of either map class
+static void map_bounds(const Map* m, uint32_t* mn3, uint32_t* mx3, double* wmn3, double* wmx3)
+{
+    V3u a, b; V3d wa, wb;
+    m->bounds(a, b); m->bounds(wa, wb);
+    mn3[0] = a.x; mn3[1] = a.y; mn3[2] = a.z; mx3[0] = b.x; mx3[1] = b.y; mx3[2] = b.z;
+    wmn3[0] = wa.x; wmn3[1] = wa.y; wmn3[2] = wa.z; wmx3[0] = wb.x; wmx3[1] = wb.y; wmx3[2] = wb.z;
+}
+static int64_t map_cells(const Map* m, uint32_t* xy, uint64_t cap)
+{
+    uint64_t n = 0;
+    m->visit_all_cells([&](const V3u& c) { if (n < cap) { xy[2 * n] = c.x; xy[2 * n + 1] = c.y; } ++n; });
+    return (int64_t)n;
+}
+void orc_occ_bounds(void* h, uint32_t* mn3, uint32_t* mx3, double* wmn3, double* wmx3) { map_bounds((const FrequencyOccupancyMap*)h, mn3, mx3, wmn3, wmx3); }
+void orc_dm_bounds(void* h, uint32_t* mn3, uint32_t* mx3, double* wmn3, double* wmx3) { map_bounds((const DynamicDistanceMap*)h, mn3, mx3, wmn3, wmx3); }
+int64_t orc_occ_cells(void* h, uint32_t* xy, uint64_t cap) { return map_cells((const FrequencyOccupancyMap*)h, xy, cap); }
+int64_t orc_dm_cells(void* h, uint32_t* xy, uint64_t cap) { return map_cells((const DynamicDistanceMap*)h, xy, cap); }
 int orc_occ_patch_ids(void* h, uint64_t* ids, int cap) { return patch_ids((const FrequencyOccupancyMap*)h, ids, cap); }
 int orc_occ_patch_read(void* h, uint64_t id, uint8_t* cells, uint64_t* mask) { return patch_read((const FrequencyOccupancyMap*)h, id, cells, mask); }
 

@@ -136,7 +136,39 @@ def default_options(**kw):
     return o
 
 
+def _bind_map_queries():
+    L = lib()
+    if getattr(L, "_map_queries_bound", False):
+        return L
+    vp = C.c_void_p
+    for pre in ("orc_occ", "orc_dm"):
+        getattr(L, pre + "_bounds").restype = None
+        getattr(L, pre + "_bounds").argtypes = [vp, vp, vp, vp, vp]
+        getattr(L, pre + "_cells").restype = C.c_int64
+        getattr(L, pre + "_cells").argtypes = [vp, vp, C.c_uint64]
+    L.orc_occ_state.restype = C.c_int
+    L.orc_occ_state.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32]
+    L._map_queries_bound = True
+    return L
+
+
 class _MapBase:
+    def bounds(self):
+        """Map::bounds: (min cell, max cell, min world, max world)."""
+        L = _bind_map_queries()
+        mn, mx = np.zeros(3, dtype=np.uint32), np.zeros(3, dtype=np.uint32)
+        wmn, wmx = np.zeros(3), np.zeros(3)
+        getattr(L, self._pre + "_bounds")(self.h, _p(mn), _p(mx), _p(wmn), _p(wmx))
+        return mn, mx, wmn, wmx
+
+    def cells(self):
+        """Map::visit_all_cells: (n, 2) cell coordinates whose mask bit is on."""
+        L = _bind_map_queries()
+        n = getattr(L, self._pre + "_cells")(self.h, None, 0)
+        out = np.zeros((n, 2), dtype=np.uint32)
+        getattr(L, self._pre + "_cells")(self.h, _p(out), n)
+        return out
+
     _pre = None
     _dtype = None
 
@@ -236,6 +268,11 @@ class Occ(_MapBase):
 
     def probability(self, x, y, z=0):
         return lib().orc_occ_probability(self.h, x, y, z)
+
+    def state(self, x, y, z=0):
+        """(isFree, isOccupied, isUnknown)"""
+        b = _bind_map_queries().orc_occ_state(self.h, int(x), int(y), int(z))
+        return bool(b & 1), bool(b & 2), bool(b & 4)
 
 
 PROB_T = np.dtype([("prob", "<f4")])

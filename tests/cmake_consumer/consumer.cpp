@@ -32,6 +32,19 @@ int main()
         std::printf("device path ran: updates %d %d, %zu particles, pose %.3f %.3f %.3f\n", (int)first, (int)second,
                     slam.getParticles().size(), p.x(), p.y(), p.rotation());
         if (!second || std::fabs(p.x() - 1.0) > 0.2 || std::fabs(p.y() - 2.0) > 0.2) return 3;
+        // what pf_slam2d_ros does to publish the map: walk the occupancy map of the best particle
+        const lama::FrequencyOccupancyMap* map = slam.getOccupancyMap();
+        if (!map) return 4;
+        lama::Vector3ui imin, imax;
+        map->bounds(imin, imax);
+        size_t free_cells = 0, occupied_cells = 0;
+        map->visit_all_cells([&](const lama::Vector3ui& c) {
+            if (map->isFree(c)) ++free_cells; else if (map->isOccupied(c)) ++occupied_cells;
+        });
+        const lama::DynamicDistanceMap* dm = slam.getDistanceMap();
+        std::printf("map: %u x %u cells, %zu free, %zu occupied; distance at the prior %.3f m\n", imax(0) - imin(0), imax(1) - imin(1),
+                    free_cells, occupied_cells, dm ? dm->distance(lama::Vector3d(1.0, 2.0, 0.0)) : -1.0);
+        if (free_cells < 1000 || occupied_cells < 100 || !dm) return 5;
     } catch (const std::runtime_error& e) {
         std::printf("no device: %s\n", e.what());                // expected on a box without an MI355X
         return 0;

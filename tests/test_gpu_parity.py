@@ -269,6 +269,26 @@ def test_loc2d_gpu_vs_oracle(F):
     h.close()
 
 
+def test_slam2d_map_accessors_gpu(F):
+    """Slam2D::getOccupancyMap() / getDistanceMap(): snapshots of the device maps answer the reference's const map queries
+    (bounds, visit_all_cells, isFree / isOccupied / isUnknown / getProbability, distance, gradient) exactly like the oracle's
+    maps built from the same scans at the same (teacher-forced) poses."""
+    from _cmp import check_slam_views
+    steps = 8
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    o, h = O.Slam(), F.Slam2D()
+    assert h.engine_origin().endswith("liblama_hip.so")
+    o.set_pose(O.se2(*odom[0])); h.set_pose(*odom[0])
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+        assert np.abs(o.pose() - h.pose()).max() < 1e-8
+        p = o.pose()
+        h.set_pose(p[2], p[3], float(np.arctan2(p[1], p[0])))      # teacher forcing keeps the integer maps comparable
+        o.set_pose(h.pose())
+    check_slam_views(o, h, np.random.default_rng(4))
+    h.close()
+
+
 def test_loc2d_rank_deficient_covariance_gpu(F):
     """Rank-deficient branch of Solver::calculateCovariance (src/nlls/solver.cpp:143-149) on the device path: corridor
     with its ends out of sight, x unobservable -> variance 3.0 along x, (J^T J)-eigen pairs elsewhere."""

@@ -137,6 +137,20 @@ def test_slam2d_host_matches_oracle_bitwise():
     assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "occ")
 
 
+def test_slam2d_map_accessors_answer_like_the_reference_maps():
+    """Slam2D::getOccupancyMap() / getDistanceMap() (host snapshots, include/lama/sdm_maps.h) against the oracle's maps after a
+    run on the oracle-backed engine double: every query must agree exactly."""
+    from _cmp import check_slam_views
+    steps = 8
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o, h = O.Slam(), F.Slam2D()
+    assert h.view_bounds(0) is None and h.view_cells(1) is None          # before the first scan: nullptr
+    o.set_pose(O.se2(*odom[0])); h.set_pose(*odom[0])
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+    check_slam_views(o, h, np.random.default_rng(3))
+
+
 def test_loc2d_host_matches_oracle():
     """cfg 1: lama::Loc2D (predict + Solve with covariance + RMSE on a pre-built 0.05 m distance map) vs the oracle
     restatement of src/loc2d.cpp (engine = oracle-backed double, so the poses must agree bit for bit)."""
