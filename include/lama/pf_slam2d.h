@@ -101,6 +101,15 @@ public:
     double getNeff() const { return neff_; }
     void setPrior(const Pose2D& prior) { pose_ = prior; }
     uint64_t getMemoryUsage() const;
+    // src/pf_slam2d.cpp:164-176: P times the memory of particle 0's maps (the reference indexes particle 0 in its loop); patch
+    // payloads in the reference's record sizes.  Sharded: the first locally owned particle stands in when particle 0 lives elsewhere.
+    uint64_t getMemoryUsage(uint64_t& occmem, uint64_t& dmmem) const;
+    // include/lama/pf_slam2d.h:227: PNG of the best particle's occupancy map (sdm::export_to_png on its snapshot)
+    void saveOccImage(const std::string& name) const
+    {
+        const FrequencyOccupancyMap* m = getOccupancyMap();
+        if (m) sdm::export_to_png(m->snapshot(), name);
+    }
 
     // Best particle's maps in the reference's on-host record formats; patch ids are Map::m2p indices.
     // cells: 10240 B (distance_t) or 4096 B (frequency) per patch, masks: 16 x uint64 per patch.

@@ -95,6 +95,17 @@ public:
         }
         return dm_view_.get();
     }
+    // include/lama/slam2d.h:157-161
+    void saveOccImage(const std::string& name) const { const FrequencyOccupancyMap* m = getOccupancyMap(); if (m) sdm::export_to_png(m->snapshot(), name); }
+    void saveDistImage(const std::string& name) const { const DynamicDistanceMap* m = getDistanceMap(); if (m) sdm::export_to_png(m->snapshot(), name); }
+    // src/slam2d.cpp getMemoryUsage(occmem, dmmem): patch payloads in the reference's record sizes
+    uint64_t getMemoryUsage(uint64_t& occmem, uint64_t& dmmem) const
+    {
+        const FrequencyOccupancyMap* o = getOccupancyMap();
+        const DynamicDistanceMap* d = getDistanceMap();
+        occmem = o ? (uint64_t)o->patches() * 4096ull : 0; dmmem = d ? (uint64_t)d->patches() * 10240ull : 0;
+        return occmem + dmmem;
+    }
     lama_hip_ctx* deviceContext() const { return ctx_; }
     const HipEngine* engine() const { return eng_.get(); }
 

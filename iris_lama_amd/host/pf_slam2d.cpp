@@ -312,6 +312,17 @@ uint64_t PFSlam2D::getMemoryUsage() const
     return c.dm_patches * 10240ull + c.occ_patches * 4096ull;
 }
 
+uint64_t PFSlam2D::getMemoryUsage(uint64_t& occmem, uint64_t& dmmem) const
+{
+    occmem = 0; dmmem = 0;
+    if (!has_first_scan) return 0;
+    uint32_t nd = 0, no = 0;
+    if (eng_->pf_map_patches(ctx_, 0, LAMA_HIP_MAP_DISTANCE, &nd) != 0 || eng_->pf_map_patches(ctx_, 0, LAMA_HIP_MAP_OCCUPANCY, &no) != 0) return 0;
+    occmem = (uint64_t)options_.particles * no * 4096ull;
+    dmmem = (uint64_t)options_.particles * nd * 10240ull;
+    return occmem + dmmem;
+}
+
 static bool download(const HipEngine* e, lama_hip_ctx* ctx, uint32_t particle, int kind, size_t cell_bytes,
                      std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks)
 {

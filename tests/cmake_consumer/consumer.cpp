@@ -45,6 +45,9 @@ int main()
         std::printf("map: %u x %u cells, %zu free, %zu occupied; distance at the prior %.3f m\n", imax(0) - imin(0), imax(1) - imin(1),
                     free_cells, occupied_cells, dm ? dm->distance(lama::Vector3d(1.0, 2.0, 0.0)) : -1.0);
         if (free_cells < 1000 || occupied_cells < 100 || !dm) return 5;
+        uint64_t occmem = 0, dmmem = 0;
+        if (slam.getMemoryUsage(occmem, dmmem) != occmem + dmmem || occmem == 0 || dmmem == 0 || slam.getMemoryUsage() == 0) return 6;
+        slam.saveOccImage("/tmp/lama_consumer_occ.png");
     } catch (const std::runtime_error& e) {
         std::printf("no device: %s\n", e.what());                // expected on a box without an MI355X
         return 0;
