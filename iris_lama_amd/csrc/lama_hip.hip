@@ -86,11 +86,15 @@ struct lama_hip_ctx {
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
     PinVec<uint64_t> h_stats;
-    PinVec<double> h_tfs, h_pts, h_ll;
-    PinVec<int32_t> h_it;
+    PinVec<double> h_tfs, h_pts;
     PinVec<int32_t> h_err;
     double* d_tfs = nullptr;
     double* d_loglik = nullptr; int32_t* d_iters = nullptr;
+    // d_poses | d_loglik | d_iters | d_err are carved out of ONE allocation so that a scan match brings all of its results
+    // (and the error word) back with a single device-to-host copy
+    uint8_t* d_results = nullptr;
+    size_t results_bytes = 0;
+    PinVec<uint8_t> h_results;
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
@@ -199,7 +203,7 @@ void resolve_timers(lama_hip_ctx* c);
 
 // End of an API call: one stream synchronisation that brings back the device error word and, when asked, the
 // per-particle patch counts and statistics (a single host round trip per call).
-int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false)
+int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false, bool err_in_results = false)
 {
     c->h_err.resize(1);
     int32_t& e = c->h_err[0];
@@ -210,8 +214,9 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
         HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
     }
-    HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
     if (e != 0) {
         HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
@@ -414,7 +419,12 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
         CHK(hipMalloc(&ps.occ_mask, P * oc * 128));  CHK(hipMemset(ps.occ_mask, 0, P * oc * 128));
         CHK(hipMalloc(&ps.counts, P * 2 * 4));       CHK(hipMemset(ps.counts, 0, P * 2 * 4));
     }
-    CHK(hipMalloc(&c->d_poses, P * 4 * 8));
+    c->results_bytes = P * 4 * 8 + P * 8 + P * 4 + 8;
+    CHK(hipMalloc(&c->d_results, c->results_bytes));   CHK(hipMemset(c->d_results, 0, c->results_bytes));
+    c->d_poses = reinterpret_cast<double*>(c->d_results);
+    c->d_loglik = c->d_poses + P * 4;
+    c->d_iters = reinterpret_cast<int32_t*>(c->d_loglik + P);
+    c->d_err = c->d_iters + P;
     CHK(hipMalloc(&c->d_qlower, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_qraise, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_stats, P * 4 * 8));          CHK(hipMemset(c->d_stats, 0, P * 4 * 8));
@@ -424,10 +434,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
     CHK(hipMalloc(&c->d_occ_hit, P * oc * 128));     CHK(hipMemset(c->d_occ_hit, 0, P * oc * 128));
-    CHK(hipMalloc(&c->d_err, 4));                    CHK(hipMemset(c->d_err, 0, 4));
     CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
-    CHK(hipMalloc(&c->d_loglik, P * 8));
-    CHK(hipMalloc(&c->d_iters, P * 4));
     CHK(hipMalloc(&c->d_idx, P * 4));
     CHK(hipMalloc(&c->d_oldcounts, P * 2 * 4));
     CHK(hipDeviceSynchronize());
@@ -448,9 +455,9 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_poses); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
-    (void)hipFree(c->d_err); (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs); (void)hipFree(c->d_loglik);
-    (void)hipFree(c->d_iters); (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
+    (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
+    (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -531,15 +538,16 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
         t.stop();
     }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_poses.data(), c->d_poses, sizeof(double) * 4 * c->P, hipMemcpyDeviceToHost, c->stream));
-    c->h_ll.resize(c->P); c->h_it.resize(c->P);
-    if (loglik_out) HIPCHK(c, hipMemcpyAsync(c->h_ll.data(), c->d_loglik, sizeof(double) * c->P, hipMemcpyDeviceToHost, c->stream));
-    if (iters_out) HIPCHK(c, hipMemcpyAsync(c->h_it.data(), c->d_iters, sizeof(int32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
-    rc = check_device_errors(c, false, c->cfg.profile != 0);   // synchronises
+    // poses, log-likelihoods, iteration counts and the error word: one copy (they share an allocation)
+    c->h_results.resize(c->results_bytes);
+    HIPCHK(c, hipMemcpyAsync(c->h_results.data(), c->d_results, c->results_bytes, hipMemcpyDeviceToHost, c->stream));
+    rc = check_device_errors(c, false, c->cfg.profile != 0, true);   // synchronises
     if (rc) return rc;
-    if (poses_out) std::memcpy(poses_out, c->h_poses.data(), sizeof(double) * 4 * c->P);
-    if (loglik_out) std::memcpy(loglik_out, c->h_ll.data(), sizeof(double) * c->P);
-    if (iters_out) std::memcpy(iters_out, c->h_it.data(), sizeof(int32_t) * c->P);
+    const uint8_t* r = c->h_results.data();
+    std::memcpy(c->h_poses.data(), r, sizeof(double) * 4 * c->P);
+    if (poses_out) std::memcpy(poses_out, r, sizeof(double) * 4 * c->P);
+    if (loglik_out) std::memcpy(loglik_out, r + sizeof(double) * 4 * c->P, sizeof(double) * c->P);
+    if (iters_out) std::memcpy(iters_out, r + sizeof(double) * 5 * c->P, sizeof(int32_t) * c->P);
     return LAMA_HIP_OK;
 }
 
