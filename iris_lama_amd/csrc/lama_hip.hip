@@ -303,7 +303,8 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
-            const int bpw = count <= 64 ? 4 : 16;                            // see k_ray_visits
+            const char* bpw_env = getenv("LAMA_HIP_RAY_BPW");
+            const int bpw = bpw_env ? atoi(bpw_env) : (count <= 64 ? 4 : 16);                            // see k_ray_visits
             hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + 4 * bpw - 1) / (4 * bpw)), dim3(256), 0, c->stream, prm,
                                c->d_pts, (int)n, c->d_tfs, (int)first, bpw);
             if (count <= 512) {
