@@ -623,6 +623,48 @@ def test_full_size_3000_particles_properties(F):
     ctx.close()
 
 
+def test_full_size_3000_distinct_particles_vs_oracle(F):
+    """BASELINE config 2 size with 3000 DIFFERENT particles: scan match of all 3000 against the oracle (poses <= 1e-8, log-lik
+    rel 1e-9, identical Gauss-Newton iteration counts), then -- at the oracle's poses -- the map update: bit-exact maps for a
+    sample of particles, and the patch counters of ALL 3000 add up to the oracle's."""
+    import os
+    P = 3000
+    pts, odom, truth = F.corridor_log(2, 1080)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=5, threads=min(64, os.cpu_count() or 1)))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(12)
+    for k in (1, 2):
+        noise = rng.normal(0, [0.04, 0.04, 0.015], size=(P, 3))
+        start = np.stack([O.se2_mul(O.se2(*truth[k]), O.se2(*noise[i])) for i in range(P)])
+        pf.set_poses(start)
+        pf.set_weights(w=np.zeros(P), ws=np.zeros(P))
+        pf.stage_set_scan(pts[k])
+        pf.stage_scan_match()
+        ctx.set_poses(start)
+        ctx.reset_counters()
+        g_poses, g_ll, g_it = ctx.scan_match(pts[k])
+        o_poses, o_ll = pf.poses(), pf.weights()[0]
+        assert np.abs(g_poses - o_poses).max() < 1e-8
+        assert np.allclose(g_ll, o_ll, rtol=1e-9, atol=0)
+        o_it = np.array([pf.counters(i)["iterations"] for i in range(P)])
+        assert ctx.counters()["gn_iterations"] == int(o_it.sum())
+        assert len(np.unique(np.round(g_poses, 6), axis=0)) > P // 2          # the particles really differ
+        ctx.set_poses(o_poses)                                               # teacher forcing: integer maps stay comparable
+        pf.stage_update_maps()
+        ctx.update_maps(pts[k])
+    c = ctx.counters()
+    assert c["dm_patches"] == sum(len(pf.dm(i).patch_ids()) for i in range(P))
+    assert c["occ_patches"] == sum(len(pf.occ(i).patch_ids()) for i in range(P))
+    for i in (0, 1, 777, 1500, 2222, 2999):
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+    ctx.close()
+
+
 def test_limits_fail_loudly_with_status_codes(F):
     """A cell outside the device window, a full patch arena, too many order-sensitive visits and an invalid configuration are
     errors with a status code and a message -- never silent truncation (include/lama_hip.h status codes)."""
