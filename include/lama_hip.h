@@ -150,6 +150,12 @@ int32_t lama_hip_sync(lama_hip_ctx* ctx);
  *   lama_hip_pf_delete_patches: Map::deletePatchAt (src/sdm/map.cpp:465-488) on BOTH maps of the particle for every listed patch
  *                               index (absent patches are skipped); the arenas stay dense.  *deleted = distance-map patches removed. */
 int32_t lama_hip_pf_patch_ids(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap, uint64_t* patch_ids, uint32_t* num_patches);
+/* One 64-bit checksum per particle of its distance / occupancy map, computed on the device: order-independent sum over the
+ * allocated patches (reference patch indices, Map::m2p) and their cells of a hash of what the reference stores per cell
+ * (distance_t / frequency, include/lama/sdm/dynamic_distance_map.h:48-53, frequency_occupancy_map.h:43-46) and of the
+ * Container mask bit (include/lama/sdm/container.h:167-183).  Two maps with equal patch sets, cells and masks have equal
+ * checksums; used to compare ALL particles of a large filter with a checker without downloading the maps.  out: P values. */
+int32_t lama_hip_pf_map_checksums(lama_hip_ctx* ctx, int32_t kind, uint64_t* out);
 int32_t lama_hip_pf_delete_patches(lama_hip_ctx* ctx, uint32_t particle, const uint64_t* patch_ids, uint32_t n, uint32_t* deleted);
 
 /* Batched evaluation on ONE particle's distance map (Loc2D::globalLocalization-style):

@@ -641,6 +641,24 @@ int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, 
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_pf_map_checksums(lama_hip_ctx* c, int32_t kind, uint64_t* out)
+{
+    if (!c || !out || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    if (c->cfg.occupancy_policy != 0 && kind == LAMA_HIP_MAP_OCCUPANCY) return fail(c, LAMA_HIP_E_INVALID, "map checksums cover the frequency occupancy policy");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    uint64_t* d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_out, sizeof(uint64_t) * c->P));
+    DevParams prm = make_params(c, c->cur);
+    hipLaunchKernelGGL(k_map_checksum, dim3(c->P), dim3(256), 0, c->stream, prm, kind == LAMA_HIP_MAP_DISTANCE ? 0 : 1, d_out);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(uint64_t) * c->P, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_out);
+    HIPCHK(c, e);
+    return LAMA_HIP_OK;
+}
+
 // Map::deletePatchAt on both maps.  The arenas are bump allocated (slot = count++), so a deleted slot is refilled with the
 // last used slot and the directory entry of that patch is redirected: the arena stays dense.  Host driven (a handful of
 // patches per scan at most): device-to-device copies + memsets on the context's stream.

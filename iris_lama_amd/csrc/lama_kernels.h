@@ -1375,6 +1375,58 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_map_checksum -- order-independent 64-bit checksum of one particle's map (lama_hip_pf_map_checksums): the sum, modulo
+// 2^64, over the allocated patches of mix(patch id) and over their cells of mix(patch id * 1024 + cell, fields), where the
+// fields are what the reference stores for the cell (distance_t: obstacle offset, sqdist, valid, queued; frequency: occupied,
+// visited) plus the Container mask bit; all-zero cells add nothing.  Lets a caller compare ALL particles' maps with maps
+// held elsewhere without downloading them (the same sum is easily computed from the reference's records).
+// ------------------------------------------------------------------------------------------------
+LAMA_HD uint64_t cks_mix(uint64_t x)                      // splitmix64 finaliser
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+LAMA_HD uint64_t cks_cell(uint64_t patch_id, uint32_t cell, uint64_t fields) { return fields ? cks_mix((patch_id * 1024ull + cell) ^ cks_mix(fields)) : 0ull; }
+
+__global__ __launch_bounds__(256) void k_map_checksum(DevParams prm, int kind /*0 distance, 1 occupancy*/, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t part[4];
+    const int p = blockIdx.x;
+    const size_t WW = (size_t)prm.W * prm.W;
+    const int16_t* dir = (kind == 0 ? prm.dm_dir : prm.occ_dir) + (size_t)p * WW;
+    uint64_t acc = 0;
+    for (uint32_t w = 0; w < (uint32_t)WW; ++w) {
+        const int slot = dir[w];
+        if (slot < 0) continue;
+        const uint32_t wy = w / prm.W, wx = w % prm.W;
+        const uint64_t id = ((uint64_t)(prm.wx0 >> 5) + wx) * 2642244ull + ((uint64_t)(prm.wy0 >> 5) + wy);
+        if (threadIdx.x == 0) acc += cks_mix(id ^ 0x5DEECE66Dull);
+        for (uint32_t c = threadIdx.x; c < 1024u; c += 256u) {
+            uint64_t f;
+            if (kind == 0) {
+                const uint64_t m = (prm.dm_mask[((size_t)p * prm.dm_cap + slot) * 16 + (c >> 6)] >> (c & 63)) & 1ull;
+                f = (uint64_t)prm.dm_sv[((size_t)p * prm.dm_cap + slot) * 1024 + c] | ((uint64_t)prm.dm_obs[((size_t)p * prm.dm_cap + slot) * 1024 + c] << 16) | (m << 48);
+            } else {
+                // Container mask of a frequency cell = "visited != 0", plus the plane bits kept for uint16 wraps (as in the download)
+                const uint32_t ov = prm.occ[((size_t)p * prm.occ_cap + slot) * 1024 + c];
+                const uint64_t m = ((prm.occ_mask[((size_t)p * prm.occ_cap + slot) * 16 + (c >> 6)] >> (c & 63)) & 1ull) | ((ov >> 16) ? 1ull : 0ull);
+                f = (uint64_t)ov | (m << 48);
+            }
+            acc += cks_cell(id, c, f);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)acc, off, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(acc >> 32), off, 64);
+        acc += ((uint64_t)hi << 32) | lo;
+    }
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[p] = part[0] + part[1] + part[2] + part[3];
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_brushfire_slow -- generic single-lane DynamicDistanceMap::update with both queues in HBM (libstdc++ heap of
 // lama_heap.h).  Runs only for particles k_brushfire flagged (queue larger than its LDS window, e.g. the very
 // first scan of a large open space) and resumes exactly where it stopped.

@@ -53,6 +53,7 @@ HIP_SYMBOLS = [
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
     "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
+    "lama_hip_pf_map_checksums",
 ]
 
 _hip = None
@@ -107,6 +108,9 @@ def _bind_hip(L):
         L.lama_hip_pf_patch_ids.argtypes = [vp, u32, i32, u32, vp, vp]
         L.lama_hip_pf_delete_patches.argtypes = [vp, u32, vp, u32, vp]
         L.lama_hip_map_sample_likelihood.argtypes = [vp, u32, vp, u32, vp, vp, C.c_double, vp, u32, u32, vp]
+        has_cks = hasattr(L, "lama_hip_pf_map_checksums")   # device-only diagnostic (absent from the engine test double)
+        if has_cks:
+            L.lama_hip_pf_map_checksums.argtypes = [vp, i32, vp]
         has_pgo = hasattr(L, "lama_hip_pgo_create")       # the engine test double (tests/cpu_engine) has no pose-graph part
         if has_pgo:
             L.lama_hip_pgo_create.argtypes = [i32, u32, vp, vp, vp, vp, u32, vp]
@@ -117,6 +121,8 @@ def _bind_hip(L):
             L.lama_hip_pgo_linearize.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
         for s in HIP_SYMBOLS:
             if s.startswith("lama_hip_pgo_") and not has_pgo:
+                continue
+            if s == "lama_hip_pf_map_checksums" and not has_cks:
                 continue
             if s not in ("lama_hip_default_cfg", "lama_hip_ctx_destroy", "lama_hip_last_error", "lama_hip_pgo_destroy",
                          "lama_hip_pgo_last_error"):
@@ -237,6 +243,12 @@ class HipContext:
 
     def sync(self):
         self._chk(self.L.lama_hip_sync(self.h))
+
+    def map_checksums(self, kind):
+        """One 64-bit checksum per particle of its distance / occupancy map (patch set, cells, masks), computed on the device."""
+        out = np.zeros(self.P, dtype=np.uint64)
+        self._chk(self.L.lama_hip_pf_map_checksums(self.h, kind, _p(out)))
+        return out
 
     def patch_ids(self, particle, kind):
         n = C.c_uint32(0)

@@ -310,6 +310,53 @@ void orc_pf_counters(void* h, int i, uint64_t* out9)
     out9[0] = c.iterations; out9[1] = c.evals; out9[2] = c.ray_cells; out9[3] = c.occ_events; out9[4] = c.bf_processed;
     out9[5] = c.n_match; out9[6] = c.n_occ; out9[7] = c.n_bf; out9[8] = c.n_match_or_bf;
 }
+// The checksum lama_hip_pf_map_checksums computes on the device (iris_lama_amd/csrc/lama_kernels.h, k_map_checksum), from the
+// checker's maps: sum mod 2^64 over the patches of mix(id ^ c0) and over their cells of mix((id * 1024 + cell) ^ mix(fields)),
+// fields = the cell's stored values in the device's packing + the Container mask bit << 48; all-zero cells add nothing.
+static uint64_t cks_mix(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+}   // extern "C"
+template <class FIELDS>
+static uint64_t map_checksum(const Map* m, FIELDS fields)
+{
+    uint64_t acc = 0;
+    for (auto& kv : m->patches) {
+        const uint64_t id = kv.first;
+        acc += cks_mix(id ^ 0x5DEECE66Dull);
+        const Container& c = *kv.second;
+        for (uint32_t cell = 0; cell < 1024u; ++cell) {
+            const uint64_t f = fields(c, cell) | (((c.mask[cell >> 6] >> (cell & 63)) & 1ull) << 48);
+            if (f) acc += cks_mix((id * 1024ull + cell) ^ cks_mix(f));
+        }
+    }
+    return acc;
+}
+extern "C" {
+void orc_pf_map_checksums(void* h, int kind /*0 distance, 1 occupancy*/, uint64_t* out)
+{
+    auto& ps = ((PFBox*)h)->pf->particles();
+    for (size_t i = 0; i < ps.size(); ++i) {
+        if (kind == 0)
+            out[i] = map_checksum(ps[i].dm.get(), [](const Container& c, uint32_t cell) {
+                distance_t d;
+                std::memcpy(&d, c.data.data() + (size_t)cell * sizeof(distance_t), sizeof(d));
+                const uint64_t sv = (uint64_t)(d.sqdist & 0x3FFFu) | (d.valid_obstacle ? 0x8000ull : 0ull) | (d.is_queued ? 0x4000ull : 0ull);
+                const uint64_t ob = (uint64_t)(uint16_t)d.obstacle[0] | ((uint64_t)(uint16_t)d.obstacle[1] << 16);
+                return sv | (ob << 16);
+            });
+        else
+            out[i] = map_checksum(ps[i].occ.get(), [](const Container& c, uint32_t cell) {
+                uint16_t ov[2];                                   // frequency { occupied, visited }
+                std::memcpy(ov, c.data.data() + (size_t)cell * 4, 4);
+                return (uint64_t)ov[0] | ((uint64_t)ov[1] << 16);
+            });
+    }
+}
 int orc_pf_last_sample_idx(void* h, int32_t* out, int cap)
 {
     auto& v = ((PFBox*)h)->pf->last_sample_idx;

@@ -432,6 +432,15 @@ class PF:
         lib().orc_pf_counters(self.h, i, _p(c))
         return dict(zip(["iterations", "evals", "ray_cells", "occ_events", "bf_processed", "n_match", "n_occ", "n_bf", "n_match_or_bf"], c.tolist()))
 
+    def map_checksums(self, kind):
+        """Per-particle map checksums, the function lama_hip_pf_map_checksums computes on the device (kind: 0 distance, 1 occupancy)."""
+        L = lib()
+        L.orc_pf_map_checksums.restype = None
+        L.orc_pf_map_checksums.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        out = np.zeros(self.P, dtype=np.uint64)
+        L.orc_pf_map_checksums(self.h, int(kind), _p(out))
+        return out
+
     def last_sample_idx(self):
         out = np.zeros(self.P, dtype=np.int32)
         n = lib().orc_pf_last_sample_idx(self.h, _p(out), self.P)

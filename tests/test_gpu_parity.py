@@ -625,8 +625,8 @@ def test_full_size_3000_particles_properties(F):
 
 def test_full_size_3000_distinct_particles_vs_oracle(F):
     """BASELINE config 2 size with 3000 DIFFERENT particles: scan match of all 3000 against the oracle (poses <= 1e-8, log-lik
-    rel 1e-9, identical Gauss-Newton iteration counts), then -- at the oracle's poses -- the map update: bit-exact maps for a
-    sample of particles, and the patch counters of ALL 3000 add up to the oracle's."""
+    rel 1e-9, identical Gauss-Newton iteration counts), then -- at the oracle's poses -- the map update: the map checksums of ALL
+    3000 particles equal the oracle's (checksum of checksums), a sample of maps compared cell by cell, patch counters add up."""
     import os
     P = 3000
     pts, odom, truth = F.corridor_log(2, 1080)
@@ -659,6 +659,10 @@ def test_full_size_3000_distinct_particles_vs_oracle(F):
     c = ctx.counters()
     assert c["dm_patches"] == sum(len(pf.dm(i).patch_ids()) for i in range(P))
     assert c["occ_patches"] == sum(len(pf.occ(i).patch_ids()) for i in range(P))
+    # a checksum of every particle's maps (patch set, every cell, every mask bit), computed on the device and by the checker
+    g_dm, g_occ = ctx.map_checksums(F.MAP_DISTANCE), ctx.map_checksums(F.MAP_OCCUPANCY)
+    assert np.array_equal(g_dm, pf.map_checksums(0)) and np.array_equal(g_occ, pf.map_checksums(1))
+    assert len(np.unique(g_dm)) > P // 2 and len(np.unique(g_occ)) > P // 2      # different particles, different maps
     for i in (0, 1, 777, 1500, 2222, 2999):
         assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
