@@ -141,6 +141,31 @@ def test_free_running_host_class_tracks_oracle_and_truth(F):
     h.close()
 
 
+def test_free_running_3000_particles_tracks_oracle(F):
+    """BASELINE config 2 size, free running (no teacher forcing): lama::PFSlam2D with 3000 particles on the GPU next to the
+    oracle with the same seed for 6 scans, default gain and the forced-resample gain: the host RNG streams are identical, so
+    every particle's pose must stay within 1e-6 m of the oracle's, with the same resampling decisions and best particle."""
+    import os
+    P, steps = 3000, 5
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    for gain in (3.0, 1e-4):                       # 1 / (gain * P) is what enters the weights (src/pf_slam2d.cpp:514)
+        h = F.PFSlam2D(F.pf_options(particles=P, seed=9, meas_sigma_gain=gain))
+        o = O.PF(O.default_options(particles=P, seed=9, meas_sigma_gain=gain, threads=min(64, os.cpu_count() or 1)))
+        h.set_prior(*odom[0])
+        o.set_prior(O.se2(*odom[0]))
+        for k in range(steps + 1):
+            assert h.update(pts[k], odom[k], float(k)) == o.update(pts[k], O.se2(*odom[k]), float(k))
+            assert np.abs(h.poses() - o.poses()).max() < 1e-6, (gain, k)
+            assert h.num_resamples() == o.num_resamples(), (gain, k)
+            assert h.best() == o.best(), (gain, k)
+            assert abs(h.neff() - o.neff()) <= 1e-6 * max(1.0, o.neff()), (gain, k)
+        if gain < 1.0:
+            assert h.num_resamples() > 0
+        gp = h.best_pose_xyr()
+        assert np.hypot(gp[0] - truth[steps][0], gp[1] - truth[steps][1]) < 0.05
+        h.close()
+
+
 def test_sharded_two_ranks_one_gpu_gloo(F):
     """G = 2 logical shards on ONE device (two processes, gloo collectives, blobs staged through the GPU):
     exercises export/import of particles in HBM and the sharded driver against the real HIP library."""
