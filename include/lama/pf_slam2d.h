@@ -148,6 +148,7 @@ public:
             sdm::HostMap m;
             if (!downloadDistanceMap(m)) return nullptr;
             dm_view_.reset(new DynamicDistanceMap(std::move(m)));
+            dm_view_->bindDevice(eng_, ctx_, (uint32_t)getBestParticleIdx() - lo_);
         }
         return dm_view_.get();
     }

@@ -28,6 +28,8 @@ struct SE2d {
     // {c, s, tx, ty}: the layout the C-ABI of include/lama_hip.h uses
     void toArray(double out4[4]) const;
     static SE2d fromArray(const double in4[4]);
+    // Sophus SE2::exp of the tangent [vx, vy, theta] (include/lama/sophus/se2.hpp:389-411; small-angle branch below 1e-10)
+    static SE2d exp(double vx, double vy, double theta);
 };
 
 struct Pose2D {

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -21,7 +22,11 @@
 #include "sdm_io.h"
 #include "types.h"
 
+struct lama_hip_ctx;
+
 namespace lama {
+
+struct HipEngine;
 
 class Map {
 public:
@@ -178,6 +183,16 @@ public:
 #pragma pack(pop)
     explicit DynamicDistanceMap(sdm::HostMap m) : Map(std::move(m)) {}
 
+    // Which live device map this snapshot was taken from (set by Slam2D / PFSlam2D::getDistanceMap()): lama::MatchSurface2D
+    // evaluates against THAT map on the GPU, not against the host copy.
+    struct DeviceBinding {
+        std::shared_ptr<HipEngine> engine;
+        ::lama_hip_ctx* ctx = nullptr;
+        uint32_t particle = 0;
+    };
+    void bindDevice(std::shared_ptr<HipEngine> e, ::lama_hip_ctx* ctx, uint32_t particle) { dev_.engine = std::move(e); dev_.ctx = ctx; dev_.particle = particle; }
+    const DeviceBinding& device() const { return dev_; }
+
     double maxDistance() const { return std::sqrt((double)host_.max_sqdist) * resolution; }                      // :149-152
     // :140-147
     double distance(const Vector3ui& coordinates) const
@@ -208,6 +223,9 @@ public:
         std::memcpy(&d, p, sizeof(d));
         return true;
     }
+
+private:
+    DeviceBinding dev_;
 };
 
 } // namespace lama

@@ -92,6 +92,7 @@ public:
             sdm::HostMap m;
             if (!downloadDistanceMap(m)) return nullptr;
             dm_view_.reset(new DynamicDistanceMap(std::move(m)));
+            dm_view_->bindDevice(eng_, ctx_, 0u);
         }
         return dm_view_.get();
     }

@@ -23,6 +23,8 @@ using Eigen::Quaterniond;
 using Eigen::Vector2d;
 using Eigen::Vector3d;
 typedef Eigen::Matrix<uint32_t, 3, 1> Vector3ui;      // include/lama/types.h of the reference
+using Eigen::MatrixXd;
+using Eigen::VectorXd;
 }
 #else
 namespace lama {
@@ -63,6 +65,38 @@ struct Vector3ui {
     uint32_t operator()(int i) const { return v[i]; }
     uint32_t& operator[](int i) { return v[i]; }
     uint32_t operator[](int i) const { return v[i]; }
+};
+
+// dynamic vector / column-major matrix with the handful of members the nlls interface touches (size / rows / cols / resize /
+// element access / data); NOT an Eigen replacement -- with Eigen installed these names are Eigen's
+struct VectorXd {
+    std::vector<double> v;
+    VectorXd() {}
+    explicit VectorXd(size_t n) : v(n, 0.0) {}
+    static VectorXd Zero(size_t n) { return VectorXd(n); }
+    size_t size() const { return v.size(); }
+    size_t rows() const { return v.size(); }
+    void resize(size_t n) { v.resize(n); }
+    double& operator[](size_t i) { return v[i]; }
+    double operator[](size_t i) const { return v[i]; }
+    double& operator()(size_t i) { return v[i]; }
+    double operator()(size_t i) const { return v[i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
+    double squaredNorm() const { double s = 0; for (double x : v) s += x * x; return s; }
+};
+struct MatrixXd {
+    size_t r = 0, c = 0;
+    std::vector<double> v;                 // column major
+    MatrixXd() {}
+    MatrixXd(size_t rows, size_t cols) : r(rows), c(cols), v(rows * cols, 0.0) {}
+    size_t rows() const { return r; }
+    size_t cols() const { return c; }
+    void resize(size_t rows, size_t cols) { r = rows; c = cols; v.resize(rows * cols); }
+    double& operator()(size_t i, size_t j) { return v[j * r + i]; }
+    double operator()(size_t i, size_t j) const { return v[j * r + i]; }
+    double* data() { return v.data(); }
+    const double* data() const { return v.data(); }
 };
 
 struct Quaterniond {

@@ -190,6 +190,23 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* ctx, uint32_t particle, const u
 int32_t lama_hip_match_solve(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
                              const double* sensor_origin3, const double* sensor_quat_wxyz, double* pose_inout,
                              double* out7, int32_t* iters_out, int32_t do_solve);
+/* The same with the strategy chosen per call (0 = GaussNewton, 1 = LevenbergMarquard) instead of cfg.solver_strategy:
+ * and its own iteration limit: Solve(options, MatchSurface2D&, &cov) of a caller that builds its own Solver::Options
+ * (include/lama/nlls/solver.h:52-67). */
+int32_t lama_hip_match_solve_with(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                                  const double* sensor_origin3, const double* sensor_quat_wxyz, double* pose_inout,
+                                  double* out7, int32_t* iters_out, int32_t strategy, uint32_t max_iterations /* 0: cfg.max_iter */);
+/* MatchSurface2D::eval (src/match_surface_2d.cpp:42-90; the reference's nlls::Problem interface, include/lama/nlls/problem.h:
+ * 40-57) against particle `particle`'s distance map at pose {c,s,tx,ty}: residuals[n] = interpolated distance at every beam's
+ * end point (no robust weight), jacobian (may be NULL) = n x 3 COLUMN-major [gx | gy | gy*hx - gx*hy]. */
+int32_t lama_hip_match_eval(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                            const double* sensor_origin3, const double* sensor_quat_wxyz, const double* pose,
+                            double* residuals, double* jacobian);
+/* The per-beam terms of MatchSurface2D::error (src/match_surface_2d.cpp:92-116): distances[i] = DynamicDistanceMap::distance
+ * of the CELL w2m(tf * p_i) (no interpolation); the caller takes sqrt(sum of squares / n). */
+int32_t lama_hip_match_cell_distances(lama_hip_ctx* ctx, uint32_t particle, const double* pts_xyz, uint32_t n,
+                                      const double* sensor_origin3, const double* sensor_quat_wxyz, const double* pose,
+                                      double* distances);
 
 /* Particle shipping for multi-GPU resampling (one context per GPU): serialise one particle (pose + both
  * maps, used patches only) into a DEVICE buffer / restore it into slot `particle` of this context.

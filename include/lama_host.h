@@ -120,6 +120,18 @@ int lama_slam_view_occupancy(lama_slam* s, uint64_t n, const uint32_t* xy, uint8
                              uint8_t* is_unknown, double* probability);
 int lama_slam_view_distance_cells(lama_slam* s, uint64_t n, const uint32_t* xy, double* distance);
 int lama_slam_view_distance_points(lama_slam* s, uint64_t n, const double* xy, double* dist_gx_gy);   /* n x 3 out */
+/* lama::MatchSurface2D / lama::Solve (include/lama/match_surface_2d.h, include/lama/nlls/solver.h) on the distance map
+ * Slam2D::getDistanceMap() returns -- the scan-matching problem a caller of the reference builds by hand:
+ *   match_eval : MatchSurface2D::eval at pose4 {c,s,tx,ty}: residuals[n], jacobian n x 3 column-major (may be NULL), rmse_out =
+ *                MatchSurface2D::error() (may be NULL);
+ *   match_solve: Solve(options, problem, &cov): strategy "gn" | "lm", weight "cauchy" | "unit" | "tukey" | "huber" with its
+ *                parameter; pose4 in/out, cov9 row-major (may be NULL).  Returns 0, or -3 when the configuration has no device
+ *                kernel (message through lama_slam_last_error). */
+int lama_slam_match_eval(lama_slam* s, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                         const double* pose4, double* residuals, double* jacobian, double* rmse_out);
+int lama_slam_match_solve(lama_slam* s, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,
+                          double* pose4, const char* strategy, const char* weight, double weight_param, uint32_t max_iterations,
+                          double* cov9, uint32_t* iterations);
 const char* lama_slam_engine_origin(const lama_slam* s);
 
 /* ---- lama::Loc2D (include/lama/loc2d.h), flattened ---- */

@@ -1011,8 +1011,64 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     return rc;
 }
 
+static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                                double* pose_inout, double* out7, int32_t* iters_out, int32_t do_solve, int32_t strategy, uint32_t max_iterations);
+
 int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
                              double* pose_inout, double* out7, int32_t* iters_out, int32_t do_solve)
+{
+    return match_solve_impl(c, particle, pts, n, origin3, quat, pose_inout, out7, iters_out, do_solve, -1, 0);
+}
+
+int32_t lama_hip_match_solve_with(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                                  double* pose_inout, double* out7, int32_t* iters_out, int32_t strategy, uint32_t max_iterations)
+{
+    if (strategy != 0 && strategy != 1) return LAMA_HIP_E_INVALID;
+    return match_solve_impl(c, particle, pts, n, origin3, quat, pose_inout, out7, iters_out, 1, strategy, max_iterations);
+}
+
+static int32_t match_eval_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                               const double* pose, double* residuals, double* jacobian, int cell_mode);
+int32_t lama_hip_match_eval(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                            const double* pose, double* residuals, double* jacobian)
+{
+    return match_eval_impl(c, particle, pts, n, origin3, quat, pose, residuals, jacobian, 0);
+}
+int32_t lama_hip_match_cell_distances(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                                      const double* pose, double* distances)
+{
+    return match_eval_impl(c, particle, pts, n, origin3, quat, pose, distances, nullptr, 1);
+}
+static int32_t match_eval_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                               const double* pose, double* residuals, double* jacobian, int cell_mode)
+{
+    if (!c || !pts || !pose || !residuals || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "lama_hip_match_eval before a map exists");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int32_t rc = upload_scan(c, pts, n);
+    if (rc) return rc;
+    double *d_pose = nullptr, *d_out = nullptr;
+    HIPCHK(c, hipMalloc(&d_pose, sizeof(double) * 4));
+    hipError_t e = hipMalloc(&d_out, sizeof(double) * 4 * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pose, pose, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const Affine mtf = moving_tf(origin3, quat);
+        DevParams prm = make_params(c, c->cur);
+        hipLaunchKernelGGL(k_match_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, d_pose, d_out,
+                           jacobian ? d_out + n : nullptr, cell_mode);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(residuals, d_out, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess && jacobian) e = hipMemcpyAsync(jacobian, d_out + n, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d_pose); (void)hipFree(d_out);
+    HIPCHK(c, e);
+    return LAMA_HIP_OK;
+}
+
+static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin3, const double* quat,
+                                double* pose_inout, double* out7, int32_t* iters_out, int32_t do_solve, int32_t strategy, uint32_t max_iterations)
 {
     if (!c || !pts || !pose_inout || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
     ENTER(c);
@@ -1030,6 +1086,8 @@ int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* p
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, pose_inout, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
     DevParams prm = make_params(c, c->cur);
+    if (strategy >= 0) prm.strategy = strategy;
+    if (max_iterations) prm.max_iter = max_iterations;
     if (c->max_sqdist > (uint32_t)SM_LUT)
         hipLaunchKernelGGL(k_match_solve<true>, dim3(1), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout,
                            c->d_iters, (int)do_solve);

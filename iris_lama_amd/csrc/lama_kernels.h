@@ -474,6 +474,29 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
     }
 }
 
+// MatchSurface2D::eval (src/match_surface_2d.cpp:42-90) as the reference's Problem interface exposes it: the UNWEIGHTED
+// residual of every beam and, optionally, its Jacobian row [gx, gy, gy*hx - gx*hy] (column-major n x 3 like Eigen's MatrixXd).
+__global__ __launch_bounds__(256) void k_match_eval(DevParams prm, int particle, const double* __restrict__ pts, int n, Affine mtf,
+                                                     const double* __restrict__ pose, double* __restrict__ r_out, double* __restrict__ j_out,
+                                                     int cell_mode /* 1: DynamicDistanceMap::distance(w2m(hit)), no interpolation (MatchSurface2D::error) */)
+{
+    __shared__ Affine tfs;
+    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
+    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    if (threadIdx.x == 0) tfs = scan_tf(SE2{pose[0], pose[1], pose[2], pose[3]}, mtf);
+    __syncthreads();
+    const Affine tf = tfs;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double px = pts[3 * i], py = pts[3 * i + 1], pz = pts[3 * i + 2];
+    const double hx = ((tf.R[0][0] * px + tf.R[0][1] * py) + tf.R[0][2] * pz) + tf.t[0];
+    const double hy = ((tf.R[1][0] * px + tf.R[1][1] * py) + tf.R[1][2] * pz) + tf.t[1];
+    if (cell_mode) { r_out[i] = dm_distance_cell(prm, dir, sv, w2m(prm, hx), w2m(prm, hy)); return; }
+    double gx, gy;
+    r_out[i] = dm_distance(prm, dir, sv, hx, hy, &gx, &gy);
+    if (j_out) { j_out[i] = gx; j_out[(size_t)n + i] = gy; j_out[2 * (size_t)n + i] = gy * hx - gx * hy; }
+}
+
 // calculateLikelihood for B poses against particle `particle`'s distance map
 template <bool BIGSQ>
 __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int particle, const double* __restrict__ pts, int n,

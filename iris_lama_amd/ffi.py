@@ -53,7 +53,7 @@ HIP_SYMBOLS = [
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
     "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
-    "lama_hip_pf_map_checksums",
+    "lama_hip_pf_map_checksums", "lama_hip_match_eval", "lama_hip_match_cell_distances", "lama_hip_match_solve_with",
 ]
 
 _hip = None
@@ -108,6 +108,9 @@ def _bind_hip(L):
         L.lama_hip_pf_patch_ids.argtypes = [vp, u32, i32, u32, vp, vp]
         L.lama_hip_pf_delete_patches.argtypes = [vp, u32, vp, u32, vp]
         L.lama_hip_map_sample_likelihood.argtypes = [vp, u32, vp, u32, vp, vp, C.c_double, vp, u32, u32, vp]
+        L.lama_hip_match_eval.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp]
+        L.lama_hip_match_cell_distances.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp]
+        L.lama_hip_match_solve_with.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32, u32]
         has_cks = hasattr(L, "lama_hip_pf_map_checksums")   # device-only diagnostic (absent from the engine test double)
         if has_cks:
             L.lama_hip_pf_map_checksums.argtypes = [vp, i32, vp]
@@ -366,6 +369,7 @@ HOST_SYMBOLS = [
     "lama_slam_get_pose", "lama_slam_update", "lama_slam_enough_motion", "lama_slam_processed_cells",
     "lama_slam_iterations", "lama_slam_device_context", "lama_slam_engine_origin", "lama_slam_deleted_patches", "lama_loc_create3",
     "lama_slam_view_bounds", "lama_slam_view_cells", "lama_slam_view_occupancy", "lama_slam_view_distance_cells", "lama_slam_view_distance_points",
+    "lama_slam_match_eval", "lama_slam_match_solve",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
@@ -404,6 +408,8 @@ def _bind_host(L):
         "lama_slam_view_bounds": (i32, [vp, i32, vp, vp, vp, vp]), "lama_slam_view_cells": (C.c_int64, [vp, i32, vp, C.c_uint64]),
         "lama_slam_view_occupancy": (i32, [vp, C.c_uint64, vp, vp, vp, vp, vp]),
         "lama_slam_view_distance_cells": (i32, [vp, C.c_uint64, vp, vp]), "lama_slam_view_distance_points": (i32, [vp, C.c_uint64, vp, vp]),
+        "lama_slam_match_eval": (i32, [vp, vp, u32, vp, vp, vp, vp, vp, vp]),
+        "lama_slam_match_solve": (i32, [vp, vp, u32, vp, vp, vp, C.c_char_p, C.c_char_p, d, u32, vp, vp]),
         "lama_loc_create": (vp, [d, d, d, d, u32, i32, vp, i32]), "lama_loc_destroy": (None, [vp]),
         "lama_loc_last_error": (C.c_char_p, [vp]), "lama_loc_engine_origin": (C.c_char_p, [vp]),
         "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_set_pose": (None, [vp, d, d, d]),
@@ -707,6 +713,27 @@ class Slam2D:
         q = np.ascontiguousarray(pts_xy, dtype=np.float64)
         out = np.zeros((len(q), 3))
         return out if self.L.lama_slam_view_distance_points(self.h, len(q), _p(q), _p(out)) >= 0 else None
+
+    # ---- lama::MatchSurface2D / lama::Solve on Slam2D::getDistanceMap() (include/lama/match_surface_2d.h, nlls/solver.h)
+    def match_eval(self, pts, pose4, origin=None, quat=None, jac=True):
+        pts, origin, quat = PFSlam2D._scan(pts, origin, quat)
+        n = len(pts)
+        r, J, rmse = np.zeros(n), (np.zeros((3, n)) if jac else None), C.c_double(0)
+        rc = self.L.lama_slam_match_eval(self.h, _p(pts), n, _p(origin), _p(quat), _p(np.ascontiguousarray(pose4, dtype=np.float64)),
+                                         _p(r), _p(J), C.byref(rmse))
+        if rc < 0:
+            raise LamaError(self.L.lama_slam_last_error(self.h).decode())
+        return r, (J.T.copy() if jac else None), rmse.value
+
+    def match_solve(self, pts, pose4, strategy="gn", weight="cauchy", weight_param=0.15, max_iterations=100, origin=None, quat=None):
+        pts, origin, quat = PFSlam2D._scan(pts, origin, quat)
+        pose = np.array(pose4, dtype=np.float64)
+        cov, it = np.zeros(9), C.c_uint32(0)
+        rc = self.L.lama_slam_match_solve(self.h, _p(pts), len(pts), _p(origin), _p(quat), _p(pose), strategy.encode(), weight.encode(),
+                                          float(weight_param), int(max_iterations), _p(cov), C.byref(it))
+        if rc < 0:
+            raise LamaError(self.L.lama_slam_last_error(self.h).decode())
+        return pose, cov.reshape(3, 3), it.value
 
     def hip_context(self):
         ctx = HipContext.__new__(HipContext)

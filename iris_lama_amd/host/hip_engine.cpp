@@ -65,6 +65,9 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(pf_patch_ids, lama_hip_pf_patch_ids)
     BIND(pf_delete_patches, lama_hip_pf_delete_patches)
     BIND(map_sample_likelihood, lama_hip_map_sample_likelihood)
+    BIND(match_eval, lama_hip_match_eval)
+    BIND(match_cell_distances, lama_hip_match_cell_distances)
+    BIND(match_solve_with, lama_hip_match_solve_with)
 #undef BIND
     return e;
 }

@@ -39,6 +39,9 @@ struct HipEngine {
     decltype(&lama_hip_pf_patch_ids) pf_patch_ids = nullptr;
     decltype(&lama_hip_pf_delete_patches) pf_delete_patches = nullptr;
     decltype(&lama_hip_map_sample_likelihood) map_sample_likelihood = nullptr;
+    decltype(&lama_hip_match_eval) match_eval = nullptr;
+    decltype(&lama_hip_match_cell_distances) match_cell_distances = nullptr;
+    decltype(&lama_hip_match_solve_with) match_solve_with = nullptr;
     ~HipEngine();
 };
 

@@ -1,8 +1,11 @@
 // host_capi.cpp -- extern "C" flattening of lama::PFSlam2D (include/lama_host.h).
 #include "lama_host.h"
+#include "lama/match_surface_2d.h"
+#include "lama/nlls/solver.h"
 
 #include <cstring>
 #include <exception>
+#include <stdexcept>
 #include <string>
 
 #include "hip_engine.hpp"
@@ -372,6 +375,60 @@ int lama_slam_view_distance_cells(lama_slam* h, uint64_t n, const uint32_t* xy, 
         return 0;
     } catch (const std::exception& e) { h->error = e.what(); return -2; }
 }
+static PointCloudXYZ::Ptr cloud_of(const double* pts, uint32_t n, const double* o, const double* q)
+{
+    PointCloudXYZ::Ptr c(new PointCloudXYZ);
+    c->points.reserve(n);
+    for (uint32_t i = 0; i < n; ++i) c->points.push_back(Vector3d(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    if (o) c->sensor_origin_ = Vector3d(o[0], o[1], o[2]);
+    if (q) c->sensor_orientation_ = Quaterniond(q[0], q[1], q[2], q[3]);
+    return c;
+}
+
+int lama_slam_match_eval(lama_slam* h, const double* pts, uint32_t n, const double* o, const double* q, const double* pose4,
+                         double* residuals, double* jacobian, double* rmse_out)
+{
+    try {
+        const DynamicDistanceMap* dm = h->s->getDistanceMap();
+        if (!dm) return -1;
+        MatchSurface2D problem(dm, cloud_of(pts, n, o, q), SE2d::fromArray(pose4));
+        VectorXd r;
+        MatrixXd J;
+        problem.eval(r, jacobian ? &J : nullptr);
+        for (uint32_t i = 0; i < n; ++i) residuals[i] = r[i];
+        if (jacobian) for (uint32_t c = 0; c < 3; ++c) for (uint32_t i = 0; i < n; ++i) jacobian[(size_t)c * n + i] = J(i, c);
+        if (rmse_out) *rmse_out = problem.error();
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+
+int lama_slam_match_solve(lama_slam* h, const double* pts, uint32_t n, const double* o, const double* q, double* pose4, const char* strategy,
+                          const char* weight, double weight_param, uint32_t max_iterations, double* cov9, uint32_t* iterations)
+{
+    try {
+        const DynamicDistanceMap* dm = h->s->getDistanceMap();
+        if (!dm) return -1;
+        MatchSurface2D problem(dm, cloud_of(pts, n, o, q), SE2d::fromArray(pose4));
+        Solver::Options so;
+        so.max_iterations = max_iterations;
+        const std::string st(strategy ? strategy : "gn"), w(weight ? weight : "cauchy");
+        if (st == "lm") so.strategy.reset(new LevenbergMarquard); else so.strategy.reset(new GaussNewton);
+        if (w == "cauchy") so.robust_cost.reset(new CauchyWeight(weight_param));
+        else if (w == "tukey") so.robust_cost.reset(new TukeyWeight(weight_param));
+        else if (w == "huber") so.robust_cost.reset(new HuberWeight(weight_param));
+        else so.robust_cost.reset(new UnitWeight);
+        Solver solver(so);
+        MatrixXd cov;
+        try {
+            solver.solve(problem, cov9 ? &cov : nullptr);
+        } catch (const std::invalid_argument& e) { h->error = e.what(); return -3; }
+        problem.getState().toArray(pose4);
+        if (cov9) for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) cov9[3 * r + c] = cov(r, c);
+        if (iterations) *iterations = solver.lastIterations();
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -2; }
+}
+
 int lama_slam_view_distance_points(lama_slam* h, uint64_t n, const double* xy, double* out)
 {
     try {

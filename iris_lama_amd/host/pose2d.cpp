@@ -45,6 +45,25 @@ SE2d SE2d::operator*(const SE2d& o) const
     return r;
 }
 
+SE2d SE2d::exp(double vx, double vy, double theta)
+{
+    SE2d r;
+    double c = std::cos(theta), s = std::sin(theta);
+    normalize(c, s);
+    r.so2_.unit_complex_ = Vector2d(c, s);
+    double a, b;                                   // sin(theta) / theta, (1 - cos(theta)) / theta
+    if (std::fabs(theta) < 1e-10) {
+        const double theta_sq = theta * theta;
+        a = 1. - (1. / 6.) * theta_sq;
+        b = 0.5 * theta - (1. / 24.) * theta * theta_sq;
+    } else {
+        a = s / theta;
+        b = (1. - c) / theta;
+    }
+    r.translation_ = Vector2d(a * vx - b * vy, b * vx + a * vy);
+    return r;
+}
+
 void SE2d::toArray(double out4[4]) const
 {
     out4[0] = so2_.unit_complex_.x(); out4[1] = so2_.unit_complex_.y();

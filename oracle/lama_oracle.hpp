@@ -1109,6 +1109,20 @@ struct MatchSurface2D {
             }
         }
     }
+    // :92-116 error(): root mean square of the NON-interpolated cell distances at w2m(tf * p_i) (z of the hit is kept)
+    void cell_distances(double* out) const
+    {
+        Affine3 tf = affine_mul(fixed_tf(state_), moving_tf(*scan_));
+        for (size_t i = 0; i < scan_->points.size(); ++i) out[i] = surface_->distance(surface_->w2m(affine_apply(tf, scan_->points[i])));
+    }
+    double error() const
+    {
+        std::vector<double> d(scan_->points.size());
+        cell_distances(d.data());
+        double s = 0;
+        for (double v : d) s += v * v;
+        return std::sqrt(s / (double)d.size());
+    }
     // :118-122
     void update(const double h[3]) { state_ = se2_mul(se2_exp(h[0], h[1], h[2]), state_); }
 };

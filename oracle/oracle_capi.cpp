@@ -202,6 +202,35 @@ int orc_solve(void* dm, const double* pts, int n, const double* origin3, const d
     if (evals_out) *evals_out = st.evals;
     return (int)st.iterations;
 }
+// Solve(GaussNewton | LevenbergMarquard, Cauchy(0.15)) with the covariance branch of Solver::solve (solver.cpp:109-116, 133-150)
+int orc_solve_full(void* dm, const double* pts, int n, const double* origin3, const double* quat4, double* pose4, uint32_t max_iter,
+                   int lm, double* cov9)
+{
+    Scan s = make_scan(pts, n, origin3, quat4);
+    MatchSurface2D ms((const DynamicDistanceMap*)dm, &s, se2_of(pose4));
+    CauchyWeight cauchy(0.15);
+    SolveStats st = lm ? solve_lm(ms, max_iter, cauchy) : solve_gn(ms, max_iter, cauchy);
+    se2_to(ms.state_, pose4);
+    if (cov9) {
+        std::vector<double> r, J;
+        ms.eval(r, &J);
+        double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (size_t i = 0; i < r.size(); ++i) {
+            const double w = std::sqrt(cauchy.value(r[i]));
+            J[3 * i] *= w; J[3 * i + 1] *= w; J[3 * i + 2] *= w;
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) A[a][b] += J[3 * i + a] * J[3 * i + b];
+        }
+        if (colpiv_qr_rank(J, r.size()) == 3) inverse3(A, cov9); else svd_cov3(J, r.size(), cov9);
+    }
+    return (int)st.iterations;
+}
+// MatchSurface2D::error (match_surface_2d.cpp:92-116)
+double orc_match_error(void* dm, const double* pts, int n, const double* origin3, const double* quat4, const double* pose4)
+{
+    Scan s = make_scan(pts, n, origin3, quat4);
+    MatchSurface2D ms((const DynamicDistanceMap*)dm, &s, se2_of(pose4));
+    return ms.error();
+}
 // PFSlam2D::calculateLikelihood (pf_slam2d.cpp:393-414)
 double orc_loglik(void* dm, const double* pts, int n, const double* origin3, const double* quat4,
                   const double* pose4, double meas_sigma)

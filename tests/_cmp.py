@@ -70,3 +70,32 @@ def check_slam_views(o, h, rng):
     for i, (x, y) in enumerate(pts):
         d, g = o.dm().distance([x, y, 0.0], grad=True)
         assert hv[i, 0] == d and hv[i, 1] == g[0] and hv[i, 2] == g[1], i
+
+
+def check_match_surface_and_solver(O, o, h, scan, rng, pose_tol, exact):
+    """lama::MatchSurface2D::eval / error and lama::Solve on Slam2D::getDistanceMap() against the oracle's MatchSurface2D / solver
+    on the oracle's distance map (built from the same scans at the same poses)."""
+    import pytest
+    base = o.pose()
+    for trial in range(3):
+        pose = O.se2_mul(base, O.se2(*rng.normal(0, [0.04, 0.04, 0.015])))
+        r, J, rmse = h.match_eval(scan, pose)
+        orr, oJ = O.eval_(o.dm(), scan, pose)
+        if exact:
+            assert np.array_equal(r, orr) and np.array_equal(J, oJ)
+        else:
+            assert np.abs(r - orr).max() < 1e-9 and np.abs(J - oJ).max() < 1e-6
+        assert abs(rmse - O.match_error(o.dm(), scan, pose)) < 1e-12
+        for strategy in ("gn", "lm"):
+            got, cov, it = h.match_solve(scan, pose, strategy=strategy)
+            want, oit, ocov = O.solve_full(o.dm(), scan, pose, lm=(strategy == "lm"))
+            assert np.abs(got - want).max() <= pose_tol, (trial, strategy)
+            assert it == oit
+            assert np.allclose(cov, ocov, rtol=1e-6, atol=1e-12)
+        got5, _, it5 = h.match_solve(scan, pose, max_iterations=2)
+        assert it5 <= 2
+    # a configuration without a device kernel is an error, not a CPU computation
+    with pytest.raises(Exception, match="no device kernel|no CPU path"):
+        h.match_solve(scan, base, weight="tukey", weight_param=4.6851)
+    with pytest.raises(Exception, match="no device kernel|no CPU path"):
+        h.match_solve(scan, base, weight="cauchy", weight_param=0.3)

@@ -362,6 +362,27 @@ def solve(dm, pts, pose, max_iter=100, origin=ZERO3, quat=IDENT_Q):
     return pose, it, ev.value
 
 
+def solve_full(dm, pts, pose, max_iter=100, lm=False, origin=ZERO3, quat=IDENT_Q):
+    """Solve(GN | LM, Cauchy(0.15), &cov): (pose, iterations, 3x3 covariance)."""
+    L = lib()
+    L.orc_solve_full.restype = C.c_int
+    L.orc_solve_full.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    pose = np.array(pose, dtype=np.float64)
+    cov = np.zeros(9)
+    it = L.orc_solve_full(dm.h, _p(pts), len(pts), _p(origin), _p(quat), _p(pose), max_iter, 1 if lm else 0, _p(cov))
+    return pose, it, cov.reshape(3, 3)
+
+
+def match_error(dm, pts, pose, origin=ZERO3, quat=IDENT_Q):
+    """MatchSurface2D::error(): rms of the non-interpolated cell distances."""
+    L = lib()
+    L.orc_match_error.restype = C.c_double
+    L.orc_match_error.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    return L.orc_match_error(dm.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(pose, dtype=np.float64)))
+
+
 def loglik(dm, pts, pose, sigma=0.05, origin=ZERO3, quat=IDENT_Q):
     pts = np.ascontiguousarray(pts, dtype=np.float64)
     return lib().orc_loglik(dm.h, _p(pts), len(pts), _p(origin), _p(quat), _p(np.ascontiguousarray(pose)), sigma)

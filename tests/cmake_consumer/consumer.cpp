@@ -1,15 +1,56 @@
 // Compiles against the mirrored class API the way a node of iris_lama_ros does (pf_slam2d_ros.cpp: fills
 // lama::PFSlam2D::Options from parameters, builds a PointCloudXYZ per scan, calls update(cloud, odom, stamp)).
 // Without a GPU the constructor must fail loudly (no CPU fallback); that is what this program checks when it runs.
+#include <cmath>
 #include <cstdio>
 #include <stdexcept>
+#include <vector>
 
 #include <lama/loc2d.h>
+#include <lama/match_surface_2d.h>
+#include <lama/nlls/solver.h>
 #include <lama/pf_slam2d.h>
 #include <lama/slam2d.h>
 
+// a user-defined nlls::Problem (include/lama/nlls/problem.h): fit y = a * exp(b * x) to samples -- the generic host loop of
+// lama::Solver drives it, nothing of it touches the GPU
+struct ExpFit : public lama::Problem {
+    double a = 1.0, b = 0.0;
+    std::vector<double> xs, ys;
+    void eval(lama::VectorXd& r, lama::MatrixXd* J) override
+    {
+        r.resize(xs.size());
+        if (J) J->resize(xs.size(), 2);
+        for (size_t i = 0; i < xs.size(); ++i) {
+            const double e = std::exp(b * xs[i]);
+            r[i] = a * e - ys[i];
+            if (J) { (*J)(i, 0) = e; (*J)(i, 1) = a * xs[i] * e; }
+        }
+    }
+    void update(const lama::VectorXd& h) override { a += h[0]; b += h[1]; }
+};
+
+static int check_generic_solver()
+{
+    for (int lm = 0; lm < 2; ++lm) {
+        ExpFit fit;
+        for (int i = 0; i < 40; ++i) { fit.xs.push_back(0.05 * i); fit.ys.push_back(2.5 * std::exp(-0.7 * 0.05 * i)); }
+        lama::Solver::Options so;
+        if (lm) so.strategy.reset(new lama::LevenbergMarquard); else so.strategy.reset(new lama::GaussNewton);
+        so.robust_cost.reset(new lama::CauchyWeight(1.0));
+        lama::MatrixXd cov;
+        lama::Solve(so, fit, &cov);
+        if (std::fabs(fit.a - 2.5) > 1e-3 || std::fabs(fit.b + 0.7) > 1e-3 || cov.rows() != 2 || !(cov(0, 0) > 0)) {
+            std::printf("generic solver (%s): a = %.6f b = %.6f\n", lm ? "lm" : "gn", fit.a, fit.b);
+            return 1;
+        }
+    }
+    return 0;
+}
+
 int main()
 {
+    if (check_generic_solver()) return 7;
     lama::PFSlam2D::Options options;
     options.particles = 4;
     options.resolution = 0.05;
@@ -45,6 +86,26 @@ int main()
         std::printf("map: %u x %u cells, %zu free, %zu occupied; distance at the prior %.3f m\n", imax(0) - imin(0), imax(1) - imin(1),
                     free_cells, occupied_cells, dm ? dm->distance(lama::Vector3d(1.0, 2.0, 0.0)) : -1.0);
         if (free_cells < 1000 || occupied_cells < 100 || !dm) return 5;
+        // the scan-matching problem built by hand, as the reference's own classes do (src/slam2d.cpp:170-176): evaluation on the
+        // device, Solve() = one fused device launch
+        {
+            lama::MatchSurface2D problem(dm, cloud, (prior + lama::Pose2D(0.03, -0.02, 0.61)).state);
+            lama::VectorXd r;
+            lama::MatrixXd J;
+            problem.eval(r, &J);
+            const double before = std::sqrt(r.squaredNorm() / r.size());
+            lama::Solver::Options so;
+            so.strategy.reset(new lama::GaussNewton);
+            so.robust_cost.reset(new lama::CauchyWeight(0.15));
+            lama::MatrixXd cov;
+            lama::Solve(so, problem, &cov);
+            problem.eval(r, nullptr);
+            const double after = std::sqrt(r.squaredNorm() / r.size());
+            std::printf("MatchSurface2D: rms residual %.4f -> %.4f m, error() %.4f, var(x) %.2e\n", before, after, problem.error(), cov(0, 0));
+            if (!(after < before) || J.rows() != r.size() || J.cols() != 3 || !(cov(0, 0) > 0)) return 8;
+            so.robust_cost.reset(new lama::HuberWeight(0.1));
+            try { lama::Solve(so, problem); return 9; } catch (const std::invalid_argument&) {}   // no device kernel: must refuse
+        }
         uint64_t occmem = 0, dmmem = 0;
         if (slam.getMemoryUsage(occmem, dmmem) != occmem + dmmem || occmem == 0 || dmmem == 0 || slam.getMemoryUsage() == 0) return 6;
         slam.saveOccImage("/tmp/lama_consumer_occ.png");

@@ -306,14 +306,50 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     return LAMA_HIP_OK;
 }
 
+static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                                double* pose, double* out7, int32_t* iters, int32_t do_solve, int32_t strategy, uint32_t max_iterations);
 int32_t lama_hip_match_solve(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
                              double* pose, double* out7, int32_t* iters, int32_t do_solve)
 {
+    return match_solve_impl(c, particle, pts, n, origin, quat, pose, out7, iters, do_solve, (int32_t)c->cfg.solver_strategy, 0);
+}
+int32_t lama_hip_match_solve_with(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                                  double* pose, double* out7, int32_t* iters, int32_t strategy, uint32_t max_iterations)
+{
+    return match_solve_impl(c, particle, pts, n, origin, quat, pose, out7, iters, 1, strategy, max_iterations);
+}
+// MatchSurface2D::eval rows (residuals, column-major n x 3 Jacobian)
+int32_t lama_hip_match_eval(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                            const double* pose, double* residuals, double* jacobian)
+{
+    Scan s = make_scan(pts, n, origin, quat);
+    MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(pose));
+    std::vector<double> r, J;
+    ms.eval(r, jacobian ? &J : nullptr);
+    for (uint32_t i = 0; i < n; ++i) {
+        residuals[i] = r[i];
+        if (jacobian) { jacobian[i] = J[3 * i]; jacobian[(size_t)n + i] = J[3 * i + 1]; jacobian[2 * (size_t)n + i] = J[3 * i + 2]; }
+    }
+    return LAMA_HIP_OK;
+}
+// per-beam terms of MatchSurface2D::error: distance of the cell w2m(tf * p_i)
+int32_t lama_hip_match_cell_distances(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                                      const double* pose, double* distances)
+{
+    Scan s = make_scan(pts, n, origin, quat);
+    MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(pose));
+    ms.cell_distances(distances);
+    return LAMA_HIP_OK;
+}
+static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
+                                double* pose, double* out7, int32_t* iters, int32_t do_solve, int32_t strategy, uint32_t max_iterations)
+{
+    const uint32_t max_iter = max_iterations ? max_iterations : c->cfg.max_iter;
     Scan s = make_scan(pts, n, origin, quat);
     MatchSurface2D ms(c->dm[particle].get(), &s, se2_of(pose));
     CauchyWeight cauchy(0.15);
     SolveStats st;
-    if (do_solve) st = c->cfg.solver_strategy == 1 ? solve_lm(ms, c->cfg.max_iter, cauchy) : solve_gn(ms, c->cfg.max_iter, cauchy);
+    if (do_solve) st = strategy == 1 ? solve_lm(ms, max_iter, cauchy) : solve_gn(ms, max_iter, cauchy);
     std::vector<double> r, J;
     ms.eval(r, &J);
     double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, s2 = 0;

@@ -314,6 +314,25 @@ def test_slam2d_map_accessors_gpu(F):
     h.close()
 
 
+def test_match_surface_2d_and_solver_api_gpu(F):
+    """lama::MatchSurface2D::eval / error as device kernels and lama::Solve as ONE fused device launch, through the reference's
+    class API, against the oracle: residuals 1e-9, Jacobian 1e-6, poses 1e-8, equal iteration counts, covariance rel 1e-6;
+    configurations without a device kernel raise."""
+    from _cmp import check_match_surface_and_solver
+    steps = 6
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    o, h = O.Slam(), F.Slam2D()
+    assert h.engine_origin().endswith("liblama_hip.so")
+    o.set_pose(O.se2(*odom[0])); h.set_pose(*odom[0])
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+        p = o.pose()
+        h.set_pose(p[2], p[3], float(np.arctan2(p[1], p[0])))
+        o.set_pose(h.pose())
+    check_match_surface_and_solver(O, o, h, pts[steps], np.random.default_rng(8), pose_tol=1e-8, exact=False)
+    h.close()
+
+
 def test_loc2d_rank_deficient_covariance_gpu(F):
     """Rank-deficient branch of Solver::calculateCovariance (src/nlls/solver.cpp:143-149) on the device path: corridor
     with its ends out of sight, x unobservable -> variance 3.0 along x, (J^T J)-eigen pairs elsewhere."""

@@ -151,6 +151,19 @@ def test_slam2d_map_accessors_answer_like_the_reference_maps():
     check_slam_views(o, h, np.random.default_rng(3))
 
 
+def test_match_surface_2d_and_solver_api_host_matches_oracle():
+    """lama::MatchSurface2D (eval, error, update) and lama::Solve with GaussNewton / LevenbergMarquard + CauchyWeight(0.15) on
+    the distance map Slam2D::getDistanceMap() hands out, against the oracle (engine = oracle-backed double: bit-equal)."""
+    from _cmp import check_match_surface_and_solver
+    steps = 6
+    pts, odom, truth = F.corridor_log(steps, 360)
+    o, h = O.Slam(), F.Slam2D()
+    o.set_pose(O.se2(*odom[0])); h.set_pose(*odom[0])
+    for k in range(steps + 1):
+        assert o.update(pts[k], O.se2(*odom[k]), float(k)) == h.update(pts[k], odom[k], float(k))
+    check_match_surface_and_solver(O, o, h, pts[steps], np.random.default_rng(8), pose_tol=0.0, exact=True)
+
+
 def test_loc2d_host_matches_oracle():
     """cfg 1: lama::Loc2D (predict + Solve with covariance + RMSE on a pre-built 0.05 m distance map) vs the oracle
     restatement of src/loc2d.cpp (engine = oracle-backed double, so the poses must agree bit for bit)."""
