@@ -26,6 +26,13 @@ struct HipEngine;
 
 class Slam2D {
 public:
+    // include/lama/slam2d.h:59-88: per-update timing / memory record, filled when Options::create_summary is set
+    struct Summary {
+        DynamicArray<double> timestamp, time, time_solving, time_mapping, memory;
+        std::string report() const;
+    };
+    Summary* summary = nullptr;
+
     struct Options {
         Options() {}
         double trans_thresh = 0.5;

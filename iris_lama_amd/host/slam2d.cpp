@@ -1,6 +1,8 @@
 // slam2d.cpp -- host-side lama::Slam2D (include/lama/slam2d.h); orchestration of src/slam2d.cpp:143-198.
 #include "lama/slam2d.h"
 
+#include <chrono>
+
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -24,6 +26,7 @@ Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.
 {
     if (o.use_compression) throw std::runtime_error("lama::Slam2D: use_compression is not supported on the device path");
     transient_map_ = o.transient_map; truncated_range_ = o.truncated_range;
+    if (o.create_summary) summary = new Summary;                 // src/slam2d.cpp:117-118
     eng_ = engineOverride() ? engineOverride() : loadHipEngine();
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
@@ -40,7 +43,46 @@ Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.
     }
 }
 
-Slam2D::~Slam2D() { if (ctx_) eng_->ctx_destroy(ctx_); }
+Slam2D::~Slam2D() { if (ctx_) eng_->ctx_destroy(ctx_); delete summary; }
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// src/slam2d.cpp:46-90 (same lines and buckets; plain loops instead of Eigen::Map)
+std::string Slam2D::Summary::report() const
+{
+    auto stats = [](const DynamicArray<double>& v, double out[4]) {
+        out[0] = out[1] = out[2] = out[3] = 0;
+        if (v.empty()) return;
+        double s = 0, mn = v[0], mx = v[0];
+        for (double x : v) { s += x; mn = std::min(mn, x); mx = std::max(mx, x); }
+        const double mean = s / v.size();
+        double ss = 0;
+        for (double x : v) ss += (x - mean) * (x - mean);
+        out[0] = mean * 1e3; out[1] = (v.size() > 1 ? std::sqrt(ss / (v.size() - 1)) : 0.0) * 1e3; out[2] = mn * 1e3; out[3] = mx * 1e3;
+    };
+    double t[4], ts[4], tm[4];
+    stats(time, t); stats(time_solving, ts); stats(time_mapping, tm);
+    double span = 0, maxmem = 0;
+    for (double x : time) span += x;
+    for (double m : memory) maxmem = std::max(maxmem, m);
+    const double stampdiff = timestamp.empty() ? 0.0 : timestamp.back() - timestamp.front();
+    char buf[1536];
+    std::snprintf(buf, sizeof(buf),
+                  "\n LaMa Slam2D - Report\n ====================\n"
+                  " Number of updates     %zu\n Max memory usage      %.2f MiB\n"
+                  " Problem time span     %d minute(s) and %d second(s)\n Execution time span   %d minute(s) and %d second(s)\n"
+                  " Execution frequency   %.2f Hz\n Realtime factor       %.2fx\n"
+                  "\n Execution time (mean +- std [min, max]) in milliseconds\n"
+                  " --------------------------------------------------------\n"
+                  " Update          %f +- %f [%f, %f]\n   Optimization  %f +- %f [%f, %f]\n   Mapping       %f +- %f [%f, %f]\n",
+                  time.size(), maxmem / 1024.0 / 1024.0, ((uint32_t)stampdiff) / 60, ((uint32_t)stampdiff) % 60,
+                  ((uint32_t)span) / 60, ((uint32_t)span) % 60, time.empty() || span <= 0 ? 0.0 : 1.0 / (span / time.size()),
+                  span > 0 ? stampdiff / span : 0.0, t[0], t[1], t[2], t[3], ts[0], ts[1], ts[2], ts[3], tm[0], tm[1], tm[2], tm[3]);
+    return std::string(buf);
+}
 
 void Slam2D::fail(int32_t rc, const char* what) const
 {
@@ -57,9 +99,10 @@ bool Slam2D::enoughMotion(const Pose2D& odometry)                 // src/slam2d.
     return true;
 }
 
-bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double /*timestamp*/)
+bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
 {
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::Slam2D::update: empty scan");
+    const double t_begin = now_s();
     occ_view_.reset(); dm_view_.reset();
     std::vector<double> pts;
     double o[3], q[4], p[4];
@@ -77,6 +120,11 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
             rc = transient::prune(eng_.get(), ctx_, *surface, pose_, resolution_, l2_max_, truncated_range_, 2.0, &last_deleted_);
             if (rc) fail(rc, "transient map");
         }
+        if (summary) {                                             // :151-157
+            const double el = now_s() - t_begin;
+            summary->timestamp.push_back(timestamp); summary->time.push_back(el); summary->time_mapping.push_back(el);
+            summary->memory.push_back((double)getMemoryUsage());
+        }
         has_first_scan = true;
         return true;
     }
@@ -87,6 +135,7 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
     pose_ = ppose;
     odom_ = odometry;
     // 2. optimise                                                 :175-181
+    const double t_solve = now_s();
     pose_.state.toArray(p);
     int32_t rc = eng_->pf_set_poses(ctx_, p);
     if (rc) fail(rc, "lama_hip_pf_set_poses");
@@ -95,7 +144,9 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
     if (rc) fail(rc, "lama_hip_pf_scan_match");
     pose_.state = SE2d::fromArray(p);
     last_iterations_ = (uint32_t)iters;
+    if (summary) summary->time_solving.push_back(now_s() - t_solve);
     // 3. update maps                                              :184-186
+    const double t_map = now_s();
     (void)eng_->get_counters(ctx_, &c0);
     rc = eng_->pf_update_maps(ctx_, pts.data(), n, o, q);
     if (rc) fail(rc, "lama_hip_pf_update_maps");
@@ -103,6 +154,12 @@ bool Slam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, d
     if (transient_map_) {                                          // :322-379
         rc = transient::prune(eng_.get(), ctx_, *surface, pose_, resolution_, l2_max_, truncated_range_, 2.0, &last_deleted_);
         if (rc) fail(rc, "transient map");
+    }
+    if (summary) {                                                 // :188-194
+        summary->time_mapping.push_back(now_s() - t_map);
+        summary->time.push_back(now_s() - t_begin);
+        summary->timestamp.push_back(timestamp);
+        summary->memory.push_back((double)getMemoryUsage());
     }
     return true;
 }

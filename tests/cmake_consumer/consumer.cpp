@@ -109,6 +109,15 @@ int main()
         uint64_t occmem = 0, dmmem = 0;
         if (slam.getMemoryUsage(occmem, dmmem) != occmem + dmmem || occmem == 0 || dmmem == 0 || slam.getMemoryUsage() == 0) return 6;
         slam.saveOccImage("/tmp/lama_consumer_occ.png");
+        // the online-SLAM class with its Summary (include/lama/slam2d.h:59-88)
+        lama::Slam2D::Options s2o;
+        s2o.create_summary = true;
+        lama::Slam2D slam2(s2o);
+        slam2.setPose(prior);
+        slam2.update(cloud, prior, 0.0);
+        slam2.update(cloud, prior + lama::Pose2D(0.0, 0.0, 0.6), 1.0);
+        if (!slam2.summary || slam2.summary->time.size() != 2 || slam2.summary->time_solving.size() != 1 || slam2.summary->memory.back() <= 0) return 10;
+        std::printf("%s", slam2.summary->report().c_str());
     } catch (const std::runtime_error& e) {
         std::printf("no device: %s\n", e.what());                // expected on a box without an MI355X
         return 0;
