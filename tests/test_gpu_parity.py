@@ -369,8 +369,9 @@ def test_sharded_collective_path_on_rccl(F):
     import torch
     import torch.distributed as dist
     from iris_lama_amd.distributed import ShardedPF
+    from test_distributed_cpu import _free_port
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("WORLD_SIZE", "1")
     torch.cuda.set_device(0)
