@@ -678,6 +678,17 @@ struct BrushfireStats {
 // test switch: maps created while this is set use update_canonical() (see there); never set for parity claims
 inline bool& canonical_default() { static bool v = false; return v; }
 
+// Instrumentation only (tools/research): when non-null, every priority-queue operation of the distance map is appended as
+// {op, prio, x, y}: op 0 = update() begins, 1 = push lower_, 2 = push raise_, 3 = pop raise_, 4 = pop lower_ (lower() did not
+// run), 5 = pop lower_ (lower() ran), 6 = update() ends.
+struct BfTraceRec { uint32_t op, prio, x, y; };
+inline std::vector<BfTraceRec>*& bf_trace() { static thread_local std::vector<BfTraceRec>* t = nullptr; return t; }
+inline void bf_trace_add(uint32_t op, uint32_t prio, const V3u& l) { if (bf_trace()) bf_trace()->push_back({op, prio, l.x, l.y}); }
+// Research only: when set, DynamicDistanceMap::update() runs this instead of the reference's loop (tools/research/lse_proto.hpp
+// checks a level-synchronous restatement against the faithful one).  Never set by tests, bench or the C API.
+class DynamicDistanceMap;
+inline uint32_t (*&bf_update_hook())(DynamicDistanceMap&) { static uint32_t (*h)(DynamicDistanceMap&) = nullptr; return h; }
+
 class DynamicDistanceMap : public Map {
 public:
     DynamicDistanceMap(double res, uint32_t patch_size = 32)       // :36-47
@@ -735,6 +746,7 @@ public:
         cell->valid_obstacle = true;
         cell->is_queued = true;
         lower_.push({0, location});
+        bf_trace_add(1, 0, location);
         ++stats.pushes;
     }
     void removeObstacle(const V3u& location)                       // :228-242
@@ -746,17 +758,21 @@ public:
         cell->valid_obstacle = false;
         cell->is_queued = true;
         raise_.push({0, location});
+        bf_trace_add(2, 0, location);
         ++stats.pushes;
     }
 
     uint32_t update()                                              // :160-197
     {
+        if (bf_update_hook()) return bf_update_hook()(*this);
         if (canonical) return update_canonical();
         uint32_t processed = 0;
         stats.max_queue_last = 0;
+        bf_trace_add(0, 0, V3u{0, 0, 0});
         while (!raise_.empty()) {
             stats.max_queue = std::max<uint64_t>(stats.max_queue, raise_.size() + lower_.size());
             stats.max_queue_last = std::max<uint64_t>(stats.max_queue_last, std::max(raise_.size(), lower_.size()));
+            bf_trace_add(3, (uint32_t)raise_.top().first, raise_.top().second);
             V3u location = raise_.top().second; raise_.pop();
             distance_t* current = (distance_t*)get(location);
             ++processed; ++stats.raise_pops;
@@ -765,9 +781,13 @@ public:
         while (!lower_.empty()) {
             stats.max_queue = std::max<uint64_t>(stats.max_queue, lower_.size());
             stats.max_queue_last = std::max<uint64_t>(stats.max_queue_last, lower_.size());
+            const uint32_t tprio_ = (uint32_t)lower_.top().first;
             V3u location = lower_.top().second; lower_.pop();
             distance_t* current = (distance_t*)get(location);
             ++processed; ++stats.lower_pops;
+            const uint64_t fired0_ = stats.lower_fired;
+            if (bf_trace()) bf_trace()->push_back({4u, tprio_, location.x, location.y});
+            const size_t trace_at_ = bf_trace() ? bf_trace()->size() - 1 : 0;
             if (current->valid_obstacle) {
                 V3u obs = offs(location, current->obstacle);
                 const distance_t* obstacle = (distance_t*)get(obs);
@@ -775,7 +795,9 @@ public:
                 if (obstacle->sqdist == 0)                         // :191 (valid_obstacle NOT tested)
                     lower(location, current);
             }
+            if (bf_trace() && stats.lower_fired != fired0_) (*bf_trace())[trace_at_].op = 5u;
         }
+        bf_trace_add(6, 0, V3u{0, 0, 0});
         return processed;
     }
 
@@ -880,6 +902,7 @@ public:
         return processed;
     }
     bool canonical = false;     // when set, update() dispatches to update_canonical() (experiments only)
+    friend struct BfResearchAccess;   // tools/research only
 
 private:
     typedef std::pair<int, V3u> queue_pair_t;                      // .h:90
@@ -913,6 +936,7 @@ private:
             neighbor = (distance_t*)get(newloc);
             if (!obstacle->valid_obstacle) {
                 raise_.push({neighbor->sqdist, newloc});
+                bf_trace_add(2, neighbor->sqdist, newloc);
                 ++stats.pushes;
                 neighbor->sqdist = 0;
                 neighbor->obstacle[0] = neighbor->obstacle[1] = neighbor->obstacle[2] = 0;
@@ -920,6 +944,7 @@ private:
                 neighbor->is_queued = true;
             } else if (!neighbor->is_queued) {
                 lower_.push({neighbor->sqdist, newloc});
+                bf_trace_add(1, neighbor->sqdist, newloc);
                 ++stats.pushes;
                 neighbor->is_queued = true;
             }
@@ -959,6 +984,7 @@ private:
             }
             if (overwrite) {                                        // :319-326
                 lower_.push({(int)new_sqdist, nl});
+                bf_trace_add(1, new_sqdist, nl);
                 ++stats.pushes;
                 neighbor->sqdist = (uint16_t)new_sqdist;
                 neighbor->valid_obstacle = true;
