@@ -325,11 +325,14 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
+        const bool lse = c->cfg.brushfire_mode != 2;        // level-synchronous lower wave (default) / pop by pop; bit-identical
         if (c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES)) {
-            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
-            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false, true>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
@@ -385,6 +388,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // tuning overrides for contexts created by the host classes (all variants are bit-identical)
     if (cfg.sequential_raycast == 0) if (const char* e = std::getenv("LAMA_HIP_SEQUENTIAL_RAYCAST")) cfg.sequential_raycast = (uint32_t)std::atoi(e);
     if (cfg.brushfire_waves == 0) if (const char* e = std::getenv("LAMA_HIP_BRUSHFIRE_WAVES")) cfg.brushfire_waves = (uint32_t)std::atoi(e);
+    if (cfg.brushfire_mode == 0) if (const char* e = std::getenv("LAMA_HIP_BRUSHFIRE_MODE")) cfg.brushfire_mode = (uint32_t)std::atoi(e);
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)
@@ -430,7 +434,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qraise, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_stats, P * 4 * 8));          CHK(hipMemset(c->d_stats, 0, P * 4 * 8));
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
-    CHK(hipMalloc(&c->d_dbg, P * 8 * 8));            CHK(hipMemset(c->d_dbg, 0, P * 8 * 8));
+    CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
@@ -1203,6 +1207,24 @@ int32_t lama_hip_debug_cycles(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
     if (!c || !out) return LAMA_HIP_E_INVALID;
     ENTER(c);
     HIPCHK(c, hipMemcpy(out, c->d_dbg, sizeof(uint64_t) * 8 * c->P, hipMemcpyDeviceToHost));
+    return LAMA_HIP_OK;
+}
+
+// second block of developer counters (-DLAMA_PROFILE_LSE): kernel-level timestamps of k_brushfire per particle
+int32_t lama_hip_debug_cycles2(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
+{
+    if (!c || !out) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    HIPCHK(c, hipMemcpy(out, c->d_dbg + 8 * (size_t)c->P, sizeof(uint64_t) * 8 * c->P, hipMemcpyDeviceToHost));
+    return LAMA_HIP_OK;
+}
+
+// developer event log of particle 0 (-DLAMA_PROFILE_LSE): out[0] = number of words, then (event << 56 | timestamp) words
+int32_t lama_hip_debug_log(lama_hip_ctx* c, uint64_t* out /* 131072 words */)
+{
+    if (!c || !out) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    HIPCHK(c, hipMemcpy(out, c->d_dbg + 16 * (size_t)c->P, 1u << 20, hipMemcpyDeviceToHost));
     return LAMA_HIP_OK;
 }
 

@@ -900,17 +900,15 @@ __device__ __forceinline__ uint64_t lds_pop_ancestors(int lane)
 // takes the slot of the last of them, everything below stays.  The descent can therefore stop at the first entry
 // that stays; nothing is read back, and the entry that ends up at the root is known from registers (returned;
 // meaningful when size > 0 afterwards).
-__device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size, int lane, uint64_t anc)
+// Sift `value` down from the hole at slot H0 of the heap h[0, len) (the loop of std::__adjust_heap followed by std::__push_heap,
+// top-down: see above).  Returns the entry that ends up at slot H0 if H0 == 0 (the new root; meaningful when len > 0).
+__device__ __forceinline__ uint64_t lds_sift_topdown(uint64_t* h, const uint32_t len, const uint32_t H0, const uint64_t value, int lane, uint64_t anc)
 {
-    --size;
-    const uint32_t len = size;
-    if (len == 0) return 0;
-    const uint64_t value = h[len];
     const uint32_t vprio = heap_prio(value);
     const uint32_t lim = (len - 1) / 2;                              // nodes below `lim` have both children
     const int d = 31 - __clz(lane + 1);
     const bool is_left = (lane & 1) != 0;
-    uint32_t H = 0;
+    uint32_t H = H0;
     uint32_t root_lo = (uint32_t)value, root_hi = (uint32_t)(value >> 32);
     bool stopped = false;
     while (H < lim) {
@@ -951,6 +949,13 @@ __device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size,
     if (lane == 0) h[H] = value;
     return ((uint64_t)root_hi << 32) | root_lo;
 }
+__device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size, int lane, uint64_t anc)
+{
+    --size;
+    const uint32_t len = size;
+    if (len == 0) return 0;
+    return lds_sift_topdown(h, len, 0u, h[len], lane, anc);
+}
 __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t value, bool writer)
 {
     uint32_t hole = size++;
@@ -962,6 +967,30 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
         hole = parent;
     }
     if (writer) h[hole] = value;
+}
+
+// push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
+// entries has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply appended, exactly
+// what the sequential push_heap calls would have done.  Returns true if the entries were appended unmoved.
+__device__ __forceinline__ bool lds_push_list(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t cnt, int lane)
+{
+    if (!cnt) return false;
+    const uint32_t l4 = (uint32_t)lane & 3u;
+    const uint64_t entry = ent[l4];
+    const uint32_t pos = n + l4;
+    if (n >= 4) {
+        const uint32_t pprio = heap_prio(heap[(pos - 1) / 2]);
+        const bool mine = (uint32_t)lane < cnt;
+        const bool up = mine && pprio > heap_prio(entry);
+        if (__ballot(up) == 0) {
+            if (mine) heap[pos] = entry;
+            n += cnt;
+            return true;
+        }
+    }
+    #pragma unroll 1
+    for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -994,10 +1023,20 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
 // acknowledged before it meets the helper wave (which never touches global memory); __syncthreads() would drain vmcnt.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+} // namespace lama_dev
+#include "lama_brushfire_lse.h"
+namespace lama_dev {
+
+// LSE: the lower wave runs level by level on the main wave (lama_brushfire_lse.h) instead of pop by pop; the raise wave and
+// everything around it are unchanged.  Bit-identical (cfg.brushfire_mode = 2 selects the pop-by-pop form).
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool LSE = false>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
+    __shared__ LseLds<LSE ? LQ_LDS : 1> lse;
+#ifdef LAMA_PROFILE_LSE
+    const uint64_t kt0 = lse_now();
+#endif
     const int p = first_particle + blockIdx.x;
     if (RESUME && prm.slow[p] == 0) return;              // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
@@ -1076,7 +1115,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             pushes(sh.lower, hnl, sh.pl_e[b], cl);
             HFT(2);
             const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
-            if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
+            if (sp || (LSE ? hnr == 0 : (hnr == 0 && hnl == 0))) break;   // the main wave takes the same decision
             if (ph_r && hnr == 0) lds_barrier();               // X: phase switch, the main wave reads lower[0] after the pushes
         }
 #ifdef LAMA_PROFILE_BF
@@ -1133,7 +1172,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     bool tw_running = false, tw_go = false;
     if (TW) {
         spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
-        tw_running = tw_go = !spill && (nr > 0 || nl > 0);
+        tw_running = tw_go = !spill && (LSE ? nr > 0 : (nr > 0 || nl > 0));
         if (lane == 0) { sh.cmd = tw_go ? nl : BF_CMD_EXIT; sh.cmd_r = nr; }
         if (tw_go) e_next = nr > 0 ? sh.raise[0] : sh.lower[0];
         __syncthreads();                                       // S0
@@ -1165,7 +1204,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const uint64_t cand_ = own_wins_ ? (((uint64_t)ohi_ << 32) | olo_) : root_;                     \
             nr += (CNT_R); nl += (CNT_L);                                                                   \
             spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);                      \
-            tw_running = !spill && (nr > 0 || nl > 0);                                                      \
+            tw_running = !spill && (LSE ? nr > 0 : (nr > 0 || nl > 0));                                     \
             if (tw_running) {                                                                               \
                 if ((WAS_RAISE) && nr == 0) { lds_barrier(); /* X */ e_next = sh.lower[0]; }                \
                 else e_next = cand_;                                                                        \
@@ -1240,7 +1279,21 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #else
     BFT(7);
 #endif
-    while (TW ? (tw_running && nl > 0) : (!spill && nl > 0)) {
+    if constexpr (LSE) {
+        if (TW && tw_go) __syncthreads();                      // F: the helper wave has applied the raise wave's last pushes and left
+#ifdef LAMA_PROFILE_LSE
+        const uint64_t kt1 = lse_now();
+        if (lane == 0) { prm.dbg[8 * (size_t)prm.P + 8 * p + 0] = kt1 - kt0; prm.dbg[8 * (size_t)prm.P + 8 * p + 2] = processed; prm.dbg[8 * (size_t)prm.P + 8 * p + 3] = nl; }
+#endif
+        if (!spill && nl > 0) {
+            if (nl + 4 > (uint32_t)LQ_LDS) spill = true;
+            else lse_lower<LQ_LDS>(prm, sh.lower, nl, lse, dc, dir, sv, obs, mask, count, processed, spill, lane, anc, p);
+        }
+#ifdef LAMA_PROFILE_LSE
+        if (lane == 0) { prm.dbg[8 * (size_t)prm.P + 8 * p + 1] = lse_now() - kt1; prm.dbg[8 * (size_t)prm.P + 8 * p + 4] = spill ? 1 : 0; }
+#endif
+    }
+    while (!LSE && (TW ? (tw_running && nl > 0) : (!spill && nl > 0))) {
         if (!TW && nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
         const uint64_t e = TW ? e_next : sh.lower[0];
         const int rx = q_rx(e), ry = q_ry(e);
@@ -1373,7 +1426,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         BFT(6);
     }
-    if (TW && tw_go) __syncthreads();                          // F: the helper has applied the last pushes
+    if (!LSE && TW && tw_go) __syncthreads();                  // F: the helper has applied the last pushes
     #undef BF_TW_TAIL
     #undef BF_LOAD_A
     #undef BF_LOAD_B

@@ -67,5 +67,8 @@ int main(int argc, char** argv)
     printf("levels %lu plans %lu passes %lu vevents %lu pops fast %lu serial %lu | hazards: nonsolid %lu sq %lu dead-target %lu | dup lanes %lu dead lanes %lu big levels %lu\n",
            st.levels, st.plans, st.passes, st.vevents, st.pops_fast, st.pops_serial, st.hz_nonsolid, st.hz_sq, st.hz_dead_target, st.dup_lanes, st.dead_lanes, st.big_levels);
     printf("sift moves/pop %.2f  pushes %lu climbs %lu\n", (double)st.sift_moves / (st.pops_fast ? st.pops_fast : 1), st.pushes, st.push_climbs);
+    printf("heap commit: passes %lu sifts %lu dirty(static) %lu (%.1f%%) zone-touching sifts %lu (%.2f%%) passes with a touch %lu (%.1f%%) depth rounds/pass %.2f underflow passes %lu climb passes %lu double climbs %lu\n",
+           st.st_passes, st.st_sifts, st.st_dirty, 100.0 * st.st_dirty / st.st_sifts, st.st_touch_sifts, 100.0 * st.st_touch_sifts / st.st_sifts,
+           st.st_touch_passes, 100.0 * st.st_touch_passes / st.st_passes, (double)st.st_depth_rounds / st.st_passes, st.st_underflow_passes, st.st_climb_passes, st.st_dbl_climb);
     return bad;
 }

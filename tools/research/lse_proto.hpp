@@ -27,6 +27,7 @@ struct LseStats {
     uint64_t levels = 0, plans = 0, passes = 0, vevents = 0, pops_fast = 0, pops_serial = 0;
     uint64_t hz_nonsolid = 0, hz_sq = 0, hz_dead_target = 0, dup_lanes = 0, dead_lanes = 0, big_levels = 0;
     uint64_t sift_moves = 0, push_climbs = 0, pushes = 0;
+    uint64_t st_passes = 0, st_dirty = 0, st_touch_sifts = 0, st_touch_passes = 0, st_sifts = 0, st_depth_rounds = 0, st_underflow_passes = 0, st_climb_passes = 0, st_dbl_climb = 0;
 };
 inline LseStats& lse_stats() { static LseStats s; return s; }
 
@@ -294,6 +295,26 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                 ((distance_t*)dm.get(V3u{l.x, l.y, 0}))->is_queued = false;
             }
             // ---------------- COMMIT heap, pops 0 .. last, serial and exact ----------------
+            // statistics for a parallel form: the zone of slots the tail of the array can interact with during this pass
+            uint32_t z_lo = (uint32_t)H.size(), z_hi = (uint32_t)H.size();
+            {
+                uint32_t sz = (uint32_t)H.size();
+                for (uint32_t i = 0; i <= last; ++i) { sz -= 1; z_lo = std::min(z_lo, sz); sz += (uint32_t)L[i].cnt; z_hi = std::max(z_hi, sz); }
+            }
+            const uint32_t p_lo = z_lo ? (z_lo - 1) / 2 : 0, p_hi = z_hi ? (z_hi - 1) / 2 : 0;
+            auto in_zone = [&](uint32_t pos) { return pos >= z_lo || (pos >= p_lo && pos <= p_hi); };
+            auto is_anc_of_zone = [&](uint32_t h) {       // h is an ancestor-or-self of a slot in [p_lo, p_hi] or [z_lo, z_hi]
+                for (int j = 0; j < 20; ++j) {
+                    const uint64_t a = ((uint64_t)(h + 1) << j) - 1, b = ((uint64_t)(h + 2) << j) - 2;
+                    if (a > z_hi) break;
+                    if ((a <= p_hi && b >= p_lo) || (a <= z_hi && b >= z_lo)) return true;
+                }
+                return false;
+            };
+            ++S.st_passes;
+            bool touch_pass = false, climb_pass = false;
+            if (z_lo + 1 < nl_pass) ++S.st_underflow_passes;
+            { uint32_t dm = 0; for (uint32_t i = 0; i <= last; ++i) if (!(vevent && i == last)) dm |= 1u << depth_of(P.holepos[I + i]); S.st_depth_rounds += (uint64_t)__builtin_popcount(dm); }
             for (uint32_t i = 0; i <= last; ++i) {
                 const uint32_t n = (uint32_t)H.size();
                 if (vevent && i == last) {
@@ -304,16 +325,20 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                     if (len > 0) {
                         uint32_t hole = P.holepos[I + i];
                         assert(hole < len);
+                        ++S.st_sifts;
+                        if (is_anc_of_zone(hole)) ++S.st_dirty;
+                        bool touched = in_zone(hole);
                         for (;;) {
                             const uint32_t c2 = 2 * hole + 2;
                             uint32_t c;
-                            if (c2 < len) c = (H[c2].first > H[c2 - 1].first) ? c2 - 1 : c2;
-                            else if (c2 == len) c = len - 1;
+                            if (c2 < len) { c = (H[c2].first > H[c2 - 1].first) ? c2 - 1 : c2; if (in_zone(c2) || in_zone(c2 - 1)) touched = true; }
+                            else if (c2 == len) { c = len - 1; touched = true; }
                             else break;
                             if (H[c].first > v.first) break;
                             H[hole] = H[c]; hole = c; ++S.sift_moves;
                         }
                         H[hole] = v;
+                        if (touched) { ++S.st_touch_sifts; touch_pass = true; }
                     }
                 }
                 const Lane& l = L[i];
@@ -322,14 +347,19 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                     const QP x{(int)l.nsq[a], V3u{l.x + DX[a], l.y + DY[a], 0}};
                     H.push_back(x);
                     uint32_t hole = (uint32_t)H.size() - 1;
+                    int climbs = 0;
                     while (hole > 0) {
                         const uint32_t parent = (hole - 1) / 2;
                         if (!(H[parent].first > x.first)) break;
-                        H[hole] = H[parent]; hole = parent; ++S.push_climbs;
+                        H[hole] = H[parent]; hole = parent; ++S.push_climbs; ++climbs;
                     }
+                    if (climbs) climb_pass = true;
+                    if (climbs > 1) ++S.st_dbl_climb;
                     H[hole] = x; ++S.pushes;
                 }
             }
+            if (touch_pass) ++S.st_touch_passes;
+            if (climb_pass) ++S.st_climb_passes;
             if (vevent) {
                 ++S.vevents;
                 // list edit: e_v moves from its place to the slot right behind the current right spine
