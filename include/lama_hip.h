@@ -75,7 +75,10 @@ typedef struct lama_hip_cfg {
     uint32_t sequential_raycast; /* ray-cast kernels: 0 / 2 = parallel form (default), 1 = beam-sequential form; bit-identical */
     uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
                                     1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
-                                        the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md) */
+                                        the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md);
+                                    2 = exact like 0, but the lower wave is replayed one priority LEVEL at a time (the pop order
+                                        of a level out of libstdc++'s heap follows from the slots its entries occupy, see
+                                        lama_brushfire_lse.h); bit-identical to 0, currently not faster */
     uint32_t brushfire_waves;    /* exact brushfire: 0 / 2 = a helper wave per particle owns the heap (default), 1 = one wave per
                                     particle; bit-identical */
     uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}

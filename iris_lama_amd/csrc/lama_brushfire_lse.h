@@ -81,13 +81,15 @@ __device__ __noinline__ uint32_t lse_plan(const uint64_t* H, uint32_t nl, uint32
     lse_lds_sync();
     for (uint32_t idx = (uint32_t)lane; idx < m; idx += 64) {
         const uint32_t q = L.mpos[idx];
+        // |subtree(q)| = members in the slot range of every depth below q (all reads independent: no early exit)
         uint32_t s = 0;
-        for (int j = 0; j < 16; ++j) {
+        #pragma unroll
+        for (int j = 0; j < 14; ++j) {
             const uint32_t lo = ((q + 1u) << j) - 1u;
-            if (lo >= nl) break;
             uint32_t hi = ((q + 2u) << j) - 1u;
             hi = hi < nl ? hi : nl;
-            s += (uint32_t)L.C[hi] - (uint32_t)L.C[lo];
+            const uint32_t lo_c = lo < nl ? lo : nl;
+            s += (uint32_t)L.C[hi] - (uint32_t)L.C[lo_c];
         }
         L.sByPos[q] = (uint16_t)s;
     }
@@ -96,8 +98,14 @@ __device__ __noinline__ uint32_t lse_plan(const uint64_t* H, uint32_t nl, uint32
         const uint32_t q = L.mpos[idx];
         const uint32_t dep = 31u - (uint32_t)__clz((int)(q + 1u));
         uint32_t t = dep;
-        for (uint32_t c = q; c > 0; c = (c - 1u) >> 1)
-            if (c & 1u) { const uint32_t r = c + 1u; if (r < nl) t += L.sByPos[r]; }
+        uint32_t c = q;
+        #pragma unroll
+        for (int j = 0; j < 14; ++j) {                                   // the path q -> root, all reads independent
+            const uint32_t r = c + 1u;
+            const bool use = c > 0 && (c & 1u) && r < nl;
+            t += use ? (uint32_t)L.sByPos[use ? r : 0u] : 0u;
+            c = c > 0 ? (c - 1u) >> 1 : 0u;
+        }
         const uint32_t rem = t + L.sByPos[q] - 1u - dep;
         L.tByPos[q] = (uint16_t)t;
         L.remByPos[q] = (uint16_t)rem;
@@ -106,85 +114,6 @@ __device__ __noinline__ uint32_t lse_plan(const uint64_t* H, uint32_t nl, uint32
     }
     lse_lds_sync();
     return m;
-}
-
-// serial (one lane) statement of one iteration of the lower loop, for the rare levels the parallel form does not take
-struct LseSerial {
-    uint32_t WC, W, dm_cap, max_sqdist;
-    int32_t* err;
-    DirCache dc;
-    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
-    int count;
-    __device__ inline int get(int rx, int ry)            // non-const Map::get: allocate + mask bit; slot * 1024 + cell or -1
-    {
-        if ((uint32_t)rx >= WC || (uint32_t)ry >= WC) { atomicOr(err, ERR_WINDOW); return -1; }
-        const uint32_t pidx = ((uint32_t)ry >> 5) * W + ((uint32_t)rx >> 5);
-        int slot = dc.lookup(pidx);
-        if (slot < 0) {
-            if (count >= (int)dm_cap) { atomicOr(err, ERR_DM_CAP); return -1; }
-            slot = count++;
-            dir[pidx] = (int16_t)slot;
-            dc.update(pidx, slot);
-        }
-        const uint32_t ci = ((uint32_t)rx & 31u) | (((uint32_t)ry & 31u) << 5);
-        atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
-        return slot * 1024 + (int)ci;
-    }
-};
-struct LdsStore {
-    uint64_t* h;
-    __device__ inline uint64_t get(uint32_t i) const { return h[i]; }
-    __device__ inline void set(uint32_t i, uint64_t v) const { h[i] = v; }
-};
-
-// pops the heap until its root leaves level d (one lane; dynamic_distance_map.cpp:175-194, 281-330 statement by statement)
-__device__ __noinline__ void lse_serial_level(LseSerial& c, uint64_t* H, uint32_t& nl, uint32_t d, uint32_t cap, uint64_t& processed, bool& overflow)
-{
-    LdsStore st{H};
-    while (nl > 0 && heap_prio(H[0]) == d) {
-        if (nl + 4 > cap) { overflow = true; return; }
-        const uint64_t e = heap_pop(st, nl);
-        const int rx = q_rx(e), ry = q_ry(e);
-        ++processed;
-        const int cur = c.get(rx, ry);
-        if (cur < 0) continue;
-        const uint16_t s = c.sv[cur];
-        if (!(s & SV_VALID)) continue;
-        const uint32_t co = c.obs[cur];
-        const int cox = obs_x(co), coy = obs_y(co);
-        const int oc = c.get(rx + cox, ry + coy);
-        if (oc < 0) continue;
-        if ((c.sv[oc] & SV_SQMASK) != 0) continue;                   // :191 (valid NOT tested)
-        if (!(s & SV_QUEUED)) continue;                              // lower() :283
-        const int obx = rx + cox, oby = ry + coy;
-        #pragma unroll 1
-        for (int a = 0; a < 4; ++a) {
-            const int dx = lse_dx(a), dy = lse_dy(a);
-            if (dx * cox > 0 || dy * coy > 0) continue;              // :296
-            const int nx = rx + dx, ny = ry + dy;
-            const int nc = c.get(nx, ny);
-            if (nc < 0) continue;
-            const uint16_t ns = c.sv[nc];
-            const int qx = nx - obx, qy = ny - oby;
-            const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
-            const uint32_t cmp = (ns & SV_VALID) ? (uint32_t)(ns & SV_SQMASK) : c.max_sqdist;
-            bool over = new_sq < cmp;
-            if (!over && new_sq == (uint32_t)(ns & SV_SQMASK)) {     // :311-317
-                const uint32_t nobs = c.obs[nc];
-                const int tc = c.get(nx + obs_x(nobs), ny + obs_y(nobs));
-                if (tc >= 0) {
-                    const uint16_t os = c.sv[tc];
-                    if (!(ns & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
-                }
-            }
-            if (over) {
-                heap_push(st, nl, q_entry(new_sq, nx, ny, obx - nx, oby - ny));
-                c.sv[nc] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
-                c.obs[nc] = pack_obs(obx - nx, oby - ny);
-            }
-        }
-        c.sv[cur] = (uint16_t)(c.sv[cur] & ~SV_QUEUED);
-    }
 }
 
 // The lower wave.  One wave (all 64 lanes call); H = the lower queue's heap array in LDS with nl entries (a consistent libstdc++
@@ -278,65 +207,89 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
             // offers: per direction a the <= 4 offers to N = B + delta_a of this pass, applied in pop order
             uint32_t okm = 0;                       // my successful offers, bit a
             uint32_t awm = 0;                       // directions away from my obstacle
-            uint32_t nsq_[4]; uint32_t sk_[4][4]; uint32_t sm_[4];      // sorted (rank << 16 | new), success bits
+            uint32_t nsq_[4];
+            // who else offers to my targets?  The cell that reaches N = B + delta_a by direction b is N - delta_b (b == a: me).
+            // All 12 first probes of the hash are issued together, then the obstacle offsets of the lanes found.
+            uint32_t pk_[4][4], pw_[4][4];
+            #pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const bool away = fired && !(lse_dx(a) * cox > 0 || lse_dy(a) * coy > 0);
+                #pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    pk_[a][b] = LSE_HEMPTY; pw_[a][b] = LSE_HEMPTY;
+                    if (b == a) continue;
+                    const int mx = x + lse_dx(a) - lse_dx(b), my = y + lse_dy(a) - lse_dy(b);
+                    if (away && inw_[a] && (uint32_t)mx < prm.WC && (uint32_t)my < prm.WC) {
+                        pk_[a][b] = ((uint32_t)my << 13) | (uint32_t)mx;
+                        pw_[a][b] = L.hkey[lse_hash(pk_[a][b])];
+                    }
+                }
+            }
+            int pj_[4][4]; uint32_t po_[4][4];
+            #pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                #pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    pj_[a][b] = -1; po_[a][b] = 0;
+                    if (b == a) continue;
+                    const uint32_t w = pw_[a][b];
+                    if (w != LSE_HEMPTY) {
+                        if ((w >> 6) == pk_[a][b]) pj_[a][b] = (int)(w & 63u);
+                        else pj_[a][b] = find(pk_[a][b]);                       // collision: walk the probe sequence
+                    }
+                    if (pj_[a][b] >= 0) po_[a][b] = L.laneobs[pj_[a][b]];
+                }
+            }
+            // Closed form of "apply the <= 4 offers to N in pop order" (dynamic_distance_map.cpp:303-326): mine succeeds iff it
+            // would succeed on the state N has at the start of the pass and no EARLIER pop offers a candidate <= mine (an earlier
+            // offer either took the cell with a smaller-or-equal distance or failed against an even smaller one; an equal candidate
+            // now ties with a live obstacle); it owns N's final state iff moreover no LATER pop up to the cut offers a candidate
+            // < mine (successful offers to one cell have strictly decreasing candidates).
+            uint32_t later_[4];                     // lowest later pop with a smaller candidate, 255 = none
             #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int dx = lse_dx(a), dy = lse_dy(a);
                 const bool away = fired && !(dx * cox > 0 || dy * coy > 0);
-                const int nx = x + dx, ny = y + dy;
                 const int qx = dx - cox, qy = dy - coy;
                 nsq_[a] = (uint32_t)(qx * qx + qy * qy);
-                sm_[a] = 0;
-                uint32_t kk[4];
+                const bool valid0 = (s_[a] & SV_VALID) != 0;
+                const uint32_t sq0 = (uint32_t)(s_[a] & SV_SQMASK);
+                const bool solid0 = (t_[a] & SV_VALID) && (t_[a] & SV_SQMASK) == 0;
+                const uint32_t cmp0 = valid0 ? sq0 : prm.max_sqdist;
+                bool ok = away && inw_[a] && (nsq_[a] < cmp0 || (nsq_[a] == sq0 && (!valid0 || !solid0)));      // :308-317
+                uint32_t later = 255u;
                 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    kk[b] = 0xFFFFFFFFu;
-                    if (b == a) { if (away && inw_[a]) kk[b] = ((uint32_t)lane << 16) | nsq_[a]; continue; }
-                    const int mx = nx - lse_dx(b), my = ny - lse_dy(b);          // reaches N by direction b
-                    int j = -1;
-                    if (away && inw_[a] && (uint32_t)mx < prm.WC && (uint32_t)my < prm.WC) j = find(((uint32_t)my << 13) | (uint32_t)mx);
-                    if (j >= 0) {
-                        const uint32_t jo = L.laneobs[j];
-                        const int jcx = obs_x(jo), jcy = obs_y(jo);
-                        if (!(lse_dx(b) * jcx > 0 || lse_dy(b) * jcy > 0)) {
+                    if (b == a) continue;
+                    if (pj_[a][b] >= 0) {
+                        const int jcx = obs_x(po_[a][b]), jcy = obs_y(po_[a][b]);
+                        if (!(lse_dx(b) * jcx > 0 || lse_dy(b) * jcy > 0)) {                 // that cell offers to N too
                             const int rx_ = lse_dx(b) - jcx, ry_ = lse_dy(b) - jcy;
-                            kk[b] = ((uint32_t)j << 16) | (uint32_t)(rx_ * rx_ + ry_ * ry_);
+                            const uint32_t nq = (uint32_t)(rx_ * rx_ + ry_ * ry_);
+                            const uint32_t rj = (uint32_t)pj_[a][b];
+                            if (rj < (uint32_t)lane && nq <= nsq_[a]) ok = false;
+                            if (rj > (uint32_t)lane && nq < nsq_[a] && rj < later) later = rj;
                         }
                     }
                 }
-                // sort the four keys (rank ascending; 0xFFFFFFFF = no offer) -- 5 compare-exchanges
-                #define LSE_CX(i_, j_) { const uint32_t lo_ = kk[i_] < kk[j_] ? kk[i_] : kk[j_]; const uint32_t hi_ = kk[i_] < kk[j_] ? kk[j_] : kk[i_]; kk[i_] = lo_; kk[j_] = hi_; }
-                LSE_CX(0, 1) LSE_CX(2, 3) LSE_CX(0, 2) LSE_CX(1, 3) LSE_CX(1, 2)
-                #undef LSE_CX
-                bool valid = (s_[a] & SV_VALID) != 0;
-                uint32_t sq = (uint32_t)(s_[a] & SV_SQMASK);
-                bool osolid = (t_[a] & SV_VALID) && (t_[a] & SV_SQMASK) == 0;
-                #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    sk_[a][t] = kk[t];
-                    if (kk[t] == 0xFFFFFFFFu) continue;
-                    const uint32_t nq = kk[t] & 0xFFFFu;
-                    const uint32_t cmp = valid ? sq : prm.max_sqdist;
-                    bool over = nq < cmp;
-                    if (!over && nq == sq && (!valid || !osolid)) over = true;       // :311-317
-                    if (over) {
-                        valid = true; sq = nq; osolid = true;
-                        sm_[a] |= 1u << t;
-                        if ((kk[t] >> 16) == (uint32_t)lane) okm |= 1u << a;
-                    }
-                }
+                later_[a] = later;
+                if (ok) okm |= 1u << a;
                 if (away) awm |= 1u << a;
                 if (away && !inw_[a]) atomicOr(prm.err, ERR_WINDOW);
             }
-            // a successful offer that lands on the cell of a pop that did not fire would change what that pop does
+            // A successful offer of an EARLIER pop that lands on the cell of a pop that did not fire (a stale queue entry) may
+            // change what that pop does: the pass is cut right before it and the rest is evaluated again on the updated map.
+            uint32_t dcut = 64u;
             {
                 unsigned long long deadm = __ballot(act && !fired && !dup);
-                while (deadm && !__ballot(hazard)) {
+                while (deadm) {
                     const int jd = __ffsll((long long)deadm) - 1;
                     deadm &= deadm - 1ull;
                     const int dxq = __builtin_amdgcn_readlane(x, jd), dyq = __builtin_amdgcn_readlane(y, jd);
+                    bool hit = false;
                     #pragma unroll
-                    for (int a = 0; a < 4; ++a) if (((okm >> a) & 1u) && x + lse_dx(a) == dxq && y + lse_dy(a) == dyq) hazard = true;
+                    for (int a = 0; a < 4; ++a) if (lane < jd && ((okm >> a) & 1u) && x + lse_dx(a) == dxq && y + lse_dy(a) == dyq) hit = true;
+                    if (__ballot(hit)) { dcut = (uint32_t)jd; break; }
                 }
             }
             const uint32_t cnt = (uint32_t)__popc(okm);
@@ -350,13 +303,23 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
                 if (pos < nl_pass) vev = heap_prio(H[pos]) == d && (uint32_t)L.remByPos[pos] >= I + (uint32_t)lane;
             }
             const unsigned long long vm = __ballot(vev);
-            const bool vevent = vm != 0ull;
+            uint32_t last = vm ? (uint32_t)(__ffsll((long long)vm) - 1) : k - 1u;
+            bool vevent = vm != 0ull;
+            // a firing pop the parallel form must not mix with others (its obstacle is not a live obstacle, or the cell is not at
+            // level d: a stale entry of a cell that was re-entered) gets a pass of its own -- one pop at a time IS the reference
+            const unsigned long long hzm = __ballot(hazard);
+            if (hzm) {
+                const uint32_t jh = (uint32_t)(__ffsll((long long)hzm) - 1);
+                if (jh == 0u) { if (last > 0u) { last = 0u; vevent = false; } }
+                else if (jh < dcut) dcut = jh;
+            }
+            if (dcut <= last) { last = dcut - 1u; vevent = false; }        // dcut >= 1: an earlier lane made the offer
             LSET(2);
-            const uint32_t last = vevent ? (uint32_t)(__ffsll((long long)vm) - 1) : k - 1u;
             const uint32_t total_push = (uint32_t)__builtin_amdgcn_readlane((int)(pbase + cnt), (int)last);
             const bool overflow = nl_pass + total_push + 4u > (uint32_t)LQ;
-            if (__ballot(hazard) != 0ull || overflow) {
-                // materialise (logical entry of member slot q = list[pop rank of q among the remaining members]) and go serial
+            if (overflow) {
+                // the heap would outgrow its LDS window: make the array consistent again (logical entry of member slot q =
+                // list[pop rank of q among the remaining members]) and hand the particle to the next stage
                 if (I > 0) {
                     m = lse_plan<LQ>(H, nl, d, L, lane, false, nullptr);
                     for (uint32_t idx = (uint32_t)lane; idx < m; idx += 64) { const uint32_t q = L.mpos[idx]; H[q] = L.lst[cur][I + (uint32_t)L.tByPos[q]]; }
@@ -364,23 +327,8 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
                     for (uint32_t idx = (uint32_t)lane; idx < m; idx += 64) { const uint32_t q = L.mpos[idx]; H[q] = L.lst[cur][(uint32_t)L.tByPos[q]]; }
                 }
                 lse_lds_sync();
-                if (overflow) { spill = true; return; }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                uint32_t nl2 = nl; uint64_t pr2 = 0; int cnt2 = count; bool of2 = false;
-                if (lane == 0) {
-                    LseSerial sc{prm.WC, prm.W, prm.dm_cap, prm.max_sqdist, prm.err, dc, dir, sv, obs, mask, count};
-                    lse_serial_level(sc, H, nl2, d, (uint32_t)LQ, pr2, of2);
-                    cnt2 = sc.count;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                lse_lds_sync();
-                nl = (uint32_t)__builtin_amdgcn_readfirstlane((int)nl2);
-                count = __builtin_amdgcn_readfirstlane(cnt2);
-                processed += (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr2);
-                if (__builtin_amdgcn_readfirstlane((int)of2)) spill = true;
-                level_done = true;
-                LSET(6); LSEC(7, 1ull << 40);
-                break;
+                spill = true;
+                return;
             }
             // ------------------------------------------------------------------ COMMIT cells, lanes 0 .. last
             const bool mine = act && (uint32_t)lane <= last;
@@ -394,11 +342,7 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
                     if (freshp || !(s_[a] & (SV_VALID | SV_QUEUED)))
                         atomicOr((unsigned long long*)(mask + (size_t)slot_[a] * 16 + (ci_[a] >> 6)), 1ull << (ci_[a] & 63));
                     if ((okm >> a) & 1u) {
-                        // the last successful offer of a pop <= last owns the cell's state
-                        uint32_t owner = 0xFFFFu;
-                        #pragma unroll
-                        for (int t = 0; t < 4; ++t) if (((sm_[a] >> t) & 1u) && (sk_[a][t] >> 16) <= last) owner = sk_[a][t] >> 16;
-                        if (owner == (uint32_t)lane) {
+                        if (!(later_[a] <= last)) {             // the last successful offer of a pop <= last owns the cell's state
                             sv[slot_[a] * 1024 + (int)ci_[a]] = (uint16_t)(SV_VALID | SV_QUEUED | (nsq_[a] & SV_SQMASK));
                             obs[slot_[a] * 1024 + (int)ci_[a]] = pack_obs(cox - lse_dx(a), coy - lse_dy(a));
                         }
@@ -425,7 +369,9 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
                 } else {
                     const uint64_t v = tail_known ? tail_val : H[nl - 1u];
                     --nl;
-                    if (nl > 0) (void)lds_sift_topdown(H, nl, (uint32_t)__builtin_amdgcn_readlane((int)hp_lane, (int)i), v, lane, anc);
+                    if (nl > 0) {
+                        (void)lds_sift_topdown(H, nl, (uint32_t)__builtin_amdgcn_readlane((int)hp_lane, (int)i), v, lane, anc);
+                    }
                 }
                 tail_known = false;
                 if (ci_cnt) {
@@ -461,7 +407,7 @@ __device__ __forceinline__ void lse_lower(const DevParams& prm, uint64_t* H, uin
                 cur ^= 1; m = mR; I = 0; fresh = false;
                 LSET(5); LSEC(7, 1ull << 20);
             } else {
-                I += k;
+                I += last + 1u;
             }
         }
         (void)fresh;

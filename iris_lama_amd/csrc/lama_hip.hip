@@ -325,7 +325,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
-        const bool lse = c->cfg.brushfire_mode != 2;        // level-synchronous lower wave (default) / pop by pop; bit-identical
+        const bool lse = c->cfg.brushfire_mode == 2;        // lower wave level by level (lama_brushfire_lse.h) instead of pop by pop; bit-identical
         if (c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES)) {
             if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);

@@ -39,8 +39,11 @@ def _angle(p):
     return np.arctan2(p[..., 1], p[..., 0])
 
 
-@pytest.mark.parametrize("P,steps,seq_ray,bf_waves", [(8, 12, 2, 0), (8, 12, 1, 1), (40, 4, 0, 2), (40, 4, 0, 1)])
-def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves):
+@pytest.mark.parametrize("P,steps,seq_ray,bf_waves,bf_mode", [(8, 12, 2, 0, 0), (8, 12, 1, 1, 0), (40, 4, 0, 2, 0), (40, 4, 0, 1, 0),
+                                                              (8, 12, 2, 0, 2), (40, 4, 0, 1, 2), (300, 3, 0, 0, 0)])
+def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
+    """bf_mode 2 = the level-synchronous form of the exact lower wave (lama_brushfire_lse.h); P = 300 is one of BASELINE's
+    particle counts."""
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
     opts = O.default_options(particles=P, seed=7)
@@ -49,7 +52,7 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves):
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
 
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves))
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves, brushfire_mode=bf_mode))
     ctx.init(pts[0], pose0)
     for i in (0, P - 1):
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"init occ p{i}")
@@ -75,8 +78,6 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves):
         dth = np.abs(_angle(g_poses) - _angle(o_poses))
         assert (dxy[same] <= POSE_TOL).all() and (dth[same] <= POSE_TOL).all(), (k, dxy, dth)
         assert np.allclose(g_ll[same], o_ll[same], rtol=LL_RTOL, atol=0), (k, g_ll, o_ll)
-        # a flipped GN decision moves the pose by at most the eps2 scale
-        assert (dxy[~same] <= 5e-4).all() and (dth[~same] <= 5e-4).all()
 
         # ---- stage (iii): resample with a fixed index vector every other step
         if k % 2 == 0:
@@ -93,7 +94,7 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves):
         for i in range(P):
             assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
             assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
-    assert flips <= P * steps // 10, f"too many Gauss-Newton decision flips: {flips}"
+    assert flips == 0, f"Gauss-Newton decision flips against the oracle: {flips}"     # identical iteration counts on these seeds
     c = ctx.counters()
     assert c["launches_scan_match"] == steps and c["launches_update_maps"] == steps + 1
     print("counters", c, "GN flips", flips)
@@ -134,8 +135,8 @@ def test_free_running_host_class_tracks_oracle_and_truth(F):
         op = o.poses()[o.best()]
         assert np.hypot(gp[0] - truth[k][0], gp[1] - truth[k][1]) < 0.03, (k, gp, truth[k])
         worst = max(worst, np.hypot(gp[0] - op[2], gp[1] - op[3]))
-    assert worst < 0.02, worst
-    assert abs(h.neff() - o.neff()) < 0.5
+    assert worst < 1e-6, worst
+    assert abs(h.neff() - o.neff()) < 1e-3
     print("free-running: max |gpu best - oracle best| = %.2e m" % worst)
     print(h.summary())
     h.close()
@@ -858,6 +859,7 @@ def test_randomized_rooms_maps_bit_exact(F, seed):
     trunc_range = float(rng.choice([0.0, 0.0, kind["R"] * 0.8]))
     seq_ray = int(rng.choice([1, 2]))
     bf_waves = int(rng.choice([1, 2]))
+    bf_mode = int(np.random.default_rng(77 + seed).choice([0, 2]))      # pop-by-pop / level-synchronous lower wave
     base = np.array([rng.uniform(-0.3, 0.3) * kind["R"], rng.uniform(-0.3, 0.3) * kind["R"], rng.uniform(-np.pi, np.pi)])
     opts = O.default_options(particles=P, seed=seed + 1, truncated_ray=trunc_ray, truncated_range=trunc_range)
     pf = O.PF(opts)
@@ -866,7 +868,7 @@ def test_randomized_rooms_maps_bit_exact(F, seed):
     pf.set_prior(pose0)
     assert pf.update(scan0, pose0)
     ctx = F.HipContext(F.default_cfg(particles=P, truncated_ray=trunc_ray, truncated_range=trunc_range, sequential_raycast=seq_ray,
-                                     brushfire_waves=bf_waves, dm_patch_capacity=1024, occ_patch_capacity=1024))
+                                     brushfire_waves=bf_waves, brushfire_mode=bf_mode, dm_patch_capacity=1024, occ_patch_capacity=1024))
     ctx.init(scan0, pose0)
     for k in range(4):
         truth = base + np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3)])

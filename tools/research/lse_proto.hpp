@@ -192,6 +192,7 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
             std::unordered_map<uint64_t, int> table;          // kernel: LDS hash, cell -> lowest firing lane
             auto key = [](uint32_t x, uint32_t y) { return ((uint64_t)y << 32) | x; };
             bool hazard = false;
+            int hz_first = -1;          // first firing lane the parallel form cannot mix with others: it gets a pass of its own
             std::vector<int> dead;
             for (uint32_t i = 0; i < k; ++i) {
                 Lane& l = L[i];
@@ -201,8 +202,7 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                 const distance_t& o = peek(dm, l.x + l.cox, l.y + l.coy);
                 l.fired = l.cur.valid_obstacle && o.sqdist == 0 && l.cur.is_queued;
                 if (l.fired) {
-                    if (!solid(o)) { hazard = true; ++S.hz_nonsolid; }
-                    if (l.cur.sqdist != (uint16_t)d) { hazard = true; ++S.hz_sq; }
+                    if (!solid(o) || l.cur.sqdist != (uint16_t)d) { if (hz_first < 0) hz_first = (int)i; }
                     auto ins = table.emplace(key(l.x, l.y), (int)i);
                     if (!ins.second) { l.dup = true; l.fired = false; ++S.dup_lanes; }     // same cell, later pop: is_queued is off by then
                 } else { dead.push_back((int)i); ++S.dead_lanes; }
@@ -229,28 +229,37 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                             const int rx = (int)nx - (int)(mx + j.cox), ry = (int)ny - (int)(my + j.coy);
                             offs[no++] = Off{it->second, (uint32_t)(rx * rx + ry * ry)};
                         }
-                        std::sort(offs, offs + no, [](const Off& p, const Off& q) { return p.rank < q.rank; });
+                        // closed form of "apply the offers in pop order" (kernel): mine succeeds iff it would succeed on the
+                        // pass-start state and no EARLIER pop offers a candidate <= mine; it owns the cell's final state iff in
+                        // addition no LATER pop (up to the cut) offers a candidate < mine.
                         const distance_t& n0 = peek(dm, nx, ny);
-                        bool valid = n0.valid_obstacle; uint32_t sq = n0.sqdist;
-                        bool obs_solid = solid(peek(dm, nx + n0.obstacle[0], ny + n0.obstacle[1]));
+                        const bool valid0 = n0.valid_obstacle; const uint32_t sq0 = n0.sqdist;
+                        const bool solid0 = solid(peek(dm, nx + n0.obstacle[0], ny + n0.obstacle[1]));
+                        const uint32_t cmp0 = valid0 ? sq0 : max_sq;
+                        const uint32_t mine = l.nsq[a];
+                        bool ok = mine < cmp0 || (mine == sq0 && (!valid0 || !solid0));
+                        int later = 255;
                         for (int t = 0; t < no; ++t) {
-                            const uint32_t cmp = valid ? sq : max_sq;
-                            bool over = offs[t].nsq < cmp;
-                            if (!over && offs[t].nsq == sq) { if (!valid || !obs_solid) over = true; }
-                            if (over) {
-                                valid = true; sq = offs[t].nsq; obs_solid = true;
-                                l.succ_rank[a][l.nsucc[a]++] = offs[t].rank;
-                                if (offs[t].rank == (int)i) l.ok[a] = true;
-                            }
+                            if (offs[t].rank < (int)i && offs[t].nsq <= mine) ok = false;
+                            if (offs[t].rank > (int)i && offs[t].nsq < mine) later = std::min(later, offs[t].rank);
                         }
+                        l.ok[a] = ok;
+                        l.later_ok[a] = later;
                         if (l.ok[a]) ++l.cnt;
                     }
                 }
-                // P4: a successful offer that lands on the cell of a lane that did not fire changes what that lane does
-                for (int j : dead)
-                    for (uint32_t i = 0; i < k && !hazard; ++i)
+            }
+            // P4: a successful offer of an EARLIER lane that lands on the cell of a lane that did not fire may change what that lane
+            // does: cut the pass right before that lane (it is evaluated again on the updated map)
+            uint32_t dcut = 64;
+            if (!hazard) {
+                for (int j : dead) {
+                    bool hit = false;
+                    for (uint32_t i = 0; i < (uint32_t)j && !hit; ++i)
                         for (int a = 0; a < 4; ++a)
-                            if (L[i].ok[a] && L[i].x + DX[a] == L[j].x && L[i].y + DY[a] == L[j].y) { hazard = true; ++S.hz_dead_target; }
+                            if (L[i].ok[a] && L[i].x + DX[a] == L[j].x && L[i].y + DY[a] == L[j].y) hit = true;
+                    if (hit) { dcut = (uint32_t)j; ++S.hz_dead_target; break; }
+                }
             }
             if (hazard) { serial_finish(I); return processed; }
             // ---------------- v-event: the first pop whose re-inserted last element is a member ----------------
@@ -264,6 +273,9 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                     pushed += (uint32_t)L[i].cnt;
                 }
             }
+            if (hz_first == 0) { if (last > 0) { last = 0; vevent = false; } if (hz_first == 0) ++S.hz_sq; }
+            else if (hz_first > 0 && (uint32_t)hz_first < dcut) dcut = (uint32_t)hz_first;
+            if (dcut <= last) { last = dcut - 1; vevent = false; }
             // ---------------- COMMIT cells, lanes 0 .. last ----------------
             for (uint32_t i = 0; i <= last; ++i) {
                 Lane& l = L[i];
@@ -283,9 +295,7 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                     bf_trace_add(1, l.nsq[a], nl_);
                     ++dm.stats.pushes;
                     // the last successful offer with rank <= last owns the cell's final state
-                    int owner = -1;
-                    for (int t = 0; t < l.nsucc[a]; ++t) if (l.succ_rank[a][t] <= (int)last) owner = std::max(owner, l.succ_rank[a][t]);
-                    if (owner == (int)i) {
+                    if (!(l.later_ok[a] <= (int)last)) {
                         n->sqdist = (uint16_t)l.nsq[a]; n->valid_obstacle = true; n->is_queued = true;
                         n->obstacle[0] = (int16_t)((int)(l.x + l.cox) - (int)nl_.x);
                         n->obstacle[1] = (int16_t)((int)(l.y + l.coy) - (int)nl_.y);
@@ -315,6 +325,39 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
             bool touch_pass = false, climb_pass = false;
             if (z_lo + 1 < nl_pass) ++S.st_underflow_passes;
             { uint32_t dm = 0; for (uint32_t i = 0; i <= last; ++i) if (!(vevent && i == last)) dm |= 1u << depth_of(P.holepos[I + i]); S.st_depth_rounds += (uint64_t)__builtin_popcount(dm); }
+            // Deferred form (what the two-wave / lane-parallel kernel relies on): the sift of a pop whose vacated slot is NOT an
+            // ancestor of any slot of the tail zone [z_lo, z_hi] ("clean") commutes with everything the tail does, so it may run
+            // any time before the next "dirty" sift (one whose slot is an ancestor of the zone) or the end of the pass.
+            auto is_dirty = [&](uint32_t h) {
+                for (int j = 0; j < 20; ++j) {
+                    const uint64_t a = ((uint64_t)(h + 1) << j) - 1, b = ((uint64_t)(h + 2) << j) - 2;
+                    if (a > z_hi) break;
+                    if (a <= z_hi && b >= z_lo) return true;
+                }
+                return false;
+            };
+            struct Pend { uint32_t hole; QP v; };
+            std::vector<Pend> pend;
+            auto do_sift = [&](uint32_t hole, const QP& v, uint32_t len) {
+                bool touched = in_zone(hole);
+                for (;;) {
+                    const uint32_t c2 = 2 * hole + 2;
+                    uint32_t c;
+                    if (c2 < len) { c = (H[c2].first > H[c2 - 1].first) ? c2 - 1 : c2; if (in_zone(c2) || in_zone(c2 - 1)) touched = true; }
+                    else if (c2 == len) { c = len - 1; touched = true; }
+                    else break;
+                    if (H[c].first > v.first) break;
+                    H[hole] = H[c]; hole = c; ++S.sift_moves;
+                }
+                H[hole] = v;
+                return touched;
+            };
+            auto flush = [&]() {
+                // deepest slots first (a slot's member descendants are vacated before it; equal depths are disjoint subtrees)
+                std::stable_sort(pend.begin(), pend.end(), [](const Pend& p, const Pend& q) { return depth_of(p.hole) > depth_of(q.hole); });
+                for (const Pend& pe : pend) { const bool t = do_sift(pe.hole, pe.v, z_lo); assert(!t); (void)t; }
+                pend.clear();
+            };
             for (uint32_t i = 0; i <= last; ++i) {
                 const uint32_t n = (uint32_t)H.size();
                 if (vevent && i == last) {
@@ -326,19 +369,11 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                         uint32_t hole = P.holepos[I + i];
                         assert(hole < len);
                         ++S.st_sifts;
-                        if (is_anc_of_zone(hole)) ++S.st_dirty;
-                        bool touched = in_zone(hole);
-                        for (;;) {
-                            const uint32_t c2 = 2 * hole + 2;
-                            uint32_t c;
-                            if (c2 < len) { c = (H[c2].first > H[c2 - 1].first) ? c2 - 1 : c2; if (in_zone(c2) || in_zone(c2 - 1)) touched = true; }
-                            else if (c2 == len) { c = len - 1; touched = true; }
-                            else break;
-                            if (H[c].first > v.first) break;
-                            H[hole] = H[c]; hole = c; ++S.sift_moves;
-                        }
-                        H[hole] = v;
-                        if (touched) { ++S.st_touch_sifts; touch_pass = true; }
+                        if (is_dirty(hole)) {
+                            ++S.st_dirty;
+                            flush();
+                            if (do_sift(hole, v, len)) { ++S.st_touch_sifts; touch_pass = true; }
+                        } else pend.push_back(Pend{hole, v});
                     }
                 }
                 const Lane& l = L[i];
@@ -358,6 +393,7 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                     H[hole] = x; ++S.pushes;
                 }
             }
+            flush();
             if (touch_pass) ++S.st_touch_passes;
             if (climb_pass) ++S.st_climb_passes;
             if (vevent) {
@@ -386,7 +422,7 @@ inline uint32_t level(DynamicDistanceMap& dm, std::vector<QP>& H, int d)
                 fresh = false; replan = true;
                 break;
             }
-            I += k;
+            I += last + 1;
         }
         if (!replan) break;
         if (H.empty() || H[0].first != d) break;
