@@ -81,7 +81,15 @@ public:
         uint32_t shard_rank = 0;
         uint32_t shard_world = 1;
         bool profile = false;              // bracket kernels with hipEvents (see lama_hip_get_counters)
-        uint32_t brushfire_mode = 0;       // 0 exact (default), 1 level-synchronous canonical tie rule (lama_hip.h)
+        uint32_t brushfire_mode = 0;       // 0 exact (default), 1 level-synchronous canonical tie rule, 2 exact level by level (lama_hip.h)
+        // Device map storage (0 = the device library's defaults).  The reference's maps are unbounded (src/sdm/map.cpp:400-411);
+        // here the patch arenas GROW on demand (doubled whenever a particle uses more than half of them), the window is fixed
+        // when the context is created: window_patches x 1.6 m at 0.05 m (default 128 = 204.8 m, at most 248), centred on the
+        // first pose.
+        uint32_t window_patches = 0;       // side of the square map window in patches (multiple of 8)
+        uint32_t dm_patch_capacity = 0;    // initial distance-map patches per particle
+        uint32_t occ_patch_capacity = 0;   // initial occupancy patches per particle
+        uint32_t queue_capacity = 0;       // brushfire queue entries per particle
     };
 
     explicit PFSlam2D(const Options& options = Options());
@@ -195,6 +203,7 @@ private:
     double neff_ = 0.0;
     uint32_t num_resamples_ = 0;
     std::deque<double> timestamps_;
+    double last_timestamp_ = 0.0;      // of the update() call in progress
     PointCloudXYZ::Ptr current_surface_;
     std::vector<double> pts_;               // n x 3
     double origin_[3] = {0, 0, 0};

@@ -51,6 +51,8 @@ public:
         bool create_summary = false;
         // ---- additions ----
         int32_t gpu_device = 0;
+        // device map storage, 0 = defaults (see PFSlam2D::Options: arenas grow on demand, the window is fixed at creation)
+        uint32_t window_patches = 0, dm_patch_capacity = 0, occ_patch_capacity = 0, queue_capacity = 0;
     };
 
     explicit Slam2D(const Options& options = Options());

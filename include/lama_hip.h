@@ -67,7 +67,8 @@ typedef struct lama_hip_cfg {
     double truncated_range;      /* Options::truncated_range                                      */
     int32_t device;              /* HIP device ordinal                                            */
     uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m; multiple of 8, <= 248) */
-    uint32_t dm_patch_capacity;  /* DM patches per particle  (default 256)                        */
+    uint32_t dm_patch_capacity;  /* DM patches per particle to start with (default 256); the arenas are doubled whenever a
+                                    particle has filled more than half of one (the reference's maps are unbounded)   */
     uint32_t occ_patch_capacity; /* occupancy patches per particle (default 256)                  */
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
     uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */
@@ -249,6 +250,7 @@ typedef struct lama_hip_counters {
     uint64_t dm_patches;        /* sum of allocated DM patches over particles (current)             */
     uint64_t occ_patches;       /* sum of allocated occupancy patches over particles (current)      */
     double ms_eval_batch;  uint64_t launches_eval_batch;     /* lama_hip_eval_batch                   */
+    uint64_t arena_growths;     /* times the patch arenas were doubled (maps grow on demand)        */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

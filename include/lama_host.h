@@ -32,6 +32,7 @@ typedef struct lama_pf_options {
     uint32_t shard_rank, shard_world;
     int32_t profile;
     uint32_t brushfire_mode;
+    uint32_t window_patches, dm_patch_capacity, occ_patch_capacity, queue_capacity;   /* device map storage, 0 = defaults */
 } lama_pf_options;
 
 typedef struct lama_pf lama_pf;

@@ -203,6 +203,8 @@ void resolve_timers(lama_hip_ctx* c);
 
 // End of an API call: one stream synchronisation that brings back the device error word and, when asked, the
 // per-particle patch counts and statistics (a single host round trip per call).
+int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm = 0, uint32_t need_occ = 0);
+
 int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false, bool err_in_results = false)
 {
     c->h_err.resize(1);
@@ -235,7 +237,55 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             dm += c->h_counts[2 * p]; oc += c->h_counts[2 * p + 1];
         }
         c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
+        if (maps) return grow_arenas(c);
     }
+    return LAMA_HIP_OK;
+}
+
+// The reference's maps allocate patches on demand without bound (src/sdm/map.cpp:400-411).  The device arenas are doubled
+// whenever a particle has filled more than half of one (checked after every map update, when the counts are on the host and
+// the stream is idle): a new allocation, one strided device-to-device copy per plane, the other particle set restarts empty
+// (resample() rewrites it completely).  `cfg` then carries the new capacities.
+int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ)      // need_*: patches an incoming particle brings
+{
+    uint32_t mdm = (need_dm + 1) / 2, mocc = (need_occ + 1) / 2;
+    for (uint32_t p = 0; p < c->P; ++p) { mdm = std::max<uint32_t>(mdm, (uint32_t)c->h_counts[2 * p]); mocc = std::max<uint32_t>(mocc, (uint32_t)c->h_counts[2 * p + 1]); }
+    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
+    uint32_t ndc = dc, noc = oc;
+    while (2 * mdm > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
+    while (2 * mocc > noc && noc < 32767u) noc = std::min<uint32_t>(2 * noc, 32767u);
+    if (ndc == dc && noc == oc) return LAMA_HIP_OK;
+    const size_t P = c->P;
+    auto regrow = [&](auto*& arr, size_t old_stride_b, size_t new_stride_b, bool keep) -> hipError_t {
+        void* fresh = nullptr;
+        hipError_t e = hipMalloc(&fresh, P * new_stride_b);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(fresh, 0, P * new_stride_b, c->stream);
+        if (e == hipSuccess && keep) e = hipMemcpy2DAsync(fresh, new_stride_b, arr, old_stride_b, old_stride_b, P, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(fresh); return e; }
+        (void)hipFree(arr);
+        arr = reinterpret_cast<std::remove_reference_t<decltype(arr)>>(fresh);
+        return hipSuccess;
+    };
+    for (int s = 0; s < 2; ++s) {
+        ParticleSet& ps = c->set[s];
+        const bool keep = s == c->cur;
+        if (ndc != dc) {
+            HIPCHK(c, regrow(ps.dm_sv, (size_t)dc * 2048, (size_t)ndc * 2048, keep));
+            HIPCHK(c, regrow(ps.dm_obs, (size_t)dc * 4096, (size_t)ndc * 4096, keep));
+            HIPCHK(c, regrow(ps.dm_mask, (size_t)dc * 128, (size_t)ndc * 128, keep));
+        }
+        if (noc != oc) {
+            HIPCHK(c, regrow(ps.occ, (size_t)oc * 4096, (size_t)noc * 4096, keep));
+            HIPCHK(c, regrow(ps.occ_mask, (size_t)oc * 128, (size_t)noc * 128, keep));
+        }
+        if (!keep) HIPCHK(c, hipMemsetAsync(ps.counts, 0, P * 2 * 4, c->stream));      // its (zeroed) arenas hold nothing
+    }
+    if (noc != oc) HIPCHK(c, regrow(c->d_occ_hit, (size_t)oc * 128, (size_t)noc * 128, false));   // all zero between scans
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->cfg.dm_patch_capacity = ndc; c->cfg.occ_patch_capacity = noc;
+    c->ctr.arena_growths += 1;
     return LAMA_HIP_OK;
 }
 
@@ -1162,6 +1212,11 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     HIPCHK(c, hipMemcpy(pose, in, 32, hipMemcpyDeviceToHost));
     HIPCHK(c, hipMemcpy(hdr, in + 32, 16, hipMemcpyDeviceToHost));
     const int dmc = hdr[0], occ = hdr[1];
+    if (dmc >= 0 && occ >= 0 && dmc <= 32767 && occ <= 32767 &&
+        ((uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity)) {
+        const int32_t rcg = grow_arenas(c, (uint32_t)dmc, (uint32_t)occ);        // the sender's arenas may have grown before ours
+        if (rcg) return rcg;
+    }
     if (dmc < 0 || occ < 0 || (uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity ||
         blob_bytes(c, dmc, occ) != bytes)
         return fail(c, LAMA_HIP_E_INVALID, "particle blob does not match this context's geometry");

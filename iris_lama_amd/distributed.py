@@ -28,6 +28,16 @@ def owner_of(i, P, G):
 
 class ShardedPF:
     def __init__(self, opts, device=None, force_collectives=False):
+        # Every shard replays the SAME host random stream (motion noise of all P particles, the resampling draw).  seed = 0
+        # means "random_device" in the reference (src/pf_slam2d.cpp:131-134): rank 0 draws it once and broadcasts it; the
+        # host class refuses seed = 0 on a sharded pool.
+        if opts.seed == 0 and dist.is_initialized() and (opts.shard_world > 1 or force_collectives):
+            dev0 = device if device is not None else (torch.device("cuda", opts.gpu_device) if dist.get_backend() == "nccl" else torch.device("cpu"))
+            t = torch.zeros(1, dtype=torch.int64, device=dev0)
+            if dist.get_rank() == 0:
+                t[0] = int(np.random.SeedSequence().generate_state(1)[0]) | 1
+            dist.broadcast(t, 0)
+            opts.seed = int(t.item())
         self.pf = F.PFSlam2D(opts)
         self.world = opts.shard_world
         self.rank = opts.shard_rank

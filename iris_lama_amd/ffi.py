@@ -38,7 +38,7 @@ class HipCounters(C.Structure):
                 ("ms_resample", C.c_double), ("launches_resample", C.c_uint64),
                 ("gn_iterations", C.c_uint64), ("gn_evals", C.c_uint64), ("ray_cells", C.c_uint64),
                 ("bf_cells", C.c_uint64), ("dm_patches", C.c_uint64), ("occ_patches", C.c_uint64),
-                ("ms_eval_batch", C.c_double), ("launches_eval_batch", C.c_uint64)]
+                ("ms_eval_batch", C.c_double), ("launches_eval_batch", C.c_uint64), ("arena_growths", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -353,7 +353,9 @@ class PFOptions(C.Structure):
                 ("truncated_ray", C.c_double), ("truncated_range", C.c_double), ("resolution", C.c_double),
                 ("patch_size", C.c_uint32), ("max_iter", C.c_uint32), ("seed", C.c_uint32),
                 ("create_summary", C.c_int32), ("gpu_device", C.c_int32), ("shard_rank", C.c_uint32),
-                ("shard_world", C.c_uint32), ("profile", C.c_int32), ("brushfire_mode", C.c_uint32)]
+                ("shard_world", C.c_uint32), ("profile", C.c_int32), ("brushfire_mode", C.c_uint32),
+                ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32), ("occ_patch_capacity", C.c_uint32),
+                ("queue_capacity", C.c_uint32)]
 
 
 HOST_SYMBOLS = [

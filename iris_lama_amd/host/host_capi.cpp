@@ -108,6 +108,8 @@ lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
         p.create_summary = o->create_summary != 0; p.gpu_device = o->gpu_device;
         p.shard_rank = o->shard_rank; p.shard_world = o->shard_world; p.profile = o->profile != 0;
         p.brushfire_mode = o->brushfire_mode;
+        p.window_patches = o->window_patches; p.dm_patch_capacity = o->dm_patch_capacity;
+        p.occ_patch_capacity = o->occ_patch_capacity; p.queue_capacity = o->queue_capacity;
         h->pf.reset(new PFSlam2D(p));
         h->origin = h->pf->engine()->origin;
         return h;

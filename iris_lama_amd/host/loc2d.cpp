@@ -36,6 +36,9 @@ bool Loc2D::OccupancyMapProxy::isOccupied(const Vector3ui& c) const { auto it = 
 void Loc2D::Init(const Options& o)
 {
     opt_ = o;
+    // a second Init() (new map, resolution, l2_max or strategy) starts from fresh maps like the reference's (src/loc2d.cpp:61-78):
+    // the device context is rebuilt from the new options by the next ensureContext()
+    if (ctx_) { eng_->ctx_destroy(ctx_); ctx_ = nullptr; }
     delete occupancy_map; delete distance_map;
     occupancy_map = new OccupancyMapProxy;
     distance_map = new DistanceMapProxy;

@@ -47,6 +47,10 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
     cfg.device = options_.gpu_device;
     cfg.profile = options_.profile ? 1 : 0;
     cfg.brushfire_mode = options_.brushfire_mode;
+    if (options_.window_patches) cfg.window_patches = options_.window_patches;
+    if (options_.dm_patch_capacity) cfg.dm_patch_capacity = options_.dm_patch_capacity;
+    if (options_.occ_patch_capacity) cfg.occ_patch_capacity = options_.occ_patch_capacity;
+    if (options_.queue_capacity) cfg.queue_capacity = options_.queue_capacity;
     const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
     if (rc != 0 || !ctx_) {
         char msg[256];
@@ -57,7 +61,11 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
     particles_.assign(options_.particles, Particle());
     local_loglik_.assign(hi_ - lo_, 0.0);
 
-    // rng seed: 0 -> random_device (src/pf_slam2d.cpp:131-134, src/random.cpp:41-49)
+    // rng seed: 0 -> random_device (src/pf_slam2d.cpp:131-134, src/random.cpp:41-49).  Every shard of a sharded pool must replay
+    // the SAME host random stream (motion noise of all P particles, the resampling draw): a per-process random seed would make
+    // the shards disagree on the resampling indices, so it is refused there -- broadcast one seed instead (distributed.py does).
+    if (options_.seed == 0 && options_.shard_world > 1)
+        throw std::runtime_error("lama::PFSlam2D: Options::seed = 0 (random_device) is not allowed with shard_world > 1: all shards need the same seed");
     if (options_.seed == 0) options_.seed = std::random_device()();
     gen_.seed(options_.seed);
     if (options_.create_summary) summary = new Summary();
@@ -130,7 +138,9 @@ std::vector<int32_t> PFSlam2D::resampleIndices(double u01) const
     uint32_t n = 0;
     for (size_t i = 0; i < P; ++i) {
         cw += particles_[i].normalized_weight;
-        while (cw > target && n < P) {     // (n < P: the reference would write past the array)
+        // n < P: the reference would write past the array.  Slots the loop does not reach (rounding of the cumulative weight)
+        // keep the vector's zero initialisation exactly as the reference's `std::vector<int32_t> sample_idx(num_particles)` does.
+        while (cw > target && n < P) {
             sample_idx[n++] = (int32_t)i;
             target += interval;
         }
@@ -161,6 +171,7 @@ PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const P
 {
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::PFSlam2D::update: empty scan");
     t_begin_ = now_s();
+    last_timestamp_ = timestamp;
     scan_resident_ = false;
     dropMapViews();
     current_surface_ = surface;
@@ -275,7 +286,7 @@ void PFSlam2D::updateMaps()
         if (rs) fail(rs, "lama_hip_sync");
         summary->time_mapping.push_back(now_s() - t0);
         summary->time.push_back(now_s() - t_begin_);
-        summary->timestamp.push_back(timestamps_.empty() ? 0.0 : timestamps_.back());
+        summary->timestamp.push_back(last_timestamp_);              // probeStamp(timestamp), src/pf_slam2d.cpp:306
         summary->memory.push_back((double)getMemoryUsage());
     }
 }

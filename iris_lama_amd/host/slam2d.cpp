@@ -35,6 +35,10 @@ Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.
     cfg.truncated_ray = o.truncated_ray; cfg.truncated_range = o.truncated_range; cfg.device = o.gpu_device;
     cfg.meas_sigma = 0.05;                       // unused by Slam2D (no likelihood)
     cfg.solver_strategy = o.strategy == "lm" ? 1u : 0u;           // makeStrategy, src/slam2d.cpp:226-233
+    if (o.window_patches) cfg.window_patches = o.window_patches;
+    if (o.dm_patch_capacity) cfg.dm_patch_capacity = o.dm_patch_capacity;
+    if (o.occ_patch_capacity) cfg.occ_patch_capacity = o.occ_patch_capacity;
+    if (o.queue_capacity) cfg.queue_capacity = o.queue_capacity;
     const int32_t rc = eng_->ctx_create(&cfg, &ctx_);
     if (rc != 0 || !ctx_) {
         char msg[200];

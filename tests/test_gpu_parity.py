@@ -101,6 +101,38 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
     ctx.close()
 
 
+def test_patch_arenas_grow_on_demand(F):
+    """The reference's maps allocate patches without bound (src/sdm/map.cpp:400-411); the device arenas start small here and
+    must be doubled on the way -- maps stay bit-identical to the oracle's, the growth counter moves, resample() still works."""
+    P, steps = 4, 14
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pose0 = O.se2(*odom[0])
+    pf.set_prior(pose0)
+    assert pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=96, occ_patch_capacity=96))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(11)
+    for k in range(1, steps + 1):
+        poses = _perturbed(rng, O.se2(*truth[k]), P)
+        if k % 3 == 0:
+            idx = np.sort(rng.integers(0, P, size=P)).astype(np.int32)
+            pf.stage_resample_with(idx)
+            ctx.resample(idx)
+        pf.set_poses(poses)
+        pf.stage_set_scan(pts[k])
+        pf.stage_update_maps()
+        ctx.set_poses(poses)
+        ctx.update_maps(pts[k])
+    for i in range(P):
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+    c = ctx.counters()
+    assert c["arena_growths"] >= 1, c
+    assert c["dm_patches"] > 96 * P / 2
+    ctx.close()
+
+
 def test_match_batch_matches_oracle_loglik(F):
     pts, odom, truth = F.corridor_log(1, 1080)
     pose0 = O.se2(*odom[0])

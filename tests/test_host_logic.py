@@ -54,6 +54,14 @@ def test_free_running_host_matches_oracle_bitwise(P, gain, expect_resample):
     assert "Number of updates" in h.summary()
 
 
+def test_sharded_pool_refuses_a_per_process_random_seed():
+    """seed = 0 is random_device in the reference; shards that seeded themselves differently would disagree on the resampling
+    indices, so the host class refuses it (ShardedPF broadcasts rank 0's seed instead)."""
+    with pytest.raises(F.LamaError, match="seed"):
+        F.PFSlam2D(F.pf_options(particles=6, seed=0, shard_rank=0, shard_world=2))
+    F.PFSlam2D(F.pf_options(particles=6, seed=0)).close()           # single shard: allowed, as in the reference
+
+
 def test_motion_gate_and_rng_stream():
     """drawFromMotion runs (and consumes RNG) on every call, also when the gate stays closed
     (src/pf_slam2d.cpp:235-243)."""
