@@ -1,11 +1,11 @@
 // lama/loc2d.h -- host-side lama::Loc2D (localisation on a fixed map) on the MI355X path.
 //
 // Same class name, Options fields and public methods as the reference's include/lama/loc2d.h:47-165; update()
-// follows src/loc2d.cpp:126-192.  The public members `occupancy_map` / `distance_map` of the reference are host maps
-// that consumers (iris_lama_ros' loc2d_ros) fill cell by cell before the first update; here they are small proxies
-// with the methods that use needs (w2m, setFree/setOccupied/setUnknown, isFree, bounds, addObstacle, update,
-// setMaxDistance): the obstacle cells are buffered on the host and DynamicDistanceMap::addObstacle + update() run on
-// the device when distance_map->update() is called.  On the device: scan matching with covariance
+// follows src/loc2d.cpp:126-192.  The public members `occupancy_map` / `distance_map` have the reference's types
+// (include/lama/loc2d.h:103-104): consumers (iris_lama_ros' loc2d_ros) fill them cell by cell before the first update.
+// The SimpleOccupancyMap is a plain host map; the DynamicDistanceMap is LIVE: addObstacle() buffers cells on the host,
+// update() runs DynamicDistanceMap::addObstacle + update() on the device, queries read a snapshot downloaded on first use
+// (lama/sdm_maps.h).  On the device: scan matching with covariance
 // (Solve(..., &cov)) and the RMSE (lama_hip_match_solve), the candidate evaluation of globalLocalization (:249-286,
 // lama_hip_eval_batch; the candidates are drawn on the host from lama::random like the reference) and the likelihood
 // samples of addSamplingCovariance (:199-247, lama_hip_map_sample_likelihood); strategy "lm" = Levenberg-Marquardt in the
@@ -19,18 +19,14 @@
 #include <vector>
 
 #include "pose2d.h"
+#include "sdm/dynamic_distance_map.h"
+#include "sdm/simple_occupancy_map.h"
 
 struct lama_hip_ctx;
 
 namespace lama {
 
 struct HipEngine;
-
-struct Matrix3d_ {      // 3x3 row-major stand-in for Eigen::Matrix3d (getCovar)
-    double m[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    double operator()(int r, int c) const { return m[3 * r + c]; }
-    double& operator()(int r, int c) { return m[3 * r + c]; }
-};
 
 class Loc2D {
 public:
@@ -44,33 +40,8 @@ public:
         int32_t gpu_device = 0;      // addition
     };
 
-    // Map::w2m of the reference (include/lama/sdm/map.h:125-126) for both proxies
-    struct MapProxy {
-        double resolution = 0.05, scale = 20.0;
-        Vector3ui w2m(const Vector3d& p) const;
-    };
-    struct OccupancyMapProxy : MapProxy {          // SimpleOccupancyMap: int8 tri-state kept on the host
-        bool setFree(const Vector3ui& c);
-        bool setOccupied(const Vector3ui& c);
-        bool setUnknown(const Vector3ui& c);
-        bool isFree(const Vector3ui& c) const;
-        bool isFree(const Vector3d& p) const { return isFree(w2m(p)); }
-        bool isOccupied(const Vector3ui& c) const;
-        // Map::bounds (src/sdm/map.cpp:139-157, include/lama/sdm/map.h:221-225): the allocated patches' extent in world units
-        void bounds(Vector3d& min, Vector3d& max) const;
-        std::unordered_map<uint64_t, int8_t> cells;
-    };
-    struct DistanceMapProxy : MapProxy {
-        void setMaxDistance(double d) { l2_max = d; }
-        void addObstacle(const Vector3ui& c) { pending.push_back(c(0)); pending.push_back(c(1)); }
-        uint32_t update();                          // uploads the pending obstacles, runs the brushfire on the device
-        double l2_max = 1.0;
-        std::vector<uint32_t> pending;
-        Loc2D* owner = nullptr;
-    };
-
-    OccupancyMapProxy* occupancy_map = nullptr;
-    DistanceMapProxy* distance_map = nullptr;
+    SimpleOccupancyMap* occupancy_map = nullptr;      // include/lama/loc2d.h:103-104
+    DynamicDistanceMap* distance_map = nullptr;
 
     Loc2D() = default;
     void Init(const Options& options = Options());
@@ -81,7 +52,7 @@ public:
     void triggerGlobalLocalization();
     void setPose(const Pose2D& pose) { pose_ = pose; has_first_scan = false; }
     const Pose2D& getPose() const { return pose_; }
-    const Matrix3d_& getCovar() const { return cov_; }
+    const Matrix3d& getCovar() const { return cov_; }     // Eigen::Matrix3d when Eigen is available (lama/types.h)
     double getRMSE() const { return rmse_; }
     bool globalLocalizationIsActive() const { return do_global_localization_; }
     // candidates and errors of the last globalLocalization call (instrumentation for the parity tests)
@@ -93,7 +64,6 @@ public:
     const HipEngine* engine() const { return eng_.get(); }
 
 private:
-    friend struct DistanceMapProxy;
     void ensureContext();
     void solve(const PointCloudXYZ& surface, bool do_solve);
     void globalLocalization(const PointCloudXYZ& surface);
@@ -104,7 +74,7 @@ private:
     std::shared_ptr<HipEngine> eng_;
     lama_hip_ctx* ctx_ = nullptr;
     Pose2D odom_, pose_;
-    Matrix3d_ cov_;
+    Matrix3d cov_;
     double rmse_ = 0.0;
     bool has_first_scan = false;
     uint32_t last_iterations_ = 0;

@@ -8,13 +8,19 @@
 //   lama::ProbabilisticOccupancyMap src/sdm/probabilistic_occupancy_map.cpp:38-46,126-175   (LidarOdometry2D's log-odds map)
 //   lama::DynamicDistanceMap      src/sdm/dynamic_distance_map.cpp:66-91,140-158   distance(cell) / distance(point, gradient) / maxDistance
 // The views own a snapshot (lama::sdm::HostMap: the reference's record formats + Container masks); they are not the
-// live maps -- those stay in HBM -- and have no mutating members.  Header only.
+// live maps -- those stay in HBM.  Two classes can also be WRITTEN on the host, because consumers of lama::Loc2D fill them cell by
+// cell (iris_lama_ros' loc2d_ros): lama::SimpleOccupancyMap (src/sdm/simple_occupancy_map.cpp, a plain host map) and a
+// lama::DynamicDistanceMap created from (resolution, patch_size), whose addObstacle() / update() are forwarded to the device
+// map of the Loc2D that owns it.  Header only.  The reference's include paths lama/sdm/<class>.h forward here.
 #pragma once
 
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
 #include <memory>
+#include <stdexcept>
+#include <vector>
 #include <string>
 #include <unordered_map>
 #include <utility>
@@ -30,6 +36,8 @@ struct HipEngine;
 
 class Map {
 public:
+    // an empty map (the reference's Map(resolution, cell_size, patch_size, is3d), src/sdm/map.cpp:42-59; 2-D only here)
+    Map(double res, sdm::MapKind kind, uint32_t patch_size = 32) : Map(emptyHost(res, kind, patch_size)) {}
     explicit Map(sdm::HostMap m) : host_(std::move(m))
     {
         resolution = host_.resolution;
@@ -98,6 +106,36 @@ public:
     const sdm::HostMap& snapshot() const { return host_; }
 
 protected:
+    static sdm::HostMap emptyHost(double res, sdm::MapKind kind, uint32_t patch_size)
+    {
+        sdm::HostMap m;
+        m.kind = kind; m.resolution = res;
+        m.patch_length = 1;
+        while (m.patch_length * 2 <= patch_size) m.patch_length *= 2;          // 1 << int(log2(patch_size)), src/sdm/map.cpp:45
+        return m;
+    }
+    void resetHost(sdm::HostMap m)              // replace the snapshot (a live map downloads a fresh one)
+    {
+        host_ = std::move(m);
+        index_.clear();
+        for (size_t i = 0; i < host_.ids.size(); ++i) index_[host_.ids[i]] = i;
+    }
+    // non-const Map::get (src/sdm/map.cpp:371-412): allocates the (zeroed) patch, turns the cell's mask bit on
+    uint8_t* getOrCreate(const Vector3ui& c)
+    {
+        const uint64_t id = uint64_t(c(0) >> log2dim_) * UNIVERSAL_CONSTANT + uint64_t(c(1) >> log2dim_);
+        auto it = index_.find(id);
+        if (it == index_.end()) {
+            it = index_.emplace(id, host_.ids.size()).first;
+            host_.ids.push_back(id);
+            host_.cells.resize(host_.cells.size() + (size_t)patch_volume * host_.cellSize(), 0);
+            host_.masks.resize(host_.masks.size() + patch_volume / 64, 0);
+        }
+        const uint32_t m = patch_length - 1;
+        const uint32_t cell = (c(0) & m) | ((c(1) & m) << log2dim_);
+        host_.masks[it->second * (patch_volume / 64) + (cell >> 6)] |= 1ull << (cell & 63);
+        return &host_.cells[(it->second * (size_t)patch_volume + cell) * host_.cellSize()];
+    }
     // const Map::get (src/sdm/map.cpp:414-455): nullptr for an absent patch or a cell whose mask bit is off
     const uint8_t* get(const Vector3ui& c) const
     {
@@ -176,12 +214,64 @@ private:
     }
 };
 
+// include/lama/sdm/simple_occupancy_map.h + src/sdm/simple_occupancy_map.cpp: int8 tri-state (-1 free, 1 occupied, 0 unknown),
+// a plain host map that can be written (Loc2D::occupancy_map is one)
+class SimpleOccupancyMap : public OccupancyMap {
+public:
+    explicit SimpleOccupancyMap(double resolution, uint32_t patch_size = 32, bool /*is3d*/ = false)
+        : OccupancyMap(resolution, sdm::kSimpleOccupancyMap, patch_size) {}
+    explicit SimpleOccupancyMap(sdm::HostMap m) : OccupancyMap(std::move(m)) {}
+    using OccupancyMap::isFree; using OccupancyMap::isOccupied; using OccupancyMap::isUnknown; using OccupancyMap::getProbability;
+    bool setFree(const Vector3d& p) { return setFree(w2m(p)); }
+    bool setOccupied(const Vector3d& p) { return setOccupied(w2m(p)); }
+    bool setUnknown(const Vector3d& p) { return setUnknown(w2m(p)); }
+    bool setFree(const Vector3ui& c) { return set(c, -1); }                             // :50-58 ("changed")
+    bool setOccupied(const Vector3ui& c) { return set(c, 1); }                          // :65-73
+    bool setUnknown(const Vector3ui& c) { return set(c, 0); }                           // :80-88
+    bool isFree(const Vector3ui& c) const override { const uint8_t* p = get(c); return p && (int8_t)*p == -1; }       // :95-102
+    bool isOccupied(const Vector3ui& c) const override { const uint8_t* p = get(c); return p && (int8_t)*p == 1; }    // :109-116
+    bool isUnknown(const Vector3ui& c) const override { const uint8_t* p = get(c); return !p || (int8_t)*p == 0; }    // :123-129
+    double getProbability(const Vector3ui& c) const override { return isFree(c) ? 0.0 : (isOccupied(c) ? 1.0 : 0.5); }   // :136-145
+    bool empty() const { return host_.ids.empty(); }
+
+private:
+    bool set(const Vector3ui& c, int8_t v) { int8_t* cell = (int8_t*)getOrCreate(c); if (*cell == v) return false; *cell = v; return true; }
+};
+
 class DynamicDistanceMap : public Map {
 public:
 #pragma pack(push, 1)
     struct distance_t { int16_t obstacle[3]; uint16_t sqdist; bool valid_obstacle; bool is_queued; };   // dynamic_distance_map.h:48-53 (10 bytes)
 #pragma pack(pop)
     explicit DynamicDistanceMap(sdm::HostMap m) : Map(std::move(m)) {}
+    // The reference's constructor (src/sdm/dynamic_distance_map.cpp:36-47).  A map made this way is LIVE: it belongs to a
+    // lama::Loc2D, which binds addObstacle() / update() to its device map (bindWriter); queries after an update() read a
+    // snapshot that is downloaded on first use.  Unbound, the mutating members throw.
+    explicit DynamicDistanceMap(double resolution, uint32_t patch_size = 32, bool /*is3d*/ = false)
+        : Map(resolution, sdm::kDistanceMap, patch_size) {}
+    struct Writer {
+        std::function<uint32_t(std::vector<uint32_t>& /*x,y pairs*/, double /*max distance*/)> apply;   // addObstacle list + update()
+        std::function<bool(sdm::HostMap&)> download;
+    };
+    void bindWriter(Writer w) { writer_ = std::move(w); }
+    void setMaxDistance(double distance)                                                                    // :149-153
+    {
+        const uint32_t r = (uint32_t)std::ceil(distance * scale);
+        host_.max_sqdist = r * r;
+        max_distance_ = distance;
+    }
+    void addObstacle(const Vector3ui& c) { pending_.push_back(c(0)); pending_.push_back(c(1)); }             // :212-226 (runs in update())
+    void addObstacle(const Vector3d& p) { addObstacle(w2m(p)); }
+    bool hasPending() const { return !pending_.empty(); }
+    uint32_t update()                                                                                        // :160-197, on the device
+    {
+        if (pending_.empty()) return 0;
+        if (!writer_.apply) throw std::logic_error("lama::DynamicDistanceMap::update: this map is a host snapshot of a device map");
+        const uint32_t n = writer_.apply(pending_, max_distance_);
+        pending_.clear();
+        stale_ = true;
+        return n;
+    }
 
     // Which live device map this snapshot was taken from (set by Slam2D / PFSlam2D::getDistanceMap()): lama::MatchSurface2D
     // evaluates against THAT map on the GPU, not against the host copy.
@@ -193,7 +283,8 @@ public:
     void bindDevice(std::shared_ptr<HipEngine> e, ::lama_hip_ctx* ctx, uint32_t particle) { dev_.engine = std::move(e); dev_.ctx = ctx; dev_.particle = particle; }
     const DeviceBinding& device() const { return dev_; }
 
-    double maxDistance() const { return std::sqrt((double)host_.max_sqdist) * resolution; }                      // :149-152
+    double maxDistance() const { return std::sqrt((double)host_.max_sqdist) * resolution; }                      // :155-158
+    double maxDistanceOption() const { return max_distance_; }
     // :140-147
     double distance(const Vector3ui& coordinates) const
     {
@@ -218,6 +309,12 @@ public:
     }
     bool cell(const Vector3ui& c, distance_t& d) const
     {
+        if (stale_ && writer_.download) {                      // live map: fetch the device map once after an update()
+            DynamicDistanceMap* self = const_cast<DynamicDistanceMap*>(this);
+            sdm::HostMap m;
+            if (writer_.download(m)) { m.resolution = resolution; self->resetHost(std::move(m)); }
+            self->stale_ = false;
+        }
         const uint8_t* p = get(c);
         if (!p) return false;
         std::memcpy(&d, p, sizeof(d));
@@ -226,6 +323,10 @@ public:
 
 private:
     DeviceBinding dev_;
+    Writer writer_;
+    std::vector<uint32_t> pending_;
+    double max_distance_ = 0.5;
+    bool stale_ = false;
 };
 
 } // namespace lama

@@ -25,6 +25,7 @@ using Eigen::Vector3d;
 typedef Eigen::Matrix<uint32_t, 3, 1> Vector3ui;      // include/lama/types.h of the reference
 using Eigen::MatrixXd;
 using Eigen::VectorXd;
+using Eigen::Matrix3d;
 }
 #else
 namespace lama {
@@ -97,6 +98,14 @@ struct MatrixXd {
     double operator()(size_t i, size_t j) const { return v[j * r + i]; }
     double* data() { return v.data(); }
     const double* data() const { return v.data(); }
+};
+
+struct Matrix3d {       // 3x3 row-major stand-in for Eigen::Matrix3d (Loc2D::getCovar)
+    double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double operator()(int r, int c) const { return m[3 * r + c]; }
+    double& operator()(int r, int c) { return m[3 * r + c]; }
+    static Matrix3d Identity() { Matrix3d a; a.m[0] = a.m[4] = a.m[8] = 1.0; return a; }
+    static Matrix3d Zero() { return Matrix3d(); }
 };
 
 struct Quaterniond {

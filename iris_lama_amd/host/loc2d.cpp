@@ -19,20 +19,6 @@ Loc2D::Options::Options()                      // src/loc2d.cpp:46-58
     gloc_particles = 3000; gloc_iters = 10; gloc_thresh = 0.15; max_iter = 100; cov_blend = 0.0;
 }
 
-Vector3ui Loc2D::MapProxy::w2m(const Vector3d& p) const
-{
-    const double off = double(2642244ull >> 1) * 32.0;        // src/sdm/map.cpp:55-58
-    return Vector3ui((uint32_t)(scale * p.x() + off + 0.5), (uint32_t)(scale * p.y() + off + 0.5), (uint32_t)(scale * p.z() + off + 0.5));
-}
-
-static uint64_t key(const Vector3ui& c) { return ((uint64_t)c(0) << 32) | c(1); }
-// SimpleOccupancyMap semantics (src/sdm/simple_occupancy_map.cpp): cell = -1 free, 1 occupied, 0 unknown; returns "changed"
-bool Loc2D::OccupancyMapProxy::setFree(const Vector3ui& c) { int8_t& v = cells[key(c)]; if (v == -1) return false; v = -1; return true; }
-bool Loc2D::OccupancyMapProxy::setOccupied(const Vector3ui& c) { int8_t& v = cells[key(c)]; if (v == 1) return false; v = 1; return true; }
-bool Loc2D::OccupancyMapProxy::setUnknown(const Vector3ui& c) { int8_t& v = cells[key(c)]; if (v == 0) return false; v = 0; return true; }
-bool Loc2D::OccupancyMapProxy::isFree(const Vector3ui& c) const { auto it = cells.find(key(c)); return it != cells.end() && it->second == -1; }
-bool Loc2D::OccupancyMapProxy::isOccupied(const Vector3ui& c) const { auto it = cells.find(key(c)); return it != cells.end() && it->second == 1; }
-
 void Loc2D::Init(const Options& o)
 {
     opt_ = o;
@@ -40,14 +26,29 @@ void Loc2D::Init(const Options& o)
     // the device context is rebuilt from the new options by the next ensureContext()
     if (ctx_) { eng_->ctx_destroy(ctx_); ctx_ = nullptr; }
     delete occupancy_map; delete distance_map;
-    occupancy_map = new OccupancyMapProxy;
-    distance_map = new DistanceMapProxy;
-    occupancy_map->resolution = distance_map->resolution = o.resolution;
-    occupancy_map->scale = distance_map->scale = 1.0 / o.resolution;
-    distance_map->l2_max = o.l2_max;
-    distance_map->owner = this;
+    occupancy_map = new SimpleOccupancyMap(o.resolution, o.patch_size);                // src/loc2d.cpp:63-66
+    distance_map = new DynamicDistanceMap(o.resolution, o.patch_size);
+    distance_map->setMaxDistance(o.l2_max);
+    DynamicDistanceMap::Writer w;
+    w.apply = [this](std::vector<uint32_t>& cells_xy, double max_distance) -> uint32_t {
+        (void)max_distance;                                 // part of the context's configuration (ensureContext)
+        ensureContext();
+        const int32_t rc = eng_->map_add_obstacles(ctx_, 0, cells_xy.data(), (uint32_t)(cells_xy.size() / 2));
+        if (rc) fail(rc, "lama_hip_map_add_obstacles");
+        lama_hip_counters c;
+        return eng_->get_counters(ctx_, &c) == 0 ? (uint32_t)c.bf_cells : 0;
+    };
+    w.download = [this](sdm::HostMap& m) -> bool {
+        if (!ctx_) return false;
+        uint32_t n = 0, got = 0;
+        if (eng_->pf_map_patches(ctx_, 0, 0 /* distance map */, &n) != 0) return false;
+        m.kind = sdm::kDistanceMap; m.max_sqdist = distance_map->snapshot().max_sqdist;
+        m.ids.assign(n, 0); m.cells.assign((size_t)n * 10 * 1024, 0); m.masks.assign((size_t)n * 16, 0);
+        return eng_->pf_download_map(ctx_, 0, 0, n, m.ids.data(), m.cells.data(), m.masks.data(), &got) == 0 && got == n;
+    };
+    distance_map->bindWriter(std::move(w));
     rmse_ = 0.0;
-    cov_ = Matrix3d_();
+    cov_ = Matrix3d::Identity();
     has_first_scan = false;
     do_global_localization_ = false;                                   // :80-90
     gloc_cur_iter_ = 0;
@@ -61,24 +62,6 @@ void Loc2D::Init(const Options& o)
         sampling_steps_.push_back(Vector2d(i * sstep, i * sstep));   sampling_steps_.push_back(Vector2d(-i * sstep, i * sstep));
         sampling_steps_.push_back(Vector2d(i * sstep, -i * sstep));  sampling_steps_.push_back(Vector2d(-i * sstep, -i * sstep));
     }
-}
-
-// Map::bounds: min/max patch anchor over the allocated patches, max + patch_length, then m2w = tf_inv_ * m with
-// Eigen's affine inverse of Translation(off) * Scaling(s) (linear = (s*s) * (1 / ((s*s)*s)), translation = -(linear*off))
-void Loc2D::OccupancyMapProxy::bounds(Vector3d& mn, Vector3d& mx) const
-{
-    uint32_t lo[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}, hi[2] = {0, 0};
-    for (const auto& kv : cells) {
-        const uint32_t ax = (uint32_t)(kv.first >> 32) & ~31u, ay = (uint32_t)(kv.first & 0xFFFFFFFFu) & ~31u;
-        lo[0] = std::min(lo[0], ax); lo[1] = std::min(lo[1], ay);
-        hi[0] = std::max(hi[0], ax); hi[1] = std::max(hi[1], ay);
-    }
-    const uint32_t zlo = cells.empty() ? 0xFFFFFFFFu : 0u, zhi = 0u + 32u;      // 2-D: the z anchor of every patch is 0
-    hi[0] += 32; hi[1] += 32;
-    const double off = double(2642244ull >> 1) * 32.0;
-    const double l = (scale * scale) * (1.0 / ((scale * scale) * scale)), t = -(l * off);
-    mn = Vector3d(l * (double)lo[0] + t, l * (double)lo[1] + t, l * (double)zlo + t);
-    mx = Vector3d(l * (double)hi[0] + t, l * (double)hi[1] + t, l * (double)zhi + t);
 }
 
 Loc2D::~Loc2D()
@@ -103,7 +86,7 @@ void Loc2D::ensureContext()
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = 1;
-    cfg.resolution = opt_.resolution; cfg.patch_size = opt_.patch_size; cfg.l2_max = distance_map->l2_max; cfg.max_iter = opt_.max_iter;
+    cfg.resolution = opt_.resolution; cfg.patch_size = opt_.patch_size; cfg.l2_max = distance_map->maxDistanceOption(); cfg.max_iter = opt_.max_iter;
     cfg.device = opt_.gpu_device;
     cfg.solver_strategy = opt_.strategy == "lm" ? 1u : 0u;       // makeStrategy, src/loc2d.cpp:288-294
     cfg.dm_patch_capacity = 4096;            // a static building-scale map; occupancy is not kept on the device
@@ -115,17 +98,6 @@ void Loc2D::ensureContext()
         std::snprintf(msg, sizeof(msg), "lama::Loc2D: lama_hip_ctx_create failed (status %d): no usable MI355X / HIP device; there is no CPU fallback", rc);
         throw std::runtime_error(msg);
     }
-}
-
-uint32_t Loc2D::DistanceMapProxy::update()
-{
-    if (pending.empty()) return 0;
-    owner->ensureContext();
-    const int32_t rc = owner->eng_->map_add_obstacles(owner->ctx_, 0, pending.data(), (uint32_t)(pending.size() / 2));
-    if (rc) owner->fail(rc, "lama_hip_map_add_obstacles");
-    pending.clear();
-    lama_hip_counters c;
-    return owner->eng_->get_counters(owner->ctx_, &c) == 0 ? (uint32_t)c.bf_cells : 0;
 }
 
 bool Loc2D::enoughMotion(const Pose2D& odometry)               // src/loc2d.cpp:113-124
@@ -153,7 +125,7 @@ void Loc2D::solve(const PointCloudXYZ& s, bool do_solve)
         last_iterations_ = (uint32_t)iters;
         double c9[9];
         detail::covariance_from_normal3(out7, c9);
-        for (int k = 0; k < 9; ++k) cov_.m[k] = c9[k];
+        for (int k = 0; k < 9; ++k) cov_(k / 3, k % 3) = c9[k];
         if (cov_blend_ > 0.0) addSamplingCovariance(s);                                 // :175-176
     }
     rmse_ = std::sqrt(out7[6] / ((double)(s.points.size() - 1)));                       // :178-180
@@ -162,7 +134,7 @@ void Loc2D::solve(const PointCloudXYZ& s, bool do_solve)
 bool Loc2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double, bool force_update)
 {
     if (!surface || surface->points.size() < 2) throw std::runtime_error("lama::Loc2D::update: empty scan");
-    if (distance_map && !distance_map->pending.empty()) distance_map->update();
+    if (distance_map && distance_map->hasPending()) distance_map->update();
     if (!has_first_scan) {                                      // :128-143
         odom_ = odometry;
         has_first_scan = true;
@@ -212,9 +184,8 @@ void Loc2D::globalLocalization(const PointCloudXYZ& surface)
     const double diff0 = mx[0] - mn[0], diff1 = mx[1] - mn[1];
     const uint32_t B = opt_.gloc_particles;
     if (B == 0) return;
-    if (occupancy_map->cells.empty()) throw std::runtime_error("lama::Loc2D::globalLocalization: the occupancy map has no free cell");
     bool any_free = false;
-    for (const auto& kv : occupancy_map->cells) if (kv.second == -1) { any_free = true; break; }
+    occupancy_map->visit_all_cells([&](const Vector3ui& c) { if (!any_free && occupancy_map->isFree(c)) any_free = true; });
     if (!any_free) throw std::runtime_error("lama::Loc2D::globalLocalization: the occupancy map has no free cell");
     gloc_poses_.assign((size_t)4 * B, 0.0);
     gloc_errors_.assign(B, 0.0);

@@ -6,11 +6,45 @@
 #include <stdexcept>
 #include <vector>
 
+// only include paths that exist in the reference's installed header tree (include/lama/...)
 #include <lama/loc2d.h>
 #include <lama/match_surface_2d.h>
+#include <lama/nlls/gauss_newton.h>
+#include <lama/nlls/levenberg_marquardt.h>
+#include <lama/nlls/robust_cost.h>
 #include <lama/nlls/solver.h>
 #include <lama/pf_slam2d.h>
+#include <lama/pose2d.h>
+#include <lama/print.h>
+#include <lama/sdm/dynamic_distance_map.h>
+#include <lama/sdm/export.h>
+#include <lama/sdm/frequency_occupancy_map.h>
+#include <lama/sdm/map.h>
+#include <lama/sdm/simple_occupancy_map.h>
 #include <lama/slam2d.h>
+#include <lama/time.h>
+#include <lama/types.h>
+
+// what iris_lama_ros' loc2d_ros does with a nav_msgs/OccupancyGrid: fill Loc2D's two public maps cell by cell
+// (src/loc2d_ros.cpp InitLoc2DFromOccupancyGridMsg), then distance_map->update()
+static int fill_loc2d_maps(lama::Loc2D& loc)
+{
+    lama::SimpleOccupancyMap* occ = loc.occupancy_map;
+    lama::DynamicDistanceMap* dm = loc.distance_map;
+    if (!occ || !dm) return 20;
+    for (int j = 0; j < 80; ++j)
+        for (int i = 0; i < 80; ++i) {
+            const lama::Vector3d coords(0.05 * i, 0.05 * j, 0.0);
+            const bool wall = i == 0 || j == 0 || i == 79 || j == 79;
+            if (wall) { occ->setOccupied(coords); dm->addObstacle(dm->w2m(coords)); }
+            else occ->setFree(coords);
+        }
+    if (!occ->isFree(lama::Vector3d(1.0, 1.0, 0.0)) || !occ->isOccupied(lama::Vector3d(0.0, 1.0, 0.0)) || !occ->isUnknown(lama::Vector3d(9.0, 9.0, 0.0))) return 21;
+    lama::Vector3d mn, mx;
+    occ->bounds(mn, mx);
+    if (!(mx[0] - mn[0] >= 4.0)) return 22;
+    return 0;
+}
 
 // a user-defined nlls::Problem (include/lama/nlls/problem.h): fit y = a * exp(b * x) to samples -- the generic host loop of
 // lama::Solver drives it, nothing of it touches the GPU
@@ -63,6 +97,13 @@ int main()
     for (int k = 0; k < 360; ++k) {
         const double a = k * 3.14159265358979323846 / 180.0;
         cloud->points.push_back(lama::Vector3d(3.0 * std::cos(a), 3.0 * std::sin(a), 0.0));
+    }
+    {   // host-only part of the Loc2D map API: works without a device
+        lama::Loc2D loc;
+        loc.Init(lama::Loc2D::Options());
+        if (const int rc = fill_loc2d_maps(loc)) return rc;
+        lama::Timer timer(true);
+        if (timer.elapsed().toSec() < 0.0 || lama::format("%d", 7) != "7") return 24;
     }
     try {
         lama::PFSlam2D slam(options);
@@ -118,6 +159,18 @@ int main()
         slam2.update(cloud, prior + lama::Pose2D(0.0, 0.0, 0.6), 1.0);
         if (!slam2.summary || slam2.summary->time.size() != 2 || slam2.summary->time_solving.size() != 1 || slam2.summary->memory.back() <= 0) return 10;
         std::printf("%s", slam2.summary->report().c_str());
+        // localisation on a map filled through the public members, as loc2d_ros does
+        lama::Loc2D loc;
+        lama::Loc2D::Options lo;
+        loc.Init(lo);
+        if (const int rc = fill_loc2d_maps(loc)) return rc;
+        const uint32_t processed = loc.distance_map->update();                   // brushfire on the device
+        const double dmid = loc.distance_map->distance(lama::Vector3d(2.0, 2.0, 0.0));
+        const lama::Matrix3d& cov = loc.getCovar();
+        lama::print("Loc2D: %u cells processed, distance at the room centre %.3f m, cov(0,0) %.2f, stamp %.0f\n", processed, dmid,
+                    cov(0, 0), lama::Time::now().toSec() > 0 ? 1.0 : 0.0);
+        if (processed == 0 || !(dmid > 0.9)) return 23;
+        lama::sdm::export_to_png(*loc.occupancy_map, "/tmp/lama_consumer_loc_occ.png");
     } catch (const std::runtime_error& e) {
         std::printf("no device: %s\n", e.what());                // expected on a box without an MI355X
         return 0;
