@@ -6,9 +6,11 @@
 
 A "step" is one PFSlam2D::update() (predict, scan-match, normalise, resample if due, map update) of ALL particles
 on one 1080-beam scan.  N = 1: BASELINE.json configs[1] (PFSlam2D, 30 particles, 1080 beams, one MI355X).
-N > 1: one process per GPU, the particle pool is sharded in contiguous blocks (30 particles per GPU: weak
-scaling), the per-scan exchange is an all-gather of the log-likelihoods (RCCL) plus particle shipping when a
-resample clones across shards.  Prints ONE JSON line on rank 0.
+N > 1: BASELINE.json configs[2] -- one process per GPU, the particle pool sharded in contiguous blocks of 375 particles per
+GPU (N = 8: the 3000 particles of configs[2]; weak scaling), the per-scan exchange is an all-gather of the log-likelihoods
+(RCCL) plus particle shipping over xGMI when a resample clones across shards; the run with meas_sigma_gain = 0.01 (which
+makes the filter resample) is part of the default output there.  The N = 1 line carries the single-GPU rate at 375
+particles too ("other_particle_counts"), the like-for-like base of the N > 1 values.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -133,10 +135,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles", type=int, default=30, help="particles per GPU")
+    ap.add_argument("--particles", type=int, default=0, help="particles per GPU (default: 30 on one GPU, 375 on several)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--sweep", type=str, default="300,3000", help="extra single-GPU particle counts (N=1 only), '' to skip")
+    ap.add_argument("--sweep", type=str, default="300,375,3000", help="extra single-GPU particle counts (N=1 only), '' to skip")
     args = ap.parse_args()
+    if args.particles <= 0:
+        args.particles = 30 if args.gpus == 1 else 375
 
     import torch
     import iris_lama_amd.ffi as F
@@ -149,9 +153,14 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    # developer switch: LAMA_BENCH_ONE_DEVICE=1 runs every rank on GPU 0 over gloo (a 1-GPU box can then execute the sharded
+    # code path end to end -- all-gather, resample planning, particle export / import -- with the real HIP engine)
+    one_device = os.environ.get("LAMA_BENCH_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        init_process_group("nccl")
+        init_process_group("gloo" if one_device else "nccl")
 
     K, W = args.steps, args.warmup
     P_total = args.particles * world
@@ -163,7 +172,7 @@ def main():
         kw = {} if gain is None else {"meas_sigma_gain": gain}
         opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
                             create_summary=1 if summary else 0, profile=1 if profile else 0, brushfire_mode=brushfire_mode, **kw)
-        pf = ShardedPF(opts)
+        pf = ShardedPF(opts, device=torch.device("cpu") if (one_device and world > 1) else None)
         assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
         pf.set_prior(*odom[0])
         pf.update(pts[0], odom[0], 0.0)                       # first scan (initialisation, untimed)
@@ -201,10 +210,8 @@ def main():
     assert main_run["updates"] == K, "every scan of the log must pass the motion gate"
     prof_run = run(P_total, K, W, profile=True)
     # with the default gain resampling is rare; a variant with meas_sigma_gain = 0.01 makes the filter resample
-    # (and, sharded, ship particles between GPUs).  Single GPU by default; LAMA_BENCH_RESAMPLE_VARIANT=1 also runs it sharded.
-    resample_run = None
-    if world == 1 or os.environ.get("LAMA_BENCH_RESAMPLE_VARIANT") == "1":
-        resample_run = run(P_total, K, W, gain=0.01)
+    # (and, sharded, ship particles between GPUs): always run, on one GPU and sharded.
+    resample_run = run(P_total, K, W, gain=0.01)
 
     if rank != 0:
         return
@@ -215,7 +222,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"PFSlam2D {P_total} particles ({args.particles}/GPU), 1080-beam synthetic corridor log "
                                f"(SURVEY.md 8(d)), res 0.05 m, patch 32, l2_max 0.5, GN+Cauchy(0.15), seed 42",
-                   "particles": P_total, "beams": 1080, "parallelism": f"particle-shard x{world}",
+                   "particles": P_total, "beams": 1080, "parallelism": f"particle-shard x{world}" + (" (all ranks on GPU 0, gloo)" if one_device and world > 1 else ""),
                    "resamples_in_timed_region": main_run["resamples"], "best_pose_error_m": main_run["pose_err_m"]},
         "kernel_ms_per_step": {"scan_match": c["ms_scan_match"] / max(c["launches_scan_match"], 1),
                                "update_maps": c["ms_update_maps"] / max(c["launches_update_maps"], 1),
@@ -244,11 +251,17 @@ def main():
     # roofline of the dominant kernel (k_brushfire): algorithmic bytes per launch / mean launch duration.
     # Algorithmic bytes (reference record sizes): every DM patch the brushfire touches is read
     # and written once = 2 x 10,368 B x n(S_bf) per particle-scan, n(S_bf) counted by the oracle on the same log.
-    traffic = None
+    # `traffic` = HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of THIS bench
+    # command, tools/profile_round.sh); it cannot be sampled from inside the process, so the committed summary is quoted together
+    # with the commit and kernel it was taken on -- a reader can see at once whether it is stale.
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_brushfire.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            traffic_src = {"file": "profiles/pmc_brushfire.json", "kernel": tj.get("kernel"), "git_head": tj.get("git_head"),
+                           "collected": tj.get("collected"), "mean_launch_us_there": tj.get("mean_launch_us_timed_region")}
         except Exception:
             traffic = None
     if base and "bytes" in base:
@@ -257,9 +270,13 @@ def main():
         dur_s = c["ms_brushfire"] / launches * 1e-3
         achieved = per_ps * args.particles / dur_s / 1e9          # GB/s on this rank's GPU
         result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire<1024,256,false,true> (+ its no-op resume stages)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
                               "mean_launch_ms": dur_s * 1e3}
+        # the whole step against the same roof: all algorithmic bytes of a particle-scan / the step time
+        step_gbs = base["bytes"]["total"] * args.particles / (main_run["ms_per_step"] * 1e-3) / 1e9
+        result["roofline_step"] = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
+                                   "bytes_per_particle_scan": round(base["bytes"]["total"])}
     if world == 1 and args.sweep:
         extra = {}
         for P in [int(x) for x in args.sweep.split(",") if x]:
@@ -270,11 +287,15 @@ def main():
                              "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1),
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1)}
+            if base and "bytes" in base:       # same log, same per-particle footprint: the P = 30 byte counts apply
+                bf_s = cc["ms_brushfire"] / max(cc["launches_brushfire"], 1) * 1e-3
+                extra[str(P)]["roofline_frac_brushfire"] = base["bytes"]["brushfire"] * P / bf_s / 1e9 / HBM_PEAK_GBS
+                extra[str(P)]["roofline_frac_step"] = base["bytes"]["total"] * P / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         result["other_particle_counts"] = extra
         # opt-in level-synchronous brushfire (cfg.brushfire_mode = 1; NOT bit-identical to the reference in the obstacle
         # offsets of tie cells) -- reported for information, never as `value`
         canon = {}
-        for P in [args.particles] + [int(x) for x in args.sweep.split(",") if x]:
+        for P in [args.particles, 3000]:
             r = run(P, K, W, profile=True, brushfire_mode=1)
             cc = r["counters"]
             canon[str(P)] = {"value": r["value"], "ms_per_step": r["ms_per_step"],

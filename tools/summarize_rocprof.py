@@ -88,5 +88,11 @@ if os.path.exists(sdb):
 os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
 open(os.path.join(ROOT, "profiles", f"{tag}_rocprof_stats.md"), "w").write("\n".join(out) + "\n")
 if pj:
+    import subprocess, datetime
+    try:
+        pj["git_head"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except Exception:
+        pj["git_head"] = None
+    pj["collected"] = datetime.date.today().isoformat() + " (" + tag + ")"
     json.dump(pj, open(os.path.join(ROOT, "profiles", "pmc_brushfire.json"), "w"), indent=1)
 print("\n".join(out))
