@@ -98,6 +98,8 @@ struct lama_hip_ctx {
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
+    uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
+    uint32_t* d_scalar = nullptr;
     bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
     PinVec<double> h_poses;           // host mirror of the particle poses (source of truth between calls)
     PinVec<int32_t> h_counts;         // host mirror of counts of the current set (refreshed after map updates)
@@ -348,8 +350,25 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        if (c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
-            c->cfg.ray_rule == 1) {      // the parallel kernels implement the frequency counters and the PF ray rule only
+        bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
+                          c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
+        // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
+        // in 11 bits (act_key): scans with more points go beam by beam
+        if (!sequential && (n > 2048u || (uint64_t)n + 4096u > c->cfg.active_capacity)) sequential = true;
+        // a uint16 `visited` counter that wraps INSIDE a scan makes the order of the visits matter (k_occ_max_visited)
+        if (!sequential && (uint64_t)c->visit_bound + n >= 65536u) {
+            uint32_t m = 0;
+            if (c->initialised) {
+                (void)hipMemsetAsync(c->d_scalar, 0, sizeof(uint32_t), c->stream);
+                hipLaunchKernelGGL(k_occ_max_visited, dim3(c->P), dim3(256), 0, c->stream, prm, c->d_scalar);
+                HIPCHK(c, hipMemcpyAsync(&m, c->d_scalar, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+            c->visit_bound = m;
+            if ((uint64_t)m + n >= 65536u) { sequential = true; c->ctr.wrap_guard_scans += 1; }
+        }
+        c->visit_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->visit_bound + n, 65535u);
+        if (sequential) {
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
@@ -486,6 +505,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
+    CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
     CHK(hipMalloc(&c->d_occ_hit, P * oc * 128));     CHK(hipMemset(c->d_occ_hit, 0, P * oc * 128));
@@ -510,7 +530,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);

@@ -1708,6 +1708,24 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_occ_max_visited -- the largest `visited` counter over all frequency cells of all particles (atomicMax into *out).  The
+// parallel ray-cast adds the visits of a scan to the uint16 counters in any order, which equals the reference's sequential
+// `visited++` (src/sdm/frequency_occupancy_map.cpp:65-91) only while no counter WRAPS inside the scan; the host keeps an upper
+// bound of the largest counter and, when bound + beams could reach 65536, refreshes it with this kernel and falls back to the
+// beam-sequential ray-cast for scans in which a wrap is possible.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_occ_max_visited(DevParams prm, uint32_t* __restrict__ out)
+{
+    const int p = blockIdx.x;
+    const uint32_t n = (uint32_t)prm.counts[2 * p + 1] * 1024u;
+    const uint32_t* cells = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    uint32_t m = 0;
+    for (uint32_t k = threadIdx.x; k < n; k += 256u) { const uint32_t v = cells[k] >> 16; m = v > m ? v : m; }
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_copy_particles -- dst particle i := src particle idx[i] (directories, counts, used slots of every
 // plane); slots of dst beyond the source's count that the old dst owner had used are re-zeroed so the
 // "unused slot == calloc'd" invariant holds.  grid = (P, 7 planes), 256 threads, 16-byte vectors.

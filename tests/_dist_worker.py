@@ -6,7 +6,7 @@ import sys
 import numpy as np
 
 
-def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir, gpu):
+def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir, gpu, checksums_only=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     here = os.path.dirname(os.path.abspath(__file__))
@@ -31,10 +31,13 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
         hist.append(dict(ok=ok, poses=pf.pf.poses()[pf.pf.lo:pf.pf.hi].copy(), w=w.copy(), ws=ws.copy(), neff=pf.pf.neff(),
                          best=pf.pf.best()))
     ctx = pf.pf.hip_context()
-    maps = {}
-    for i in range(pf.pf.lo, pf.pf.hi):
-        maps[i] = (ctx.download_map(i - pf.pf.lo, F.MAP_DISTANCE), ctx.download_map(i - pf.pf.lo, F.MAP_OCCUPANCY))
-    res = dict(lo=pf.pf.lo, hi=pf.pf.hi, hist=hist, maps=maps, resamples=pf.pf.num_resamples(), shipped=pf.shipped_particles,
+    maps, sums = {}, None
+    if checksums_only:        # large pools: one device-side checksum per particle and map instead of the maps themselves
+        sums = (ctx.map_checksums(F.MAP_DISTANCE), ctx.map_checksums(F.MAP_OCCUPANCY))
+    else:
+        for i in range(pf.pf.lo, pf.pf.hi):
+            maps[i] = (ctx.download_map(i - pf.pf.lo, F.MAP_DISTANCE), ctx.download_map(i - pf.pf.lo, F.MAP_OCCUPANCY))
+    res = dict(lo=pf.pf.lo, hi=pf.pf.hi, hist=hist, maps=maps, sums=sums, resamples=pf.pf.num_resamples(), shipped=pf.shipped_particles,
                origin=pf.pf.engine_origin())
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
         pickle.dump(res, f)

@@ -133,6 +133,38 @@ def test_patch_arenas_grow_on_demand(F):
     ctx.close()
 
 
+def test_visited_counter_wrap_inside_a_scan(F):
+    """uint16 `visited` wraps silently in the reference (src/sdm/frequency_occupancy_map.cpp:65-74).  The parallel ray-cast adds
+    a scan's visits in any order, which is only the same thing while no counter wraps INSIDE a scan: 2000 beams down one corridor
+    of cells, scan after scan from the same pose, reach 65536 visits in the 33rd scan -- the device must notice (it keeps a bound
+    of the largest counter), cast those scans beam by beam, and stay bit-identical to the oracle through the wrap."""
+    P, n = 2, 2000
+    ang = np.linspace(-0.004, 0.004, n)
+    scan = np.stack([6.0 * np.cos(ang), 6.0 * np.sin(ang), np.zeros(n)], axis=1)
+    pose0 = O.se2(1.0, 1.0, 0.3)
+    pf = O.PF(O.default_options(particles=P, seed=5))
+    pf.set_prior(pose0)
+    assert pf.update(scan, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P))
+    ctx.init(scan, pose0)
+    poses = np.stack([pose0, O.se2(1.0, 1.0, 0.3)])
+    for k in range(1, 36):
+        pf.set_poses(poses)
+        pf.stage_set_scan(scan)
+        pf.stage_update_maps()
+        ctx.set_poses(poses)
+        ctx.update_maps(scan)
+        if k in (30, 31, 32, 33, 35):
+            for i in range(P):
+                assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+                assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    occ = ctx.download_map(0, F.MAP_OCCUPANCY)
+    c = ctx.counters()
+    assert c["wrap_guard_scans"] >= 1, c          # the guard fired ...
+    assert c["wrap_guard_scans"] <= 6, c          # ... and only around the wrap, not from the first scan on
+    ctx.close()
+
+
 def test_match_batch_matches_oracle_loglik(F):
     pts, odom, truth = F.corridor_log(1, 1080)
     pose0 = O.se2(*odom[0])
@@ -237,6 +269,47 @@ def test_sharded_two_ranks_one_gpu_gloo(F):
         for i, (dm, occ) in r["maps"].items():
             assert_maps_equal(dm, c.download_map(i, F.MAP_DISTANCE), DM_FIELDS, f"dm p{i}")
             assert_maps_equal(occ, c.download_map(i, F.MAP_OCCUPANCY), OCC_FIELDS, f"occ p{i}")
+    h.close()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_config3_split_partition_invariance(F, world):
+    """BASELINE configs[2]: 3000 particles in G = 4 / 8 contiguous shards (750 / 375 per shard -- the 8-GPU split), here as G
+    processes on ONE device over gloo, with a small meas_sigma_gain so that the filter resamples and clones cross shard
+    borders.  Every shard must agree with a single-shard run of the same library bit for bit: poses, weights, resampling
+    decisions, and a device-side checksum of every particle's maps."""
+    import os, pickle, tempfile
+    import torch.multiprocessing as mp
+    from test_distributed_cpu import _free_port
+    from _dist_worker import run
+    P, steps, beams, gain = 3000, 5, 1080, 0.002
+    out = tempfile.mkdtemp()
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=run, args=(r, world, port, "gloo", None, P, steps, beams, gain, out, 0, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(900)
+        assert p.exitcode == 0
+    res = [pickle.load(open(os.path.join(out, f"rank{r}.pkl"), "rb")) for r in range(world)]
+    assert [(r["lo"], r["hi"]) for r in res] == [(k * P // world, (k + 1) * P // world) for k in range(world)]
+    assert len({r["resamples"] for r in res}) == 1 and res[0]["resamples"] > 0
+    assert sum(r["shipped"] for r in res) > 0, "no clone crossed a shard border: the test would not exercise the shipping"
+    pts, odom, _ = F.corridor_log(steps, beams)
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
+    h.set_prior(*odom[0])
+    for k in range(steps + 1):
+        h.update(pts[k], odom[k], float(k))
+        allp = np.concatenate([r["hist"][k]["poses"] for r in res])
+        assert np.array_equal(allp, h.poses()), k
+        w, nw, ws = h.weights()
+        for r in res:
+            assert np.array_equal(r["hist"][k]["w"], w) and np.array_equal(r["hist"][k]["ws"], ws) and r["hist"][k]["best"] == h.best()
+    c = h.hip_context()
+    assert np.array_equal(np.concatenate([r["sums"][0] for r in res]), c.map_checksums(F.MAP_DISTANCE))
+    assert np.array_equal(np.concatenate([r["sums"][1] for r in res]), c.map_checksums(F.MAP_OCCUPANCY))
+    assert h.num_resamples() == res[0]["resamples"]
     h.close()
 
 
