@@ -282,7 +282,7 @@ def test_config3_split_partition_invariance(F, world):
     import torch.multiprocessing as mp
     from test_distributed_cpu import _free_port
     from _dist_worker import run
-    P, steps, beams, gain = 3000, 5, 1080, 0.002
+    P, steps, beams, gain = 3000, 5, 1080, 0.0001
     out = tempfile.mkdtemp()
     port = _free_port()
     ctx = mp.get_context("spawn")
