@@ -98,6 +98,8 @@ struct lama_hip_ctx {
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
+    int cache_max_particles = 0;      // up to this many particles the pop-by-pop brushfire stages its patches in LDS (developer switch
+                                      // LAMA_HIP_BF_CACHE; measured SLOWER than the L2-served form: 2.65 vs 1.80 ms at 30 particles)
     uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
     uint32_t* d_scalar = nullptr;
     bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
@@ -397,6 +399,9 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         const bool lse = c->cfg.brushfire_mode == 2;        // lower wave level by level (lama_brushfire_lse.h) instead of pop by pop; bit-identical
         if (c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES)) {
             if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            // few particles: a workgroup has a CU (and its LDS) to itself -> the touched patches are staged in LDS (BfCells)
+            else if (count <= (uint32_t)c->cache_max_particles && c->cfg.dm_patch_capacity <= (uint32_t)BC_ARENA)
+                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
@@ -467,6 +472,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
 
     lama_hip_ctx* c = new lama_hip_ctx();
     c->cfg = cfg;
+    if (const char* e = std::getenv("LAMA_HIP_BF_CACHE")) c->cache_max_particles = std::atoi(e);
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->scale = 1.0 / cfg.resolution;

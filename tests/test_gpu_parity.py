@@ -839,10 +839,10 @@ def test_limits_fail_loudly_with_status_codes(F):
     with pytest.raises(F.LamaError, match=r"status -\d+: .*(arena|capacity)"):
         ctx.init(pts[0], pose0)
     ctx.close()
-    # the parallel ray-cast keeps order-sensitive visits in a list of active_capacity entries (1080 hits alone exceed 64)
+    # the parallel ray-cast keeps order-sensitive visits in a list of active_capacity entries (1080 hits alone exceed 64): such
+    # a scan is cast beam by beam instead (round 2; it used to be an error)
     ctx = F.HipContext(F.default_cfg(particles=2, active_capacity=64, sequential_raycast=2))
-    with pytest.raises(F.LamaError, match=r"status -\d+"):
-        ctx.init(pts[0], pose0)
+    ctx.init(pts[0], pose0)
     ctx.close()
     for bad in (dict(patch_size=16), dict(window_patches=252), dict(resolution=0.0), dict(l2_max=10.0)):
         with pytest.raises(F.LamaError, match="lama_hip_ctx_create failed"):
