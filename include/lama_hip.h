@@ -251,6 +251,7 @@ typedef struct lama_hip_counters {
     uint64_t occ_patches;       /* sum of allocated occupancy patches over particles (current)      */
     double ms_eval_batch;  uint64_t launches_eval_batch;     /* lama_hip_eval_batch                   */
     uint64_t arena_growths;     /* times the patch arenas were doubled (maps grow on demand)        */
+    uint64_t window_shifts;     /* times the map window was re-centred (the window follows the robot)  */
     uint64_t wrap_guard_scans;  /* scans ray-cast beam by beam because a uint16 `visited` counter could wrap inside them */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);

@@ -98,6 +98,7 @@ struct lama_hip_ctx {
     int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
+    double scan_reach = 0.0;          // largest point distance of the resident scan (sensor frame, metres)
     int cache_max_particles = 0;      // up to this many particles the pop-by-pop brushfire stages its patches in LDS (developer switch
                                       // LAMA_HIP_BF_CACHE; measured SLOWER than the L2-served form: 2.65 vs 1.80 ms at 30 particles)
     uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
@@ -199,6 +200,9 @@ int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
     }
     c->h_pts.resize((size_t)3 * n);                       // the caller's buffer is only borrowed for the call
     std::memcpy(c->h_pts.data(), pts, sizeof(double) * 3 * n);
+    double r2 = 0.0;
+    for (uint32_t i = 0; i < n; ++i) r2 = std::max(r2, pts[3 * i] * pts[3 * i] + pts[3 * i + 1] * pts[3 * i + 1] + pts[3 * i + 2] * pts[3 * i + 2]);
+    c->scan_reach = std::sqrt(r2);
     HIPCHK(c, hipMemcpyAsync(c->d_pts, c->h_pts.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     return LAMA_HIP_OK;
 }
@@ -341,8 +345,58 @@ void resolve_timers(lama_hip_ctx* c)      // call after the stream has been sync
     c->ctr.launches_update_maps = c->ctr.launches_raycast;
 }
 
+// The reference's maps have no extent (src/sdm/map.cpp:400-411); the device window has one, but it MOVES: before a map update
+// the window must hold every cell the scan can touch from any particle of the range (pose +- scan reach).  If it does not, the
+// window is moved to hold that box -- a patch-granular shift of the two directories of every particle (k_shift_window; the other
+// particle set's directories are the scratch destination, then the pointers are swapped).  Only a map whose extent exceeds the
+// window side remains an error.
+int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t count)
+{
+    const double reach = c->scan_reach + std::sqrt(mtf.t[0] * mtf.t[0] + mtf.t[1] * mtf.t[1]) + 2.0 * 32.0 * c->cfg.resolution;
+    double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
+    for (uint32_t p = first; p < first + count; ++p) {
+        const double x = c->h_poses[4 * p + 2], y = c->h_poses[4 * p + 3];
+        xlo = std::min(xlo, x - reach); xhi = std::max(xhi, x + reach);
+        ylo = std::min(ylo, y - reach); yhi = std::max(yhi, y + reach);
+    }
+    auto patch = [&](double w) { return (int64_t)std::floor((c->scale * w + c->off) / 32.0); };
+    const int64_t pxlo = patch(xlo), pxhi = patch(xhi), pylo = patch(ylo), pyhi = patch(yhi);
+    const int64_t ox = c->wx0 >> 5, oy = c->wy0 >> 5, W = c->W;
+    if (std::getenv("LAMA_HIP_DEBUG_WINDOW")) std::fprintf(stderr, "fit_window: reach %.2f box x [%ld, %ld] y [%ld, %ld] window x [%ld, %ld) y [%ld, %ld)\n", reach, (long)pxlo, (long)pxhi, (long)pylo, (long)pyhi, (long)ox, (long)(ox + W), (long)oy, (long)(oy + W));
+    if (pxlo >= ox && pxhi < ox + W && pylo >= oy && pyhi < oy + W) return LAMA_HIP_OK;
+    if (pxhi - pxlo + 1 > W || pyhi - pylo + 1 > W) return LAMA_HIP_OK;      // cannot hold the box: the kernels report what really falls outside
+    // the smallest move that holds the box (keeps as much of the mapped area inside as possible), plus a few patches of slack in
+    // the direction of the move so that the next scans do not shift again
+    auto place = [&](int64_t o, int64_t lo, int64_t hi) {
+        const int64_t a = hi - W + 1, b = lo;                 // admissible origins: a <= origin <= b
+        int64_t no = std::min(std::max(o, a), b);
+        if (no > o) no = std::min(no + 4, b); else if (no < o) no = std::max(no - 4, a);
+        return no;
+    };
+    const int64_t nox = c->initialised ? place(ox, pxlo, pxhi) : (pxlo + pxhi + 1) / 2 - W / 2;
+    const int64_t noy = c->initialised ? place(oy, pylo, pyhi) : (pylo + pyhi + 1) / 2 - W / 2;
+    const int dx = (int)(nox - ox), dy = (int)(noy - oy);
+    if (!c->initialised) { c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32); return LAMA_HIP_OK; }   // nothing mapped yet
+    ParticleSet& a = c->set[c->cur];
+    ParticleSet& b = c->set[1 - c->cur];
+    const size_t WW = (size_t)c->W * c->W;
+    const dim3 grid(c->P, (unsigned)((WW + 255) / 256));
+    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, b.dm_dir, c->W, dx, dy, WW, WW, c->d_err);
+    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, b.occ_dir, c->W, dx, dy, WW, WW, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    std::swap(a.dm_dir, b.dm_dir);
+    std::swap(a.occ_dir, b.occ_dir);
+    c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32);
+    c->ctr.window_shifts += 1;
+    return LAMA_HIP_OK;
+}
+
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
 {
+    {
+        const int32_t rcw = fit_window(c, mtf, first, count);
+        if (rcw) return rcw;
+    }
     PinVec<double>& tfs = c->h_tfs;
     tfs.resize((size_t)c->P * 12);
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
@@ -1208,7 +1262,7 @@ int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* bu
     const uint64_t WW = (uint64_t)c->W * c->W;
     const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
     uint8_t* o = (uint8_t*)buf;
-    int32_t hdr[4] = {dmc, occ, 0, 0};
+    int32_t hdr[4] = {dmc, occ, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5)};      // counts + the window origin (patches) the directories refer to
     HIPCHK(c, hipMemcpyAsync(o, &c->h_poses[4 * particle], 32, hipMemcpyHostToDevice, c->stream)); o += 32;
     HIPCHK(c, hipMemcpyAsync(o, hdr, 16, hipMemcpyHostToDevice, c->stream)); o += 16;
     auto d2d = [&](const void* src, uint64_t nbytes) -> hipError_t {
@@ -1257,8 +1311,18 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
         return e;
     };
     auto zero = [&](void* dst, uint64_t nbytes) -> hipError_t { return nbytes ? hipMemsetAsync(dst, 0, nbytes, c->stream) : hipSuccess; };
-    HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
-    HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
+    // the sender's window may sit elsewhere (every shard follows its own particles): translate the directories
+    const int wdx = (int)((int64_t)(c->wx0 >> 5) - (int64_t)hdr[2]), wdy = (int)((int64_t)(c->wy0 >> 5) - (int64_t)hdr[3]);
+    if (wdx == 0 && wdy == 0) {
+        HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
+        HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
+    } else {
+        const dim3 grid(1, (unsigned)((WW + 255) / 256));
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, reinterpret_cast<const int16_t*>(in), s.dm_dir + particle * WW, c->W, wdx, wdy, (size_t)0, (size_t)0, c->d_err);
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, reinterpret_cast<const int16_t*>(in + WW * 2), s.occ_dir + particle * WW, c->W, wdx, wdy, (size_t)0, (size_t)0, c->d_err);
+        HIPCHK(c, hipGetLastError());
+        in += 2 * WW * 2;
+    }
     HIPCHK(c, d2d(s.dm_sv + particle * dcap * 1024, (uint64_t)dmc * 2048));
     HIPCHK(c, d2d(s.dm_obs + particle * dcap * 1024, (uint64_t)dmc * 4096));
     HIPCHK(c, d2d(s.dm_mask + particle * dcap * 16, (uint64_t)dmc * 128));

@@ -1827,6 +1827,25 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_shift_window -- the window directory of every particle seen through a window whose origin moved by (dx, dy) patches:
+// dst[p][wy][wx] = src[p][wy + dy][wx + dx], -1 where that lies outside the old window.  Cells are addressed window-relative
+// and patches live in per-particle arenas, so moving the window only permutes directory entries.  A patch that would leave
+// the window means the map no longer fits it: ERR_WINDOW (nothing is dropped silently).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_shift_window(const int16_t* __restrict__ src, int16_t* __restrict__ dst, uint32_t W, int dx, int dy,
+                                                       size_t src_stride, size_t dst_stride, int32_t* err)
+{
+    const uint32_t p = blockIdx.x, idx = blockIdx.y * 256u + threadIdx.x;
+    if (idx >= W * W) return;
+    const int wy = (int)(idx / W), wx = (int)(idx % W);
+    const int sx = wx + dx, sy = wy + dy;
+    const bool in = sx >= 0 && sy >= 0 && sx < (int)W && sy < (int)W;
+    dst[p * dst_stride + idx] = in ? src[p * src_stride + (size_t)sy * W + (size_t)sx] : (int16_t)-1;
+    const int tx = wx - dx, ty = wy - dy;                  // where the old entry (wx, wy) ends up
+    if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && src[p * src_stride + idx] >= 0) atomicOr(err, ERR_WINDOW);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_occ_max_visited -- the largest `visited` counter over all frequency cells of all particles (atomicMax into *out).  The
 // parallel ray-cast adds the visits of a scan to the uint16 counters in any order, which equals the reference's sequential
 // `visited++` (src/sdm/frequency_occupancy_map.cpp:65-91) only while no counter WRAPS inside the scan; the host keeps an upper

@@ -133,6 +133,65 @@ def test_patch_arenas_grow_on_demand(F):
     ctx.close()
 
 
+def test_map_window_follows_the_robot(F):
+    """The reference's maps have no extent.  The device window has one (here 40 patches = 64 m) but it is re-centred when a scan
+    could leave it.  The corridor scans are integrated from poses that also drift sideways by 1 m per scan (not a consistent
+    world, but the oracle integrates the same thing: pose + sensor reach leaves the window centred on the first pose after a few
+    scans, the window moves, the maps stay bit-identical to the oracle's."""
+    P, steps = 3, 44
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pose0 = O.se2(*odom[0])
+    pf.set_prior(pose0)
+    assert pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, window_patches=40))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(12)
+    for k in range(1, steps + 1):
+        poses = _perturbed(rng, O.se2(truth[k][0], truth[k][1] + 1.0 * k, truth[k][2]), P)
+        if k % 5 == 0:
+            idx = np.sort(rng.integers(0, P, size=P)).astype(np.int32)
+            pf.stage_resample_with(idx)
+            ctx.resample(idx)
+        pf.set_poses(poses)
+        pf.stage_set_scan(pts[k])
+        pf.stage_update_maps()
+        ctx.set_poses(poses)
+        ctx.update_maps(pts[k])
+        if k in (20, 44):
+            for i in range(P):
+                assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+                assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    c = ctx.counters()
+    assert c["window_shifts"] >= 1, c
+    # scan matching against the shifted window still sees the map
+    g_poses, g_ll, g_it = ctx.scan_match(pts[steps])
+    pf.stage_set_scan(pts[steps]); pf.set_weights(w=np.zeros(P), ws=np.zeros(P)); pf.stage_scan_match()
+    assert np.abs(g_poses - pf.poses()).max() <= 1e-6        # (a smeared map: the solver wanders, both sides alike)
+    ctx.close()
+
+
+def test_particle_blob_between_contexts_with_different_windows(F):
+    """Every shard's window follows its own particles, so a shipped particle may come from a window that sits elsewhere: the blob
+    carries its origin and the importer translates the directories -- the imported particle's maps are the exported ones."""
+    import torch
+    pts, odom, truth = F.corridor_log(3, 1080)
+    a = F.HipContext(F.default_cfg(particles=2, window_patches=64))
+    b = F.HipContext(F.default_cfg(particles=2, window_patches=64))
+    a.init(pts[0], O.se2(*odom[0]))
+    b.init(pts[3], O.se2(truth[3][0] + 9.0, truth[3][1] + 5.0, 0.4))          # another place: another window origin
+    a.set_poses(np.tile(O.se2(*truth[1]), (2, 1)))
+    a.update_maps(pts[1])
+    n = a.export_bytes(1)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    a.export_particle(1, buf.data_ptr(), n)
+    b.import_particle(0, buf.data_ptr(), n)
+    for kind, fields in ((F.MAP_DISTANCE, DM_FIELDS), (F.MAP_OCCUPANCY, OCC_FIELDS)):
+        assert_maps_equal(b.download_map(0, kind), a.download_map(1, kind), fields, f"kind {kind}")
+    assert np.array_equal(b.get_poses()[0], a.get_poses()[1])
+    a.close(); b.close()
+
+
 def test_visited_counter_wrap_inside_a_scan(F):
     """uint16 `visited` wraps silently in the reference (src/sdm/frequency_occupancy_map.cpp:65-74).  The parallel ray-cast adds
     a scan's visits in any order, which is only the same thing while no counter wraps INSIDE a scan: 2000 beams down one corridor
