@@ -28,6 +28,42 @@ DM_PATCH_B = 10240 + 128    # reference record sizes: distance_
 OCC_PATCH_B = 4096 + 128
 
 
+def reference_baseline(pts, odom, P, updates, warm):
+    """THE REFERENCE ITSELF (oracle/_ref/liblama_ref.so: the reference's own sources compiled from /root/reference by
+    oracle/Makefile.ref in the build container; the prebuilt library travels to the GPU box) timed on the host cores: its
+    ThreadPool with one worker per host thread, and its serial path (Options::threads <= 1).  None when the library is absent."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    try:
+        import _oracle as O
+        import _reference as R
+        if not R.available():
+            return None
+        R.lib()
+    except Exception:
+        return None
+    cores = os.cpu_count() or 1
+    res = {"cores": cores}
+    for label, threads, Pk, n_upd, n_warm in (("pool", cores, P, updates, warm), ("serial", 1, P, updates, warm),
+                                              ("pool_300", cores, 300, 8, 2), ("pool_3000", cores, 3000, 8, 2)):
+        try:
+            pf = R.PF(O.default_options(particles=Pk, seed=42, threads=threads))
+            pf.set_prior(odom[0])
+            pf.update(pts[0], odom[0], 0.0)
+            t_tot, n = 0.0, 0
+            for k in range(1, min(n_warm + n_upd, len(pts) - 1) + 1):
+                t0 = time.perf_counter()
+                ok = pf.update(pts[k], odom[k], float(k))
+                dt = time.perf_counter() - t0
+                if k > n_warm and ok:
+                    t_tot += dt
+                    n += 1
+            res[label] = dict(value=Pk * n / t_tot, seconds=t_tot, updates=n, particles=Pk)
+            del pf
+        except Exception as e:      # e.g. not enough host memory for 3000 reference particles
+            res[label] = dict(error=str(e))
+    return res
+
+
 def cpu_baseline(pts, odom, P, updates, warm):
     """Oracle (CPU restatement of the reference's thread_pool path) timed on the host cores: same log, same P,
     same updates.  Also returns the algorithmic bytes per particle-scan from the oracle's touch counters."""
@@ -241,13 +277,27 @@ def main():
     cores, base = (None, None)
     if not args.no_cpu:
         cores, base = cpu_baseline(pts, odom, args.particles, K, W)
-        result["cpu_baseline"] = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
-                                  "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
-                                            f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s; "
-                                            f"pool at P=300/3000 (8 updates each): "
-                                            + "/".join(f"{v.get('value', float('nan')):.0f}" for v in base["pool_other"].values()) + "/s",
-                                  "serial_value": base["serial"]["value"],
-                                  "pool_other_particle_counts": base["pool_other"]}
+        port = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
+                "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
+                          f"{cores} host threads ({base['pool']['seconds']:.2f} s); serial: {base['serial']['value']:.1f}/s; "
+                          f"pool at P=300/3000 (8 updates each): "
+                          + "/".join(f"{v.get('value', float('nan')):.0f}" for v in base["pool_other"].values()) + "/s",
+                "serial_value": base["serial"]["value"],
+                "pool_other_particle_counts": base["pool_other"]}
+        ref = reference_baseline(pts, odom, args.particles, K, W)
+        if ref is not None and "value" in ref.get("pool", {}):
+            # the reference's own code (thread_pool path) on this box's host cores; the oracle's figures stay alongside
+            result["cpu_baseline"] = {"value": ref["pool"]["value"], "unit": "particle-scans/s", "cores": ref["cores"], "kind": "reference",
+                                      "sample": f"the reference's PFSlam2D (oracle/_ref/liblama_ref.so, built from /root/reference by oracle/Makefile.ref "
+                                                f"against the Eigen stand-in), same log, P={args.particles}, {K} updates after {W} warm-up, its ThreadPool "
+                                                f"with {ref['cores']} workers ({ref['pool']['seconds']:.2f} s); Options::threads<=1 (serial): "
+                                                f"{ref['serial'].get('value', float('nan')):.1f}/s; pool at P=300/3000 (8 updates each): "
+                                                f"{ref['pool_300'].get('value', float('nan')):.0f}/{ref['pool_3000'].get('value', float('nan')):.0f}/s",
+                                      "serial_value": ref["serial"].get("value"),
+                                      "pool_other_particle_counts": {"300": ref["pool_300"], "3000": ref["pool_3000"]},
+                                      "oracle_port": port}
+        else:
+            result["cpu_baseline"] = port
     # roofline of the dominant kernel (k_brushfire): algorithmic bytes per launch / mean launch duration.
     # Algorithmic bytes (reference record sizes): every DM patch the brushfire touches is read
     # and written once = 2 x 10,368 B x n(S_bf) per particle-scan, n(S_bf) counted by the oracle on the same log.

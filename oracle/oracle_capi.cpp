@@ -556,6 +556,7 @@ void orc_pgo_linearize(const double* poses4, uint32_t N, const int32_t* fi, cons
 }
 void orc_random_set_seed(uint32_t seed) { orc::random::setSeed(seed); }
 double orc_random_uniform() { return orc::random::uniform(); }
+double orc_random_normal(double stddev) { return orc::random::normal(stddev); }
 // cells: (x, y) map coordinates; state -1 free / 0 unknown / 1 occupied (SimpleOccupancyMap)
 void orc_loc_occ_set(void* h, const uint32_t* cells_xy, uint32_t n, int state)
 {

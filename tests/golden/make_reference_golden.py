@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_golden.npz by RUNNING THE REFERENCE ITSELF: oracle/_ref/liblama_ref.so is the reference's
+own sources compiled from /root/reference (recipe oracle/Makefile.ref; Eigen3 is absent from this image, so they compile
+against the stand-in under oracle/ref_shim/ -- see its header for what that pins).  The fixtures travel to boxes where
+/root/reference does not exist: the CPU oracle and the HIP path are both checked against them (tests/test_reference_golden.py).
+
+Content (seeded corridor log of SURVEY 8(d), 1080 beams):
+  pf_*      PFSlam2D, P = 4, seed 42, 9 scans, default gains: poses / weights / Neff / best index after every update and sha256
+            digests of particle 0's distance and occupancy maps (patch ids + cell records + Container masks)
+  rs_*      the same with meas_sigma_gain = 0.01 (resampling happens), P = 6, 12 scans; digests of the best particle's maps
+  slam_*    Slam2D: pose after every update, map digests
+  kat_*     known answers: SE2 exp / compose / inverse-compose, Map::computeRay, bilinear distance + gradient, CauchyWeight,
+            lama::random after setSeed(7), MatchSurface2D::eval residual / Jacobian rows, Solve() results (GN and LM, with covariance)
+Run from the repo root (needs /root/reference):  make -f oracle/Makefile.ref && python tests/golden/make_reference_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import _oracle as O                      # noqa: E402  (option struct only)
+import _reference as R                   # noqa: E402
+import iris_lama_amd.ffi as F            # noqa: E402  (workload generator only)
+from golden.make_golden import map_digest  # noqa: E402
+
+KAT_EXP_IN = np.array([[0.3, -0.2, 0.0], [0.0, 0.0, 0.7], [0.4, 0.1, 0.5], [-0.05, 0.02, -1e-12], [1.5, -2.5, 3.0]])
+KAT_POSE_A, KAT_POSE_B = np.array([1.0, 2.0, 0.3]), np.array([-0.5, 0.25, -1.1])
+KAT_DIST_IN = np.array([[3.1, 1.7, 0.0], [5.02, 0.93, 0.0], [10.0, 3.9, 0.0], [25.0, 2.0, 0.0], [2.0, 2.0, 0.0]])
+KAT_RAYS = [([100, 200, 0], [131, 187, 0]), ([42275904, 42275904, 0], [42275890, 42275950, 0]), ([10, 10, 0], [10, 40, 0]), ([7, 9, 0], [7, 9, 0])]
+PF_STEPS, PF_P, RS_STEPS, RS_P, SLAM_STEPS = 8, 4, 11, 6, 10
+
+
+def run_pf(pts, odom, steps, P, seed, gain):
+    pf = R.PF(O.default_options(particles=P, seed=seed, meas_sigma_gain=gain, threads=1))
+    pf.set_prior(odom[0])
+    out = dict(poses=[], weights=[], neff=[], best=[], dm=[], occ=[])
+    for k in range(steps + 1):
+        assert pf.update(pts[k], odom[k], float(k))
+        b = pf.best()
+        out["poses"].append(pf.poses()); out["weights"].append(pf.weights()[0]); out["neff"].append(pf.neff()); out["best"].append(b)
+        which = 0 if gain == 3.0 else b
+        out["dm"].append(map_digest(pf.dm(which).dump())); out["occ"].append(map_digest(pf.occ(which).dump()))
+    return pf, {k: np.array(v) for k, v in out.items()}
+
+
+def main():
+    L = R.lib()
+    pts, odom, truth = F.corridor_log(max(PF_STEPS, RS_STEPS, SLAM_STEPS), 1080)
+    # random stream first (PFSlam2D's constructor re-seeds the global generator)
+    L.ref_random_set_seed(7)
+    kat_random = np.array([L.ref_random_uniform() for _ in range(4)] + [L.ref_random_normal(0.5) for _ in range(4)] + [L.ref_random_uniform()])
+    pf, g = run_pf(pts, odom, PF_STEPS, PF_P, 42, 3.0)
+    _, rs = run_pf(pts, odom, RS_STEPS, RS_P, 11, 0.01)
+    # KATs
+    kat_exp = np.zeros((len(KAT_EXP_IN), 4))
+    for i, v in enumerate(KAT_EXP_IN):
+        L.ref_se2_exp(O._p(np.ascontiguousarray(v)), O._p(kat_exp[i]))
+    kat_plus, kat_minus = np.zeros(4), np.zeros(4)
+    L.ref_pose_plus_xyr(O._p(KAT_POSE_A), O._p(KAT_POSE_B), O._p(kat_plus))
+    L.ref_pose_minus_xyr(O._p(KAT_POSE_A), O._p(KAT_POSE_B), O._p(kat_minus))
+    dm = pf.dm(0)
+    rays = [dm.compute_ray(a, b) for a, b in KAT_RAYS]
+    kat_dist = np.array([list((lambda d, gr: (d, gr[0], gr[1]))(*dm.distance(p, grad=True))) for p in KAT_DIST_IN])
+    kat_cauchy = np.array([L.ref_cauchy(0.15, x) for x in (0.0, 0.15, -0.4, 2.0)])
+    xyr = np.array([odom[PF_STEPS][0] + 0.07, odom[PF_STEPS][1] - 0.05, odom[PF_STEPS][2] + 0.02])
+    r, J = R.eval_(dm, pts[PF_STEPS], xyr)
+    sel = np.arange(0, 1080, 45)
+    gn, gn_cov = R.solve(dm, pts[PF_STEPS], xyr, cov=True)
+    lm, lm_cov = R.solve(dm, pts[PF_STEPS], xyr, lm=True, cov=True)
+    # Slam2D
+    s = L.ref_slam_new(0.5, 0.5, 0.5, 0.0, 0.0, 0.05, 32, 100, 0, 0)
+    L.ref_slam_set_pose(s, O._p(np.ascontiguousarray(odom[0])))
+    slam_poses, slam_dm, slam_occ = [], [], []
+    I, Z = R.IDENT_Q, R.ZERO3
+    for k in range(SLAM_STEPS + 1):
+        L.ref_slam_update(s, O._p(np.ascontiguousarray(pts[k])), len(pts[k]), O._p(Z), O._p(I), O._p(np.ascontiguousarray(odom[k])), float(k))
+        p = np.zeros(4); L.ref_slam_get_pose(s, O._p(p)); slam_poses.append(p)
+        slam_dm.append(map_digest(R.DM(L.ref_slam_dm(s)).dump())); slam_occ.append(map_digest(R.Occ(L.ref_slam_occ(s)).dump()))
+    L.ref_slam_free(s)
+    out = os.path.join(HERE, "reference_golden.npz")
+    np.savez_compressed(
+        out, odom=odom, truth=truth,
+        pf_poses=g["poses"], pf_weights=g["weights"], pf_neff=g["neff"], pf_best=g["best"], pf_dm_digest=g["dm"], pf_occ_digest=g["occ"],
+        rs_poses=rs["poses"], rs_weights=rs["weights"], rs_neff=rs["neff"], rs_best=rs["best"], rs_dm_digest=rs["dm"], rs_occ_digest=rs["occ"],
+        slam_poses=np.stack(slam_poses), slam_dm_digest=np.array(slam_dm), slam_occ_digest=np.array(slam_occ),
+        kat_random=kat_random, kat_exp=kat_exp, kat_plus=kat_plus, kat_minus=kat_minus,
+        kat_ray_sizes=np.array([len(x) for x in rays]), kat_rays=np.concatenate(rays) if len(rays) else np.zeros((0, 3)),
+        kat_dist=kat_dist, kat_cauchy=kat_cauchy, kat_eval_xyr=xyr, kat_eval_r=r[sel], kat_eval_J=J[sel],
+        kat_gn=gn, kat_gn_cov=gn_cov, kat_lm=lm, kat_lm_cov=lm_cov)
+    print("wrote", out, os.path.getsize(out), "bytes; resampling steps in rs run:",
+          int(np.sum(np.any(np.diff(rs["weights"], axis=0) != 0, axis=1))))
+
+
+if __name__ == "__main__":
+    main()

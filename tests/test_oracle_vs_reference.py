@@ -1,0 +1,210 @@
+"""The CPU oracle against THE REFERENCE ITSELF (oracle/_ref/liblama_ref.so = the reference's own sources compiled from
+/root/reference against the Eigen stand-in under oracle/ref_shim/; built by `__graft_entry__.build()` / oracle/Makefile.ref
+where /root/reference exists).  Everything here must be bit-identical: both sides run the same libstdc++ / libm on the same
+inputs, and the stand-in evaluates Eigen's small products in the order the oracle's restatement does.  Skipped where the
+library cannot be built (no /root/reference); tests/test_reference_golden.py carries fixtures from it for those boxes."""
+import numpy as np
+import pytest
+
+import _oracle as O
+import _reference as R
+import iris_lama_amd.ffi as F
+from _worlds import corridor_obstacles, open_corridor, open_corridor_scan
+
+pytestmark = pytest.mark.skipif(not R.available(), reason="oracle/_ref/liblama_ref.so not built (needs /root/reference)")
+
+
+def same_maps(a, b):
+    da, db = a.dump(), b.dump()
+    assert sorted(da) == sorted(db)
+    for pid in da:
+        assert np.array_equal(da[pid][0].view(np.uint8), db[pid][0].view(np.uint8)), pid       # every byte of every cell record
+        assert np.array_equal(da[pid][1], db[pid][1]), pid                                    # Container mask
+
+
+def test_addressing_and_rays():
+    rng = np.random.default_rng(1)
+    dm = R.DM.new()
+    for _ in range(300):
+        p = np.append(rng.uniform(-500, 500, 2), 0.0)
+        c = dm.w2m(p)
+        assert np.array_equal(c, O.w2m(p))
+        assert R.lib().ref_dm_m2p(dm.h, O._p(c)) == O.lib().orc_m2p(0.05, 32, O._p(c))
+        assert R.lib().ref_dm_m2c(dm.h, O._p(c)) == O.lib().orc_m2c(0.05, 32, O._p(c))
+    for _ in range(200):
+        a = rng.integers(42275000, 42276800, 3).astype(np.uint32); a[2] = 0
+        b = (a.astype(np.int64) + np.append(rng.integers(-300, 300, 2), 0)).astype(np.uint32)
+        assert np.array_equal(dm.compute_ray(a, b), O.compute_ray(a, b))
+
+
+def test_se2_and_weights():
+    rng = np.random.default_rng(2)
+    L = R.lib()
+    for _ in range(200):
+        v = rng.normal(0, 1.5, 3)
+        out = np.zeros(4); L.ref_se2_exp(O._p(v), O._p(out))
+        assert np.array_equal(out, O.se2_exp(v))
+        a, b = rng.normal(0, 3, 3), rng.normal(0, 3, 3)
+        L.ref_pose_plus_xyr(O._p(a), O._p(b), O._p(out))
+        assert np.array_equal(out, O.se2_mul(O.se2(*a), O.se2(*b)))
+        L.ref_pose_minus_xyr(O._p(a), O._p(b), O._p(out))
+        assert np.array_equal(out, O.se2_mul(O.se2_inverse(O.se2(*a)), O.se2(*b)))
+        assert L.ref_pose_rotation(*a) == O.lib().orc_se2_rotation(O._p(O.se2(*a)))
+        x = rng.normal(0, 0.5)
+        assert L.ref_cauchy(0.15, x) == O.lib().orc_cauchy(0.15, x)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_dynamic_brushfire_with_removals_and_ties(seed):
+    """Random obstacle insertions / removals on a small grid (many equidistant obstacles => many equal-priority pops): the
+    distance maps must agree in every byte, including the obstacle offsets that depend on std::priority_queue's tie order."""
+    rng = np.random.default_rng(seed)
+    a, b = R.DM.new(), O.DM.new()
+    base = 42275904 + 40
+    live = set()
+    for rnd in range(25):
+        for _ in range(int(rng.integers(1, 40))):
+            c = (base + int(rng.integers(0, 48)), base + int(rng.integers(0, 48)))
+            if c in live and rng.random() < 0.5:
+                live.discard(c); a.remove(*c); b.remove(*c)
+            else:
+                live.add(c); a.add(*c); b.add(*c)
+        if rng.random() < 0.3 and live:                      # remove a whole row of a wall
+            for c in [c for c in live if c[1] == next(iter(live))[1]]:
+                live.discard(c); a.remove(*c); b.remove(*c)
+        assert a.update() == b.update()
+        same_maps(a, b)
+    for _ in range(100):
+        p = np.append(rng.uniform(1.5, 4.5, 2), 0.0)
+        da, ga = a.distance(p, grad=True); db, gb = b.distance(p, grad=True)
+        assert da == db and np.array_equal(ga, gb)
+
+
+def test_frequency_occupancy_counters():
+    rng = np.random.default_rng(5)
+    a, b = R.Occ.new(), O.Occ.new()
+    base = 42275904
+    for _ in range(4000):
+        c = (base + int(rng.integers(0, 40)), base + int(rng.integers(0, 40)))
+        if rng.random() < 0.35:
+            assert a.set_occupied(*c) == b.set_occupied(*c)
+        else:
+            assert a.set_free(*c) == b.set_free(*c)
+    same_maps(a, b)
+    for _ in range(100):
+        c = (base + int(rng.integers(0, 40)), base + int(rng.integers(0, 40)))
+        assert a.probability(*c) == b.probability(*c)
+
+
+@pytest.mark.parametrize("gain,trunc_ray,trunc_range", [(3.0, 0.0, 0.0), (0.01, 0.0, 0.0), (0.02, 3.0, 8.0)])
+def test_pfslam2d_free_running(gain, trunc_ray, trunc_range):
+    steps, P = 22, 8
+    pts, odom, _ = F.corridor_log(steps, 1080)
+    opts = O.default_options(particles=P, seed=5, meas_sigma_gain=gain, truncated_ray=trunc_ray, truncated_range=trunc_range, threads=2)
+    a, b = R.PF(opts), O.PF(opts)
+    a.set_prior(odom[0]); b.set_prior(O.se2(*odom[0]))
+    origin, quat = np.array([0.1, -0.05, 0.3]), np.array([np.cos(0.2), 0.0, 0.0, np.sin(0.2)])      # sensor mounted off-centre, yawed 0.4 rad
+    for k in range(steps + 1):
+        assert a.update(pts[k], odom[k], float(k), origin, quat) == b.update(pts[k], O.se2(*odom[k]), float(k), origin, quat)
+        assert np.array_equal(a.poses(), b.poses()), k
+        wa, wb = a.weights(), b.weights()
+        assert all(np.array_equal(x, y) for x, y in zip(wa, wb)), k
+        assert a.best() == b.best()
+        if k > 0:
+            assert a.neff() == b.neff()
+    if gain < 1.0:
+        assert b.num_resamples() >= 1
+    for i in range(P):
+        same_maps(a.dm(i), b.dm(i))
+        same_maps(a.occ(i), b.occ(i))
+
+
+@pytest.mark.parametrize("lm", [False, True])
+def test_scan_matching_solver(lm):
+    steps = 6
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    opts = O.default_options(particles=1, seed=3, threads=1)
+    a, b = R.PF(opts), O.PF(opts)
+    a.set_prior(odom[0]); b.set_prior(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        a.update(pts[k], odom[k], float(k)); b.update(pts[k], O.se2(*odom[k]), float(k))
+    rng = np.random.default_rng(9)
+    for _ in range(12):
+        xyr = truth[steps] + rng.normal(0, [0.08, 0.08, 0.03])
+        ra, Ja = R.eval_(a.dm(0), pts[steps], xyr)
+        rb, Jb = O.eval_(b.dm(0), pts[steps], O.se2(*xyr))
+        assert np.array_equal(ra, rb) and np.array_equal(Ja, Jb)
+        pa, ca = R.solve(a.dm(0), pts[steps], xyr, lm=lm, cov=True)
+        pb, _, cb = O.solve_full(b.dm(0), pts[steps], O.se2(*xyr), lm=lm)
+        assert np.array_equal(pa, pb)
+        assert np.allclose(ca, cb, rtol=1e-12, atol=0)          # 3x3 inverse: cofactors * (1/det) vs adjugate / det
+
+
+@pytest.mark.parametrize("transient", [0, 1])
+def test_slam2d(transient):
+    steps = 14
+    pts, odom, _ = F.corridor_log(steps, 1080)
+    L = R.lib()
+    a = L.ref_slam_new(0.5, 0.5, 0.5, 0.0, 0.0, 0.05, 32, 100, transient, 0)
+    b = O.Slam(transient_map=bool(transient)) if transient else O.Slam()
+    L.ref_slam_set_pose(a, O._p(np.ascontiguousarray(odom[0]))); b.set_pose(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        p = np.ascontiguousarray(pts[k])
+        ua = L.ref_slam_update(a, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(np.ascontiguousarray(odom[k])), float(k))
+        ub = b.update(pts[k], O.se2(*odom[k]), float(k))
+        assert bool(ua) == bool(ub)
+        pa = np.zeros(4); L.ref_slam_get_pose(a, O._p(pa))
+        assert np.array_equal(pa, b.pose()), k
+    same_maps(R.DM(L.ref_slam_dm(a)), b.dm())
+    same_maps(R.Occ(L.ref_slam_occ(a)), b.occ())
+    L.ref_slam_free(a)
+
+
+def test_loc2d_full_rank_and_rank_deficient_covariance():
+    L = R.lib()
+    # corridor world: full-rank Jacobian
+    steps = 8
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    cells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in corridor_obstacles())], dtype=np.uint32)
+    a = L.ref_loc_new(0.5, 0.5, 1.0, 0.05, 32, 100, 0)
+    L.ref_loc_occ_set(a, O._p(cells), len(cells), 1)
+    b = O.Loc()
+    for cx, cy in cells:
+        b.dm().add(int(cx), int(cy))
+    b.dm().update()
+    same_maps(R.DM(L.ref_loc_dm(a)), b.dm())
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    L.ref_loc_set_pose(a, O._p(start)); b.set_pose(O.se2(*start))
+    for k in range(steps + 1):
+        p = np.ascontiguousarray(pts[k])
+        ua = L.ref_loc_update(a, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(np.ascontiguousarray(odom[k])), float(k), 0)
+        ub = b.update(pts[k], O.se2(*odom[k]), float(k))
+        assert bool(ua) == bool(ub)
+        pa = np.zeros(4); L.ref_loc_get_pose(a, O._p(pa))
+        assert np.array_equal(pa, b.pose()), k
+        ca = np.zeros(9); L.ref_loc_covar(a, O._p(ca))
+        assert np.allclose(ca.reshape(3, 3), b.covar(), rtol=1e-11, atol=1e-18), k
+        assert L.ref_loc_rmse(a) == b.rmse()
+    L.ref_loc_free(a)
+    # open corridor: x unobservable -> ColPivHouseholderQR::rank() < 3 -> the SVD branch
+    obst = open_corridor()
+    cells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in obst)], dtype=np.uint32)
+    a = L.ref_loc_new(0.5, 0.5, 1.0, 0.05, 32, 100, 0)
+    L.ref_loc_occ_set(a, O._p(cells), len(cells), 1)
+    b = O.Loc()
+    for cx, cy in cells:
+        b.dm().add(int(cx), int(cy))
+    b.dm().update()
+    t = np.array([1.3, 1.7, 0.12])
+    scan = np.ascontiguousarray(open_corridor_scan(*t, beams=1080))
+    start = t + np.array([0.0, 0.06, -0.02])
+    L.ref_loc_set_pose(a, O._p(start)); b.set_pose(O.se2(*start))
+    ua = L.ref_loc_update(a, O._p(scan), len(scan), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(start), 0.0, 1)
+    ub = b.update(scan, O.se2(*start), 0.0, force=True)
+    assert bool(ua) == bool(ub) and b.rank_deficient()
+    pa = np.zeros(4); L.ref_loc_get_pose(a, O._p(pa))
+    assert np.array_equal(pa, b.pose())
+    ca = np.zeros(9); L.ref_loc_covar(a, O._p(ca))
+    assert np.allclose(ca.reshape(3, 3), b.covar(), rtol=1e-9, atol=1e-12)
+    assert abs(ca[0] - 3.0) < 1e-9                            # :147-148, the unobservable direction
+    L.ref_loc_free(a)
