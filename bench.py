@@ -285,19 +285,23 @@ def main():
                 "serial_value": base["serial"]["value"],
                 "pool_other_particle_counts": base["pool_other"]}
         ref = reference_baseline(pts, odom, args.particles, K, W)
+        result["cpu_baseline"] = port
         if ref is not None and "value" in ref.get("pool", {}):
-            # the reference's own code (thread_pool path) on this box's host cores; the oracle's figures stay alongside
-            result["cpu_baseline"] = {"value": ref["pool"]["value"], "unit": "particle-scans/s", "cores": ref["cores"], "kind": "reference",
-                                      "sample": f"the reference's PFSlam2D (oracle/_ref/liblama_ref.so, built from /root/reference by oracle/Makefile.ref "
-                                                f"against the Eigen stand-in), same log, P={args.particles}, {K} updates after {W} warm-up, its ThreadPool "
-                                                f"with {ref['cores']} workers ({ref['pool']['seconds']:.2f} s); Options::threads<=1 (serial): "
-                                                f"{ref['serial'].get('value', float('nan')):.1f}/s; pool at P=300/3000 (8 updates each): "
-                                                f"{ref['pool_300'].get('value', float('nan')):.0f}/{ref['pool_3000'].get('value', float('nan')):.0f}/s",
-                                      "serial_value": ref["serial"].get("value"),
-                                      "pool_other_particle_counts": {"300": ref["pool_300"], "3000": ref["pool_3000"]},
-                                      "oracle_port": port}
-        else:
-            result["cpu_baseline"] = port
+            # The reference's own code timed on this box as well.  It is compiled against the Eigen STAND-IN (eager evaluation, no
+            # vectorisation), which costs it speed real Eigen would not: whichever of the two CPU figures is higher is the baseline.
+            rb = {"value": ref["pool"]["value"], "unit": "particle-scans/s", "cores": ref["cores"], "kind": "reference",
+                  "sample": f"the reference's PFSlam2D (oracle/_ref/liblama_ref.so, built from /root/reference by oracle/Makefile.ref "
+                            f"against the Eigen stand-in), same log, P={args.particles}, {K} updates after {W} warm-up, its ThreadPool "
+                            f"with {ref['cores']} workers ({ref['pool']['seconds']:.2f} s); Options::threads<=1 (serial): "
+                            f"{ref['serial'].get('value', float('nan')):.1f}/s; pool at P=300/3000 (8 updates each): "
+                            f"{ref['pool_300'].get('value', float('nan')):.0f}/{ref['pool_3000'].get('value', float('nan')):.0f}/s",
+                  "serial_value": ref["serial"].get("value"),
+                  "pool_other_particle_counts": {"300": ref["pool_300"], "3000": ref["pool_3000"]}}
+            if rb["value"] > port["value"]:
+                rb["oracle_port"] = port
+                result["cpu_baseline"] = rb
+            else:
+                result["cpu_baseline"]["reference_build"] = rb
     # roofline of the dominant kernel (k_brushfire): algorithmic bytes per launch / mean launch duration.
     # Algorithmic bytes (reference record sizes): every DM patch the brushfire touches is read
     # and written once = 2 x 10,368 B x n(S_bf) per particle-scan, n(S_bf) counted by the oracle on the same log.

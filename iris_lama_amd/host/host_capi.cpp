@@ -491,7 +491,12 @@ int lama_loc_update(lama_loc* h, const double* pts, uint32_t n, const double* or
         return h->l.update(make_cloud(pts, n, origin3, quat), Pose2D(odom_xyr[0], odom_xyr[1], odom_xyr[2]), ts, force != 0) ? 1 : 0;
     } catch (const std::exception& e) { h->error = e.what(); return -1; }
 }
-int lama_loc_covar(const lama_loc* h, double* out9) { std::memcpy(out9, h->l.getCovar().m, 72); return 0; }
+int lama_loc_covar(const lama_loc* h, double* out9)      // row-major, whatever lama::Matrix3d is (Eigen's is column-major)
+{
+    const lama::Matrix3d& c = h->l.getCovar();
+    for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) out9[3 * r + k] = c(r, k);
+    return 0;
+}
 double lama_loc_rmse(const lama_loc* h) { return h->l.getRMSE(); }
 uint32_t lama_loc_iterations(const lama_loc* h) { return h->l.getLastIterations(); }
 

@@ -23,6 +23,8 @@
 #include "lama/pf_slam2d.h"
 #include "lama/slam2d.h"
 #include "lama/loc2d.h"
+#include "lama/lidar_odometry_2d.h"
+#include "lama/sdm/probabilistic_occupancy_map.h"
 
 using namespace lama;
 
@@ -246,5 +248,15 @@ int ref_loc_update(void* h, const double* pts, int n, const double* origin3, con
 }
 void ref_loc_covar(void* h, double* out9) { const Matrix3d& c = ((Loc2D*)h)->getCovar(); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out9[3 * i + j] = c(i, j); }
 double ref_loc_rmse(void* h) { return ((Loc2D*)h)->getRMSE(); }
+
+// ---- LidarOdometry2D (src/lidar_odometry_2d.cpp)
+void* ref_lo_new(double resolution, uint32_t max_iter) { LidarOdometry2D::Options o; o.resolution = resolution; o.max_iter = max_iter; return new LidarOdometry2D(o); }
+void ref_lo_free(void* h) { delete (LidarOdometry2D*)h; }
+int ref_lo_update(void* h, const double* pts, int n, const double* origin3, const double* quat4, double ts) { return ((LidarOdometry2D*)h)->update(make_cloud(pts, n, origin3, quat4), ts) ? 1 : 0; }
+void ref_lo_get_odom(void* h, double* out4) { pose_to(((LidarOdometry2D*)h)->odom, out4); }
+void* ref_lo_dm(void* h) { return ((LidarOdometry2D*)h)->distance_map; }
+void* ref_lo_occ(void* h) { return ((LidarOdometry2D*)h)->occupancy_map; }
+int ref_pocc_patch_ids(void* h, uint64_t* ids, int cap) { return patch_ids((const lama::Map*)(ProbabilisticOccupancyMap*)h, ids, cap); }
+int ref_pocc_patch_read(void* h, uint64_t id, uint8_t* cells, uint64_t* mask) { return patch_read((const lama::Map*)(ProbabilisticOccupancyMap*)h, id, cells, mask); }
 
 } // extern "C"

@@ -49,6 +49,9 @@ def lib():
             "ref_loc_new": (vp, [d, d, d, d, u32, u32, i32]), "ref_loc_free": (None, [vp]), "ref_loc_dm": (vp, [vp]),
             "ref_loc_occ_set": (None, [vp, vp, u32, i32]), "ref_loc_set_pose": (None, [vp, vp]), "ref_loc_get_pose": (None, [vp, vp]),
             "ref_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "ref_loc_covar": (None, [vp, vp]), "ref_loc_rmse": (d, [vp]),
+            "ref_lo_new": (vp, [d, u32]), "ref_lo_free": (None, [vp]), "ref_lo_update": (i32, [vp, vp, i32, vp, vp, d]),
+            "ref_lo_get_odom": (None, [vp, vp]), "ref_lo_dm": (vp, [vp]), "ref_lo_occ": (vp, [vp]),
+            "ref_pocc_patch_ids": (i32, [vp, vp, i32]), "ref_pocc_patch_read": (i32, [vp, u64, vp, vp]),
         }
         for name, (res, args) in sig.items():
             f = getattr(L, name)
@@ -148,6 +151,11 @@ class Occ(Map):
 
     def probability(self, x, y, z=0):
         return lib().ref_occ_probability(self.h, x, y, z)
+
+
+class POcc(Map):
+    from _oracle import PROB_T as cell_dtype
+    _ids, _read = "ref_pocc_patch_ids", "ref_pocc_patch_read"
 
 
 def pose_from_xyr(x, y, r):

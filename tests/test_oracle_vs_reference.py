@@ -208,3 +208,21 @@ def test_loc2d_full_rank_and_rank_deficient_covariance():
     assert np.allclose(ca.reshape(3, 3), b.covar(), rtol=1e-9, atol=1e-12)
     assert abs(ca[0] - 3.0) < 1e-9                            # :147-148, the unobservable direction
     L.ref_loc_free(a)
+
+
+def test_lidar_odometry_2d():
+    """src/lidar_odometry_2d.cpp: ProbabilisticOccupancyMap log-odds cells (float), the last-metre ray rule, transient map."""
+    steps = 26
+    pts, _, _ = F.corridor_log(steps, 1080)
+    L = R.lib()
+    a = L.ref_lo_new(0.05, 100)
+    b = O.LidarOdometry()
+    for k in range(steps + 1):
+        p = np.ascontiguousarray(pts[k][np.hypot(pts[k][:, 0], pts[k][:, 1]) < 4.0])
+        ua = L.ref_lo_update(a, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), float(k))
+        assert bool(ua) == b.update(p, float(k))
+        pa = np.zeros(4); L.ref_lo_get_odom(a, O._p(pa))
+        assert np.array_equal(pa, b.odom()), k
+    same_maps(R.DM(L.ref_lo_dm(a)), b.dm())
+    same_maps(R.POcc(L.ref_lo_occ(a)), b.occ())
+    L.ref_lo_free(a)
