@@ -119,7 +119,7 @@ def cpu_baseline(pts, odom, P, updates, warm):
     return cores, res
 
 
-def next_rows(F):
+def next_rows(F, with_cpu=True):
     """Informational timings of the SURVEY 8(f) rows that run on the device (never part of `value`)."""
     import numpy as np
     out = {}
@@ -163,6 +163,98 @@ def next_rows(F):
         g.close()
     except Exception as e:          # informational only: never let it break the headline line
         out["error"] = str(e)
+    try:
+        out.update(single_pose_rows(F, with_cpu))
+    except Exception as e:
+        out["error_single_pose"] = str(e)
+    return out
+
+
+def single_pose_rows(F, with_cpu):
+    """BASELINE configs 1 and 4 -- lama::Loc2D::update on a pre-built map and lama::Slam2D::update (one pose, one map): wall-clock
+    latency per update through the host classes on the device, with the CPU beside it (the oracle port and, where the library is
+    present, the reference's own build).  One pose means no particle parallelism: these rows show the latency regime of the path."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    out = {}
+    steps = 24
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    # ---- config 4: Slam2D online
+    s = F.Slam2D()
+    s.set_pose(*odom[0])
+    s.update(pts[0], odom[0], 0.0)
+    t = []
+    for k in range(1, steps + 1):
+        t0 = time.perf_counter(); s.update(pts[k], odom[k], float(k)); t.append(time.perf_counter() - t0)
+    s.close()
+    row = {"updates": steps - 4, "gpu_ms_per_update": 1e3 * float(np.mean(t[4:]))}
+    if with_cpu:
+        import _oracle as O
+        o = O.Slam()
+        o.set_pose(O.se2(*odom[0])); o.update(pts[0], O.se2(*odom[0]), 0.0)
+        t = []
+        for k in range(1, steps + 1):
+            t0 = time.perf_counter(); o.update(pts[k], O.se2(*odom[k]), float(k)); t.append(time.perf_counter() - t0)
+        row["cpu_oracle_port_ms_per_update"] = 1e3 * float(np.mean(t[4:]))
+        try:
+            import _reference as R
+            if R.available():
+                L = R.lib()
+                h = L.ref_slam_new(0.5, 0.5, 0.5, 0.0, 0.0, 0.05, 32, 100, 0, 0)
+                L.ref_slam_set_pose(h, O._p(np.ascontiguousarray(odom[0])))
+                t = []
+                for k in range(0, steps + 1):
+                    p = np.ascontiguousarray(pts[k])
+                    t0 = time.perf_counter()
+                    L.ref_slam_update(h, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(np.ascontiguousarray(odom[k])), float(k))
+                    t.append(time.perf_counter() - t0)
+                L.ref_slam_free(h)
+                row["cpu_reference_build_ms_per_update"] = 1e3 * float(np.mean(t[5:]))
+        except Exception:
+            pass
+    out["slam2d_update_cfg4"] = row
+    # ---- config 1: Loc2D on a pre-built distance map (scan match only, no map update)
+    from _worlds import corridor_obstacles
+    obst = corridor_obstacles()
+    h = F.Loc2D()
+    h.set_obstacles_world(obst)
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    h.set_pose(*start)
+    t = []
+    for k in range(0, steps + 1):
+        t0 = time.perf_counter(); h.update(pts[k], odom[k], float(k), force=True); t.append(time.perf_counter() - t0)
+    h.close()
+    row = {"updates": steps - 3, "gpu_ms_per_update": 1e3 * float(np.mean(t[4:]))}
+    if with_cpu:
+        import _oracle as O
+        o = O.Loc()
+        for x, y in obst:
+            c = O.w2m([x, y, 0.0]); o.dm().add(int(c[0]), int(c[1]))
+        o.dm().update()
+        o.set_pose(O.se2(*start))
+        t = []
+        for k in range(0, steps + 1):
+            t0 = time.perf_counter(); o.update(pts[k], O.se2(*odom[k]), float(k), force=True); t.append(time.perf_counter() - t0)
+        row["cpu_oracle_port_ms_per_update"] = 1e3 * float(np.mean(t[4:]))
+        try:
+            import _reference as R
+            if R.available():
+                L = R.lib()
+                cells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in obst)], dtype=np.uint32)
+                a = L.ref_loc_new(0.5, 0.5, 1.0, 0.05, 32, 100, 0)
+                L.ref_loc_occ_set(a, O._p(cells), len(cells), 1)
+                L.ref_loc_set_pose(a, O._p(np.ascontiguousarray(start)))
+                t = []
+                for k in range(0, steps + 1):
+                    p = np.ascontiguousarray(pts[k])
+                    t0 = time.perf_counter()
+                    L.ref_loc_update(a, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(np.ascontiguousarray(odom[k])), float(k), 1)
+                    t.append(time.perf_counter() - t0)
+                L.ref_loc_free(a)
+                row["cpu_reference_build_ms_per_update"] = 1e3 * float(np.mean(t[4:]))
+        except Exception:
+            pass
+    out["loc2d_update_cfg1"] = row
     return out
 
 
@@ -356,7 +448,7 @@ def main():
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1)}
         result["canonical_brushfire_mode"] = canon
-        result["next_rows"] = next_rows(F)
+        result["next_rows"] = next_rows(F, with_cpu=not args.no_cpu)
     print(json.dumps(result))
 
 

@@ -9,6 +9,8 @@ Content (seeded corridor log of SURVEY 8(d), 1080 beams):
             digests of particle 0's distance and occupancy maps (patch ids + cell records + Container masks)
   rs_*      the same with meas_sigma_gain = 0.01 (resampling happens), P = 6, 12 scans; digests of the best particle's maps
   slam_*    Slam2D: pose after every update, map digests
+  loc_*     Loc2D on the corridor's static map (config 1): pose / covariance / RMSE after every update
+  lo_*      LidarOdometry2D on range-limited scans: odometry after every update, map digests at the end
   kat_*     known answers: SE2 exp / compose / inverse-compose, Map::computeRay, bilinear distance + gradient, CauchyWeight,
             lama::random after setSeed(7), MatchSurface2D::eval residual / Jacobian rows, Solve() results (GN and LM, with covariance)
 Run from the repo root (needs /root/reference):  make -f oracle/Makefile.ref && python tests/golden/make_reference_golden.py
@@ -30,7 +32,8 @@ KAT_EXP_IN = np.array([[0.3, -0.2, 0.0], [0.0, 0.0, 0.7], [0.4, 0.1, 0.5], [-0.0
 KAT_POSE_A, KAT_POSE_B = np.array([1.0, 2.0, 0.3]), np.array([-0.5, 0.25, -1.1])
 KAT_DIST_IN = np.array([[3.1, 1.7, 0.0], [5.02, 0.93, 0.0], [10.0, 3.9, 0.0], [25.0, 2.0, 0.0], [2.0, 2.0, 0.0]])
 KAT_RAYS = [([100, 200, 0], [131, 187, 0]), ([42275904, 42275904, 0], [42275890, 42275950, 0]), ([10, 10, 0], [10, 40, 0]), ([7, 9, 0], [7, 9, 0])]
-PF_STEPS, PF_P, RS_STEPS, RS_P, SLAM_STEPS = 8, 4, 11, 6, 10
+PF_STEPS, PF_P, RS_STEPS, RS_P, SLAM_STEPS, LOC_STEPS, LO_STEPS = 8, 4, 11, 6, 10, 10, 26
+LOC_START_OFFSET = np.array([0.05, -0.04, 0.01])
 
 
 def run_pf(pts, odom, steps, P, seed, gain):
@@ -48,7 +51,7 @@ def run_pf(pts, odom, steps, P, seed, gain):
 
 def main():
     L = R.lib()
-    pts, odom, truth = F.corridor_log(max(PF_STEPS, RS_STEPS, SLAM_STEPS), 1080)
+    pts, odom, truth = F.corridor_log(max(PF_STEPS, RS_STEPS, SLAM_STEPS, LOC_STEPS, LO_STEPS), 1080)
     # random stream first (PFSlam2D's constructor re-seeds the global generator)
     L.ref_random_set_seed(7)
     kat_random = np.array([L.ref_random_uniform() for _ in range(4)] + [L.ref_random_normal(0.5) for _ in range(4)] + [L.ref_random_uniform()])
@@ -80,12 +83,38 @@ def main():
         p = np.zeros(4); L.ref_slam_get_pose(s, O._p(p)); slam_poses.append(p)
         slam_dm.append(map_digest(R.DM(L.ref_slam_dm(s)).dump())); slam_occ.append(map_digest(R.Occ(L.ref_slam_occ(s)).dump()))
     L.ref_slam_free(s)
+    # Loc2D (config 1): static map from the corridor's obstacle points, scan match + covariance per update
+    from _worlds import corridor_obstacles
+    cells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in corridor_obstacles())], dtype=np.uint32)
+    a = L.ref_loc_new(0.5, 0.5, 1.0, 0.05, 32, 100, 0)
+    L.ref_loc_occ_set(a, O._p(cells), len(cells), 1)
+    start = truth[0] + LOC_START_OFFSET
+    L.ref_loc_set_pose(a, O._p(np.ascontiguousarray(start)))
+    loc_poses, loc_cov, loc_rmse, loc_upd = [], [], [], []
+    for k in range(LOC_STEPS + 1):
+        p = np.ascontiguousarray(pts[k])
+        loc_upd.append(L.ref_loc_update(a, O._p(p), len(p), O._p(Z), O._p(I), O._p(np.ascontiguousarray(odom[k])), float(k), 0))
+        pp, cc = np.zeros(4), np.zeros(9)
+        L.ref_loc_get_pose(a, O._p(pp)); L.ref_loc_covar(a, O._p(cc))
+        loc_poses.append(pp); loc_cov.append(cc.reshape(3, 3)); loc_rmse.append(L.ref_loc_rmse(a))
+    L.ref_loc_free(a)
+    # LidarOdometry2D on range-limited scans
+    lo = L.ref_lo_new(0.05, 100)
+    lo_odom, lo_upd = [], []
+    for k in range(LO_STEPS + 1):
+        p = np.ascontiguousarray(pts[k][np.hypot(pts[k][:, 0], pts[k][:, 1]) < 4.0])
+        lo_upd.append(L.ref_lo_update(lo, O._p(p), len(p), O._p(Z), O._p(I), float(k)))
+        pp = np.zeros(4); L.ref_lo_get_odom(lo, O._p(pp)); lo_odom.append(pp)
+    lo_dm, lo_occ = map_digest(R.DM(L.ref_lo_dm(lo)).dump()), map_digest(R.POcc(L.ref_lo_occ(lo)).dump())
+    L.ref_lo_free(lo)
     out = os.path.join(HERE, "reference_golden.npz")
     np.savez_compressed(
         out, odom=odom, truth=truth,
         pf_poses=g["poses"], pf_weights=g["weights"], pf_neff=g["neff"], pf_best=g["best"], pf_dm_digest=g["dm"], pf_occ_digest=g["occ"],
         rs_poses=rs["poses"], rs_weights=rs["weights"], rs_neff=rs["neff"], rs_best=rs["best"], rs_dm_digest=rs["dm"], rs_occ_digest=rs["occ"],
         slam_poses=np.stack(slam_poses), slam_dm_digest=np.array(slam_dm), slam_occ_digest=np.array(slam_occ),
+        loc_poses=np.stack(loc_poses), loc_cov=np.stack(loc_cov), loc_rmse=np.array(loc_rmse), loc_updated=np.array(loc_upd),
+        lo_odom=np.stack(lo_odom), lo_updated=np.array(lo_upd), lo_dm_digest=np.array(lo_dm), lo_occ_digest=np.array(lo_occ),
         kat_random=kat_random, kat_exp=kat_exp, kat_plus=kat_plus, kat_minus=kat_minus,
         kat_ray_sizes=np.array([len(x) for x in rays]), kat_rays=np.concatenate(rays) if len(rays) else np.zeros((0, 3)),
         kat_dist=kat_dist, kat_cauchy=kat_cauchy, kat_eval_xyr=xyr, kat_eval_r=r[sel], kat_eval_J=J[sel],
