@@ -4,7 +4,7 @@
 // vendored Sophus SE2 (include/lama/sophus/se2.hpp).  Eigen is a hard external dependency there and is NOT
 // available in the build image of this repository, so:
 //   * when <Eigen/Core> is found, lama::Vector2d/Vector3d/Quaterniond ARE the Eigen types (the configuration
-//     an iris_lama_ros build uses; untested here -- see INTEGRATION.md);
+//     an iris_lama_ros build uses; compiled and run by the tests against an Eigen API stand-in -- see INTEGRATION.md);
 //   * otherwise the minimal stand-ins below provide exactly the members this path touches
 //     (x()/y()/z()/w(), operator[], norm()).  They are not an Eigen replacement.
 #pragma once
