@@ -83,6 +83,10 @@ struct lama_hip_ctx {
     uint64_t* d_dbg = nullptr;
     uint32_t* d_slow = nullptr;
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
+    // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
+    lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; size_t rrec_cap = 0;
+    int32_t* d_rev = nullptr; size_t rev_cap = 0;
+    int ray_mode = 0;          // 0 = patch-centric visits (default), 1 = k_ray_visits (beam-centric, LDS-aggregated atomics)
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
     PinVec<uint64_t> h_stats;
@@ -427,11 +431,38 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         if (sequential) {
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
-            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
+            if (c->ray_mode == 0) {
+                // patch-centric visits: a workgroup owns one occupancy patch of one particle, no global atomics on the counters
+                const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
+                if (need > c->rrec_cap) {
+                    (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
+                    HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
+                    HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
+                    c->rrec_cap = need;
+                }
+                if (need_rev > c->rev_cap) {
+                    (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
+                    HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
+                    c->rev_cap = need_rev;
+                }
+                hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
+                                   c->d_rrec, c->d_rbbox);
+                const int rw_seg = count <= 64 ? 8 : 2;
+                hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
+                const uint32_t WW = c->W * c->W;
+                hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+                const char* gy_env = getenv("LAMA_HIP_RAY_GRIDY");
+                const unsigned gy = gy_env ? (unsigned)atoi(gy_env) : (count <= 64 ? 128u : 32u);        // patches of a particle in flight at once
+                hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
+                                   (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
+            } else {
+            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
+                               (lama_dev::RayRec*)nullptr, (uint64_t*)nullptr);
             const char* bpw_env = getenv("LAMA_HIP_RAY_BPW");
             const int bpw = bpw_env ? atoi(bpw_env) : (count <= 64 ? 4 : 16);                            // see k_ray_visits
             hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + 4 * bpw - 1) / (4 * bpw)), dim3(256), 0, c->stream, prm,
                                c->d_pts, (int)n, c->d_tfs, (int)first, bpw);
+            }
             if (count <= 512) {
                 hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
                 hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
@@ -527,6 +558,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     lama_hip_ctx* c = new lama_hip_ctx();
     c->cfg = cfg;
     if (const char* e = std::getenv("LAMA_HIP_BF_CACHE")) c->cache_max_particles = std::atoi(e);
+    if (const char* e = std::getenv("LAMA_HIP_RAY_MODE")) c->ray_mode = std::atoi(e);      // developer switch: 1 = beam-centric k_ray_visits
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->scale = 1.0 / cfg.resolution;
@@ -590,7 +622,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);

@@ -1765,6 +1765,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
 
 } // namespace lama_dev
 #include "lama_raycast_par.h"
+#include "lama_raycast_patch.h"
 #include "lama_brushfire_canon.h"
 namespace lama_dev {
 

@@ -34,15 +34,19 @@ constexpr int RP_BLOCK_SMALL = 256, RP_BLOCK_LARGE = 1024;   // k_ray_replay wor
 
 // ---- directory entry (int16 inside an aligned 32-bit word) with lock-free allocation ----------------------
 // -1 = absent, -2 = being allocated, -3 = allocation failed (arena full), >= 0 = slot (never changes afterwards)
-__device__ inline int dir_get_or_alloc(int16_t* dir, uint32_t pidx, int32_t* count, int cap, int errbit, int32_t* err)
+//
+// dir_alloc_one is the allocation proper, for ONE lane of a wave at a time: it may spin on an entry another WAVE is allocating.
+// It must never be entered by two lanes of the same wave that want the same entry -- the winner's critical section and the
+// losers' spin are one SIMT instruction stream, and wherever the compiler places the critical section after the spin loop's exit
+// (it does, depending on the call site) the losers spin forever on a lock their own wave holds.  dir_get_or_alloc therefore
+// elects, among the lanes that are active at the call, one leader per distinct entry; the others take the leader's result.
+__device__ inline int dir_alloc_one(int16_t* dir, uint32_t pidx, int32_t* count, int cap, int errbit, int32_t* err)
 {
-    int s = dir[pidx];
-    if (s >= 0) return s;
     uint32_t* w = reinterpret_cast<uint32_t*>(dir) + (pidx >> 1);
     const int sh = (int)(pidx & 1u) * 16;
     for (;;) {
         const uint32_t v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s = (int)(int16_t)((v >> sh) & 0xFFFFu);
+        const int s = (int)(int16_t)((v >> sh) & 0xFFFFu);
         if (s >= 0) return s;
         if (s == -3) return -1;
         if (s == -1) {
@@ -60,6 +64,28 @@ __device__ inline int dir_get_or_alloc(int16_t* dir, uint32_t pidx, int32_t* cou
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+__device__ inline int dir_get_or_alloc(int16_t* dir, uint32_t pidx, int32_t* count, int cap, int errbit, int32_t* err)
+{
+    int s = dir[pidx];
+    if (s >= 0) return s;
+    // slow path: one leader per distinct (directory, entry) among the lanes that got here together
+    const int lane = (int)(threadIdx.x & 63u);
+    const uint64_t key = ((uint64_t)(uintptr_t)dir << 20) ^ (uint64_t)pidx;       // directories are >= 2 KB apart, pidx < 2^16
+    int res = -1;
+    bool pending = true;
+    for (;;) {
+        const unsigned long long m = __ballot(pending);              // only the active lanes vote
+        if (m == 0ull) break;
+        const int leader = __ffsll((long long)m) - 1;
+        const uint32_t klo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, leader);
+        const uint32_t khi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), leader);
+        int r = 0;
+        if (lane == leader) r = dir_alloc_one(dir, pidx, count, cap, errbit, err);
+        r = __builtin_amdgcn_readlane(r, leader);
+        if (pending && (uint32_t)key == klo && (uint32_t)(key >> 32) == khi) { res = r; pending = false; }
+    }
+    return res;
 }
 
 struct BeamGeom {
@@ -130,27 +156,55 @@ __device__ inline void act_append(const DevParams& prm, int p, uint64_t key)
 }
 
 // ------------------------------------------------------------------------------------------------
+// With `rec_out` (the patch-centric form, lama_raycast_patch.h) the thread also stores its beam's ray record and the bounding box
+// of the cells the ray visits; k_ray_alloc_walk then allocates the occupancy patches the rays cross, so that the patch pass finds
+// every patch in the directory.
+struct RayRec;
+__device__ inline void ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out);
+
 __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* __restrict__ pts, int n,
-                                                   const double* __restrict__ tfs, int first_particle)
+                                                   const double* __restrict__ tfs, int first_particle,
+                                                   RayRec* __restrict__ rec_out = nullptr, uint64_t* __restrict__ bbox_out = nullptr)
 {
     const int p = first_particle + blockIdx.x;
     const int i = blockIdx.y * 256 + threadIdx.x;
-    if (i >= n) return;
+    const int lane = threadIdx.x & 63;
+    const bool live = i < n;
+    const int ic = live ? i : n - 1;
     const size_t WW = (size_t)prm.W * prm.W;
     double T[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
-    const BeamGeom g = beam_geometry(prm, T, pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    if (g.steps < 0) { atomicOr(prm.err, ERR_WINDOW); return; }
-    if (g.steps > 0) atomicAdd((unsigned long long*)(prm.stats + 4 * p + 2), (unsigned long long)g.steps);
-    if (!g.mark_hit) return;
+    const BeamGeom g = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
+    if (rec_out && live) ray_hits_record(prm, g, p, i, n, rec_out, bbox_out);
+    if (live && g.steps < 0) atomicOr(prm.err, ERR_WINDOW);
+    // ray cells of the scan (statistics): one atomic per wave, not one per beam on the particle's single counter
+    {
+        uint32_t st = (live && g.steps > 0) ? (uint32_t)g.steps : 0u;
+        for (int off = 32; off > 0; off >>= 1) st += (uint32_t)__shfl_xor((int)st, off, 64);
+        if (lane == 0 && st) atomicAdd((unsigned long long*)(prm.stats + 4 * p + 2), (unsigned long long)st);
+    }
+    bool hit = live && g.steps >= 0 && g.mark_hit;
     const uint32_t rx = g.mhx - prm.wx0, ry = g.mhy - prm.wy0;
-    if (rx >= prm.WC || ry >= prm.WC) { atomicOr(prm.err, ERR_WINDOW); return; }
+    if (hit && (rx >= prm.WC || ry >= prm.WC)) { atomicOr(prm.err, ERR_WINDOW); hit = false; }
     const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
-    const int slot = dir_get_or_alloc(prm.occ_dir + (size_t)p * WW, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
-    if (slot < 0) return;
-    atomicOr((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), 1ull << (ci & 63));
-    act_append(prm, p, act_key(rx, ry, (uint32_t)i, 0u));
+    int slot = -1;
+    if (hit) slot = dir_get_or_alloc(prm.occ_dir + (size_t)p * WW, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+    hit = hit && slot >= 0;
+    if (hit) atomicOr((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), 1ull << (ci & 63));
+    // the hits are order-sensitive visits (t = 0): appended with one counter update per wave (their order in the list is free,
+    // k_ray_replay sorts)
+    const unsigned long long hm = __ballot(hit);
+    if (hm) {
+        uint32_t base = 0;
+        if (lane == (__ffsll((long long)hm) - 1)) base = atomicAdd(prm.act_count + p, (uint32_t)__popcll(hm));
+        base = (uint32_t)__shfl((int)base, __ffsll((long long)hm) - 1, 64);
+        if (hit) {
+            const uint32_t k = base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull));
+            if (k < prm.act_cap) prm.act[(size_t)p * prm.act_cap + k] = act_key(rx, ry, (uint32_t)i, 0u);
+            else atomicOr(prm.err, ERR_QUEUE);
+        }
+    }
 }
 
 // Neighbouring beams share most of their cells near the sensor (0.25 deg apart: one cell at 11 m), and agent-scope
