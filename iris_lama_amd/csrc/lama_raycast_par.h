@@ -7,7 +7,9 @@
 //
 //   k_ray_hits   (thread / beam)   : the hit cells of this scan are flagged (one bit per cell) and queued as
 //                                    "active" visits;
-//   k_ray_visits (wave / 4 beams)  : every free-cell visit (beam, t) in parallel.  A visit is INERT when its cell
+//   k_ray_visits (wave / 4 beams)  : [round 1; since round 2 the default is the patch-centric k_ray_patches of lama_raycast_patch.h,
+//                                    same classification, no global atomics; LAMA_HIP_RAY_MODE=1 selects this kernel]
+//                                    every free-cell visit (beam, t) in parallel.  A visit is INERT when its cell
 //                                    is not hit in this scan and is already free (4*occupied < visited: a miss can
 //                                    never raise an event, src/sdm/frequency_occupancy_map.cpp:65-74) or brand new
 //                                    (visited == 0: its first miss always raises removeObstacle, which is a no-op
