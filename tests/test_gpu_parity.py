@@ -101,6 +101,35 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
     ctx.close()
 
 
+def test_beam_centric_visit_kernel_still_bit_exact(F, monkeypatch):
+    """The default parallel ray-cast counts the free-cell visits per occupancy patch (k_ray_patches, round 2); the round-1
+    beam-centric kernel (k_ray_visits, LDS-aggregated atomics) stays selectable with LAMA_HIP_RAY_MODE=1 and must give the same
+    maps: both against the oracle, with truncation and a mounted sensor so that start cells differ per beam."""
+    P, steps = 6, 8
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    origin, quat = np.array([0.15, -0.1, 0.2]), np.array([np.cos(0.1), 0.0, 0.0, np.sin(0.1)])
+    rng = np.random.default_rng(11)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LAMA_HIP_RAY_MODE", mode)
+        pf = O.PF(O.default_options(particles=P, seed=7, truncated_ray=4.0, truncated_range=9.0))
+        pose0 = O.se2(*odom[0])
+        pf.set_prior(pose0)
+        assert pf.update(pts[0], pose0, 0.0, origin=origin, quat=quat)
+        ctx = F.HipContext(F.default_cfg(particles=P, truncated_ray=4.0, truncated_range=9.0))
+        ctx.init(pts[0], pose0, origin=origin, quat=quat)
+        for k in range(1, steps + 1):
+            poses = _perturbed(rng, O.se2(*truth[k]), P, 0.02, 0.005)
+            pf.set_poses(poses)
+            pf.stage_set_scan(pts[k], origin=origin, quat=quat)
+            pf.stage_update_maps()
+            ctx.set_poses(poses)
+            ctx.update_maps(pts[k], origin=origin, quat=quat)
+            for i in range(P):
+                assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"mode {mode} scan {k} occ p{i}")
+                assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"mode {mode} scan {k} dm p{i}")
+        ctx.close()
+
+
 def test_patch_arenas_grow_on_demand(F):
     """The reference's maps allocate patches without bound (src/sdm/map.cpp:400-411); the device arenas start small here and
     must be doubled on the way -- maps stay bit-identical to the oracle's, the growth counter moves, resample() still works."""
