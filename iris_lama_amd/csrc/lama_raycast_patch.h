@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
 __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle)
 {
     const int p = first_particle + blockIdx.x;
-    const uint32_t WW = prm.W * prm.W;                       // a multiple of 8 (W is even ... W * W of an even W is a multiple of 4; checked by the host)
+    const uint32_t WW = prm.W * prm.W;                       // eight entries per thread (one 16-byte load where the run is whole and aligned)
     const uint32_t w0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
     if (w0 >= WW) return;
     const int16_t* d = prm.occ_dir + (size_t)p * WW + w0;
