@@ -46,11 +46,12 @@ __device__ inline int dir_alloc_one(int16_t* dir, uint32_t pidx, int32_t* count,
 {
     uint32_t* w = reinterpret_cast<uint32_t*>(dir) + (pidx >> 1);
     const int sh = (int)(pidx & 1u) * 16;
-    for (;;) {
+    for (uint32_t spins = 0;; ++spins) {
         const uint32_t v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int s = (int)(int16_t)((v >> sh) & 0xFFFFu);
         if (s >= 0) return s;
         if (s == -3) return -1;
+        if (spins > (1u << 22)) { atomicOr(err, errbit); return -1; }       // never seen; a reported error beats a hung device
         if (s == -1) {
             const uint32_t locked = (v & ~(0xFFFFu << sh)) | (0xFFFEu << sh);
             if (atomicCAS(w, v, locked) == v) {
