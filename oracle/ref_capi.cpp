@@ -25,6 +25,9 @@
 #include "lama/loc2d.h"
 #include "lama/lidar_odometry_2d.h"
 #include "lama/sdm/probabilistic_occupancy_map.h"
+#include "lama/sdm/export.h"
+#include "lama/image.h"
+#include "lama/image_io.h"
 
 using namespace lama;
 
@@ -258,5 +261,23 @@ void* ref_lo_dm(void* h) { return ((LidarOdometry2D*)h)->distance_map; }
 void* ref_lo_occ(void* h) { return ((LidarOdometry2D*)h)->occupancy_map; }
 int ref_pocc_patch_ids(void* h, uint64_t* ids, int cap) { return patch_ids((const lama::Map*)(ProbabilisticOccupancyMap*)h, ids, cap); }
 int ref_pocc_patch_read(void* h, uint64_t id, uint8_t* cells, uint64_t* mask) { return patch_read((const lama::Map*)(ProbabilisticOccupancyMap*)h, id, cells, mask); }
+
+// ---- .sdm files (Map::write / Map::read, src/sdm/map.cpp:489-575) and the export images (src/sdm/export.cpp, src/image_io.cpp)
+int ref_dm_write(void* h, const char* file) { return ((DynamicDistanceMap*)h)->write(file) ? 1 : 0; }
+int ref_dm_read(void* h, const char* file) { return ((DynamicDistanceMap*)h)->read(file) ? 1 : 0; }
+int ref_occ_write(void* h, const char* file) { return ((FrequencyOccupancyMap*)h)->write(file) ? 1 : 0; }
+int ref_occ_read(void* h, const char* file) { return ((FrequencyOccupancyMap*)h)->read(file) ? 1 : 0; }
+int ref_dm_export_png(void* h, const char* file) { sdm::export_to_png(*(const DistanceMap*)(DynamicDistanceMap*)h, file); return 1; }
+int ref_occ_export_png(void* h, const char* file) { sdm::export_to_png(*(const OccupancyMap*)(FrequencyOccupancyMap*)h, file); return 1; }
+// decode an image file with the reference's reader (stb): returns 1 and the size; pixels (grey) into out when it is large enough
+int ref_image_read(const char* file, uint32_t* w, uint32_t* hgt, uint8_t* out, uint64_t cap)
+{
+    Image im;
+    if (!image_read(im, file)) return 0;
+    *w = im.width; *hgt = im.height;
+    const uint64_t n = (uint64_t)im.width * im.height;
+    if (out && cap >= n) std::memcpy(out, im.data.get(), n);
+    return 1;
+}
 
 } // extern "C"

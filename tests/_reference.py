@@ -49,6 +49,10 @@ def lib():
             "ref_loc_new": (vp, [d, d, d, d, u32, u32, i32]), "ref_loc_free": (None, [vp]), "ref_loc_dm": (vp, [vp]),
             "ref_loc_occ_set": (None, [vp, vp, u32, i32]), "ref_loc_set_pose": (None, [vp, vp]), "ref_loc_get_pose": (None, [vp, vp]),
             "ref_loc_update": (i32, [vp, vp, i32, vp, vp, vp, d, i32]), "ref_loc_covar": (None, [vp, vp]), "ref_loc_rmse": (d, [vp]),
+            "ref_dm_write": (i32, [vp, C.c_char_p]), "ref_dm_read": (i32, [vp, C.c_char_p]),
+            "ref_occ_write": (i32, [vp, C.c_char_p]), "ref_occ_read": (i32, [vp, C.c_char_p]),
+            "ref_dm_export_png": (i32, [vp, C.c_char_p]), "ref_occ_export_png": (i32, [vp, C.c_char_p]),
+            "ref_image_read": (i32, [C.c_char_p, vp, vp, vp, u64]),
             "ref_lo_new": (vp, [d, u32]), "ref_lo_free": (None, [vp]), "ref_lo_update": (i32, [vp, vp, i32, vp, vp, d]),
             "ref_lo_get_odom": (None, [vp, vp]), "ref_lo_dm": (vp, [vp]), "ref_lo_occ": (vp, [vp]),
             "ref_pocc_patch_ids": (i32, [vp, vp, i32]), "ref_pocc_patch_read": (i32, [vp, u64, vp, vp]),
@@ -156,6 +160,15 @@ class Occ(Map):
 class POcc(Map):
     from _oracle import PROB_T as cell_dtype
     _ids, _read = "ref_pocc_patch_ids", "ref_pocc_patch_read"
+
+
+def image_read(filename):
+    """Decode an image file with the reference's reader (grey pixels, rows top to bottom)."""
+    w, h = C.c_uint32(0), C.c_uint32(0)
+    assert lib().ref_image_read(filename.encode(), C.byref(w), C.byref(h), None, 0)
+    out = np.zeros((h.value, w.value), dtype=np.uint8)
+    assert lib().ref_image_read(filename.encode(), C.byref(w), C.byref(h), _p(out), out.size)
+    return out
 
 
 def pose_from_xyr(x, y, r):

@@ -226,3 +226,55 @@ def test_lidar_odometry_2d():
     same_maps(R.DM(L.ref_lo_dm(a)), b.dm())
     same_maps(R.POcc(L.ref_lo_occ(a)), b.occ())
     L.ref_lo_free(a)
+
+
+def test_sdm_files_and_export_images_interoperate_with_the_reference(tmp_path):
+    """The reference's OWN Map::write / Map::read (src/sdm/map.cpp:489-575) and sdm::export_to_png (src/sdm/export.cpp) against
+    the product's host module lama::sdm (include/lama/sdm_io.h) and the oracle: files written by one side load in the others with
+    identical contents, and the exported images have identical pixels (decoded by the reference's reader)."""
+    from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+    steps = 5
+    pts, odom, _ = F.corridor_log(steps, 720)
+    opts = O.default_options(particles=1, seed=5, threads=1)
+    a, b = R.PF(opts), O.PF(opts)
+    a.set_prior(odom[0]); b.set_prior(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        a.update(pts[k], odom[k], float(k)); b.update(pts[k], O.se2(*odom[k]), float(k))
+    L = R.lib()
+    typed = lambda patches, dt: {k: (np.ascontiguousarray(c).view(dt).reshape(-1), m) for k, (c, m) in patches.items()}
+    # reference writes -> product and oracle read
+    fd, fo = str(tmp_path / "ref_dm.sdm"), str(tmp_path / "ref_occ.sdm")
+    assert L.ref_dm_write(a.dm(0).h, fd.encode()) and L.ref_occ_write(a.occ(0).h, fo.encode())
+    kind, res, msq, patches = F.sdm_read(fd)
+    assert kind == F.MAP_DISTANCE and msq == b.dm(0).max_sqdist() and abs(res - 0.05) < 1e-8
+    assert_maps_equal(typed(patches, O.DIST_T), a.dm(0).dump(), DM_FIELDS, "reference .sdm -> product")
+    kind, _, _, patches = F.sdm_read(fo)
+    assert kind == F.MAP_OCCUPANCY
+    assert_maps_equal(typed(patches, O.FREQ_T), a.occ(0).dump(), OCC_FIELDS, "reference .sdm -> product (occupancy)")
+    d2 = O.DM.new(0.05, 32, 0.1)
+    assert d2.read(fd) and d2.max_sqdist() == b.dm(0).max_sqdist()
+    same_maps(a.dm(0), d2)
+    # the files themselves are byte-identical whoever writes them (patch order aside: all three walk an unordered_map / a dict)
+    fp = str(tmp_path / "prod_dm.sdm")
+    F.sdm_write(fp, b.dm(0).dump(), F.MAP_DISTANCE, 0.05, b.dm(0).max_sqdist())
+    assert open(fp, "rb").read()[:36] == open(fd, "rb").read()[:36]                 # IOHeader + parameters
+    assert len(open(fp, "rb").read()) == len(open(fd, "rb").read())
+    # product writes -> reference reads
+    r2 = R.DM.new(0.05, 32, 0.1)
+    assert L.ref_dm_read(r2.h, fp.encode())
+    same_maps(r2, b.dm(0))
+    fp2 = str(tmp_path / "prod_occ.sdm")
+    F.sdm_write(fp2, b.occ(0).dump(), F.MAP_OCCUPANCY)
+    r3 = R.Occ.new()
+    assert L.ref_occ_read(r3.h, fp2.encode())
+    same_maps(r3, b.occ(0))
+    # export images: the reference's PNGs decode to the pixels the product computes (and writes)
+    for which, m, kind in (("dm", a.dm(0), F.MAP_DISTANCE), ("occ", a.occ(0), F.MAP_OCCUPANCY)):
+        f_ref, f_prod = str(tmp_path / f"ref_{which}.png"), str(tmp_path / f"prod_{which}.png")
+        getattr(L, f"ref_{which}_export_png")(m.h, f_ref.encode())
+        want = R.image_read(f_ref)
+        src = b.dm(0) if which == "dm" else b.occ(0)
+        got = F.sdm_image(src.dump(), kind, 0.05, b.dm(0).max_sqdist())
+        assert got.shape == want.shape and np.array_equal(got, want), which
+        F.sdm_export_png(f_prod, src.dump(), kind, 0.05, b.dm(0).max_sqdist())
+        assert np.array_equal(R.image_read(f_prod), want), which
