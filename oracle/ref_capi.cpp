@@ -232,6 +232,27 @@ void* ref_loc_new(double trans_thresh, double rot_thresh, double l2_max, double 
     l->Init(o);
     return l;
 }
+void* ref_loc_new2(double trans_thresh, double rot_thresh, double l2_max, double resolution, uint32_t patch_size, uint32_t max_iter,
+                   uint32_t gloc_particles, uint32_t gloc_iters, double gloc_thresh, double cov_blend)
+{
+    Loc2D::Options o;
+    o.trans_thresh = trans_thresh; o.rot_thresh = rot_thresh; o.l2_max = l2_max; o.resolution = resolution; o.patch_size = patch_size; o.max_iter = max_iter;
+    o.strategy = "gn"; o.gloc_particles = gloc_particles; o.gloc_iters = gloc_iters; o.gloc_thresh = gloc_thresh; o.cov_blend = cov_blend;
+    auto* l = new Loc2D;
+    l->Init(o);
+    return l;
+}
+// SimpleOccupancyMap cells of the static map: state -1 free / 1 occupied (occupied cells also become distance-map obstacles)
+void ref_loc_occ_set_state(void* h, const uint32_t* cells_xy, uint32_t n, int state)
+{
+    Loc2D* l = (Loc2D*)h;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Vector3ui c(cells_xy[2 * i], cells_xy[2 * i + 1], 0);
+        if (state > 0) l->occupancy_map->setOccupied(c); else if (state < 0) l->occupancy_map->setFree(c); else l->occupancy_map->setUnknown(c);
+    }
+}
+void ref_loc_trigger_gloc(void* h) { ((Loc2D*)h)->triggerGlobalLocalization(); }
+int ref_loc_gloc_active(void* h) { return ((Loc2D*)h)->globalLocalizationIsActive() ? 1 : 0; }
 void ref_loc_free(void* h) { delete (Loc2D*)h; }
 void* ref_loc_dm(void* h) { return ((Loc2D*)h)->distance_map; }
 void ref_loc_occ_set(void* h, const uint32_t* cells_xy, uint32_t n, int occupied)

@@ -53,6 +53,8 @@ def lib():
             "ref_occ_write": (i32, [vp, C.c_char_p]), "ref_occ_read": (i32, [vp, C.c_char_p]),
             "ref_dm_export_png": (i32, [vp, C.c_char_p]), "ref_occ_export_png": (i32, [vp, C.c_char_p]),
             "ref_image_read": (i32, [C.c_char_p, vp, vp, vp, u64]),
+            "ref_loc_new2": (vp, [d, d, d, d, u32, u32, u32, u32, d, d]), "ref_loc_occ_set_state": (None, [vp, vp, u32, i32]),
+            "ref_loc_trigger_gloc": (None, [vp]), "ref_loc_gloc_active": (i32, [vp]),
             "ref_lo_new": (vp, [d, u32]), "ref_lo_free": (None, [vp]), "ref_lo_update": (i32, [vp, vp, i32, vp, vp, d]),
             "ref_lo_get_odom": (None, [vp, vp]), "ref_lo_dm": (vp, [vp]), "ref_lo_occ": (vp, [vp]),
             "ref_pocc_patch_ids": (i32, [vp, vp, i32]), "ref_pocc_patch_read": (i32, [vp, u64, vp, vp]),

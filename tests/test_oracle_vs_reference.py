@@ -278,3 +278,42 @@ def test_sdm_files_and_export_images_interoperate_with_the_reference(tmp_path):
         assert got.shape == want.shape and np.array_equal(got, want), which
         F.sdm_export_png(f_prod, src.dump(), kind, 0.05, b.dm(0).max_sqdist())
         assert np.array_equal(R.image_read(f_prod), want), which
+
+
+def test_loc2d_global_localization_and_sampling_covariance():
+    """Loc2D::globalLocalization (src/loc2d.cpp:249-286: candidates from lama::random, isFree on the SimpleOccupancyMap, squared
+    residual norm) and addSamplingCovariance (:199-247, cov_blend > 0): the oracle follows the reference's own build pose for
+    pose through a triggered global localisation -- same candidates (same random stream), same winner, same covariance."""
+    from _worlds import corridor_free_cells
+    steps = 4
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    obst = corridor_obstacles()
+    free = corridor_free_cells(O.w2m)
+    ocells = np.array([[int(c[0]), int(c[1])] for c in (O.w2m([x, y, 0.0]) for x, y in obst)], dtype=np.uint32)
+    L = R.lib()
+    kw = dict(gloc_particles=600, gloc_iters=3, gloc_thresh=0.15, cov_blend=0.35)
+    a = L.ref_loc_new2(0.5, 0.5, 1.0, 0.05, 32, 100, kw["gloc_particles"], kw["gloc_iters"], kw["gloc_thresh"], kw["cov_blend"])
+    L.ref_loc_occ_set_state(a, O._p(free), len(free), -1)
+    L.ref_loc_occ_set(a, O._p(ocells), len(ocells), 1)              # occupied + distance-map obstacles + brushfire
+    b = O.Loc(**kw)
+    for cx, cy in ocells:
+        b.dm().add(int(cx), int(cy))
+    b.dm().update()
+    b.occ_set_cells(free, -1)
+    b.occ_set_cells(ocells, 1)
+    L.ref_random_set_seed(77); O.random_set_seed(77)
+    start = np.array([20.0, 1.0, 2.0])
+    L.ref_loc_set_pose(a, O._p(start)); b.set_pose(O.se2(*start))
+    L.ref_loc_trigger_gloc(a); b.trigger_global_localization()
+    for k in range(steps + 1):
+        p = np.ascontiguousarray(pts[k])
+        ua = L.ref_loc_update(a, O._p(p), len(p), O._p(O.ZERO3), O._p(O.IDENT_Q), O._p(np.ascontiguousarray(odom[k])), float(k), 1)
+        ub = b.update(pts[k], O.se2(*odom[k]), float(k), force=True)
+        assert bool(ua) == bool(ub), k
+        pa = np.zeros(4); L.ref_loc_get_pose(a, O._p(pa))
+        assert np.array_equal(pa, b.pose()), (k, pa, b.pose())
+        ca = np.zeros(9); L.ref_loc_covar(a, O._p(ca))
+        assert np.allclose(ca.reshape(3, 3), b.covar(), rtol=1e-10, atol=1e-16), k
+        assert L.ref_loc_rmse(a) == b.rmse(), k
+        assert bool(L.ref_loc_gloc_active(a)) == b.global_localization_active(), k
+    L.ref_loc_free(a)
