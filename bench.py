@@ -1,16 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- particle-scans/sec of the MI355X PFSlam2D path on the seeded synthetic corridor log.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P_per_gpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--particles P_total]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one PFSlam2D::update() (predict, scan-match, normalise, resample if due, map update) of ALL particles
 on one 1080-beam scan.  N = 1: BASELINE.json configs[1] (PFSlam2D, 30 particles, 1080 beams, one MI355X).
-N > 1: BASELINE.json configs[2] -- one process per GPU, the particle pool sharded in contiguous blocks of 375 particles per
-GPU (N = 8: the 3000 particles of configs[2]; weak scaling), the per-scan exchange is an all-gather of the log-likelihoods
-(RCCL) plus particle shipping over xGMI when a resample clones across shards; the run with meas_sigma_gain = 0.01 (which
-makes the filter resample) is part of the default output there.  The N = 1 line carries the single-GPU rate at 375
-particles too ("other_particle_counts"), the like-for-like base of the N > 1 values.  Prints ONE JSON line on rank 0.
+N > 1: BASELINE.json configs[2] -- the 3000 particles of configs[2] sharded in contiguous blocks over N processes, one per GPU
+(STRONG scaling: the pool is fixed, 3000 / N particles per GPU); the per-scan exchange is an all-gather of the log-likelihoods
+(RCCL) plus particle shipping over xGMI when a resample clones across shards.  Besides the default options the sharded run is
+repeated with a measurement gain that makes the 3000-particle filter resample (meas_sigma_gain = 1e-4); that
+variant must resample and ship particles (asserted) and reports the time spent in the all-gather and in shipping per step.
+The N = 1 line carries the single-GPU rate at 3000 particles ("other_particle_counts"), the base of the N > 1 values.
+Launched as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) it spawns the N ranks itself
+(torch.distributed.run, rendezvous on 127.0.0.1).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -64,14 +67,15 @@ def reference_baseline(pts, odom, P, updates, warm):
     return res
 
 
-def cpu_baseline(pts, odom, P, updates, warm):
+def cpu_baseline(pts, odom, P, updates, warm, bytes_only=False):
     """Oracle (CPU restatement of the reference's thread_pool path) timed on the host cores: same log, same P,
-    same updates.  Also returns the algorithmic bytes per particle-scan from the oracle's touch counters."""
+    same updates.  Also returns the algorithmic bytes per particle-scan from the oracle's touch counters (bytes_only: just
+    the serial pass that counts them)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     cores = os.cpu_count() or 1
     res = {}
-    for label, threads in (("pool", cores), ("serial", -1)):
+    for label, threads in ((("serial", -1),) if bytes_only else (("pool", cores), ("serial", -1))):
         pf = O.PF(O.default_options(particles=P, seed=42, threads=threads))
         pf.set_prior(O.se2(*odom[0]))
         if threads <= 1:
@@ -99,7 +103,7 @@ def cpu_baseline(pts, odom, P, updates, warm):
                                 brushfire=b_bf / (P * n), raycast=b_ray / (P * n))
     # the thread pool only fills the host at larger particle counts: time it there too (bounded: 8 updates each)
     res["pool_other"] = {}
-    for Pk in (300, 3000):
+    for Pk in (() if bytes_only else (300, 3000)):
         try:
             pf = O.PF(O.default_options(particles=Pk, seed=42, threads=cores))
             pf.set_prior(O.se2(*odom[0]))
@@ -258,17 +262,31 @@ def single_pose_rows(F, with_cpu):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--particles", type=int, default=0, help="particles per GPU (default: 30 on one GPU, 375 on several)")
+    ap.add_argument("--particles", type=int, default=0, help="particles of the whole pool (default: 30 on one GPU, 3000 sharded over several)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--sweep", type=str, default="300,375,3000", help="extra single-GPU particle counts (N=1 only), '' to skip")
     args = ap.parse_args()
     if args.particles <= 0:
-        args.particles = 30 if args.gpus == 1 else 375
+        args.particles = 30 if args.gpus == 1 else 3000
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: spawn the N ranks (one process per GPU) and let rank 0's line through
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     import torch
     import iris_lama_amd.ffi as F
@@ -278,7 +296,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     # developer switch: LAMA_BENCH_ONE_DEVICE=1 runs every rank on GPU 0 over gloo (a 1-GPU box can then execute the sharded
@@ -286,21 +304,24 @@ def main():
     one_device = os.environ.get("LAMA_BENCH_ONE_DEVICE") == "1"
     if one_device:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(f"--gpus {world} but only {torch.cuda.device_count()} device(s) are visible (LAMA_BENCH_ONE_DEVICE=1 runs all ranks on GPU 0)")
     torch.cuda.set_device(local_rank)
     if world > 1:
         init_process_group("gloo" if one_device else "nccl")
 
     K, W = args.steps, args.warmup
-    P_total = args.particles * world
+    P_total = args.particles
     pts, odom, truth = F.corridor_log(W + K, 1080)
 
-    def run(P, updates, warm, profile=True, brushfire_mode=0, gain=None, summary=False):
+    def run(P, updates, warm, profile=True, brushfire_mode=0, gain=None, summary=False, sharded=True):
         # summary=True: PFSlam2D::Summary buckets (each update then waits for its map kernels); False: the map update of scan t
         # overlaps with the host part (motion sampling) of scan t+1, the default of the host class
         kw = {} if gain is None else {"meas_sigma_gain": gain}
-        opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=rank, shard_world=world,
+        w_, r_ = (world, rank) if sharded else (1, 0)
+        opts = F.pf_options(particles=P, seed=42, gpu_device=local_rank, shard_rank=r_, shard_world=w_,
                             create_summary=1 if summary else 0, profile=1 if profile else 0, brushfire_mode=brushfire_mode, **kw)
-        pf = ShardedPF(opts, device=torch.device("cpu") if (one_device and world > 1) else None)
+        pf = ShardedPF(opts, device=torch.device("cpu") if (one_device and w_ > 1) else None)
         assert pf.pf.engine_origin().endswith("liblama_hip.so"), pf.pf.engine_origin()
         pf.set_prior(*odom[0])
         pf.update(pts[0], odom[0], 0.0)                       # first scan (initialisation, untimed)
@@ -309,6 +330,7 @@ def main():
         ctx = pf.pf.hip_context()
         ctx.reset_counters()
         r0 = pf.pf.num_resamples()
+        ship0 = (pf.shipped_particles, pf.shipped_bytes, pf.t_allgather, pf.t_ship, pf.t_import, pf.resample_steps)
         pf.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -326,20 +348,47 @@ def main():
         err = float(np.linalg.norm(pf.pf.best_pose_xyr()[:2] - truth[warm + updates][:2])) if pf.owns_best() else None
         out = dict(P=P, seconds=dt, updates=done, value=P * done / dt, ms_per_step=1e3 * dt / max(done, 1), counters=c,
                    resamples=pf.pf.num_resamples() - r0, pose_err_m=err,
-                   shipped_particles=pf.shipped_particles, shipped_bytes=pf.shipped_bytes,
+                   shipped_particles=pf.shipped_particles - ship0[0], shipped_bytes=pf.shipped_bytes - ship0[1],
+                   exchange_ms_per_step={"all_gather": 1e3 * pf.max_over_ranks(pf.t_allgather - ship0[2]) / max(done, 1),
+                                         "ship_per_resample": 1e3 * pf.max_over_ranks(pf.t_ship - ship0[3]) / max(pf.resample_steps - ship0[5], 1),
+                                         "import_per_resample": 1e3 * pf.max_over_ranks(pf.t_import - ship0[4]) / max(pf.resample_steps - ship0[5], 1),
+                                         "note": "wall clock on the slowest rank; all_gather includes its H2D / D2H copies of the P log-likelihoods"},
                    buckets_ms=dict(zip(("total", "solving", "normalizing", "resampling", "mapping"), (1e3 * buckets / max(done, 1)).tolist())))
+        if w_ > 1:                                           # whole-job totals (every rank ships its own clones)
+            tt = torch.tensor([float(out["shipped_particles"]), float(out["shipped_bytes"])], dtype=torch.float64, device=pf.device)
+            torch.distributed.all_reduce(tt)
+            out["shipped_particles"], out["shipped_bytes"] = int(tt[0].item()), int(tt[1].item())
         pf.close()
         return out
+
+    def effective_modes(c):
+        return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"], "brushfire_packed": c["brushfire_packed"],
+                "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"]}
 
     # `value` comes from a pass WITHOUT the per-kernel hipEvent brackets (they cost two extra device-to-host copies and four
     # event records per step); the kernel breakdown and the roofline durations come from a second pass of the same K steps
     # with the brackets on.
     main_run = run(P_total, K, W, profile=False)
     assert main_run["updates"] == K, "every scan of the log must pass the motion gate"
+    # `value` is only ever the EXACT brushfire (bit-identical to the reference): what ran is read back from the library
+    assert main_run["counters"]["brushfire_mode"] == 0, main_run["counters"]
     prof_run = run(P_total, K, W, profile=True)
-    # with the default gain resampling is rare; a variant with meas_sigma_gain = 0.01 makes the filter resample
-    # (and, sharded, ship particles between GPUs): always run, on one GPU and sharded.
-    resample_run = run(P_total, K, W, gain=0.01)
+    # with the default gain (1 / (3 P)) resampling is rare; a variant with a smaller measurement gain makes the
+    # filter resample (and, sharded, ship particles between GPUs): always run, on one GPU and sharded.  0.01 resamples at 30
+    # particles; 3000 particles need 1e-4 (at 0.01 they never resample on this log).
+    forced_gain = 0.01 if P_total < 1000 else 1e-4
+    resample_run = run(P_total, K, W, gain=forced_gain)
+    if world > 1:
+        assert resample_run["resamples"] > 0, "the forced-resample variant did not resample"
+        assert resample_run["shipped_particles"] > 0 and resample_run["shipped_bytes"] > 0, "no particle crossed a shard boundary"
+    single = None
+    if world > 1 and rank == 0:
+        pass
+    if world > 1:
+        # base of the strong-scaling figure: the same pool on ONE GPU (rank 0's), unsharded; the other ranks wait
+        if rank == 0:
+            single = run(P_total, K, W, profile=False, sharded=False)
+        torch.distributed.barrier()
 
     if rank != 0:
         return
@@ -347,11 +396,13 @@ def main():
     result = {
         "metric": "particle-scans/sec", "value": main_run["value"], "unit": "particle-scans/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": main_run["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"PFSlam2D {P_total} particles ({args.particles}/GPU), 1080-beam synthetic corridor log "
+        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"PFSlam2D {P_total} particles" + (f" ({P_total // world}/GPU, fixed pool sharded over {world} GPUs)" if world > 1 else "") +
+                               ", 1080-beam synthetic corridor log "
                                f"(SURVEY.md 8(d)), res 0.05 m, patch 32, l2_max 0.5, GN+Cauchy(0.15), seed 42",
                    "particles": P_total, "beams": 1080, "parallelism": f"particle-shard x{world}" + (" (all ranks on GPU 0, gloo)" if one_device and world > 1 else ""),
-                   "resamples_in_timed_region": main_run["resamples"], "best_pose_error_m": main_run["pose_err_m"]},
+                   "resamples_in_timed_region": main_run["resamples"], "best_pose_error_m": main_run["pose_err_m"],
+                   "kernels_that_ran": effective_modes(main_run["counters"])},
         "kernel_ms_per_step": {"scan_match": c["ms_scan_match"] / max(c["launches_scan_match"], 1),
                                "update_maps": c["ms_update_maps"] / max(c["launches_update_maps"], 1),
                                "raycast": c["ms_raycast"] / max(c["launches_raycast"], 1),
@@ -361,13 +412,22 @@ def main():
     }
     if world == 1:
         result["summary_buckets_ms_per_update"] = run(P_total, K, W, summary=True)["buckets_ms"]
+    else:
+        result["exchange_ms_per_step"] = main_run["exchange_ms_per_step"]
+        result["single_gpu_same_pool"] = {"value": single["value"], "ms_per_step": single["ms_per_step"],
+                                          "note": f"the same {P_total} particles unsharded on one GPU (rank 0's), same steps: the base of the strong-scaling figure"}
     if resample_run is not None:
-        result["forced_resample_variant"] = {"meas_sigma_gain": 0.01, "value": resample_run["value"], "ms_per_step": resample_run["ms_per_step"],
+        result["forced_resample_variant"] = {"meas_sigma_gain": forced_gain, "value": resample_run["value"], "ms_per_step": resample_run["ms_per_step"],
                                              "resamples": resample_run["resamples"], "shipped_particles": resample_run["shipped_particles"],
                                              "shipped_bytes": resample_run["shipped_bytes"],
+                                             "exchange_ms_per_step": resample_run["exchange_ms_per_step"] if world > 1 else None,
                                              "resample_kernel_ms": resample_run["counters"]["ms_resample"] / max(resample_run["counters"]["launches_resample"], 1)}
     cores, base = (None, None)
-    if not args.no_cpu:
+    if not args.no_cpu and world > 1:
+        # the CPU baseline is reported by the N = 1 line only; the sharded line still needs the algorithmic bytes per
+        # particle-scan (a property of the log, counted by the oracle's instrumentation on a 30-particle serial pass)
+        cores, base = cpu_baseline(pts, odom, 30, K, W, bytes_only=True)
+    if not args.no_cpu and world == 1:
         cores, base = cpu_baseline(pts, odom, args.particles, K, W)
         port = {"value": base["pool"]["value"], "unit": "particle-scans/s", "cores": cores, "kind": "port",
                 "sample": f"same log, P={args.particles}, {K} updates after {W} warm-up, oracle thread pool on "
@@ -414,13 +474,13 @@ def main():
         per_ps = base["bytes"]["brushfire"]
         launches = max(c["launches_brushfire"], 1)
         dur_s = c["ms_brushfire"] / launches * 1e-3
-        achieved = per_ps * args.particles / dur_s / 1e9          # GB/s on this rank's GPU
-        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire<1024,256,false,true> (+ its no-op resume stages)", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        achieved = per_ps * (P_total / world) / dur_s / 1e9       # GB/s on this rank's GPU (its share of the pool)
+        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire (exact, %s; + its no-op resume stages)" % ("two particles per wave pair" if c["brushfire_packed"] else ("wave pair per particle" if c["brushfire_waves"] == 2 else "one wave per particle")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
                               "mean_launch_ms": dur_s * 1e3}
         # the whole step against the same roof: all algorithmic bytes of a particle-scan / the step time
-        step_gbs = base["bytes"]["total"] * args.particles / (main_run["ms_per_step"] * 1e-3) / 1e9
+        step_gbs = base["bytes"]["total"] * (P_total / world) / (main_run["ms_per_step"] * 1e-3) / 1e9
         result["roofline_step"] = {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": step_gbs / HBM_PEAK_GBS,
                                    "bytes_per_particle_scan": round(base["bytes"]["total"])}
     if world == 1 and args.sweep:

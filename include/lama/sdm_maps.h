@@ -14,6 +14,8 @@
 // map of the Loc2D that owns it.  Header only.  The reference's include paths lama/sdm/<class>.h forward here.
 #pragma once
 
+#include <mutex>
+#include <atomic>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -71,6 +73,7 @@ public:
     // src/sdm/map.cpp:139-157 (cells) and include/lama/sdm/map.h:221-225 (world): extent of the allocated patches
     void bounds(Vector3ui& min, Vector3ui& max) const
     {
+        sync();
         min = Vector3ui(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
         max = Vector3ui(0, 0, 0);
         for (uint64_t id : host_.ids) {
@@ -89,6 +92,7 @@ public:
     template <typename F>
     void visit_all_cells(F&& walker) const
     {
+        sync();
         for (size_t i = 0; i < host_.ids.size(); ++i) {
             const Vector3ui anchor = p2m(host_.ids[i]);
             const uint64_t* mask = &host_.masks[i * (patch_volume / 64)];
@@ -98,14 +102,17 @@ public:
         }
     }
     template <typename F>
-    void visit_all_patches(F&& walker) const { for (uint64_t id : host_.ids) walker(p2m(id)); }
+    void visit_all_patches(F&& walker) const { sync(); for (uint64_t id : host_.ids) walker(p2m(id)); }
 
-    size_t patches() const { return host_.ids.size(); }                                  // number of allocated patches
-    size_t memory() const { return host_.cells.size() + host_.masks.size() * sizeof(uint64_t); }
-    bool write(const std::string& filename) const { return sdm::write(host_, filename); }   // the reference's .sdm format
-    const sdm::HostMap& snapshot() const { return host_; }
+    size_t patches() const { sync(); return host_.ids.size(); }                          // number of allocated patches
+    size_t memory() const { sync(); return host_.cells.size() + host_.masks.size() * sizeof(uint64_t); }
+    bool write(const std::string& filename) const { sync(); return sdm::write(host_, filename); }   // the reference's .sdm format
+    const sdm::HostMap& snapshot() const { sync(); return host_; }
 
 protected:
+    // Every accessor of the host copy goes through sync() first: a map that mirrors a live device map (DynamicDistanceMap bound to
+    // a Loc2D) refreshes its copy there when the device map has changed since; plain snapshots have nothing to do.
+    virtual void sync() const {}
     static sdm::HostMap emptyHost(double res, sdm::MapKind kind, uint32_t patch_size)
     {
         sdm::HostMap m;
@@ -114,7 +121,7 @@ protected:
         while (m.patch_length * 2 <= patch_size) m.patch_length *= 2;          // 1 << int(log2(patch_size)), src/sdm/map.cpp:45
         return m;
     }
-    void resetHost(sdm::HostMap m)              // replace the snapshot (a live map downloads a fresh one)
+    void resetHost(sdm::HostMap m) const        // replace the snapshot (a live map downloads a fresh one)
     {
         host_ = std::move(m);
         index_.clear();
@@ -139,6 +146,7 @@ protected:
     // const Map::get (src/sdm/map.cpp:414-455): nullptr for an absent patch or a cell whose mask bit is off
     const uint8_t* get(const Vector3ui& c) const
     {
+        sync();
         const uint64_t id = uint64_t(c(0) >> log2dim_) * UNIVERSAL_CONSTANT + uint64_t(c(1) >> log2dim_);   // m2p, map.h:153-161
         const auto it = index_.find(id);
         if (it == index_.end()) return nullptr;
@@ -152,8 +160,8 @@ protected:
         return Vector3ui(uint32_t((id / UNIVERSAL_CONSTANT) << log2dim_), uint32_t((id % UNIVERSAL_CONSTANT) << log2dim_), 0);
     }
 
-    sdm::HostMap host_;
-    std::unordered_map<uint64_t, size_t> index_;
+    mutable sdm::HostMap host_;                              // mutable: sync() of a live map replaces the copy behind const accessors
+    mutable std::unordered_map<uint64_t, size_t> index_;
     uint32_t log2dim_ = 5;
     double off_ = 0.0;
 };
@@ -267,9 +275,9 @@ public:
     {
         if (pending_.empty()) return 0;
         if (!writer_.apply) throw std::logic_error("lama::DynamicDistanceMap::update: this map is a host snapshot of a device map");
-        const uint32_t n = writer_.apply(pending_, max_distance_);
+        const uint32_t n = writer_.apply(pending_, max_distance_);      // cells the brushfire processed in THIS update (:196)
         pending_.clear();
-        stale_ = true;
+        stale_.store(true, std::memory_order_release);
         return n;
     }
 
@@ -285,6 +293,7 @@ public:
 
     double maxDistance() const { return std::sqrt((double)host_.max_sqdist) * resolution; }                      // :155-158
     double maxDistanceOption() const { return max_distance_; }
+    uint32_t maxSqDist() const { return host_.max_sqdist; }       // the configured squared radius in cells (no refresh)
     // :140-147
     double distance(const Vector3ui& coordinates) const
     {
@@ -309,16 +318,25 @@ public:
     }
     bool cell(const Vector3ui& c, distance_t& d) const
     {
-        if (stale_ && writer_.download) {                      // live map: fetch the device map once after an update()
-            DynamicDistanceMap* self = const_cast<DynamicDistanceMap*>(this);
-            sdm::HostMap m;
-            if (writer_.download(m)) { m.resolution = resolution; self->resetHost(std::move(m)); }
-            self->stale_ = false;
-        }
         const uint8_t* p = get(c);
         if (!p) return false;
         std::memcpy(&d, p, sizeof(d));
         return true;
+    }
+
+protected:
+    // live map: fetch the device map once after an update(), whichever accessor comes first (distance(), write(), snapshot(),
+    // bounds(), the visitors ...); concurrent readers are serialised on the refresh
+    void sync() const override
+    {
+        if (!stale_.load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> lock(sync_mutex_);
+        if (!stale_.load(std::memory_order_relaxed)) return;
+        if (writer_.download) {
+            sdm::HostMap m;
+            if (writer_.download(m)) { m.resolution = resolution; resetHost(std::move(m)); }
+        }
+        stale_.store(false, std::memory_order_release);
     }
 
 private:
@@ -326,7 +344,8 @@ private:
     Writer writer_;
     std::vector<uint32_t> pending_;
     double max_distance_ = 0.5;
-    bool stale_ = false;
+    mutable std::atomic<bool> stale_{false};
+    mutable std::mutex sync_mutex_;
 };
 
 } // namespace lama

@@ -3,6 +3,7 @@
 // path depends on them.  Own implementation on std::chrono.
 #pragma once
 
+#include <queue>
 #include <chrono>
 #include <cstdint>
 #include <thread>
@@ -88,14 +89,33 @@ struct Rate {
         const Duration left = end - t;
         actual_cycle = t - start;
         start = end;
-        if (left <= Duration(0.0)) {                     // overran (or the clock jumped): re-anchor when a full cycle was lost
-            if (actual_cycle > cycle || t < start - cycle) start = t;
+        if (left <= Duration(0.0)) {                     // overran: keep the phase and catch up, unless more than a full cycle
+            if (t > end + cycle) start = t;              // was lost (or the clock jumped) -- only then re-anchor at `now`
             return;
         }
         left.sleep();
     }
     void reset() { start = Time::now(); }
     Duration cycleTime() const { return actual_cycle; }
+};
+
+// rate of the last `window` events (include/lama/time.h: EventFrequency): event() stamps the stopwatch's elapsed time, event(t)
+// a caller-supplied (simulated) time; getFrequency() = (events - 1) / (newest - oldest), 0 with fewer than two events
+struct EventFrequency {
+    const uint32_t window;
+    Timer timer;
+    std::queue<Duration> queue;
+    explicit EventFrequency(uint32_t window_size = 30) : window(window_size) { timer.start(); }
+    void reset() { timer.reset(); queue = std::queue<Duration>(); }
+    void event() { push(timer.elapsed()); }
+    void event(const double timestamp) { push(Duration(timestamp)); }
+    double getFrequency() const
+    {
+        if (queue.size() < 2) return 0.0;
+        return (double)(queue.size() - 1) / (queue.back() - queue.front()).toSec();
+    }
+private:
+    void push(const Duration& d) { queue.push(d); if (queue.size() > window) queue.pop(); }
 };
 
 } // namespace lama

@@ -76,10 +76,10 @@ typedef struct lama_hip_cfg {
     uint32_t sequential_raycast; /* ray-cast kernels: 0 / 2 = parallel form (default), 1 = beam-sequential form; bit-identical */
     uint32_t brushfire_mode;     /* 0 = exact (default): bit-identical to the reference incl. libstdc++'s tie order;
                                     1 = level-synchronous with a canonical tie rule (parallel; identical sqdist/valid/masks on
-                                        the measured logs, obstacle offsets of tie cells may differ -- see DESIGN.md);
-                                    2 = exact like 0, but the lower wave is replayed one priority LEVEL at a time (the pop order
-                                        of a level out of libstdc++'s heap follows from the slots its entries occupy, see
-                                        lama_brushfire_lse.h); bit-identical to 0, currently not faster */
+                                        the measured logs, obstacle offsets of tie cells -- and, once in millions of cells, a
+                                        distance -- may differ).  NOT bit-identical: only a caller that sets
+                                        this field gets it (no environment variable selects it) and lama_hip_get_counters
+                                        reports the mode that ran.  Other values are rejected. */
     uint32_t brushfire_waves;    /* exact brushfire: 0 / 2 = a helper wave per particle owns the heap (default), 1 = one wave per
                                     particle; bit-identical */
     uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}
@@ -253,6 +253,14 @@ typedef struct lama_hip_counters {
     uint64_t arena_growths;     /* times the patch arenas were doubled (maps grow on demand)        */
     uint64_t window_shifts;     /* times the map window was re-centred (the window follows the robot)  */
     uint64_t wrap_guard_scans;  /* scans ray-cast beam by beam because a uint16 `visited` counter could wrap inside them */
+    /* what actually ran (set by every map update; not cleared by lama_hip_reset_counters' zeroing of the sums above): */
+    uint32_t brushfire_mode;    /* cfg.brushfire_mode of the last map update: 0 = exact, 1 = canonical tie rule (not bit-identical) */
+    uint32_t brushfire_waves;   /* exact brushfire of the last map update: 2 = wave pair per particle (or per two particles, see
+                                   brushfire_packed), 1 = one wave per particle                                              */
+    uint64_t sequential_raycast_scans;  /* map updates whose ray-cast ran beam by beam (k_raycast)                           */
+    uint64_t parallel_raycast_scans;    /* map updates whose ray-cast ran in the parallel, patch-centric form                */
+    uint32_t brushfire_packed;  /* 1 = the last map update ran the brushfire with two particles per wave pair (many particles) */
+    uint32_t reserved0;
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

@@ -86,7 +86,6 @@ struct lama_hip_ctx {
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; size_t rrec_cap = 0;
     int32_t* d_rev = nullptr; size_t rev_cap = 0;
-    int ray_mode = 0;          // 0 = patch-centric visits (default), 1 = k_ray_visits (beam-centric, LDS-aggregated atomics)
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
     PinVec<uint64_t> h_stats;
@@ -103,8 +102,6 @@ struct lama_hip_ctx {
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
     double scan_reach = 0.0;          // largest point distance of the resident scan (sensor frame, metres)
-    int cache_max_particles = 0;      // up to this many particles the pop-by-pop brushfire stages its patches in LDS (developer switch
-                                      // LAMA_HIP_BF_CACHE; measured SLOWER than the L2-served form: 2.65 vs 1.80 ms at 30 particles)
     uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
     uint32_t* d_scalar = nullptr;
     bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
@@ -206,6 +203,8 @@ int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
     std::memcpy(c->h_pts.data(), pts, sizeof(double) * 3 * n);
     double r2 = 0.0;
     for (uint32_t i = 0; i < n; ++i) r2 = std::max(r2, pts[3 * i] * pts[3 * i] + pts[3 * i + 1] * pts[3 * i + 1] + pts[3 * i + 2] * pts[3 * i + 2]);
+    // a non-finite coordinate has no cell (the reference's w2m casts it to an integer: undefined behaviour, include/lama/sdm/map.h:125-128)
+    if (!std::isfinite(r2)) { c->last_n = 0; return fail(c, LAMA_HIP_E_INVALID, "the scan holds a non-finite point (filter NaN / inf ranges before the update, as iris_lama_ros does)"); }
     c->scan_reach = std::sqrt(r2);
     HIPCHK(c, hipMemcpyAsync(c->d_pts, c->h_pts.data(), sizeof(double) * 3 * n, hipMemcpyHostToDevice, c->stream));
     return LAMA_HIP_OK;
@@ -356,7 +355,11 @@ void resolve_timers(lama_hip_ctx* c)      // call after the stream has been sync
 // window side remains an error.
 int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t count)
 {
-    const double reach = c->scan_reach + std::sqrt(mtf.t[0] * mtf.t[0] + mtf.t[1] * mtf.t[1]) + 2.0 * 32.0 * c->cfg.resolution;
+    // no cell further than truncated_range from the sensor is touched (src/pf_slam2d.cpp:470-476): "no return" readings far
+    // beyond it must not push mapped patches out of the window
+    double far = c->scan_reach;
+    if (c->cfg.ray_rule == 0 && c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
+    const double reach = far + std::sqrt(mtf.t[0] * mtf.t[0] + mtf.t[1] * mtf.t[1]) + 2.0 * 32.0 * c->cfg.resolution;
     double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
     for (uint32_t p = first; p < first + count; ++p) {
         const double x = c->h_poses[4 * p + 2], y = c->h_poses[4 * p + 3];
@@ -428,41 +431,32 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             if ((uint64_t)m + n >= 65536u) { sequential = true; c->ctr.wrap_guard_scans += 1; }
         }
         c->visit_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->visit_bound + n, 65535u);
+        if (sequential) c->ctr.sequential_raycast_scans += 1; else c->ctr.parallel_raycast_scans += 1;
         if (sequential) {
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
-            if (c->ray_mode == 0) {
-                // patch-centric visits: a workgroup owns one occupancy patch of one particle, no global atomics on the counters
-                const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
-                if (need > c->rrec_cap) {
-                    (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
-                    HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
-                    HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
-                    c->rrec_cap = need;
-                }
-                if (need_rev > c->rev_cap) {
-                    (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
-                    HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
-                    c->rev_cap = need_rev;
-                }
-                hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
-                                   c->d_rrec, c->d_rbbox);
-                const int rw_seg = count <= 64 ? 8 : 2;
-                hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
-                const uint32_t WW = c->W * c->W;
-                hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
-                const char* gy_env = getenv("LAMA_HIP_RAY_GRIDY");
-                const unsigned gy = gy_env ? (unsigned)atoi(gy_env) : (count <= 64 ? 128u : 32u);        // patches of a particle in flight at once
-                hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
-                                   (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
-            } else {
-            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
-                               (lama_dev::RayRec*)nullptr, (uint64_t*)nullptr);
-            const char* bpw_env = getenv("LAMA_HIP_RAY_BPW");
-            const int bpw = bpw_env ? atoi(bpw_env) : (count <= 64 ? 4 : 16);                            // see k_ray_visits
-            hipLaunchKernelGGL(k_ray_visits, dim3(count, (n + 4 * bpw - 1) / (4 * bpw)), dim3(256), 0, c->stream, prm,
-                               c->d_pts, (int)n, c->d_tfs, (int)first, bpw);
+            // patch-centric visits: a workgroup owns one occupancy patch of one particle, no global atomics on the counters
+            const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
+            if (need > c->rrec_cap) {
+                (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
+                HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
+                HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
+                c->rrec_cap = need;
             }
+            if (need_rev > c->rev_cap) {
+                (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
+                HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
+                c->rev_cap = need_rev;
+            }
+            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
+                               c->d_rrec, c->d_rbbox);
+            const int rw_seg = count <= 64 ? 8 : 2;
+            hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
+            const uint32_t WW = c->W * c->W;
+            hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+            const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
+            hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
+                               (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
             if (count <= 512) {
                 hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
                 hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
@@ -481,17 +475,14 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
-        const bool lse = c->cfg.brushfire_mode == 2;        // lower wave level by level (lama_brushfire_lse.h) instead of pop by pop; bit-identical
-        if (c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES)) {
-            if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-            // few particles: a workgroup has a CU (and its LDS) to itself -> the touched patches are staged in LDS (BfCells)
-            else if (count <= (uint32_t)c->cache_max_particles && c->cfg.dm_patch_capacity <= (uint32_t)BC_ARENA)
-                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+        const bool two_waves = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
+        c->ctr.brushfire_mode = c->cfg.brushfire_mode;
+        c->ctr.brushfire_waves = two_waves ? 2u : 1u;
+        if (two_waves) {
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
-            if (lse) hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false, true>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
-            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
@@ -544,10 +535,10 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
     if (cfg.active_capacity == 0) cfg.active_capacity = 8192;
     if (cfg.active_capacity > 8192) cfg.active_capacity = 8192;      // largest k_ray_replay stage
-    // tuning overrides for contexts created by the host classes (all variants are bit-identical)
-    if (cfg.sequential_raycast == 0) if (const char* e = std::getenv("LAMA_HIP_SEQUENTIAL_RAYCAST")) cfg.sequential_raycast = (uint32_t)std::atoi(e);
-    if (cfg.brushfire_waves == 0) if (const char* e = std::getenv("LAMA_HIP_BRUSHFIRE_WAVES")) cfg.brushfire_waves = (uint32_t)std::atoi(e);
-    if (cfg.brushfire_mode == 0) if (const char* e = std::getenv("LAMA_HIP_BRUSHFIRE_MODE")) cfg.brushfire_mode = (uint32_t)std::atoi(e);
+    // No environment variable changes what a context computes or which kernels it runs: the variants are chosen through the
+    // configuration only (cfg.brushfire_mode = 1, the one variant that is NOT bit-identical to the reference, must be asked for
+    // by the caller), and lama_hip_get_counters reports what actually ran.
+    if (cfg.brushfire_mode > 1) return LAMA_HIP_E_INVALID;
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)
@@ -557,8 +548,6 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
 
     lama_hip_ctx* c = new lama_hip_ctx();
     c->cfg = cfg;
-    if (const char* e = std::getenv("LAMA_HIP_BF_CACHE")) c->cache_max_particles = std::atoi(e);
-    if (const char* e = std::getenv("LAMA_HIP_RAY_MODE")) c->ray_mode = std::atoi(e);      // developer switch: 1 = beam-centric k_ray_visits
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->scale = 1.0 / cfg.resolution;
@@ -1276,7 +1265,7 @@ static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double
 static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
 {
     const uint64_t WW = (uint64_t)c->W * c->W;
-    return 32 + 16 + 2 * WW * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
+    return 32 + 32 + 2 * WW * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
 }
 
 int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* buf, uint64_t cap, uint64_t* bytes)
@@ -1294,9 +1283,11 @@ int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* bu
     const uint64_t WW = (uint64_t)c->W * c->W;
     const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
     uint8_t* o = (uint8_t*)buf;
-    int32_t hdr[4] = {dmc, occ, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5)};      // counts + the window origin (patches) the directories refer to
+    // counts + the window origin (patches) the directories refer to + the exporter's upper bound of the `visited` counters (the
+    // importer's uint16 wrap guard must cover the cells this particle brings, see run_update_maps)
+    int32_t hdr[8] = {dmc, occ, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5), (int32_t)c->visit_bound, 0, 0, 0};
     HIPCHK(c, hipMemcpyAsync(o, &c->h_poses[4 * particle], 32, hipMemcpyHostToDevice, c->stream)); o += 32;
-    HIPCHK(c, hipMemcpyAsync(o, hdr, 16, hipMemcpyHostToDevice, c->stream)); o += 16;
+    HIPCHK(c, hipMemcpyAsync(o, hdr, 32, hipMemcpyHostToDevice, c->stream)); o += 32;
     auto d2d = [&](const void* src, uint64_t nbytes) -> hipError_t {
         hipError_t e = nbytes ? hipMemcpyAsync(o, src, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
         o += nbytes;
@@ -1315,14 +1306,17 @@ int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* bu
 
 int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const void* buf, uint64_t bytes)
 {
-    if (!c || !buf || particle >= c->P || bytes < 48) return LAMA_HIP_E_INVALID;
+    if (!c || !buf || particle >= c->P || bytes < 64) return LAMA_HIP_E_INVALID;
     ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "import before init");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const uint8_t* in = (const uint8_t*)buf;
-    double pose[4]; int32_t hdr[4];
-    HIPCHK(c, hipMemcpy(pose, in, 32, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(hdr, in + 32, 16, hipMemcpyDeviceToHost));
+    double pose[4]; int32_t hdr[8];
+    {
+        uint8_t head[64];
+        HIPCHK(c, hipMemcpy(head, in, 64, hipMemcpyDeviceToHost));
+        std::memcpy(pose, head, 32); std::memcpy(hdr, head + 32, 32);
+    }
     const int dmc = hdr[0], occ = hdr[1];
     if (dmc >= 0 && occ >= 0 && dmc <= 32767 && occ <= 32767 &&
         ((uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity)) {
@@ -1336,7 +1330,7 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     const uint64_t WW = (uint64_t)c->W * c->W;
     const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
     const int odm = c->h_counts[2 * particle], oocc = c->h_counts[2 * particle + 1];
-    in += 48;
+    in += 64;
     auto d2d = [&](void* dst, uint64_t nbytes) -> hipError_t {
         hipError_t e = nbytes ? hipMemcpyAsync(dst, in, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
         in += nbytes;
@@ -1375,6 +1369,8 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     HIPCHK(c, hipMemcpyAsync(c->d_poses + 4 * particle, pose, 32, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->h_counts[2 * particle] = dmc; c->h_counts[2 * particle + 1] = occ;
+    // the wrap guard's bound must hold for the counters this particle brings (they may be far above this context's own)
+    c->visit_bound = std::max<uint32_t>(c->visit_bound, (uint32_t)std::min<int32_t>(std::max<int32_t>(hdr[4], 0), 65535));
     return LAMA_HIP_OK;
 }
 
@@ -1417,9 +1413,10 @@ int32_t lama_hip_reset_counters(lama_hip_ctx* c)
 {
     if (!c) return LAMA_HIP_E_INVALID;
     ENTER(c);
-    const uint64_t dm = c->ctr.dm_patches, oc = c->ctr.occ_patches;
+    const lama_hip_counters old = c->ctr;
     std::memset(&c->ctr, 0, sizeof(c->ctr));
-    c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
+    c->ctr.dm_patches = old.dm_patches; c->ctr.occ_patches = old.occ_patches;
+    c->ctr.brushfire_mode = old.brushfire_mode; c->ctr.brushfire_waves = old.brushfire_waves; c->ctr.brushfire_packed = old.brushfire_packed;
     return LAMA_HIP_OK;
 }
 

@@ -1023,132 +1023,10 @@ __device__ __forceinline__ bool lds_push_list(uint64_t* heap, uint32_t& n, const
 // acknowledged before it meets the helper wave (which never touches global memory); __syncthreads() would drain vmcnt.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-} // namespace lama_dev
-#include "lama_brushfire_lse.h"
-namespace lama_dev {
-
-// ---- LDS cache of distance-map patches (north star: "SDM patches staged into LDS") -------------------------------------------
-// The main wave of the pop-by-pop kernel is a chain of dependent loads: directory entry -> cell (+ the cell its offset points
-// to).  With one workgroup per CU (few particles) the patches a particle's brushfire touches in a scan (about 26 on the corridor
-// log) fit the CU's LDS: plane A as it is (uint16 per cell), plane B with the offsets narrowed to 2 x int8 (|offset| <= 127, the
-// limit lama_hip_ctx_create enforces) = 4 KB per patch.  A patch is filled on its first touch (one coalesced 6 KB read by the
-// wave), written back once at the end; every access works whether or not its patch is cached (a patch that does not fit, or was
-// evicted, is simply accessed in HBM), so the cache changes timing only.
-constexpr int BC_SLOTS = 26;                // x 4 KB = 104 KB of the CU's 160 KB
-constexpr int BC_ARENA = 4096;              // arena slots the map `arena slot -> cache slot` covers (larger arenas: uncached kernel)
-struct BfCache {
-    uint16_t sv[BC_SLOTS][1024];
-    uint16_t ob[BC_SLOTS][1024];            // int8 x | int8 y << 8
-    uint8_t of_arena[BC_ARENA];             // arena slot -> cache slot, 0xFF = not cached
-    int16_t arena[BC_SLOTS];                // cache slot -> arena slot, -1 = free
-    uint8_t dirty[BC_SLOTS];
-};
-template <bool CACHE>
-struct BfCells {
-    uint16_t* sv; uint32_t* obs;            // the particle's planes in HBM
-    BfCache* C;
-    int victim;
-    __device__ __forceinline__ static uint16_t pack8(uint32_t o) { return (uint16_t)((o & 0xFFu) | ((o >> 8) & 0xFF00u)); }
-    __device__ __forceinline__ static uint32_t unpack8(uint16_t b) { return pack_obs((int)(int8_t)(b & 0xFFu), (int)(int8_t)(b >> 8)); }
-    __device__ __forceinline__ void init(int lane)
-    {
-        if (!CACHE) return;
-        for (int k = lane; k < BC_ARENA / 4; k += 64) reinterpret_cast<uint32_t*>(C->of_arena)[k] = 0xFFFFFFFFu;
-        if (lane < BC_SLOTS) { C->arena[lane] = -1; C->dirty[lane] = 0; }
-        victim = 0;
-    }
-    __device__ __forceinline__ void write_back(int cs, int lane)        // all 64 lanes
-    {
-        const int a = C->arena[cs];
-        const uint4* src = reinterpret_cast<const uint4*>(C->sv[cs]);
-        uint4* dst = reinterpret_cast<uint4*>(sv + (size_t)a * 1024);
-        dst[lane] = src[lane]; dst[lane + 64] = src[lane + 64];
-        uint32_t* od = obs + (size_t)a * 1024 + lane * 16;
-        const uint16_t* os_ = C->ob[cs] + lane * 16;
-        #pragma unroll
-        for (int k = 0; k < 16; k += 4) {
-            uint4 v; v.x = unpack8(os_[k]); v.y = unpack8(os_[k + 1]); v.z = unpack8(os_[k + 2]); v.w = unpack8(os_[k + 3]);
-            reinterpret_cast<uint4*>(od)[k / 4] = v;
-        }
-    }
-    // fills the patches of the lanes with `need` that are not cached yet (all 64 lanes call)
-    __device__ __forceinline__ void ensure(bool need, int slot, int lane)
-    {
-        if (!CACHE) return;
-        bool miss = need && slot >= 0 && slot < BC_ARENA && C->of_arena[slot] == 0xFFu;
-        unsigned long long m = __ballot(miss);
-        while (m) {
-            const int leader = __ffsll((long long)m) - 1;
-            const int a = __builtin_amdgcn_readlane(slot, leader);
-            const int cs = victim;
-            victim = victim + 1 == BC_SLOTS ? 0 : victim + 1;
-            const int old = C->arena[cs];
-            if (old >= 0) {
-                if (C->dirty[cs]) write_back(cs, lane);
-                if (lane == 0) C->of_arena[old] = 0xFFu;
-            }
-            // fill: plane A 2 KB, plane B 4 KB -> 2 KB
-            const uint4* src = reinterpret_cast<const uint4*>(sv + (size_t)a * 1024);
-            uint4* dst = reinterpret_cast<uint4*>(C->sv[cs]);
-            const uint4 a0 = src[lane], a1 = src[lane + 64];
-            const uint4* osrc = reinterpret_cast<const uint4*>(obs + (size_t)a * 1024 + lane * 16);
-            const uint4 b0 = osrc[0], b1 = osrc[1], b2 = osrc[2], b3 = osrc[3];
-            dst[lane] = a0; dst[lane + 64] = a1;
-            uint4 p0, p1;
-            p0.x = pack8(b0.x) | ((uint32_t)pack8(b0.y) << 16); p0.y = pack8(b0.z) | ((uint32_t)pack8(b0.w) << 16);
-            p0.z = pack8(b1.x) | ((uint32_t)pack8(b1.y) << 16); p0.w = pack8(b1.z) | ((uint32_t)pack8(b1.w) << 16);
-            p1.x = pack8(b2.x) | ((uint32_t)pack8(b2.y) << 16); p1.y = pack8(b2.z) | ((uint32_t)pack8(b2.w) << 16);
-            p1.z = pack8(b3.x) | ((uint32_t)pack8(b3.y) << 16); p1.w = pack8(b3.z) | ((uint32_t)pack8(b3.w) << 16);
-            uint4* od = reinterpret_cast<uint4*>(C->ob[cs] + lane * 16);
-            od[0] = p0; od[1] = p1;
-            if (lane == 0) { C->arena[cs] = (int16_t)a; C->dirty[cs] = 0; C->of_arena[a] = (uint8_t)cs; }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            miss = miss && slot != a;
-            m = __ballot(miss);
-        }
-    }
-    __device__ __forceinline__ int cslot(int slot) const { return (CACHE && slot < BC_ARENA) ? (int)C->of_arena[slot] : 0xFF; }
-    __device__ __forceinline__ uint16_t ld_sv(int slot, uint32_t ci) const
-    {
-        const int cs = cslot(slot);
-        return cs != 0xFF ? C->sv[cs][ci] : sv[slot * 1024 + (int)ci];
-    }
-    __device__ __forceinline__ uint32_t ld_ob(int slot, uint32_t ci) const
-    {
-        const int cs = cslot(slot);
-        return cs != 0xFF ? unpack8(C->ob[cs][ci]) : obs[slot * 1024 + (int)ci];
-    }
-    __device__ __forceinline__ void st_sv(int slot, uint32_t ci, uint16_t v) const
-    {
-        const int cs = cslot(slot);
-        if (cs != 0xFF) { C->sv[cs][ci] = v; C->dirty[cs] = 1; } else sv[slot * 1024 + (int)ci] = v;
-    }
-    __device__ __forceinline__ void st_ob(int slot, uint32_t ci, uint32_t o) const
-    {
-        const int cs = cslot(slot);
-        if (cs != 0xFF) { C->ob[cs][ci] = pack8(o); C->dirty[cs] = 1; } else obs[slot * 1024 + (int)ci] = o;
-    }
-    __device__ __forceinline__ void flush(int lane)                     // all 64 lanes: write every dirty patch back
-    {
-        if (!CACHE) return;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int cs = 0; cs < BC_SLOTS; ++cs)
-            if (C->arena[cs] >= 0 && C->dirty[cs]) write_back(cs, lane);
-    }
-};
-
-// LSE: the lower wave runs level by level on the main wave (lama_brushfire_lse.h) instead of pop by pop; the raise wave and
-// everything around it are unchanged.  Bit-identical (cfg.brushfire_mode = 2 selects the pop-by-pop form).
-// CACHE: the main wave's cell accesses go through an LDS cache of the patches it touches (BfCells; one workgroup per CU).
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool LSE = false, bool CACHE = false>
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
-    __shared__ LseLds<LSE ? LQ_LDS : 1> lse;
-    __shared__ typename std::conditional<CACHE, BfCache, char>::type bcache;
-#ifdef LAMA_PROFILE_LSE
-    const uint64_t kt0 = lse_now();
-#endif
     const int p = first_particle + blockIdx.x;
     if (RESUME && prm.slow[p] == 0) return;              // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
@@ -1227,7 +1105,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             pushes(sh.lower, hnl, sh.pl_e[b], cl);
             HFT(2);
             const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
-            if (sp || (LSE ? hnr == 0 : (hnr == 0 && hnl == 0))) break;   // the main wave takes the same decision
+            if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
             if (ph_r && hnr == 0) lds_barrier();               // X: phase switch, the main wave reads lower[0] after the pushes
         }
 #ifdef LAMA_PROFILE_BF
@@ -1240,9 +1118,6 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         return;
     }
     const DirCache dc{sh.dc, dir, prm.W};
-    BfCells<CACHE> cells{sv, obs, CACHE ? reinterpret_cast<BfCache*>(&bcache) : nullptr, 0};
-    cells.init(lane);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
     const int ddx = lane == 0 ? 1 : (lane == 2 ? -1 : 0), ddy = lane == 1 ? 1 : (lane == 3 ? -1 : 0);
     const bool is_cur = lane == 4, is_nb = lane < 4;
@@ -1262,8 +1137,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);                               \
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;                                                  \
         uint16_t s = 0; uint32_t ob = 0;                                                                    \
-        cells.ensure(slot >= 0, slot, lane);                                                                \
-        if (slot >= 0) { s = cells.ld_sv(slot, ci); ob = cells.ld_ob(slot, ci); }
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; ob = obs[slot * 1024 + (int)ci]; }
     // round B: the cell my offset points to (obstacle cell); offset 0 -> myself
     #define BF_LOAD_B()                                                                                     \
         const int ox = x + obs_x(ob), oy = y + obs_y(ob);                                                   \
@@ -1272,8 +1146,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const bool oin = role && slot >= 0 && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC;           \
             const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);                       \
             const int oslot = oin ? dc.lookup(opidx) : -1;                                                  \
-            cells.ensure(oslot >= 0, oslot, lane);                                                          \
-            if (oslot >= 0) os = cells.ld_sv(oslot, ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5));    \
+            if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))]; \
         }
     // pop() of the LDS heap H with both load rounds issued underneath the sift-down
     #define BF_POP_WITH_LOADS(H, N)                                                                         \
@@ -1289,7 +1162,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     bool tw_running = false, tw_go = false;
     if (TW) {
         spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
-        tw_running = tw_go = !spill && (LSE ? nr > 0 : (nr > 0 || nl > 0));
+        tw_running = tw_go = !spill && (nr > 0 || nl > 0);
         if (lane == 0) { sh.cmd = tw_go ? nl : BF_CMD_EXIT; sh.cmd_r = nr; }
         if (tw_go) e_next = nr > 0 ? sh.raise[0] : sh.lower[0];
         __syncthreads();                                       // S0
@@ -1321,7 +1194,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             const uint64_t cand_ = own_wins_ ? (((uint64_t)ohi_ << 32) | olo_) : root_;                     \
             nr += (CNT_R); nl += (CNT_L);                                                                   \
             spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);                      \
-            tw_running = !spill && (LSE ? nr > 0 : (nr > 0 || nl > 0));                                     \
+            tw_running = !spill && (nr > 0 || nl > 0);                                                     \
             if (tw_running) {                                                                               \
                 if ((WAS_RAISE) && nr == 0) { lds_barrier(); /* X */ e_next = sh.lower[0]; }                \
                 else e_next = cand_;                                                                        \
@@ -1383,9 +1256,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                 else lds_push(sh.lower, nl, q_entry(prio, ex, ey, obs_x(eo), obs_y(eo)), lane == 0);
             }
         }
-        if (to_raise) { cells.st_sv(slot, ci, SV_QUEUED); cells.st_ob(slot, ci, 0u); }
-        if (to_lower) cells.st_sv(slot, ci, (uint16_t)(s | SV_QUEUED));
-        if (is_cur && slot >= 0) cells.st_sv(slot, ci, (uint16_t)(s & ~SV_QUEUED));      // :278
+        if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0u; }
+        if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
+        if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
         if (TW) BF_TW_TAIL(true, nr, rw_cnt_r, rw_cnt_l, rw_entry_r, rw_rm)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
@@ -1396,21 +1269,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #else
     BFT(7);
 #endif
-    if constexpr (LSE) {
-        if (TW && tw_go) __syncthreads();                      // F: the helper wave has applied the raise wave's last pushes and left
-#ifdef LAMA_PROFILE_LSE
-        const uint64_t kt1 = lse_now();
-        if (lane == 0) { prm.dbg[8 * (size_t)prm.P + 8 * p + 0] = kt1 - kt0; prm.dbg[8 * (size_t)prm.P + 8 * p + 2] = processed; prm.dbg[8 * (size_t)prm.P + 8 * p + 3] = nl; }
-#endif
-        if (!spill && nl > 0) {
-            if (nl + 4 > (uint32_t)LQ_LDS) spill = true;
-            else lse_lower<LQ_LDS>(prm, sh.lower, nl, lse, dc, dir, sv, obs, mask, count, processed, spill, lane, anc, p);
-        }
-#ifdef LAMA_PROFILE_LSE
-        if (lane == 0) { prm.dbg[8 * (size_t)prm.P + 8 * p + 1] = lse_now() - kt1; prm.dbg[8 * (size_t)prm.P + 8 * p + 4] = spill ? 1 : 0; }
-#endif
-    }
-    while (!LSE && (TW ? (tw_running && nl > 0) : (!spill && nl > 0))) {
+    while (TW ? (tw_running && nl > 0) : (!spill && nl > 0)) {
         if (!TW && nl + 4 > (uint32_t)LQ_LDS) { spill = true; break; }
         const uint64_t e = TW ? e_next : sh.lower[0];
         const int rx = q_rx(e), ry = q_ry(e);
@@ -1425,8 +1284,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;
         uint16_t s = 0; uint32_t ob = 0;
-        cells.ensure(slot >= 0, slot, lane);
-        if (slot >= 0) { s = cells.ld_sv(slot, ci); if (!is_oc) ob = cells.ld_ob(slot, ci); }
+        if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) ob = obs[slot * 1024 + (int)ci]; }
         BFT(1);
         uint32_t tw_cnt = 0, tw_om = 0;
         uint64_t tw_entry = 0;
@@ -1445,7 +1303,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
             uint16_t t = 0;
             if ((uint32_t)ox2 < prm.WC && (uint32_t)oy2 < prm.WC) {
                 const int os2 = dc.lookup(((uint32_t)oy2 >> 5) * prm.W + ((uint32_t)ox2 >> 5));
-                if (os2 >= 0) t = cells.ld_sv(os2, ((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5));
+                if (os2 >= 0) t = sv[os2 * 1024 + (int)(((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5))];
             }
             cos_ = t;
         }
@@ -1490,17 +1348,17 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                         os = 0;
                         if ((uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) {
                             const int oslot = dc.lookup(((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5));
-                            if (oslot >= 0) os = cells.ld_sv(oslot, ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5));
+                            if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))];
                         }
                     }
                 }
                 if (tie && (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0))) over = true;
             }
             if (over) {
-                cells.st_sv(slot, ci, (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK)));
-                cells.st_ob(slot, ci, pack_obs(obx - x, oby - y));
+                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
             }
-            if (is_cur && slot >= 0) cells.st_sv(slot, ci, (uint16_t)(cs & ~SV_QUEUED));   // :329
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
             BFT(4);
             // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
             // to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply
@@ -1544,12 +1402,11 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         BFT(6);
     }
-    if (!LSE && TW && tw_go) __syncthreads();                  // F: the helper has applied the last pushes
+    if (TW && tw_go) __syncthreads();                  // F: the helper has applied the last pushes
     #undef BF_TW_TAIL
     #undef BF_LOAD_A
     #undef BF_LOAD_B
     #undef BF_POP_WITH_LOADS
-    cells.flush(lane);                                         // cached patches back to HBM (the next stage / kernel reads them there)
     if (spill) {      // hand the particle over, state intact, to k_brushfire_slow
         __syncthreads();
         for (uint32_t k = lane; k < nl; k += UM_BLOCK) g_lower[k] = sh.lower[k];

@@ -9,6 +9,8 @@ a neighbouring shard and pairwise P2P is the right primitive (a ring collective 
 
 torch is plumbing here (process group, device buffers); the work is in liblama_hip.so / liblama_host.so.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -62,6 +64,11 @@ class ShardedPF:
         self.maxblk = max(hi - lo for lo, hi in self.blocks)
         self.shipped_particles = 0
         self.shipped_bytes = 0
+        # wall-clock seconds this rank spent in the exchange steps (bench.py reports them per step)
+        self.t_allgather = 0.0      # all-gather of the log-likelihoods incl. its two small copies
+        self.t_ship = 0.0           # export + P2P transfer of the particles cloned across shards
+        self.t_import = 0.0         # import of the received particles into this shard's slots
+        self.resample_steps = 0
 
     def close(self):
         self.pf.close()
@@ -107,8 +114,11 @@ class ShardedPF:
     def _ship(self, idx):
         """Returns {local slot (global index): blob tensor} for slots whose source lives on another shard."""
         P, G = self.P, self.world
-        transfers = sorted({(owner_of(int(idx[i]), P, G), owner_of(i, P, G), int(idx[i]))
-                            for i in range(P) if owner_of(int(idx[i]), P, G) != owner_of(i, P, G)})
+        ia = np.asarray(idx, dtype=np.int64)
+        src_owner = (ia * G) // P
+        dst_owner = (np.arange(P, dtype=np.int64) * G) // P
+        cross = np.nonzero(src_owner != dst_owner)[0]
+        transfers = sorted({(int(src_owner[i]), int(dst_owner[i]), int(ia[i])) for i in cross})
         if not transfers:
             return {}
         ctx = self.pf.hip_context()
@@ -154,12 +164,20 @@ class ShardedPF:
             return False
         if phase == 1:
             return True
+        t0 = time.perf_counter()
         all_ll = self._all_gather_loglik(self.pf.local_loglik())
+        t1 = time.perf_counter()
+        self.t_allgather += t1 - t0
         idx = self.pf.plan_resample(all_ll)
         if idx is not None:
+            self.resample_steps += 1
+            t1 = time.perf_counter()
             incoming = self._ship(idx)
+            t2 = time.perf_counter()
+            self.t_ship += t2 - t1
             self.pf.apply_resample(idx)
             if incoming:
+                t2 = time.perf_counter()
                 ctx = self.pf.hip_context()
                 for i, buf in incoming.items():
                     ctx.import_particle(i - self.pf.lo, buf.data_ptr(), buf.numel())
@@ -167,5 +185,6 @@ class ShardedPF:
                 poses = ctx.get_poses()
                 for i in incoming:
                     self.pf.set_pose(i, poses[i - self.pf.lo])
+                self.t_import += time.perf_counter() - t2
         self.pf.update_maps()
         return True

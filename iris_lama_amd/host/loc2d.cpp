@@ -33,16 +33,18 @@ void Loc2D::Init(const Options& o)
     w.apply = [this](std::vector<uint32_t>& cells_xy, double max_distance) -> uint32_t {
         (void)max_distance;                                 // part of the context's configuration (ensureContext)
         ensureContext();
+        lama_hip_counters c0, c1;
+        const bool have0 = eng_->get_counters(ctx_, &c0) == 0;
         const int32_t rc = eng_->map_add_obstacles(ctx_, 0, cells_xy.data(), (uint32_t)(cells_xy.size() / 2));
         if (rc) fail(rc, "lama_hip_map_add_obstacles");
-        lama_hip_counters c;
-        return eng_->get_counters(ctx_, &c) == 0 ? (uint32_t)c.bf_cells : 0;
+        // DynamicDistanceMap::update returns the cells processed by THIS call (src/sdm/dynamic_distance_map.cpp:196)
+        return (have0 && eng_->get_counters(ctx_, &c1) == 0) ? (uint32_t)(c1.bf_cells - c0.bf_cells) : 0;
     };
     w.download = [this](sdm::HostMap& m) -> bool {
         if (!ctx_) return false;
         uint32_t n = 0, got = 0;
         if (eng_->pf_map_patches(ctx_, 0, 0 /* distance map */, &n) != 0) return false;
-        m.kind = sdm::kDistanceMap; m.max_sqdist = distance_map->snapshot().max_sqdist;
+        m.kind = sdm::kDistanceMap; m.max_sqdist = distance_map->maxSqDist();
         m.ids.assign(n, 0); m.cells.assign((size_t)n * 10 * 1024, 0); m.masks.assign((size_t)n * 16, 0);
         return eng_->pf_download_map(ctx_, 0, 0, n, m.ids.data(), m.cells.data(), m.masks.data(), &got) == 0 && got == n;
     };

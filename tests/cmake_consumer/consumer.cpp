@@ -165,6 +165,13 @@ int main()
         loc.Init(lo);
         if (const int rc = fill_loc2d_maps(loc)) return rc;
         const uint32_t processed = loc.distance_map->update();                   // brushfire on the device
+        // the first accessor after update() -- whichever it is -- must already see the device map (a live map refreshes its host
+        // copy in every accessor, not only in distance())
+        if (loc.distance_map->patches() == 0 || !loc.distance_map->write("/tmp/lama_consumer_loc_dm.sdm")) return 24;
+        if (loc.distance_map->update() != 0) return 25;                          // nothing pending: no cells processed by THIS call
+        lama::EventFrequency freq(4);
+        freq.event(0.0); freq.event(0.5); freq.event(1.0);
+        if (!(freq.getFrequency() > 1.99 && freq.getFrequency() < 2.01)) return 26;
         const double dmid = loc.distance_map->distance(lama::Vector3d(2.0, 2.0, 0.0));
         const lama::Matrix3d& cov = loc.getCovar();
         lama::print("Loc2D: %u cells processed, distance at the room centre %.3f m, cov(0,0) %.2f, stamp %.0f\n", processed, dmid,

@@ -19,11 +19,8 @@ print("| P | gain | resamples (exact / mode 1) | max pose gap over the run [m, r
 print("|---:|---:|---|---:|---:|---:|---:|---:|---:|---:|")
 for P in (30, 300, 3000):
     for gain in (3.0, 0.01):
-        os.environ["LAMA_HIP_BRUSHFIRE_MODE"] = "0"
-        a = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
-        os.environ["LAMA_HIP_BRUSHFIRE_MODE"] = "1"
-        b = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
-        os.environ["LAMA_HIP_BRUSHFIRE_MODE"] = "0"
+        a = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, brushfire_mode=0))
+        b = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, brushfire_mode=1))
         a.set_prior(*odom[0]); b.set_prior(*odom[0])
         gap = 0.0
         for k in range(steps + 1):
