@@ -25,6 +25,15 @@
 
 #include "lama_heap.h"
 
+// The lanes of a wave execute in lock step on the device: "every lane reads X, then lane 0 overwrites X" needs no synchronisation
+// there.  The lane-level simulator of tests/sim (test infrastructure; this source compiled for the host) runs the lanes as
+// cooperative fibers and needs that ordering spelled out as a wave rendezvous.
+#ifdef LAMA_WAVE_SIM
+#define LAMA_LOCKSTEP() ((void)__ballot(true))
+#else
+#define LAMA_LOCKSTEP() ((void)0)
+#endif
+
 namespace lama_dev {
 
 constexpr uint16_t SV_VALID = 0x8000;

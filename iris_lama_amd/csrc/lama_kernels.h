@@ -937,6 +937,7 @@ __device__ __forceinline__ uint64_t lds_sift_topdown(uint64_t* h, const uint32_t
         }
         if (mvm != pathm) { stopped = true; break; }
     }
+    LAMA_LOCKSTEP();                                                  // every lane has read what it needs of the old array
     if (!stopped && (len & 1) == 0 && H == (len - 2) / 2) {          // the hole has a lone left child, the array's last entry
         const uint64_t c = h[len - 1];
         const bool up = (uint32_t)__builtin_amdgcn_readfirstlane((int)heap_prio(c)) <= (uint32_t)__builtin_amdgcn_readfirstlane((int)vprio);
@@ -947,6 +948,7 @@ __device__ __forceinline__ uint64_t lds_sift_topdown(uint64_t* h, const uint32_t
         }
     }
     if (lane == 0) h[H] = value;
+    LAMA_LOCKSTEP();                                                  // the next reader of the heap (any lane) sees lane 0's store
     return ((uint64_t)root_hi << 32) | root_lo;
 }
 __device__ __forceinline__ uint64_t lds_pop_topdown(uint64_t* h, uint32_t& size, int lane, uint64_t anc)
@@ -967,6 +969,7 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
         hole = parent;
     }
     if (writer) h[hole] = value;
+    LAMA_LOCKSTEP();
 }
 
 // push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
@@ -985,6 +988,7 @@ __device__ __forceinline__ bool lds_push_list(uint64_t* heap, uint32_t& n, const
         if (__ballot(up) == 0) {
             if (mine) heap[pos] = entry;
             n += cnt;
+            LAMA_LOCKSTEP();
             return true;
         }
     }
@@ -1021,14 +1025,18 @@ __device__ __forceinline__ bool lds_push_list(uint64_t* heap, uint32_t& n, const
 // The sequence of heap operations is exactly the sequential one, so the result stays bit-identical.
 // Workgroup barrier that orders LDS traffic only: the main wave's global stores / atomics of the iteration need not be
 // acknowledged before it meets the helper wave (which never touches global memory); __syncthreads() would drain vmcnt.
+#ifdef LAMA_WAVE_SIM       // tests/sim: this source compiled for the host under the lane-level simulator (test infrastructure only)
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+#else
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#endif
 
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     const int p = first_particle + blockIdx.x;
-    if (RESUME && prm.slow[p] == 0) return;              // resume stage: only particles an earlier stage handed over
+    const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
     const size_t WW = (size_t)prm.W * prm.W;
@@ -1040,6 +1048,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
     int count = prm.counts[2 * p];
     uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
+    // BOTH waves must have read the hand-over flag before thread 0 clears it (the helper wave may start later than the main wave)
+    if (RESUME && TW) __syncthreads(); else LAMA_LOCKSTEP();
+    if (RESUME && handed == 0) return;
     if (tid == 0) prm.slow[p] = 0;
     if (nl == 0 && nr == 0) return;
     if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) prm.slow[p] = 1; return; }
@@ -1080,6 +1091,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                     if (mine) heap[pos] = entry;
                     n += cnt;
                     done = true;
+                    LAMA_LOCKSTEP();
                 }
             }
             if (!done) {
@@ -1384,6 +1396,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
                     if (over) sh.lower[pos] = q_entry(new_sq, x, y, obx - x, oby - y);
                     nl += (uint32_t)ocnt;
                     done = true;
+                    LAMA_LOCKSTEP();
                 }
             }
             if (!done) {

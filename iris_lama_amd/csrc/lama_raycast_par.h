@@ -71,6 +71,9 @@ __device__ inline int dir_get_or_alloc(int16_t* dir, uint32_t pidx, int32_t* cou
 {
     int s = dir[pidx];
     if (s >= 0) return s;
+#ifdef LAMA_WAVE_SIM      // tests/sim (lane-level simulator): lanes are cooperative fibers, a lane's critical section cannot be
+    return dir_alloc_one(dir, pidx, count, cap, errbit, err);     // interleaved with another lane's spin -- no election needed
+#endif
     // slow path: one leader per distinct (directory, entry) among the lanes that got here together
     const int lane = (int)(threadIdx.x & 63u);
     const uint64_t key = ((uint64_t)(uintptr_t)dir << 20) ^ (uint64_t)pidx;       // directories are >= 2 KB apart, pidx < 2^16

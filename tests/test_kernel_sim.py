@@ -1,0 +1,74 @@
+"""The kernel SOURCES of iris_lama_amd/csrc executed lane by lane on the CPU (tests/sim: every thread a fiber, wave64 rendezvous for
+ballot / shuffle / readlane / DPP, workgroup barriers) and compared with the oracle.  This is test infrastructure for the build
+container, which has no GPU: it checks the kernels' LOGIC (the same C++ the device compiler gets, compiled for the host against
+tests/sim/hip/hip_runtime.h), not their timing, memory ordering or generated code -- the `-m gpu` tests on the MI355X remain the
+parity tests proper.  Small cases only (a particle-scan takes seconds here)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _oracle as O
+from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SIM_LIB = os.path.join(HERE, "sim", "_build", "liblama_hip_sim.so")
+
+
+@pytest.fixture(scope="module")
+def Fsim():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "sim")], check=True)
+    import iris_lama_amd.ffi as F
+    saved, saved_lib = F.HIP_LIB, getattr(F, "_hip", None)
+    F.HIP_LIB = SIM_LIB
+    F._hip = None
+    yield F
+    F.HIP_LIB, F._hip = saved, saved_lib
+
+
+def _run(F, P, steps, **cfg):
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, device=0, **cfg))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(0)
+    for k in range(1, steps + 1):
+        start = np.stack([O.se2_mul(O.se2(*truth[k]), O.se2(*rng.normal(0, [0.03, 0.03, 0.01]))) for _ in range(P)])
+        pf.set_poses(start)
+        pf.set_weights(w=np.zeros(P), ws=np.zeros(P))
+        pf.stage_set_scan(pts[k])
+        pf.stage_scan_match()
+        ctx.set_poses(start)
+        g_poses, g_ll, g_it = ctx.scan_match(pts[k])
+        o_poses, o_ll = pf.poses(), pf.weights()[0]
+        assert np.abs(g_poses - o_poses).max() < 1e-8
+        assert np.allclose(g_ll, o_ll, rtol=1e-9)
+        if k == 1 and P > 1:                         # a resample in between: particle copies
+            idx = np.sort(rng.integers(0, P, size=P)).astype(np.int32)
+            pf.stage_resample_with(idx)
+            ctx.resample(idx)
+            o_poses = pf.poses()
+        ctx.set_poses(o_poses)
+        pf.stage_update_maps()
+        ctx.update_maps(pts[k])
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    c = ctx.counters()
+    ctx.close()
+    return c
+
+
+def test_default_kernels_under_the_lane_simulator(Fsim):
+    """Patch-centric parallel ray-cast, fused scan match, wave-pair exact brushfire: bit-exact maps, poses within 1e-8."""
+    c = _run(Fsim, 2, 2)
+    assert c["parallel_raycast_scans"] == 3 and c["brushfire_waves"] == 2 and c["brushfire_mode"] == 0
+
+
+def test_sequential_raycast_and_one_wave_brushfire_under_the_lane_simulator(Fsim):
+    c = _run(Fsim, 1, 1, sequential_raycast=1, brushfire_waves=1)
+    assert c["sequential_raycast_scans"] == 2 and c["brushfire_waves"] == 1
