@@ -80,8 +80,10 @@ typedef struct lama_hip_cfg {
                                         distance -- may differ).  NOT bit-identical: only a caller that sets
                                         this field gets it (no environment variable selects it) and lama_hip_get_counters
                                         reports the mode that ran.  Other values are rejected. */
-    uint32_t brushfire_waves;    /* exact brushfire: 0 / 2 = a helper wave per particle owns the heap (default), 1 = one wave per
-                                    particle; bit-identical */
+    uint32_t brushfire_waves;    /* exact brushfire, all bit-identical: 0 = automatic (a wave pair per particle -- the main wave and a
+                                    helper wave that owns the heaps -- up to 1023 particles, two particles per wave pair from 1024
+                                    on); 1 = one wave per particle; 2 = always a wave pair per particle; 3 = always two particles
+                                    per wave pair */
     uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}
                                     (PFSlam2D, Slam2D); 1 = ProbabilisticOccupancyMap {float log-odds}
                                     (src/sdm/probabilistic_occupancy_map.cpp:53-107; LidarOdometry2D) -- beam-sequential ray-cast */

@@ -475,11 +475,15 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
-        const bool two_waves = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
+        // many particles: two particles per wave pair (lama_brushfire_packed.h; cfg.brushfire_waves = 3 forces it, 2 forbids it)
+        const bool packed = c->cfg.brushfire_waves == 3 || (c->cfg.brushfire_waves == 0 && count >= BF_PACKED_MIN_PARTICLES);
+        const bool two_waves = packed || c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
         c->ctr.brushfire_mode = c->cfg.brushfire_mode;
         c->ctr.brushfire_waves = two_waves ? 2u : 1u;
+        c->ctr.brushfire_packed = packed ? 1u : 0u;
         if (two_waves) {
-            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            if (packed) hipLaunchKernelGGL((k_brushfire_packed<LQ_SMALL, RQ_SMALL>), dim3((count + 1) / 2), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, (int)count);
+            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
