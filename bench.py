@@ -362,7 +362,7 @@ def main():
         return out
 
     def effective_modes(c):
-        return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"], "brushfire_packed": c["brushfire_packed"],
+        return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"],
                 "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"]}
 
     # `value` comes from a pass WITHOUT the per-kernel hipEvent brackets (they cost two extra device-to-host copies and four
@@ -475,7 +475,7 @@ def main():
         launches = max(c["launches_brushfire"], 1)
         dur_s = c["ms_brushfire"] / launches * 1e-3
         achieved = per_ps * (P_total / world) / dur_s / 1e9       # GB/s on this rank's GPU (its share of the pool)
-        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire (exact, %s; + its no-op resume stages)" % ("two particles per wave pair" if c["brushfire_packed"] else ("wave pair per particle" if c["brushfire_waves"] == 2 else "one wave per particle")), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        result["roofline"] = {"bound": "hbm", "kernel": "k_brushfire (exact, %s; + its no-op resume stages)" % ("wave pair per particle" if c["brushfire_waves"] == 2 else "one wave per particle"), "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                               "algorithmic_bytes_per_particle_scan": {k: round(v) for k, v in base["bytes"].items()},
                               "mean_launch_ms": dur_s * 1e3}

@@ -80,10 +80,8 @@ typedef struct lama_hip_cfg {
                                         distance -- may differ).  NOT bit-identical: only a caller that sets
                                         this field gets it (no environment variable selects it) and lama_hip_get_counters
                                         reports the mode that ran.  Other values are rejected. */
-    uint32_t brushfire_waves;    /* exact brushfire, all bit-identical: 0 = automatic (a wave pair per particle -- the main wave and a
-                                    helper wave that owns the heaps -- up to 1023 particles, two particles per wave pair from 1024
-                                    on); 1 = one wave per particle; 2 = always a wave pair per particle; 3 = always two particles
-                                    per wave pair */
+    uint32_t brushfire_waves;    /* exact brushfire: 0 / 2 = a helper wave per particle owns the heap (default), 1 = one wave per
+                                    particle; bit-identical */
     uint32_t occupancy_policy;   /* cell policy of the occupancy map: 0 = FrequencyOccupancyMap {uint16 occupied, uint16 visited}
                                     (PFSlam2D, Slam2D); 1 = ProbabilisticOccupancyMap {float log-odds}
                                     (src/sdm/probabilistic_occupancy_map.cpp:53-107; LidarOdometry2D) -- beam-sequential ray-cast */
@@ -257,12 +255,10 @@ typedef struct lama_hip_counters {
     uint64_t wrap_guard_scans;  /* scans ray-cast beam by beam because a uint16 `visited` counter could wrap inside them */
     /* what actually ran (set by every map update; not cleared by lama_hip_reset_counters' zeroing of the sums above): */
     uint32_t brushfire_mode;    /* cfg.brushfire_mode of the last map update: 0 = exact, 1 = canonical tie rule (not bit-identical) */
-    uint32_t brushfire_waves;   /* exact brushfire of the last map update: 2 = wave pair per particle (or per two particles, see
-                                   brushfire_packed), 1 = one wave per particle                                              */
+    uint32_t brushfire_waves;   /* exact brushfire of the last map update: 2 = wave pair per particle, 1 = one wave per particle */
     uint64_t sequential_raycast_scans;  /* map updates whose ray-cast ran beam by beam (k_raycast)                           */
     uint64_t parallel_raycast_scans;    /* map updates whose ray-cast ran in the parallel, patch-centric form                */
-    uint32_t brushfire_packed;  /* 1 = the last map update ran the brushfire with two particles per wave pair (many particles) */
-    uint32_t reserved0;
+    uint32_t reserved0, reserved1;
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

@@ -475,15 +475,11 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         // stage 1: small LDS window, every particle; stage 2: big window, resumes particles whose queue outgrew stage 1
         // (e.g. the first scan); stage 3: generic HBM-queue kernel for anything larger still
         // few particles: CUs are idle, spend a helper wave per particle on the heap (see k_brushfire, TW)
-        // many particles: two particles per wave pair (lama_brushfire_packed.h; cfg.brushfire_waves = 3 forces it, 2 forbids it)
-        const bool packed = c->cfg.brushfire_waves == 3 || (c->cfg.brushfire_waves == 0 && count >= BF_PACKED_MIN_PARTICLES);
-        const bool two_waves = packed || c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
+        const bool two_waves = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
         c->ctr.brushfire_mode = c->cfg.brushfire_mode;
         c->ctr.brushfire_waves = two_waves ? 2u : 1u;
-        c->ctr.brushfire_packed = packed ? 1u : 0u;
         if (two_waves) {
-            if (packed) hipLaunchKernelGGL((k_brushfire_packed<LQ_SMALL, RQ_SMALL>), dim3((count + 1) / 2), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, (int)count);
-            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
@@ -542,7 +538,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // No environment variable changes what a context computes or which kernels it runs: the variants are chosen through the
     // configuration only (cfg.brushfire_mode = 1, the one variant that is NOT bit-identical to the reference, must be asked for
     // by the caller), and lama_hip_get_counters reports what actually ran.
-    if (cfg.brushfire_mode > 1) return LAMA_HIP_E_INVALID;
+    if (cfg.brushfire_mode > 1 || cfg.brushfire_waves > 2) return LAMA_HIP_E_INVALID;
     if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)
@@ -1420,7 +1416,7 @@ int32_t lama_hip_reset_counters(lama_hip_ctx* c)
     const lama_hip_counters old = c->ctr;
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->ctr.dm_patches = old.dm_patches; c->ctr.occ_patches = old.occ_patches;
-    c->ctr.brushfire_mode = old.brushfire_mode; c->ctr.brushfire_waves = old.brushfire_waves; c->ctr.brushfire_packed = old.brushfire_packed;
+    c->ctr.brushfire_mode = old.brushfire_mode; c->ctr.brushfire_waves = old.brushfire_waves;
     return LAMA_HIP_OK;
 }
 

@@ -24,7 +24,6 @@ constexpr int LQ_SMALL = 1024, RQ_SMALL = 256;     // 8 + 2 KiB
 #endif
 constexpr int LQ_BIG = 8192, RQ_BIG = 2048;        // 64 + 16 KiB
 constexpr uint32_t BF_TW_MAX_PARTICLES = 1u << 30;     // the helper-wave form wins at every measured particle count (30 .. 3000); cfg.brushfire_waves = 1 forces one wave
-constexpr uint32_t BF_PACKED_MIN_PARTICLES = 1024;     // from here on two particles share a wave pair (lama_brushfire_packed.h): the chip is full, instructions count
 
 // ------------------------------------------------------------------------------------------------
 // wave / block reductions (fixed shape => results do not depend on how particles are sharded)
@@ -1443,10 +1442,6 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #endif
     }
 }
-
-} // namespace lama_dev
-#include "lama_brushfire_packed.h"
-namespace lama_dev {
 
 // ------------------------------------------------------------------------------------------------
 // k_map_checksum -- order-independent 64-bit checksum of one particle's map (lama_hip_pf_map_checksums): the sum, modulo

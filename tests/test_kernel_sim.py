@@ -14,17 +14,27 @@ from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SIM_LIB = os.path.join(HERE, "sim", "_build", "liblama_hip_sim.so")
+SIM_LIB_SMALLQ = os.path.join(HERE, "sim", "_build", "liblama_hip_sim_smallq.so")      # first-stage brushfire queues of 320 / 80 entries
 
 
-@pytest.fixture(scope="module")
-def Fsim():
+def _with_lib(path):
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "sim")], check=True)
     import iris_lama_amd.ffi as F
     saved, saved_lib = F.HIP_LIB, getattr(F, "_hip", None)
-    F.HIP_LIB = SIM_LIB
+    F.HIP_LIB = path
     F._hip = None
     yield F
     F.HIP_LIB, F._hip = saved, saved_lib
+
+
+@pytest.fixture()
+def Fsim():
+    yield from _with_lib(SIM_LIB)
+
+
+@pytest.fixture()
+def Fsim_smallq():
+    yield from _with_lib(SIM_LIB_SMALLQ)
 
 
 def _run(F, P, steps, **cfg):
@@ -72,3 +82,10 @@ def test_default_kernels_under_the_lane_simulator(Fsim):
 def test_sequential_raycast_and_one_wave_brushfire_under_the_lane_simulator(Fsim):
     c = _run(Fsim, 1, 1, sequential_raycast=1, brushfire_waves=1)
     assert c["sequential_raycast_scans"] == 2 and c["brushfire_waves"] == 1
+
+
+@pytest.mark.parametrize("waves", [2, 1])
+def test_hand_over_to_the_resume_stage_in_the_middle_of_an_update(Fsim_smallq, waves):
+    """First-stage queues of 320 / 80 entries: particles outgrow them while the brushfire runs and are handed, state intact, to the
+    resume stage (wave-pair and one-wave first stage)."""
+    _run(Fsim_smallq, 2, 2, brushfire_waves=waves)

@@ -1,3 +1,22 @@
+// RESEARCH ARCHIVE (round 3; not compiled into the product).  Bit-exact on the MI355X (all 80 GPU parity tests incl. the randomised
+// rooms ran it, as cfg.brushfire_waves = 3) and under tests/sim -- and NOT faster, which is why it was removed again:
+//
+//   brushfire per scan, teacher-forced corridor scans 5-14 (2,840 pops per particle-scan), tools/bf_waves_sweep.py:
+//     particles      one wave / particle   wave pair / particle (product)   two particles / wave pair (this file)
+//        30               5.54 ms                  3.92 ms                          4.91 ms
+//       300               6.31                     4.61                             5.88
+//      1000               7.51                     5.81                             7.06
+//      2000               8.67                     7.21                             7.90
+//      3000               9.15                     8.01                             8.37
+//   wave-instructions per launch at 3000 particles (rocprofv3 --pmc SQ_INSTS_*): wave pair 1.91 G VALU + 2.29 G SALU + 0.15 G LDS;
+//   packed 1.56 G VALU + 1.31 G SALU + 0.14 G LDS.
+//
+// Why: packing halves the work that was already scalar (SALU, per wave) but turns every per-particle decision -- queue lengths,
+// the next top, "fires", the sift state -- into per-HALF values that live in vector registers, so the VALU stream per iteration
+// nearly doubles (365 VALU per two-particle iteration against 224 per pop): -18 % VALU per particle-pop, while the latency chain
+// of an iteration grows by 25 % (ds_bpermute instead of readlane, three 5-level sift rounds instead of two 6-level ones, both
+// halves' paths executed).  And even at 3000 particles the kernel is only partly issue bound (it takes 2x the 30-particle time for
+// 100x the particles): the chain dominates.  See DESIGN.md 4c.
 // lama_brushfire_packed.h -- the exact brushfire (DynamicDistanceMap::update / raise / lower, src/sdm/dynamic_distance_map.cpp:
 // 160-197, 244-279, 281-330) with TWO particles per wave pair, for contexts with many particles.
 //
