@@ -143,6 +143,8 @@ public:
     template <class O> PlainObject cwiseProduct(const DenseBase<O>& o) const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = coeff(i, j) * o.coeff(i, j); return r; }
     template <class O> PlainObject cwiseMin(const DenseBase<O>& o) const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = std::min(coeff(i, j), o.coeff(i, j)); return r; }
     template <class O> PlainObject cwiseMax(const DenseBase<O>& o) const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = std::max(coeff(i, j), o.coeff(i, j)); return r; }
+    PlainObject cwiseSqrt() const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = std::sqrt(coeff(i, j)); return r; }
+    PlainObject cwiseInverse() const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = Scalar(1) / coeff(i, j); return r; }
     PlainObject cwiseAbs() const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = std::abs(coeff(i, j)); return r; }
     PlainObject operator-() const { PlainObject r; r.resize(rows(), cols()); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) r(i, j) = -coeff(i, j); return r; }
     template <class O> bool operator==(const DenseBase<O>& o) const { if (rows() != o.rows() || cols() != o.cols()) return false; for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) if (!(coeff(i, j) == o.coeff(i, j))) return false; return true; }
@@ -218,6 +220,7 @@ public:
     void normalize() { const Scalar n = this->norm(); for (Index j = 0; j < cols(); ++j) for (Index i = 0; i < rows(); ++i) coeffRef(i, j) = coeffRef(i, j) / n; }
     using Base::array;
     ArrayLvalue<D> array();
+    D& noalias() { return derived(); }                                  // evaluation is eager here: nothing can alias
     CommaInit<Scalar, D> operator<<(Scalar first) { return CommaInit<Scalar, D>(&coeffRef(0, 0), derived().ld_(), rows(), cols(), first, &derived()); }
 
     // sub-blocks
@@ -245,6 +248,7 @@ public:
     Matrix<Scalar, Dynamic, 1> head(Index n) const { Matrix<Scalar, Dynamic, 1> m; m.resize(n, 1); for (Index i = 0; i < n; ++i) m(i, 0) = this->coeff(i); return m; }
     Matrix<Scalar, Dynamic, 1> tail(Index n) const { Matrix<Scalar, Dynamic, 1> m; m.resize(n, 1); for (Index i = 0; i < n; ++i) m(i, 0) = this->coeff(size() - n + i); return m; }
     template <int NR, int NC> Matrix<Scalar, NR, NC> topLeftCorner() const { return block<NR, NC>(0, 0); }
+    Matrix<Scalar, Dynamic, 1> segment(Index s, Index n) const { Matrix<Scalar, Dynamic, 1> m; m.resize(n, 1); for (Index i = 0; i < n; ++i) m(i, 0) = this->coeff(s + i); return m; }
 private:
     template <int N> Block<Scalar, (Base::ColsAtCompileTime == 1 ? N : 1), (Base::ColsAtCompileTime == 1 ? 1 : N)> seg_(Index s)
     {
@@ -314,6 +318,7 @@ public:
     // A.selfadjointView<Lower>().ldlt().solve(b)  (src/nlls/gauss_newton.cpp:66)
     template <int UpLo> struct SelfAdjointView;
     template <int UpLo> SelfAdjointView<UpLo> selfadjointView() const;
+    template <int UpLo> SelfAdjointView<UpLo> selfadjointView();
 private:
     template <class T0, class T1> void two_(T0 a, T1 b) { st_.resize(C == 1 ? 2 : 1, C == 1 ? 1 : 2); st_.data()[0] = (S)a; st_.data()[1] = (S)b; }
     template <class O> void copy_(const DenseBase<O>& o)
@@ -627,6 +632,9 @@ class LLT {
 public:
     LLT() : n_(0), ok_(false) {}
     template <class D> explicit LLT(const DenseBase<D>& a) { compute(a); }
+    template <class V, class = decltype(std::declval<const V&>().m)> explicit LLT(const V& view) { compute(view.m); }      // LLT<MatrixXd>(A.selfadjointView<Upper>())
+    Matrix<S, Dynamic, Dynamic> matrixL() const { return L_; }
+    Matrix<S, Dynamic, Dynamic> matrixU() const { Matrix<S, Dynamic, Dynamic> u; u.resize(n_, n_); for (Index i = 0; i < n_; ++i) for (Index j = 0; j < n_; ++j) u(i, j) = L_(j, i); return u; }
     template <class D> LLT& compute(const DenseBase<D>& ain)
     {
         n_ = ain.rows(); ok_ = true;
@@ -658,11 +666,26 @@ public:
 template <class S, int R, int C, int O, int MR, int MC> template <int UpLo>
 struct Matrix<S, R, C, O, MR, MC>::SelfAdjointView {
     Matrix m;
+    Matrix* target = nullptr;      // set by the non-const selfadjointView(): rankUpdate writes through
+    // this += u * u^T on the viewed triangle (Eigen: SelfAdjointView::rankUpdate; sums in index order)
+    template <class D> SelfAdjointView& rankUpdate(const DenseBase<D>& u)
+    {
+        Matrix& t = target ? *target : m;
+        for (Index j = 0; j < t.cols(); ++j) for (Index i = 0; i < t.rows(); ++i) {
+            if ((UpLo == Lower) ? (i < j) : (i > j)) continue;
+            S acc = t(i, j);
+            for (Index k = 0; k < u.cols(); ++k) acc += u.coeff(i, k) * u.coeff(j, k);
+            t(i, j) = acc;
+        }
+        return *this;
+    }
     LDLT<Matrix<S, Dynamic, Dynamic>, UpLo> ldlt() const { static_assert(UpLo == Lower, "only Lower"); return LDLT<Matrix<S, Dynamic, Dynamic>, UpLo>(m); }
     LLT<Matrix<S, Dynamic, Dynamic>, UpLo> llt() const { return LLT<Matrix<S, Dynamic, Dynamic>, UpLo>(m); }
 };
 template <class S, int R, int C, int O, int MR, int MC> template <int UpLo>
-typename Matrix<S, R, C, O, MR, MC>::template SelfAdjointView<UpLo> Matrix<S, R, C, O, MR, MC>::selfadjointView() const { return SelfAdjointView<UpLo>{*this}; }
+typename Matrix<S, R, C, O, MR, MC>::template SelfAdjointView<UpLo> Matrix<S, R, C, O, MR, MC>::selfadjointView() const { return SelfAdjointView<UpLo>{*this, nullptr}; }
+template <class S, int R, int C, int O, int MR, int MC> template <int UpLo>
+typename Matrix<S, R, C, O, MR, MC>::template SelfAdjointView<UpLo> Matrix<S, R, C, O, MR, MC>::selfadjointView() { return SelfAdjointView<UpLo>{*this, this}; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // typedefs

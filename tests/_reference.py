@@ -38,6 +38,7 @@ def lib():
             "ref_occ_set_free": (i32, [vp, u32, u32, u32]), "ref_occ_set_occupied": (i32, [vp, u32, u32, u32]),
             "ref_occ_probability": (d, [vp, u32, u32, u32]),
             "ref_eval": (None, [vp, vp, i32, vp, vp, vp, vp, vp]),
+            "ref_pgo_linearize": (i32, [vp, u32, vp, vp, vp, vp, u32, vp, vp, vp]),
             "ref_solve": (None, [vp, vp, i32, vp, vp, vp, u32, i32, vp, vp]),
             "ref_pf_new": (vp, [vp]), "ref_pf_free": (None, [vp]), "ref_pf_set_prior": (None, [vp, vp]),
             "ref_pf_update": (i32, [vp, vp, i32, vp, vp, vp, d]), "ref_pf_neff": (d, [vp]), "ref_pf_best": (i32, [vp]),
@@ -239,3 +240,17 @@ class PF:
 
     def occ(self, i):
         return Occ(lib().ref_pf_particle_occ(self.h, i))
+
+
+def pgo_linearize(poses, fi, fj, meas, sqrt_info):
+    """minisam's own linearzationLowerHessian (vendor/minisam, compiled into liblama_ref.so) on a graph built like
+    SimplePGO::optimize's: dense symmetric H (3N x 3N, pose order), b = Atb (N x 3), whitened errors (F x 3)."""
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 4)
+    fi = np.ascontiguousarray(fi, dtype=np.int32); fj = np.ascontiguousarray(fj, dtype=np.int32)
+    meas = np.ascontiguousarray(meas, dtype=np.float64).reshape(-1, 4)
+    sq = np.ascontiguousarray(sqrt_info, dtype=np.float64).reshape(-1, 3)
+    N, F = len(poses), len(fi)
+    H, b, err = np.zeros((3 * N, 3 * N)), np.zeros((N, 3)), np.zeros((F, 3))
+    rc = lib().ref_pgo_linearize(_p(poses), N, _p(fi), _p(fj), _p(meas), _p(sq), F, _p(H), _p(b), _p(err))
+    assert rc == 0, "the reference's linearisation threw"
+    return {"H": H, "b": b, "err": err}

@@ -11,6 +11,8 @@ Content (seeded corridor log of SURVEY 8(d), 1080 beams):
   slam_*    Slam2D: pose after every update, map digests
   loc_*     Loc2D on the corridor's static map (config 1): pose / covariance / RMSE after every update
   lo_*      LidarOdometry2D on range-limited scans: odometry after every update, map digests at the end
+  pgo_*     minisam's linearzationLowerHessian on a SimplePGO-shaped graph (tests/_posegraph.make_graph(40, 30, seed 11)
+            plus a duplicate pair and a backward loop closure) at the dead-reckoned poses: whitened errors, Atb, the dense Hessian
   kat_*     known answers: SE2 exp / compose / inverse-compose, Map::computeRay, bilinear distance + gradient, CauchyWeight,
             lama::random after setSeed(7), MatchSurface2D::eval residual / Jacobian rows, Solve() results (GN and LM, with covariance)
 Run from the repo root (needs /root/reference):  make -f oracle/Makefile.ref && python tests/golden/make_reference_golden.py
@@ -34,6 +36,29 @@ KAT_DIST_IN = np.array([[3.1, 1.7, 0.0], [5.02, 0.93, 0.0], [10.0, 3.9, 0.0], [2
 KAT_RAYS = [([100, 200, 0], [131, 187, 0]), ([42275904, 42275904, 0], [42275890, 42275950, 0]), ([10, 10, 0], [10, 40, 0]), ([7, 9, 0], [7, 9, 0])]
 PF_STEPS, PF_P, RS_STEPS, RS_P, SLAM_STEPS, LOC_STEPS, LO_STEPS = 8, 4, 11, 6, 10, 10, 26
 LOC_START_OFFSET = np.array([0.05, -0.04, 0.01])
+
+
+def pgo_case():
+    """The pose graph of the pgo_* fixtures (built from the seeded generator; the oracle's SE2 operations are only the generator)."""
+    from _posegraph import make_graph
+    fi, fj, meas, sq, truth, init = make_graph(40, 30, seed=11)
+    fi = np.concatenate([fi, [3, 17]]).astype(np.int32); fj = np.concatenate([fj, [4, 5]]).astype(np.int32)
+    meas = np.concatenate([meas, meas[4:5], [O.se2_mul(O.se2_inverse(truth[17]), truth[5])]])
+    sq = np.concatenate([sq, [[2.0, 2.0, 10.0], [1.0, 3.0, 7.0]]])
+    return {"fi": fi, "fj": fj, "meas": meas, "sq": sq, "x": init}
+
+
+def dense_hessian(N, fi, fj, lin):
+    """Blocks of a pgo_linearize result (oracle or device) scattered the way minisam's value_ptr walk accumulates them."""
+    H = np.zeros((3 * N, 3 * N))
+    for v in range(N):
+        H[3 * v:3 * v + 3, 3 * v:3 * v + 3] = lin["Hdiag"][v]
+    for k in range(len(fi)):
+        i, j = int(fi[k]), int(fj[k])
+        if j >= 0:
+            H[3 * i:3 * i + 3, 3 * j:3 * j + 3] += lin["Hoff"][k]
+            H[3 * j:3 * j + 3, 3 * i:3 * i + 3] += lin["Hoff"][k].T
+    return H
 
 
 def run_pf(pts, odom, steps, P, seed, gain):
@@ -107,6 +132,9 @@ def main():
         pp = np.zeros(4); L.ref_lo_get_odom(lo, O._p(pp)); lo_odom.append(pp)
     lo_dm, lo_occ = map_digest(R.DM(L.ref_lo_dm(lo)).dump()), map_digest(R.POcc(L.ref_lo_occ(lo)).dump())
     L.ref_lo_free(lo)
+    # pose-graph linearisation (minisam itself)
+    pgo = pgo_case()
+    pgo_ref = R.pgo_linearize(pgo["x"], pgo["fi"], pgo["fj"], pgo["meas"], pgo["sq"])
     out = os.path.join(HERE, "reference_golden.npz")
     np.savez_compressed(
         out, odom=odom, truth=truth,
@@ -118,7 +146,8 @@ def main():
         kat_random=kat_random, kat_exp=kat_exp, kat_plus=kat_plus, kat_minus=kat_minus,
         kat_ray_sizes=np.array([len(x) for x in rays]), kat_rays=np.concatenate(rays) if len(rays) else np.zeros((0, 3)),
         kat_dist=kat_dist, kat_cauchy=kat_cauchy, kat_eval_xyr=xyr, kat_eval_r=r[sel], kat_eval_J=J[sel],
-        kat_gn=gn, kat_gn_cov=gn_cov, kat_lm=lm, kat_lm_cov=lm_cov)
+        kat_gn=gn, kat_gn_cov=gn_cov, kat_lm=lm, kat_lm_cov=lm_cov,
+        pgo_err=pgo_ref["err"], pgo_b=pgo_ref["b"], pgo_H=pgo_ref["H"])
     print("wrote", out, os.path.getsize(out), "bytes; resampling steps in rs run:",
           int(np.sum(np.any(np.diff(rs["weights"], axis=0) != 0, axis=1))))
 

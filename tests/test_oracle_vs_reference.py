@@ -317,3 +317,35 @@ def test_loc2d_global_localization_and_sampling_covariance():
         assert L.ref_loc_rmse(a) == b.rmse(), k
         assert bool(L.ref_loc_gloc_active(a)) == b.global_localization_active(), k
     L.ref_loc_free(a)
+
+
+@pytest.mark.parametrize("n_poses,n_loops,seed", [(12, 6, 1), (60, 40, 9), (200, 300, 4)])
+def test_pose_graph_linearisation(n_poses, n_loops, seed):
+    """the oracle's restatement of minisam's linearzationLowerHessian (PriorFactor / BetweenFactor<SE2d>,
+    DiagonalLoss) against minisam ITSELF -- vendor/minisam's factor / loss / sparsity-pattern / linearisation sources compiled
+    unchanged into oracle/_ref (oracle/Makefile.ref, oracle/ref_pgo_capi.cpp), driven like SimplePGO::optimize builds its graph
+    (src/simple_pgo.cpp:48-105) and the optimiser linearises it (default variable ordering, lower-Hessian sparsity cache).
+    Whitened errors, the assembled Hessian (every block, loop closures in both directions, several factors on one pair) and
+    the gradient: bit for bit."""
+    from _posegraph import make_graph
+    fi, fj, meas, sq, truth, init = make_graph(n_poses, n_loops, seed=seed)
+    # a second factor on an existing pair and a loop closure "backwards": accumulation into one block, transposed insertion
+    fi = np.concatenate([fi, [3, 7]]).astype(np.int32); fj = np.concatenate([fj, [4, 2]]).astype(np.int32)
+    meas = np.concatenate([meas, meas[4:5], [O.se2_mul(O.se2_inverse(truth[7]), truth[2])]])
+    sq = np.concatenate([sq, [[2.0, 2.0, 10.0], [1.0, 3.0, 7.0]]])
+    for x in (init, truth):
+        ref = R.pgo_linearize(x, fi, fj, meas, sq)
+        orc = O.pgo_linearize(x, fi, fj, meas, sq)
+        N = n_poses
+        H = np.zeros((3 * N, 3 * N))
+        for v in range(N):
+            H[3 * v:3 * v + 3, 3 * v:3 * v + 3] = orc["Hdiag"][v]
+        # off-diagonal blocks accumulate in factor order into ONE block per pair, as the reference's value_ptr walk does
+        for k in range(len(fi)):
+            i, j = int(fi[k]), int(fj[k])
+            if j >= 0:
+                H[3 * i:3 * i + 3, 3 * j:3 * j + 3] += orc["Hoff"][k]
+                H[3 * j:3 * j + 3, 3 * i:3 * i + 3] += orc["Hoff"][k].T
+        assert np.array_equal(orc["err"], ref["err"])
+        assert np.array_equal(orc["b"], ref["b"])
+        assert np.array_equal(H, ref["H"]), float(np.abs(H - ref["H"]).max())
