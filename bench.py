@@ -361,6 +361,37 @@ def main():
         pf.close()
         return out
 
+    def run_cpp_multi(P, gpus, updates, warm, gain=None):
+        """The same pool as ONE lama::PFSlam2D object with Options::gpus = N: the sharded step entirely in C++ (a host thread and a
+        device context per GPU, host-side gather of the log-likelihoods, peer copies of the clones) -- no Python, no process group."""
+        kw = {} if gain is None else {"meas_sigma_gain": gain}
+        pf = F.PFSlam2D(F.pf_options(particles=P, seed=42, gpu_device=0, gpus=gpus, create_summary=0, **kw))
+        assert pf.engine_origin().endswith("liblama_hip.so"), pf.engine_origin()
+        pf.set_prior(*odom[0])
+        for k in range(0, warm + 1):
+            pf.update(pts[k], odom[k], float(k))
+        r0 = pf.num_resamples()
+        for d in range(torch.cuda.device_count()):
+            torch.cuda.synchronize(d)
+        t0 = time.perf_counter()
+        done, xs = 0, []
+        for k in range(warm + 1, warm + updates + 1):
+            done += 1 if pf.update(pts[k], odom[k], float(k)) else 0
+            xs.append(pf.exchange_times())
+        for r in range(gpus):                                   # the map kernels of the last update are still in flight
+            pf.shard_context(r).sync()
+        dt = time.perf_counter() - t0
+        res = pf.num_resamples() - r0
+        ships = [x for x in xs if x["shipped_particles"] > 0]
+        out = dict(value=P * done / dt, ms_per_step=1e3 * dt / max(done, 1), resamples=res,
+                   shipped_particles=int(sum(x["shipped_particles"] for x in xs)), shipped_bytes=int(sum(x["shipped_bytes"] for x in xs)),
+                   exchange_ms={"gather_per_step": 1e3 * float(np.mean([x["gather_s"] for x in xs])),
+                                "ship_per_resample": 1e3 * float(np.mean([x["ship_s"] for x in ships])) if ships else 0.0,
+                                "import_per_resample": 1e3 * float(np.mean([x["import_s"] for x in ships])) if ships else 0.0},
+                   devices=min(gpus, torch.cuda.device_count()))
+        pf.close()
+        return out
+
     def effective_modes(c):
         return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"],
                 "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"]}
@@ -381,13 +412,15 @@ def main():
     if world > 1:
         assert resample_run["resamples"] > 0, "the forced-resample variant did not resample"
         assert resample_run["shipped_particles"] > 0 and resample_run["shipped_bytes"] > 0, "no particle crossed a shard boundary"
-    single = None
-    if world > 1 and rank == 0:
-        pass
+    single, cpp_multi, cpp_multi_forced = None, None, None
     if world > 1:
-        # base of the strong-scaling figure: the same pool on ONE GPU (rank 0's), unsharded; the other ranks wait
+        # base of the strong-scaling figure: the same pool on ONE GPU (rank 0's), unsharded; then the same pool as one C++ object
+        # over all N devices (lama::PFSlam2D, Options::gpus = N); the other ranks have released their contexts and wait
         if rank == 0:
             single = run(P_total, K, W, profile=False, sharded=False)
+            cpp_multi = run_cpp_multi(P_total, world, K, W)
+            cpp_multi_forced = run_cpp_multi(P_total, world, K, W, gain=forced_gain)
+            assert cpp_multi_forced["resamples"] > 0 and cpp_multi_forced["shipped_particles"] > 0, cpp_multi_forced
         torch.distributed.barrier()
 
     if rank != 0:
@@ -416,6 +449,9 @@ def main():
         result["exchange_ms_per_step"] = main_run["exchange_ms_per_step"]
         result["single_gpu_same_pool"] = {"value": single["value"], "ms_per_step": single["ms_per_step"],
                                           "note": f"the same {P_total} particles unsharded on one GPU (rank 0's), same steps: the base of the strong-scaling figure"}
+        result["cpp_multi_gpu_object"] = {"note": f"the same pool as ONE lama::PFSlam2D with Options::gpus = {world} (one process, a host thread per GPU, peer copies; "
+                                                  "no Python or process group in the step), run by rank 0 after the ranks released their devices",
+                                          "default_gain": cpp_multi, "forced_resample_variant": cpp_multi_forced}
     if resample_run is not None:
         result["forced_resample_variant"] = {"meas_sigma_gain": forced_gain, "value": resample_run["value"], "ms_per_step": resample_run["ms_per_step"],
                                              "resamples": resample_run["resamples"], "shipped_particles": resample_run["shipped_particles"],

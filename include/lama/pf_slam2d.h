@@ -12,7 +12,9 @@
 //   * Particle::dm / Particle::occ are not host objects any more; getDistanceMap()/getOccupancyMap() are
 //     replaced by downloadDistanceMap()/downloadOccupancyMap() which return the best particle's patches in the
 //     reference's record formats (see INTEGRATION.md for rebuilding a host lama::Map from them);
-//   * Options gains `gpu_device`, `shard_rank`, `shard_world` at the END (aggregate/default use is unchanged).
+//   * Options gains `gpu_device`, `shard_rank`, `shard_world`, ..., `gpus` at the END (aggregate/default use is unchanged).
+//     With gpus > 1 ONE object drives several GPUs from C++ (a host thread per device, peer copies for cross-shard clones):
+//     update() stays the whole step, nothing else changes for the consumer.
 //     With shard_world > 1 one process per GPU owns a contiguous block of the particle pool and the step-wise
 //     API (updateBegin / planResample / applyResample / updateMaps) is driven by the caller with an
 //     all-gather of the per-particle log-likelihoods in between (iris_lama_amd/distributed.py).
@@ -90,6 +92,14 @@ public:
         uint32_t dm_patch_capacity = 0;    // initial distance-map patches per particle
         uint32_t occ_patch_capacity = 0;   // initial occupancy patches per particle
         uint32_t queue_capacity = 0;       // brushfire queue entries per particle
+        // Several GPUs behind ONE object (shard_world must stay 1): the pool is split in `gpus` contiguous blocks (particle i on
+        // shard floor(i * gpus / P)), shard r runs on HIP device (gpu_device + r) mod (visible devices), each driven by
+        // its own host thread.  update() is then the whole sharded step -- the reference's two parallel regions
+        // (src/pf_slam2d.cpp:254-266, 292-302) run on all devices at once, the log-likelihoods are gathered on the host (they are
+        // host results of the scan match already), normalisation / Neff / resampling indices are computed once per shard from the
+        // same random stream, and a clone whose source lives on another shard is exported, copied GPU to GPU
+        // (hipMemcpyPeerAsync: xGMI) and imported.  Results are bit-identical for every value of `gpus`.
+        int32_t gpus = 1;
     };
 
     explicit PFSlam2D(const Options& options = Options());
@@ -156,7 +166,9 @@ public:
             sdm::HostMap m;
             if (!downloadDistanceMap(m)) return nullptr;
             dm_view_.reset(new DynamicDistanceMap(std::move(m)));
-            dm_view_->bindDevice(eng_, ctx_, (uint32_t)getBestParticleIdx() - lo_);
+            const uint32_t b = (uint32_t)getBestParticleIdx();
+            const PFSlam2D* o = ownerOf(b);
+            dm_view_->bindDevice(o->eng_, o->ctx_, b - o->lo_);
         }
         return dm_view_.get();
     }
@@ -176,9 +188,16 @@ public:
     // owned by another shard must afterwards be filled with importParticle().
     void applyResample(const std::vector<int32_t>& sample_idx);
     void updateMaps();                                      // region 2 on the local shard
-    lama_hip_ctx* deviceContext() const { return ctx_; }    // for export/import of particles (multi-GPU)
-    const HipEngine* engine() const { return eng_.get(); }
+    lama_hip_ctx* deviceContext() const;                    // for export/import of particles (multi-process sharding); gpus > 1: shard 0's
+    const HipEngine* engine() const;
     uint32_t numResamples() const { return num_resamples_; }
+    // gpus > 1: the shard objects (each a PFSlam2D with shard_rank = r, shard_world = gpus on its own device); empty otherwise
+    size_t numShards() const;
+    const PFSlam2D* shard(size_t r) const;
+    // seconds the last update() spent in the exchange steps of a multi-GPU object: gathering the log-likelihoods, shipping
+    // particles between devices (export + peer copy), importing them
+    struct ExchangeTimes { double gather = 0, ship = 0, import_ = 0; uint64_t shipped_particles = 0, shipped_bytes = 0; };
+    const ExchangeTimes& exchangeTimes() const { return xt_; }
 
     // Exposed for tests (host logic, identical formulas to src/pf_slam2d.cpp:365-391,511-556)
     void drawFromMotion(const Pose2D& delta, Pose2D& pose);
@@ -186,6 +205,13 @@ public:
     std::vector<int32_t> resampleIndices(double u01) const;
 
 private:
+    struct Group;                           // shards + their worker threads (Options::gpus > 1)
+    std::unique_ptr<Group> group_;
+    ExchangeTimes xt_;
+    bool updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp);
+    void mirrorShards(bool poses_changed);
+    const PFSlam2D* ownerOf(uint32_t i) const;
+    void syncDevice();
     double normal(double stddev);
     void fail(int32_t rc, const char* what) const;
     void uploadLocalPoses();

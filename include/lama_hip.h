@@ -218,6 +218,14 @@ int32_t lama_hip_match_cell_distances(lama_hip_ctx* ctx, uint32_t particle, cons
 int32_t lama_hip_pf_export_particle(lama_hip_ctx* ctx, uint32_t particle, void* device_buf, uint64_t cap, uint64_t* bytes);
 int32_t lama_hip_pf_import_particle(lama_hip_ctx* ctx, uint32_t particle, const void* device_buf, uint64_t bytes);
 
+/* Device staging buffers for particle shipping when ONE process drives several contexts (lama::PFSlam2D with Options::gpus > 1: a
+ * host thread per GPU, src/pf_slam2d.cpp:254-302's two parallel regions become G device streams): allocate / free a buffer on the
+ * context's device, and copy between buffers of two contexts -- hipMemcpyPeerAsync when they live on different GPUs (xGMI), a
+ * plain device copy otherwise.  The copy is complete when the call returns. */
+int32_t lama_hip_blob_alloc(lama_hip_ctx* ctx, uint64_t bytes, void** device_buf);
+int32_t lama_hip_blob_free(lama_hip_ctx* ctx, void* device_buf);
+int32_t lama_hip_blob_copy(lama_hip_ctx* dst_ctx, void* dst_device_buf, lama_hip_ctx* src_ctx, const void* src_device_buf, uint64_t bytes);
+
 /* SE2 pose-graph linearisation: the per-factor body and the accumulation of minisam's
  * linearzationLowerHessian (vendor/minisam/minisam/nonlinear/linearization.cpp:150-272,290-341) for PriorFactor<SE2d> /
  * BetweenFactor<SE2d> with DiagonalLoss, as built by SimplePGO::optimize (src/simple_pgo.cpp:48-105) and

@@ -33,6 +33,7 @@ typedef struct lama_pf_options {
     int32_t profile;
     uint32_t brushfire_mode;
     uint32_t window_patches, dm_patch_capacity, occ_patch_capacity, queue_capacity;   /* device map storage, 0 = defaults */
+    int32_t gpus;                 /* PFSlam2D::Options::gpus: > 1 = one object drives that many shards / devices from C++ (0 / 1: one) */
 } lama_pf_options;
 
 typedef struct lama_pf lama_pf;
@@ -76,6 +77,11 @@ double lama_pf_neff(const lama_pf* pf);
 int lama_pf_best(const lama_pf* pf);
 int lama_pf_best_pose_xyr(const lama_pf* pf, double* xyr);
 uint32_t lama_pf_num_resamples(const lama_pf* pf);
+/* Options::gpus > 1: seconds the last update spent gathering log-likelihoods / shipping (export + peer copy) / importing particles,
+ * particles and bytes shipped between shards by it.  out5 = {gather_s, ship_s, import_s, particles, bytes}.  Returns the number of shards. */
+int lama_pf_exchange_times(const lama_pf* pf, double* out5);
+/* lama_hip_ctx* of shard r of a gpus > 1 object (NULL when out of range) */
+void* lama_pf_shard_context(const lama_pf* pf, uint32_t r);
 uint64_t lama_pf_memory_usage(const lama_pf* pf);
 /* Summary::report() into buf; returns the length needed */
 int lama_pf_summary(const lama_pf* pf, char* buf, int cap);

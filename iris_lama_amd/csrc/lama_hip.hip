@@ -1374,6 +1374,35 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_blob_alloc(lama_hip_ctx* c, uint64_t bytes, void** buf)
+{
+    if (!c || !buf || bytes == 0) return LAMA_HIP_E_INVALID;
+    *buf = nullptr;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMalloc(buf, bytes));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_blob_free(lama_hip_ctx* c, void* buf)
+{
+    if (!c) return LAMA_HIP_E_INVALID;
+    if (!buf) return LAMA_HIP_OK;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipFree(buf));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_blob_copy(lama_hip_ctx* dc, void* dst, lama_hip_ctx* sc, const void* src, uint64_t bytes)
+{
+    if (!dc || !sc || !dst || !src) return LAMA_HIP_E_INVALID;
+    if (bytes == 0) return LAMA_HIP_OK;
+    HIPCHK(dc, hipSetDevice(dc->cfg.device));
+    if (dc->cfg.device == sc->cfg.device) HIPCHK(dc, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dc->stream));
+    else HIPCHK(dc, hipMemcpyPeerAsync(dst, dc->cfg.device, src, sc->cfg.device, bytes, dc->stream));      // GPU to GPU over xGMI
+    HIPCHK(dc, hipStreamSynchronize(dc->stream));
+    return LAMA_HIP_OK;
+}
+
 // profiling builds only (-DLAMA_PROFILE_BF): per-particle cycle counters of the last k_brushfire launch
 int32_t lama_hip_debug_cycles(lama_hip_ctx* c, uint64_t* out /* P x 8 */)
 {

@@ -57,6 +57,7 @@ HIP_SYMBOLS = [
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
     "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
     "lama_hip_pf_map_checksums", "lama_hip_match_eval", "lama_hip_match_cell_distances", "lama_hip_match_solve_with",
+    "lama_hip_blob_alloc", "lama_hip_blob_free", "lama_hip_blob_copy",
 ]
 
 _hip = None
@@ -358,7 +359,7 @@ class PFOptions(C.Structure):
                 ("create_summary", C.c_int32), ("gpu_device", C.c_int32), ("shard_rank", C.c_uint32),
                 ("shard_world", C.c_uint32), ("profile", C.c_int32), ("brushfire_mode", C.c_uint32),
                 ("window_patches", C.c_uint32), ("dm_patch_capacity", C.c_uint32), ("occ_patch_capacity", C.c_uint32),
-                ("queue_capacity", C.c_uint32)]
+                ("queue_capacity", C.c_uint32), ("gpus", C.c_int32)]
 
 
 HOST_SYMBOLS = [
@@ -367,7 +368,7 @@ HOST_SYMBOLS = [
     "lama_pf_update_begin", "lama_pf_local_range", "lama_pf_local_loglik", "lama_pf_plan_resample",
     "lama_pf_apply_resample", "lama_pf_update_maps", "lama_pf_device_context", "lama_pf_get_poses",
     "lama_pf_set_pose", "lama_pf_get_weights", "lama_pf_set_weights", "lama_pf_neff", "lama_pf_best",
-    "lama_pf_best_pose_xyr", "lama_pf_num_resamples", "lama_pf_memory_usage", "lama_pf_summary",
+    "lama_pf_best_pose_xyr", "lama_pf_num_resamples", "lama_pf_exchange_times", "lama_pf_shard_context", "lama_pf_memory_usage", "lama_pf_summary",
     "lama_pf_last_times", "lama_pf_draw_from_motion", "lama_pf_normalize", "lama_pf_resample_indices",
     "lama_pose_minus", "lama_pose_from_xyr",
     "lama_slam_default_options", "lama_slam_create", "lama_slam_destroy", "lama_slam_last_error", "lama_slam_set_pose",
@@ -400,6 +401,7 @@ def _bind_host(L):
         "lama_pf_set_pose": (i32, [vp, u32, vp]), "lama_pf_get_weights": (i32, [vp, vp, vp, vp]),
         "lama_pf_set_weights": (i32, [vp, vp, vp]), "lama_pf_neff": (d, [vp]), "lama_pf_best": (i32, [vp]),
         "lama_pf_best_pose_xyr": (i32, [vp, vp]), "lama_pf_num_resamples": (u32, [vp]),
+        "lama_pf_exchange_times": (i32, [vp, vp]), "lama_pf_shard_context": (vp, [vp, u32]),
         "lama_pf_memory_usage": (C.c_uint64, [vp]), "lama_pf_summary": (i32, [vp, vp, i32]),
         "lama_pf_last_times": (i32, [vp, vp]), "lama_pf_draw_from_motion": (i32, [vp, vp, vp]),
         "lama_pf_normalize": (d, [vp]), "lama_pf_resample_indices": (i32, [vp, d, vp]),
@@ -578,6 +580,23 @@ class PFSlam2D:
 
     def num_resamples(self):
         return self.L.lama_pf_num_resamples(self.h)
+
+    def exchange_times(self):
+        """Options::gpus > 1: what the last update spent exchanging (seconds) and shipped between shards."""
+        t = np.zeros(5)
+        n = self.L.lama_pf_exchange_times(self.h, _p(t))
+        return dict(shards=n, gather_s=t[0], ship_s=t[1], import_s=t[2], shipped_particles=int(t[3]), shipped_bytes=int(t[4]))
+
+    def shard_context(self, r):
+        """HipContext view of shard r's device context (Options::gpus > 1), None when out of range."""
+        h = self.L.lama_pf_shard_context(self.h, r)
+        if not h:
+            return None
+        ctx = self.hip_context()
+        ctx.h = C.c_void_p(h)
+        G = self.opts.gpus
+        ctx.P = ((r + 1) * self.P + G - 1) // G - (r * self.P + G - 1) // G
+        return ctx
 
     def memory_usage(self):
         return self.L.lama_pf_memory_usage(self.h)

@@ -42,6 +42,9 @@ struct HipEngine {
     decltype(&lama_hip_match_eval) match_eval = nullptr;
     decltype(&lama_hip_match_cell_distances) match_cell_distances = nullptr;
     decltype(&lama_hip_match_solve_with) match_solve_with = nullptr;
+    decltype(&lama_hip_blob_alloc) blob_alloc = nullptr;
+    decltype(&lama_hip_blob_free) blob_free = nullptr;
+    decltype(&lama_hip_blob_copy) blob_copy = nullptr;
     ~HipEngine();
 };
 

@@ -110,6 +110,7 @@ lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
         p.brushfire_mode = o->brushfire_mode;
         p.window_patches = o->window_patches; p.dm_patch_capacity = o->dm_patch_capacity;
         p.occ_patch_capacity = o->occ_patch_capacity; p.queue_capacity = o->queue_capacity;
+        p.gpus = o->gpus > 1 ? o->gpus : 1;
         h->pf.reset(new PFSlam2D(p));
         h->origin = h->pf->engine()->origin;
         return h;
@@ -121,6 +122,17 @@ lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
 }
 
 void lama_pf_destroy(lama_pf* pf) { delete pf; }
+int lama_pf_exchange_times(const lama_pf* h, double* out5)
+{
+    const PFSlam2D::ExchangeTimes& x = h->pf->exchangeTimes();
+    out5[0] = x.gather; out5[1] = x.ship; out5[2] = x.import_; out5[3] = (double)x.shipped_particles; out5[4] = (double)x.shipped_bytes;
+    return (int)h->pf->numShards();
+}
+void* lama_pf_shard_context(const lama_pf* h, uint32_t r)
+{
+    const PFSlam2D* s = h->pf->shard(r);
+    return s ? (void*)s->deviceContext() : nullptr;
+}
 const char* lama_pf_last_error(const lama_pf* pf) { return pf ? pf->error.c_str() : "null handle"; }
 const char* lama_pf_engine_origin(const lama_pf* pf) { return pf ? pf->origin.c_str() : ""; }
 

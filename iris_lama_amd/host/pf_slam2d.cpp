@@ -6,9 +6,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "hip_engine.hpp"
 
@@ -21,12 +26,113 @@ double now_s()
 }
 } // namespace
 
+// ---- Options::gpus > 1: one object, several devices -------------------------------------------------------------------------
+// The shards are ordinary PFSlam2D objects (shard_rank = r, shard_world = gpus), each bound to its own device context and driven
+// by its own persistent host thread: run(f) executes f(r) on every shard's thread and returns when all are done -- the two
+// parallel regions of the reference's update() (src/pf_slam2d.cpp:254-266, 292-302) become `gpus` device streams fed concurrently.
+struct PFSlam2D::Group {
+    std::vector<std::unique_ptr<PFSlam2D>> shards;
+    std::vector<std::thread> threads;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const std::function<void(uint32_t)>* job = nullptr;
+    uint64_t epoch = 0;
+    uint32_t pending = 0;
+    bool quit = false;
+    std::vector<std::exception_ptr> errors;
+    std::vector<void*> stage;               // per shard: device staging buffer for particle blobs (outgoing, then incoming)
+    std::vector<uint64_t> stage_cap;
+
+    void start()
+    {
+        const uint32_t G = (uint32_t)shards.size();
+        errors.assign(G, nullptr);
+        stage.assign(G, nullptr); stage_cap.assign(G, 0);
+        for (uint32_t r = 0; r < G; ++r)
+            threads.emplace_back([this, r]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    const std::function<void(uint32_t)>* f = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lk(m);
+                        cv_go.wait(lk, [&] { return quit || epoch != seen; });
+                        if (quit) return;
+                        seen = epoch; f = job;
+                    }
+                    try { (*f)(r); } catch (...) { errors[r] = std::current_exception(); }
+                    {
+                        std::lock_guard<std::mutex> lk(m);
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                }
+            });
+    }
+    void run(const std::function<void(uint32_t)>& f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f; pending = (uint32_t)shards.size(); ++epoch;
+        }
+        cv_go.notify_all();
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+        for (auto& e : errors)
+            if (e) { std::exception_ptr x = e; for (auto& y : errors) y = nullptr; std::rethrow_exception(x); }
+    }
+    void reserve_stage(uint32_t r, uint64_t bytes)
+    {
+        if (bytes <= stage_cap[r]) return;
+        PFSlam2D& s = *shards[r];
+        if (stage[r]) (void)s.eng_->blob_free(s.ctx_, stage[r]);
+        stage[r] = nullptr; stage_cap[r] = 0;
+        const uint64_t want = bytes + bytes / 2;
+        const int32_t rc = s.eng_->blob_alloc(s.ctx_, want, &stage[r]);
+        if (rc) s.fail(rc, "lama_hip_blob_alloc");
+        stage_cap[r] = want;
+    }
+    ~Group()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv_go.notify_all();
+        for (auto& t : threads) t.join();
+        for (size_t r = 0; r < shards.size(); ++r)
+            if (stage[r]) (void)shards[r]->eng_->blob_free(shards[r]->ctx_, stage[r]);
+    }
+};
+
 PFSlam2D::PFSlam2D(const Options& options) : options_(options)
 {
     if (options_.particles == 0) throw std::runtime_error("lama::PFSlam2D: Options::particles must be > 0");
     if (options_.use_compression) throw std::runtime_error("lama::PFSlam2D: use_compression is not supported on the device path");
     if (options_.shard_world == 0 || options_.shard_rank >= options_.shard_world)
         throw std::runtime_error("lama::PFSlam2D: invalid shard_rank / shard_world");
+    if (options_.gpus < 1) options_.gpus = 1;
+    if (options_.gpus > 1) {
+        if (options_.shard_world != 1) throw std::runtime_error("lama::PFSlam2D: Options::gpus > 1 needs shard_world == 1 (one process drives all shards)");
+        if ((uint32_t)options_.gpus > options_.particles) throw std::runtime_error("lama::PFSlam2D: more GPUs than particles");
+        // all shards replay the same host random stream: settle the seed first (0 = random_device, src/pf_slam2d.cpp:131-134)
+        if (options_.seed == 0) options_.seed = std::random_device()() | 1u;
+        eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+        int32_t ndev = 0;
+        if (eng_->device_count(&ndev) != 0 || ndev <= 0)
+            throw std::runtime_error("lama::PFSlam2D: no usable MI355X / HIP device; there is no CPU fallback");
+        group_.reset(new Group());
+        for (int32_t r = 0; r < options_.gpus; ++r) {
+            Options so = options_;
+            so.gpus = 1; so.shard_rank = (uint32_t)r; so.shard_world = (uint32_t)options_.gpus;
+            so.gpu_device = (options_.gpu_device + r) % ndev;
+            so.create_summary = false;              // the Summary is the whole object's: kept by this object
+            group_->shards.emplace_back(new PFSlam2D(so));
+        }
+        group_->start();
+        lo_ = 0; hi_ = options_.particles;
+        particles_.assign(options_.particles, Particle());
+        if (options_.create_summary) summary = new Summary();
+        return;
+    }
     // contiguous blocks: particle i lives on shard floor(i * G / P)  
     const uint64_t P = options_.particles, G = options_.shard_world, r = options_.shard_rank;
     lo_ = (uint32_t)((r * P + G - 1) / G);
@@ -73,8 +179,183 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
 
 PFSlam2D::~PFSlam2D()
 {
+    group_.reset();                         // joins the shard threads, destroys the shard objects (and their contexts)
     if (ctx_) eng_->ctx_destroy(ctx_);
     delete summary;
+}
+
+lama_hip_ctx* PFSlam2D::deviceContext() const { return group_ ? group_->shards[0]->ctx_ : ctx_; }
+const HipEngine* PFSlam2D::engine() const { return eng_.get(); }
+size_t PFSlam2D::numShards() const { return group_ ? group_->shards.size() : 0; }
+const PFSlam2D* PFSlam2D::shard(size_t r) const { return group_ && r < group_->shards.size() ? group_->shards[r].get() : nullptr; }
+const PFSlam2D* PFSlam2D::ownerOf(uint32_t i) const
+{
+    if (!group_) return this;
+    const uint64_t G = group_->shards.size(), P = options_.particles;
+    return group_->shards[(size_t)(((uint64_t)i * G) / P)].get();
+}
+void PFSlam2D::syncDevice()
+{
+    const int32_t rs = eng_->sync(ctx_);
+    if (rs) fail(rs, "lama_hip_sync");
+}
+
+// Host mirror of a multi-GPU object: weights are replicated on every shard (shard 0's are taken), a particle's pose is its owner's.
+void PFSlam2D::mirrorShards(bool poses_changed)
+{
+    const PFSlam2D& s0 = *group_->shards[0];
+    const uint32_t P = options_.particles;
+    for (uint32_t i = 0; i < P; ++i) {
+        particles_[i].weight = s0.particles_[i].weight;
+        particles_[i].normalized_weight = s0.particles_[i].normalized_weight;
+        particles_[i].weight_sum = s0.particles_[i].weight_sum;
+        if (poses_changed) particles_[i].pose = ownerOf(i)->particles_[i].pose;
+    }
+    neff_ = s0.neff_;
+    num_resamples_ = s0.num_resamples_;
+}
+
+// PFSlam2D::update (src/pf_slam2d.cpp:178-312) over `gpus` shards in one process.
+bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
+{
+    Group& g = *group_;
+    const uint32_t G = (uint32_t)g.shards.size(), P = options_.particles;
+    const double t_begin = now_s();
+    dropMapViews();
+    xt_ = ExchangeTimes();
+    const bool first = !has_first_scan;
+    for (auto& sh : g.shards) sh->pose_ = pose_;                 // setPrior() of this object reaches the shards
+    std::vector<Phase> ph(G, kNoUpdate);
+    g.run([&](uint32_t r) { ph[r] = g.shards[r]->updateBegin(surface, odometry, timestamp); });
+    const double t_solved = now_s();
+    if (first) {                                                 // :185-228
+        has_first_scan = true;
+        timestamps_.push_back(timestamp);
+        mirrorShards(true);
+        for (uint32_t i = 0; i < P; ++i) { particles_[i].pose = pose_; particles_[i].poses.push_back(pose_); }
+        if (summary) {
+            g.run([&](uint32_t r) { g.shards[r]->syncDevice(); });
+            const double el = now_s() - t_begin;
+            summary->timestamp.push_back(timestamp); summary->time.push_back(el); summary->time_mapping.push_back(el);
+            summary->memory.push_back((double)getMemoryUsage());
+        }
+        return true;
+    }
+    if (ph[0] == kNoUpdate) { mirrorShards(true); return false; }   // motion gate closed on every shard alike
+    // the poses of this update (history like the single-shard object: pushed before resampling reorders the particles)
+    mirrorShards(true);
+    for (uint32_t i = 0; i < P; ++i) particles_[i].poses.push_back(particles_[i].pose);
+    if (summary) summary->time_solving.push_back(t_solved - t_begin);
+
+    // ---- exchange 1: the P log-likelihoods.  They are host results of the scan match already (include/lama_hip.h,
+    // lama_hip_pf_scan_match): the gather is a concatenation in host memory, no device collective could be cheaper.
+    double t0 = now_s();
+    std::vector<double> all_ll(P);
+    for (uint32_t r = 0; r < G; ++r) {
+        const PFSlam2D& sh = *g.shards[r];
+        std::copy(sh.local_loglik_.begin(), sh.local_loglik_.end(), all_ll.begin() + sh.lo_);
+    }
+    xt_.gather = now_s() - t0;
+    // normalise / Neff / resampling indices: every shard from its own (identical) copy of the state and random stream
+    t0 = now_s();
+    std::vector<std::vector<int32_t>> idxs(G);
+    std::vector<char> due(G, 0);
+    g.run([&](uint32_t r) { due[r] = g.shards[r]->planResample(all_ll.data(), idxs[r]) ? 1 : 0; });
+    if (summary) summary->time_normalizing.push_back(now_s() - t0);
+    if (due[0]) {                                                // :280-287
+        const double tr0 = now_s();
+        const std::vector<int32_t>& idx = idxs[0];
+        auto owner = [&](uint32_t i) { return (uint32_t)(((uint64_t)i * G) / P); };
+        // ---- exchange 2: clones whose source lives on another shard.  One blob per (source particle, destination shard).
+        struct Xfer { uint32_t src_shard, dst_shard, particle; uint64_t bytes, src_off, dst_off; };
+        std::vector<Xfer> xf;
+        {
+            std::map<std::pair<uint32_t, uint32_t>, bool> seen;      // (destination shard, source particle)
+            for (uint32_t i = 0; i < P; ++i) {
+                const uint32_t sp = (uint32_t)idx[i], ss = owner(sp), ds = owner(i);
+                if (ss == ds || seen.count({ds, sp})) continue;
+                seen[{ds, sp}] = true;
+                xf.push_back(Xfer{ss, ds, sp, 0, 0, 0});
+            }
+        }
+        double ts0 = now_s();
+        if (!xf.empty()) {
+            // sizes and offsets first: a shard's staging buffer holds its outgoing blobs, then (behind them) the incoming ones
+            std::vector<uint64_t> out_bytes(G, 0), in_bytes(G, 0);
+            for (auto& x : xf) {
+                const PFSlam2D& sh = *g.shards[x.src_shard];
+                const int32_t rc = sh.eng_->pf_export_particle(sh.ctx_, x.particle - sh.lo_, nullptr, 0, &x.bytes);
+                if (rc) sh.fail(rc, "lama_hip_pf_export_particle (size)");
+                x.src_off = out_bytes[x.src_shard]; out_bytes[x.src_shard] += (x.bytes + 255) & ~255ull;
+            }
+            for (auto& x : xf) { x.dst_off = out_bytes[x.dst_shard] + in_bytes[x.dst_shard]; in_bytes[x.dst_shard] += (x.bytes + 255) & ~255ull; }
+            // every source shard exports its outgoing particles into its buffer (concurrently) ...
+            g.run([&](uint32_t r) {
+                if (out_bytes[r] + in_bytes[r] == 0) return;
+                g.reserve_stage(r, out_bytes[r] + in_bytes[r]);
+                PFSlam2D& sh = *g.shards[r];
+                for (auto& x : xf) {
+                    if (x.src_shard != r) continue;
+                    uint64_t nb = 0;
+                    const int32_t rc = sh.eng_->pf_export_particle(sh.ctx_, x.particle - sh.lo_, (uint8_t*)g.stage[r] + x.src_off, x.bytes, &nb);
+                    if (rc) sh.fail(rc, "lama_hip_pf_export_particle");
+                }
+            });
+            // ... and every destination shard pulls its blobs GPU to GPU (hipMemcpyPeerAsync over xGMI between different devices)
+            g.run([&](uint32_t r) {
+                PFSlam2D& dsh = *g.shards[r];
+                for (auto& x : xf) {
+                    if (x.dst_shard != r) continue;
+                    PFSlam2D& ssh = *g.shards[x.src_shard];
+                    const int32_t rc = dsh.eng_->blob_copy(dsh.ctx_, (uint8_t*)g.stage[r] + x.dst_off, ssh.ctx_, (const uint8_t*)g.stage[x.src_shard] + x.src_off, x.bytes);
+                    if (rc) dsh.fail(rc, "lama_hip_blob_copy");
+                }
+            });
+            for (auto& x : xf) { xt_.shipped_particles += 1; xt_.shipped_bytes += x.bytes; }
+        }
+        xt_.ship = now_s() - ts0;
+        // local copies on every shard, then the imports into the slots whose source was remote
+        ts0 = now_s();
+        g.run([&](uint32_t r) {
+            PFSlam2D& sh = *g.shards[r];
+            sh.applyResample(idx);
+            bool any = false;
+            for (uint32_t i = sh.lo_; i < sh.hi_; ++i) {
+                const uint32_t sp = (uint32_t)idx[i];
+                if (owner(sp) == r) continue;
+                for (auto& x : xf)
+                    if (x.dst_shard == r && x.particle == sp) {
+                        const int32_t rc = sh.eng_->pf_import_particle(sh.ctx_, i - sh.lo_, (const uint8_t*)g.stage[r] + x.dst_off, x.bytes);
+                        if (rc) sh.fail(rc, "lama_hip_pf_import_particle");
+                        any = true;
+                        break;
+                    }
+            }
+            if (any) {                                           // the pose travels inside the blob: refresh the host mirror
+                std::vector<double> poses((size_t)(sh.hi_ - sh.lo_) * 4);
+                const int32_t rc = sh.eng_->pf_get_poses(sh.ctx_, poses.data());
+                if (rc) sh.fail(rc, "lama_hip_pf_get_poses");
+                for (uint32_t i = sh.lo_; i < sh.hi_; ++i)
+                    if (owner((uint32_t)idx[i]) != r) sh.particles_[i].pose.state = SE2d::fromArray(&poses[4 * (size_t)(i - sh.lo_)]);
+            }
+        });
+        xt_.import_ = now_s() - ts0;
+        // this object's particle list follows the same permutation (histories included), :561-570
+        std::vector<Particle> next(P);
+        for (uint32_t i = 0; i < P; ++i) { next[i] = particles_[(uint32_t)idx[i]]; }
+        particles_.swap(next);
+        if (summary) summary->time_resampling.push_back(now_s() - tr0);
+    }
+    t0 = now_s();
+    g.run([&](uint32_t r) { g.shards[r]->updateMaps(); if (summary) g.shards[r]->syncDevice(); });    // :289-302
+    mirrorShards(due[0] != 0);
+    if (summary) {
+        summary->time_mapping.push_back(now_s() - t0);
+        summary->time.push_back(now_s() - t_begin);
+        summary->timestamp.push_back(timestamp);
+        summary->memory.push_back((double)getMemoryUsage());
+    }
+    return true;
 }
 
 void PFSlam2D::fail(int32_t rc, const char* what) const
@@ -169,6 +450,7 @@ void PFSlam2D::uploadLocalPoses()
 
 PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
 {
+    if (group_) throw std::runtime_error("lama::PFSlam2D: the step-wise API belongs to single shards; an object with Options::gpus > 1 runs the whole step in update()");
     if (!surface || surface->points.empty()) throw std::runtime_error("lama::PFSlam2D::update: empty scan");
     t_begin_ = now_s();
     last_timestamp_ = timestamp;
@@ -293,6 +575,7 @@ void PFSlam2D::updateMaps()
 
 bool PFSlam2D::update(const PointCloudXYZ::Ptr& surface, const Pose2D& odometry, double timestamp)
 {
+    if (group_) return updateGroup(surface, odometry, timestamp);
     if (options_.shard_world != 1)
         throw std::runtime_error("lama::PFSlam2D::update: with shard_world > 1 drive the step-wise API (all-gather needed)");
     const Phase ph = updateBegin(surface, odometry, timestamp);
@@ -317,6 +600,7 @@ Pose2D PFSlam2D::getPose() const { return particles_[getBestParticleIdx()].pose;
 
 uint64_t PFSlam2D::getMemoryUsage() const
 {
+    if (group_) { uint64_t t = 0; for (auto& sh : group_->shards) t += sh->getMemoryUsage(); return t; }
     lama_hip_counters c;
     if (eng_->get_counters(ctx_, &c) != 0) return 0;
     // patch payloads in the reference's record sizes (Container::memory, src/sdm/container.cpp:92-95)
@@ -327,6 +611,7 @@ uint64_t PFSlam2D::getMemoryUsage(uint64_t& occmem, uint64_t& dmmem) const
 {
     occmem = 0; dmmem = 0;
     if (!has_first_scan) return 0;
+    if (group_) return group_->shards[0]->getMemoryUsage(occmem, dmmem);
     uint32_t nd = 0, no = 0;
     if (eng_->pf_map_patches(ctx_, 0, LAMA_HIP_MAP_DISTANCE, &nd) != 0 || eng_->pf_map_patches(ctx_, 0, LAMA_HIP_MAP_OCCUPANCY, &no) != 0) return 0;
     occmem = (uint64_t)options_.particles * no * 4096ull;
@@ -350,6 +635,7 @@ bool PFSlam2D::downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8
 {
     if (!has_first_scan) return false;
     const size_t b = getBestParticleIdx();
+    if (group_) return ownerOf((uint32_t)b)->downloadDistanceMap(ids, cells, masks);     // its replicated weights name the same best particle
     if (!ownsParticle((uint32_t)b)) return false;
     return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_DISTANCE, 10, ids, cells, masks);
 }
@@ -358,6 +644,7 @@ bool PFSlam2D::downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint
 {
     if (!has_first_scan) return false;
     const size_t b = getBestParticleIdx();
+    if (group_) return ownerOf((uint32_t)b)->downloadOccupancyMap(ids, cells, masks);
     if (!ownsParticle((uint32_t)b)) return false;
     return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_OCCUPANCY, 4, ids, cells, masks);
 }

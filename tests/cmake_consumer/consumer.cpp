@@ -150,6 +150,27 @@ int main()
         uint64_t occmem = 0, dmmem = 0;
         if (slam.getMemoryUsage(occmem, dmmem) != occmem + dmmem || occmem == 0 || dmmem == 0 || slam.getMemoryUsage() == 0) return 6;
         slam.saveOccImage("/tmp/lama_consumer_occ.png");
+        // several GPUs behind the same class (Options::gpus; the shards share the devices that are there): update() is the whole
+        // sharded step, the results do not depend on the number of shards
+        {
+            lama::PFSlam2D::Options mo = options;
+            mo.gpus = 2; mo.meas_sigma_gain = 0.01;
+            lama::PFSlam2D::Options so = mo;
+            so.gpus = 1;
+            lama::PFSlam2D multi(mo), single(so);
+            multi.setPrior(prior); single.setPrior(prior);
+            for (int k = 0; k < 4; ++k) {
+                const lama::Pose2D od = prior + lama::Pose2D(0.6 * k, 0.0, 0.02 * k);
+                const bool u1 = multi.update(cloud, od, (double)k), u2 = single.update(cloud, od, (double)k);
+                if (u1 != u2) return 30;
+            }
+            if (multi.numShards() != 2 || single.numShards() != 0) return 31;
+            const lama::Pose2D pm = multi.getPose(), ps = single.getPose();
+            if (pm.x() != ps.x() || pm.y() != ps.y() || pm.rotation() != ps.rotation()) return 32;
+            if (multi.getBestParticleIdx() != single.getBestParticleIdx() || multi.getNeff() != single.getNeff()) return 33;
+            std::printf("multi-GPU object: %zu shards, best particle %zu, pose (%.6f, %.6f, %.6f) == single shard\n", multi.numShards(),
+                        multi.getBestParticleIdx(), pm.x(), pm.y(), pm.rotation());
+        }
         // the online-SLAM class with its Summary (include/lama/slam2d.h:59-88)
         lama::Slam2D::Options s2o;
         s2o.create_summary = true;

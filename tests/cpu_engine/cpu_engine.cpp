@@ -5,6 +5,7 @@
 // gloo tests.  It lives under tests/, links the oracle, and is never shipped, built or loaded by the product:
 // it is only reachable through lama_host_set_engine_library(), which only the test-suite calls.
 // "Device buffers" of export/import are plain host pointers here.
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -59,7 +60,7 @@ void lama_hip_default_cfg(lama_hip_cfg* cfg)
     cfg->particles = 30; cfg->resolution = 0.05; cfg->patch_size = 32; cfg->l2_max = 0.5; cfg->meas_sigma = 0.05;
     cfg->max_iter = 100; cfg->window_patches = 128; cfg->dm_patch_capacity = 256; cfg->occ_patch_capacity = 256; cfg->queue_capacity = 32768;
 }
-int32_t lama_hip_device_count(int32_t* n) { if (n) *n = 0; return LAMA_HIP_OK; }
+int32_t lama_hip_device_count(int32_t* n) { if (n) *n = 1; return LAMA_HIP_OK; }      // one pretend device: contexts of a multi-shard object all land on it
 const char* lama_hip_last_error(const lama_hip_ctx* c) { return c ? c->error.c_str() : "null"; }
 
 int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg, lama_hip_ctx** out)
@@ -278,6 +279,11 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     c->dm[particle] = dm; c->occ[particle] = occ;
     return LAMA_HIP_OK;
 }
+
+// "device" staging buffers of the test double are host memory
+int32_t lama_hip_blob_alloc(lama_hip_ctx*, uint64_t bytes, void** buf) { *buf = std::malloc(bytes); return *buf ? LAMA_HIP_OK : LAMA_HIP_E_HIP; }
+int32_t lama_hip_blob_free(lama_hip_ctx*, void* buf) { std::free(buf); return LAMA_HIP_OK; }
+int32_t lama_hip_blob_copy(lama_hip_ctx*, void* dst, lama_hip_ctx*, const void* src, uint64_t bytes) { std::memcpy(dst, src, bytes); return LAMA_HIP_OK; }
 
 int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
 {

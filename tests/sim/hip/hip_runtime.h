@@ -83,6 +83,7 @@ inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); re
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void* d, int, const void* s, int, size_t n, hipStream_t = nullptr) { std::memmove(d, s, n); return hipSuccess; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr)
 {
     for (size_t r = 0; r < height; ++r) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);

@@ -69,3 +69,46 @@ def test_sharded_equals_single_process_oracle(world, P):
         for i, (dm, occ) in r["maps"].items():
             assert_maps_equal(dm, o.dm(i).dump(), DM_FIELDS, f"dm p{i}")
             assert_maps_equal(occ, o.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+
+
+@pytest.mark.parametrize("gpus,P", [(2, 10), (3, 11), (4, 9)])
+def test_multi_gpu_object_equals_single_process_oracle(gpus, P):
+    """lama::PFSlam2D with Options::gpus > 1 -- ONE object, a host thread and a device context per shard, the whole sharded step
+    inside update() (gather of the log-likelihoods, identical resampling decisions, export / peer copy / import of the clones that
+    cross a shard boundary) -- against the single-process oracle: bit-identical poses, weights, Neff, best particle and maps for
+    every number of shards.  The device C-ABI is bound to the oracle-backed test double here (host logic under test)."""
+    import iris_lama_amd.ffi as F
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpu_engine")], check=True)
+    steps, beams, gain = 10, 360, 0.01
+    pts, odom, _ = F.corridor_log(steps, beams)
+    F.set_engine_library(CPU_ENGINE)
+    try:
+        pf = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, gpus=gpus))
+        assert pf.engine_origin().endswith("liblama_cpu_engine.so")
+        o = O.PF(O.default_options(particles=P, seed=42, meas_sigma_gain=gain))
+        pf.set_prior(*odom[0]); o.set_prior(O.se2(*odom[0]))
+        shipped = 0
+        for k in range(steps + 1):
+            ok = o.update(pts[k], O.se2(*odom[k]), float(k))
+            assert bool(pf.update(pts[k], odom[k], float(k))) == ok
+            x = pf.exchange_times()
+            assert x["shards"] == gpus
+            shipped += x["shipped_particles"]
+            w, nw, ws = o.weights()
+            gw, gnw, gws = pf.weights()
+            assert np.array_equal(pf.poses(), o.poses()), k
+            assert np.array_equal(gw, w) and np.array_equal(gws, ws)
+            if k > 0:
+                assert pf.neff() == o.neff()
+            assert pf.best() == o.best()
+        assert o.num_resamples() > 0 and pf.num_resamples() == o.num_resamples()
+        assert shipped > 0, "the test must exercise cross-shard particle shipping"
+        for r in range(gpus):
+            ctx = pf.shard_context(r)
+            lo = (r * P + gpus - 1) // gpus
+            for j in range(ctx.P):
+                assert_maps_equal(ctx.download_map(j, F.MAP_DISTANCE), o.dm(lo + j).dump(), DM_FIELDS, f"dm p{lo + j}")
+                assert_maps_equal(ctx.download_map(j, F.MAP_OCCUPANCY), o.occ(lo + j).dump(), OCC_FIELDS, f"occ p{lo + j}")
+        pf.close()
+    finally:
+        F.set_engine_library(None)

@@ -404,6 +404,37 @@ def test_config3_split_partition_invariance(F, world):
     h.close()
 
 
+@pytest.mark.parametrize("gpus,P,gain", [(2, 30, 0.01), (3, 301, 0.01), (8, 3000, 0.0001)])
+def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
+    """lama::PFSlam2D with Options::gpus > 1 (one process, a host thread + device context per shard, here all on the one device of
+    the box): update() is the whole sharded step in C++ -- no Python, no process group.  With a gain that makes the filter resample
+    and clone across shard borders it must agree with the gpus = 1 object bit for bit: poses, weights, Neff, best particle,
+    resampling decisions and a device-side checksum of every particle's maps.  (8, 3000) is BASELINE configs[2]'s split."""
+    steps = 6 if P >= 3000 else 12
+    pts, odom, _ = F.corridor_log(steps, 1080)
+    a = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
+    b = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, gpus=gpus))
+    assert b.engine_origin().endswith("liblama_hip.so")
+    a.set_prior(*odom[0]); b.set_prior(*odom[0])
+    shipped = 0
+    for k in range(steps + 1):
+        assert a.update(pts[k], odom[k], float(k)) == b.update(pts[k], odom[k], float(k))
+        x = b.exchange_times()
+        assert x["shards"] == gpus
+        shipped += x["shipped_particles"]
+        assert np.array_equal(a.poses(), b.poses()), k
+        for u, v in zip(a.weights(), b.weights()):
+            assert np.array_equal(u, v), k
+        assert a.best() == b.best() and (k == 0 or a.neff() == b.neff())
+    assert a.num_resamples() > 0 and a.num_resamples() == b.num_resamples()
+    assert shipped > 0, "no clone crossed a shard border: the test would not exercise the shipping"
+    ca = a.hip_context()
+    for kind in (F.MAP_DISTANCE, F.MAP_OCCUPANCY):
+        assert np.array_equal(np.concatenate([b.shard_context(r).map_checksums(kind) for r in range(gpus)]), ca.map_checksums(kind))
+    assert np.array_equal(a.best_pose_xyr(), b.best_pose_xyr())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("seq_ray", [2, 1])
 @pytest.mark.parametrize("radius", [4.0, 8.0, 12.0, 20.0])
 def test_large_queue_paths_round_room(F, radius, seq_ray):
