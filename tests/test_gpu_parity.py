@@ -404,7 +404,7 @@ def test_config3_split_partition_invariance(F, world):
     h.close()
 
 
-@pytest.mark.parametrize("gpus,P,gain", [(2, 30, 0.01), (3, 301, 0.01), (8, 3000, 0.0001)])
+@pytest.mark.parametrize("gpus,P,gain", [(2, 30, 0.01), (3, 301, 0.001), (8, 3000, 0.0001)])
 def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
     """lama::PFSlam2D with Options::gpus > 1 (one process, a host thread + device context per shard, here all on the one device of
     the box): update() is the whole sharded step in C++ -- no Python, no process group.  With a gain that makes the filter resample
