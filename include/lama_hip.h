@@ -67,8 +67,11 @@ typedef struct lama_hip_cfg {
     double truncated_range;      /* Options::truncated_range                                      */
     int32_t device;              /* HIP device ordinal                                            */
     uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m; multiple of 8, <= 248) */
-    uint32_t dm_patch_capacity;  /* DM patches per particle to start with (default 256); the arenas are doubled whenever a
-                                    particle has filled more than half of one (the reference's maps are unbounded)   */
+    uint32_t dm_patch_capacity;  /* DM patches per particle to start with (default 256).  The reference's maps are unbounded; here the
+                                    arenas grow on demand: doubled whenever a particle has filled more than half of one, and a
+                                    map update that needs more patches than are free reports that BEFORE it modifies any cell
+                                    (its allocation phase comes first), upon which the arenas are doubled and the update is
+                                    run again.  LAMA_HIP_E_CAPACITY remains only for the hard limit of 32767 patches / particle */
     uint32_t occ_patch_capacity; /* occupancy patches per particle (default 256)                  */
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
     uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
     __shared__ CanonLds sh;
     const int p = first_particle + blockIdx.x;
     const int tid = threadIdx.x;
+    if (map_update_aborted(prm)) return;
     const size_t WW = (size_t)prm.W * prm.W;
     const CnMap M{prm, p, prm.dm_dir + (size_t)p * WW, prm.dm_sv + (size_t)p * prm.dm_cap * 1024,
                   prm.dm_obs + (size_t)p * prm.dm_cap * 1024, prm.dm_mask + (size_t)p * prm.dm_cap * 16};

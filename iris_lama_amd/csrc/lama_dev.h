@@ -45,6 +45,10 @@ constexpr int ERR_DM_CAP = 2;
 constexpr int ERR_OCC_CAP = 4;
 constexpr int ERR_QUEUE = 8;
 constexpr int ERR_NUMERIC = 16;
+// set by the first map-modifying kernel of an update when the ALLOCATION phase before it (hit cells, ray patches, the bound on the
+// distance-map patches the update can need) reported a capacity / window error: every modifying kernel then returns at once, the
+// maps are untouched, and the host can grow the arenas and run the update again (lama_hip.hip, recover_update)
+constexpr int ERR_CLEAN_ABORT = 32;
 
 struct Affine {            // rows 0..2 of [R | t]
     double R[3][3];
@@ -83,6 +87,8 @@ struct DevParams {
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
     uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused
+    uint32_t* guard;       // [P][2] upper bound of the distance-map patches the update may still allocate; block ticket (k_occ_reverse_dir)
+    uint32_t guard_r;      // patches around an occupancy patch the brushfire can reach: ceil((sqrt(max_sqdist) + 1) / 32)
     // occupancy cell policy / ray rule (cfg.occupancy_policy, cfg.ray_rule)
     uint32_t occ_policy, ray_rule;
     uint32_t strategy;     // 0 = GaussNewton, 1 = LevenbergMarquard (cfg.solver_strategy; Slam2D / Loc2D "lm")
@@ -292,6 +298,12 @@ __device__ inline int q_ox(uint64_t e) { return (int)((e >> 32) & 0xFFu) - 128; 
 __device__ inline int q_oy(uint64_t e) { return (int)((e >> 40) & 0xFFu) - 128; }
 __device__ inline int q_rx(uint64_t e) { return (int)(e & 0xFFFFu); }
 __device__ inline int q_ry(uint64_t e) { return (int)((e >> 16) & 0xFFFFu); }
+
+// True when the allocation phase of this map update failed (see ERR_CLEAN_ABORT): the calling kernel must not touch the maps.
+__device__ inline bool map_update_aborted(const DevParams& prm)
+{
+    return (__hip_atomic_load(prm.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (ERR_WINDOW | ERR_DM_CAP | ERR_OCC_CAP | ERR_CLEAN_ABORT)) != 0;
+}
 
 __device__ inline uint32_t pack_obs(int ox, int oy) { return ((uint32_t)(uint16_t)(int16_t)ox) | (((uint32_t)(uint16_t)(int16_t)oy) << 16); }
 __device__ inline int obs_x(uint32_t o) { return (int)(int16_t)(o & 0xFFFFu); }

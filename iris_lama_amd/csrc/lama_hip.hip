@@ -104,6 +104,11 @@ struct lama_hip_ctx {
     double scan_reach = 0.0;          // largest point distance of the resident scan (sensor frame, metres)
     uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
     uint32_t* d_scalar = nullptr;
+    uint32_t* d_guard = nullptr;      // [P][2] bound on the distance-map patches an update may still allocate + block ticket (k_occ_reverse_dir)
+    // what the last run_update_maps was asked to do: a cleanly aborted update (ERR_CLEAN_ABORT) is run again after the arenas grew
+    Affine last_mtf; uint32_t last_first = 0, last_count = 0;
+    bool last_guarded = false;        // the update went through the parallel ray-cast (its allocation phase precedes every modification)
+    int recover_depth = 0;
     bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
     PinVec<double> h_poses;           // host mirror of the particle poses (source of truth between calls)
     PinVec<int32_t> h_counts;         // host mirror of counts of the current set (refreshed after map updates)
@@ -171,6 +176,8 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     const ParticleSet& s = c->set[which];
     p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
+    p.guard = c->d_guard;
+    p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
@@ -215,6 +222,8 @@ void resolve_timers(lama_hip_ctx* c);
 // End of an API call: one stream synchronisation that brings back the device error word and, when asked, the
 // per-particle patch counts and statistics (a single host round trip per call).
 int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm = 0, uint32_t need_occ = 0);
+int32_t recover_update(lama_hip_ctx* c, int32_t e);
+int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count);
 
 int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false, bool err_in_results = false)
 {
@@ -233,6 +242,11 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
     resolve_timers(c);
     if (e != 0) {
         HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+        // The allocation phase of a map update ran out of patches before any cell was modified: grow and run the update again.
+        if (maps && (e & ERR_CLEAN_ABORT) && (e & (ERR_DM_CAP | ERR_OCC_CAP)) && !(e & ERR_WINDOW) && c->last_guarded && c->recover_depth < 10) {
+            const int32_t rr = recover_update(c, e);
+            if (rr != LAMA_HIP_E_CAPACITY) return rr;      // done (or another error); E_CAPACITY: the arenas are at their limit
+        }
         if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (raise cfg.window_patches)");
         if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
         if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
@@ -257,6 +271,8 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
 // whenever a particle has filled more than half of one (checked after every map update, when the counts are on the host and
 // the stream is idle): a new allocation, one strided device-to-device copy per plane, the other particle set restarts empty
 // (resample() rewrites it completely).  `cfg` then carries the new capacities.
+int32_t resize_arenas(lama_hip_ctx* c, uint32_t ndc, uint32_t noc);
+
 int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ)      // need_*: patches an incoming particle brings
 {
     uint32_t mdm = (need_dm + 1) / 2, mocc = (need_occ + 1) / 2;
@@ -265,6 +281,13 @@ int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ)      /
     uint32_t ndc = dc, noc = oc;
     while (2 * mdm > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
     while (2 * mocc > noc && noc < 32767u) noc = std::min<uint32_t>(2 * noc, 32767u);
+    return resize_arenas(c, ndc, noc);
+}
+
+// new capacities (>= the current ones) for both particle sets; the current set's contents are kept
+int32_t resize_arenas(lama_hip_ctx* c, uint32_t ndc, uint32_t noc)
+{
+    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
     if (ndc == dc && noc == oc) return LAMA_HIP_OK;
     const size_t P = c->P;
     auto regrow = [&](auto*& arr, size_t old_stride_b, size_t new_stride_b, bool keep) -> hipError_t {
@@ -298,6 +321,32 @@ int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ)      /
     c->cfg.dm_patch_capacity = ndc; c->cfg.occ_patch_capacity = noc;
     c->ctr.arena_growths += 1;
     return LAMA_HIP_OK;
+}
+
+// A map update whose allocation phase failed (ERR_CLEAN_ABORT: no cell was modified): clear what the phase left behind, double the
+// arena that ran out and run the same update again.  The reference's maps simply allocate (src/sdm/map.cpp:400-411).
+int32_t recover_update(lama_hip_ctx* c, int32_t e)
+{
+    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
+    const uint32_t ndc = (e & ERR_DM_CAP) ? std::min<uint32_t>(2 * dc, 32767u) : dc, noc = (e & ERR_OCC_CAP) ? std::min<uint32_t>(2 * oc, 32767u) : oc;
+    if (ndc == dc && noc == oc) return LAMA_HIP_E_CAPACITY;
+    ++c->recover_depth;
+    DevParams prm = make_params(c, c->cur);
+    const size_t WW = (size_t)c->W * c->W;
+    hipLaunchKernelGGL(k_update_cleanup, dim3(c->P, (unsigned)((WW + 255) / 256)), dim3(256), 0, c->stream, prm);
+    HIPCHK(c, hipMemsetAsync(c->d_occ_hit, 0, (size_t)c->P * oc * 128, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_act_count, 0, (size_t)c->P * 4, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_guard, 0, (size_t)c->P * 8, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
+    // the failed allocations may have raised the patch counts: the host mirror must hold them before the arenas are re-laid out
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    int32_t rc = resize_arenas(c, ndc, noc);
+    if (rc == LAMA_HIP_OK) rc = run_update_maps(c, c->last_n, c->last_mtf, c->last_first, c->last_count);
+    if (rc == LAMA_HIP_OK) rc = check_device_errors(c, true, false);
+    --c->recover_depth;
+    if (rc == LAMA_HIP_OK) c->ctr.arena_growths += 0;      // (resize_arenas counted the growth)
+    return rc;
 }
 
 // Collects the status of a map update queued by lama_hip_pf_update_maps_begin (one synchronisation); called at the start of
@@ -398,12 +447,38 @@ int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t 
     return LAMA_HIP_OK;
 }
 
+// allocation phase of a map update (ray records, hit cells' patches, the patches the rays cross, the bound on the distance-map patches
+// still to come): afterwards either every patch the update needs exists or an error bit is set and no map cell has been modified
+int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t n, uint32_t first, uint32_t count, int alloc_only)
+{
+    const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
+    if (need > c->rrec_cap) {
+        (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
+        HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
+        c->rrec_cap = need;
+    }
+    if (need_rev > c->rev_cap) {
+        (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
+        HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
+        c->rev_cap = need_rev;
+    }
+    hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
+                       c->d_rrec, c->d_rbbox, alloc_only);
+    const int rw_seg = count <= 64 ? 8 : 2;
+    hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
+    const uint32_t WW = c->W * c->W;
+    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+    return LAMA_HIP_OK;
+}
+
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
 {
     {
         const int32_t rcw = fit_window(c, mtf, first, count);
         if (rcw) return rcw;
     }
+    c->last_mtf = mtf; c->last_first = first; c->last_count = count;
     PinVec<double>& tfs = c->h_tfs;
     tfs.resize((size_t)c->P * 12);
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
@@ -432,28 +507,31 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         }
         c->visit_bound = (uint32_t)std::min<uint64_t>((uint64_t)c->visit_bound + n, 65535u);
         if (sequential) c->ctr.sequential_raycast_scans += 1; else c->ctr.parallel_raycast_scans += 1;
+        // The patches an update needs are allocated BEFORE any cell is modified, so that running out of patches is recoverable
+        // (grow + run again, recover_update).  The allocation walk uses the PF ray rule; LidarOdometry's rule / log-odds cells
+        // (one-particle contexts) get a conservative pre-grown arena instead: every patch a scan of this reach can touch.
+        c->last_guarded = c->cfg.ray_rule == 0;
+        if (!c->last_guarded) {
+            const double side = 32.0 * c->cfg.resolution;
+            const double rp = c->scan_reach / side + 2.5;
+            const uint32_t bound = (uint32_t)std::min(32767.0, std::ceil(3.1416 * rp * rp));
+            uint32_t mdm = 0, mocc = 0;
+            for (uint32_t p = 0; p < c->P; ++p) { mdm = std::max<uint32_t>(mdm, (uint32_t)c->h_counts[2 * p]); mocc = std::max<uint32_t>(mocc, (uint32_t)c->h_counts[2 * p + 1]); }
+            uint32_t ndc = c->cfg.dm_patch_capacity, noc = c->cfg.occ_patch_capacity;
+            while (mdm + bound > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
+            while (mocc + bound > noc && noc < 32767u) noc = std::min<uint32_t>(2 * noc, 32767u);
+            if (ndc != c->cfg.dm_patch_capacity || noc != c->cfg.occ_patch_capacity) {
+                const int32_t rg = resize_arenas(c, ndc, noc);
+                if (rg) return rg;
+                prm = make_params(c, c->cur);
+            }
+        }
         if (sequential) {
+            if (c->last_guarded) { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 1); if (ra) return ra; }
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             // patch-centric visits: a workgroup owns one occupancy patch of one particle, no global atomics on the counters
-            const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
-            if (need > c->rrec_cap) {
-                (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
-                HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
-                c->rrec_cap = need;
-            }
-            if (need_rev > c->rev_cap) {
-                (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
-                HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
-                c->rev_cap = need_rev;
-            }
-            hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
-                               c->d_rrec, c->d_rbbox);
-            const int rw_seg = count <= 64 ? 8 : 2;
-            hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
-            const uint32_t WW = c->W * c->W;
-            hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+            { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
                                (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
@@ -587,6 +665,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
     CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
+    CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
     CHK(hipMalloc(&c->d_occ_hit, P * oc * 128));     CHK(hipMemset(c->d_occ_hit, 0, P * oc * 128));
@@ -611,7 +690,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -659,6 +738,8 @@ int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const d
     if (rc) return rc;
     const Affine mtf = moving_tf(origin3, quat);
     rc = run_update_maps(c, n, mtf, 0, 1);                          // particle 0 only (pf_slam2d.cpp:204)
+    if (rc) return rc;
+    rc = check_device_errors(c, true, false);                        // (grows the arenas and repeats the update if it ran out of patches)
     if (rc) return rc;
     if (c->P > 1) {                                                 // copy-construct the others (:206-216)
         std::vector<int32_t> idx(c->P, 0);
@@ -1147,6 +1228,33 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
         for (uint32_t p = 0; p < c->P; ++p) { c->h_poses[4 * p] = 1.0; c->h_poses[4 * p + 1] = 0.0; c->h_poses[4 * p + 2] = 0.0; c->h_poses[4 * p + 3] = 0.0; }
         HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
         c->initialised = true;
+    }
+    {   // every distance-map patch this call can allocate lies within guard_r patches of a listed cell's patch: make room first
+        const int r = (int)(((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u);
+        std::vector<uint64_t> keys;
+        keys.reserve((size_t)n);
+        uint64_t last = ~0ull;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint64_t k = ((uint64_t)(cells_xy[2 * i + 1] >> 5) << 32) | (uint64_t)(cells_xy[2 * i] >> 5);
+            if (k != last) { keys.push_back(k); last = k; }
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        std::vector<uint64_t> dil;
+        dil.reserve(keys.size() * (size_t)((2 * r + 1) * (2 * r + 1)));
+        for (uint64_t k : keys)
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) dil.push_back((((k >> 32) + (uint64_t)(int64_t)dy) << 32) | (uint32_t)((uint32_t)k + (uint32_t)dx));
+        std::sort(dil.begin(), dil.end());
+        dil.erase(std::unique(dil.begin(), dil.end()), dil.end());
+        const uint64_t want = (uint64_t)c->h_counts[2 * particle] + dil.size();
+        uint32_t ndc = c->cfg.dm_patch_capacity;
+        while (want > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
+        if (ndc != c->cfg.dm_patch_capacity) {
+            const int32_t rg = resize_arenas(c, ndc, c->cfg.occ_patch_capacity);
+            if (rg) return rg;
+        }
+        c->last_guarded = false;
     }
     uint32_t* d_cells = nullptr;
     HIPCHK(c, hipMalloc(&d_cells, sizeof(uint32_t) * 2 * (size_t)n));

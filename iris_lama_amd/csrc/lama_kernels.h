@@ -658,6 +658,8 @@ __device__ inline int coop_slot(const DirCache& dc, int16_t* dir, int& count, in
 __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const double* __restrict__ pts, int n,
                                                        const double* __restrict__ tfs /*[P][12]*/, int first_particle)
 {
+    // (when the allocation phase that precedes this kernel failed, nothing is touched: the host grows the arenas and retries)
+    if (map_update_aborted(prm)) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(prm.err, ERR_CLEAN_ABORT); return; }
     __shared__ uint32_t lds_dc[2 * DC_SIZE];
     const int p = first_particle + blockIdx.x;
     const int lane = threadIdx.x;
@@ -1040,6 +1042,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     const int p = first_particle + blockIdx.x;
+    if (!RESUME && map_update_aborted(prm)) return;      // the update's allocation phase failed: nothing was queued, nothing is touched
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
@@ -1727,6 +1730,18 @@ __global__ __launch_bounds__(256) void k_shift_window(const int16_t* __restrict_
 // bound of the largest counter and, when bound + beams could reach 65536, refreshes it with this kernel and falls back to the
 // beam-sequential ray-cast for scans in which a wrap is possible.
 // ------------------------------------------------------------------------------------------------
+// After a cleanly aborted update (ERR_CLEAN_ABORT): directory entries the failed allocations left marked (-2 / -3) are absent again.
+__global__ __launch_bounds__(256) void k_update_cleanup(DevParams prm)
+{
+    const size_t WW = (size_t)prm.W * prm.W;
+    const size_t k = (size_t)blockIdx.y * 256 + threadIdx.x;
+    if (k >= WW) return;
+    int16_t* a = prm.occ_dir + (size_t)blockIdx.x * WW + k;
+    int16_t* b = prm.dm_dir + (size_t)blockIdx.x * WW + k;
+    if (*a < -1) *a = -1;
+    if (*b < -1) *b = -1;
+}
+
 __global__ __launch_bounds__(256) void k_occ_max_visited(DevParams prm, uint32_t* __restrict__ out)
 {
     const int p = blockIdx.x;

@@ -167,9 +167,11 @@ __device__ inline void act_append(const DevParams& prm, int p, uint64_t key)
 struct RayRec;
 __device__ inline void ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out);
 
+// alloc_only: the beam-sequential ray-cast (k_raycast) follows -- only the allocation phase is wanted here (ray records for the
+// allocation walk, the hit cells' patches); no hit bits, no active-visit list.
 __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* __restrict__ pts, int n,
                                                    const double* __restrict__ tfs, int first_particle,
-                                                   RayRec* __restrict__ rec_out = nullptr, uint64_t* __restrict__ bbox_out = nullptr)
+                                                   RayRec* __restrict__ rec_out = nullptr, uint64_t* __restrict__ bbox_out = nullptr, int alloc_only = 0)
 {
     const int p = first_particle + blockIdx.x;
     const int i = blockIdx.y * 256 + threadIdx.x;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     if (rec_out && live) ray_hits_record(prm, g, p, i, n, rec_out, bbox_out);
     if (live && g.steps < 0) atomicOr(prm.err, ERR_WINDOW);
     // ray cells of the scan (statistics): one atomic per wave, not one per beam on the particle's single counter
-    {
+    if (!alloc_only) {
         uint32_t st = (live && g.steps > 0) ? (uint32_t)g.steps : 0u;
         for (int off = 32; off > 0; off >>= 1) st += (uint32_t)__shfl_xor((int)st, off, 64);
         if (lane == 0 && st) atomicAdd((unsigned long long*)(prm.stats + 4 * p + 2), (unsigned long long)st);
@@ -195,7 +197,7 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
     int slot = -1;
     if (hit) slot = dir_get_or_alloc(prm.occ_dir + (size_t)p * WW, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
-    hit = hit && slot >= 0;
+    hit = hit && slot >= 0 && !alloc_only;
     if (hit) atomicOr((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), 1ull << (ci & 63));
     // the hits are order-sensitive visits (t = 0): appended with one counter update per wave (their order in the list is free,
     // k_ray_replay sorts)
@@ -246,6 +248,7 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
     __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
     const int p = first_particle + blockIdx.x;
     const uint32_t n = prm.act_count[p];
+    if (map_update_aborted(prm)) return;                      // the allocation phase failed: the maps stay untouched (ERR_CLEAN_ABORT)
     if (RESUME && prm.slow[p] == 0) return;
     if (n > prm.act_cap) return;                              // overflow already reported by act_append
     if (n > (uint32_t)SORT_CAP) {                             // hand over to the next (bigger) stage

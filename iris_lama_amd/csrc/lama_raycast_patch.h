@@ -128,26 +128,71 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
 }
 
 // arena slot -> directory position of every occupancy patch of the particle (rebuilt per scan: the directories change with
-// allocation, resampling, window shifts and patch deletion; 32 KB of directory per particle)
+// allocation, resampling, window shifts and patch deletion; 32 KB of directory per particle).
+//
+// The same pass closes the ALLOCATION phase of the update: every occupancy patch the scan touches exists by now (k_ray_hits,
+// k_ray_alloc_walk), and every distance-map patch the update can allocate -- first misses and hits in those patches, the
+// brushfire's neighbours at most sqrt(max_sqdist) + 1 cells from a changed obstacle -- lies within `guard_r` patches of an
+// occupancy patch.  The number of window positions without a distance-map patch but with an occupancy patch that close bounds what
+// is still to come; the last workgroup of the particle compares it with the free slots and raises ERR_DM_CAP BEFORE any map cell
+// is modified, so that the host can grow the arena and run the update again.
 __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle)
 {
     const int p = first_particle + blockIdx.x;
-    const uint32_t WW = prm.W * prm.W;                       // eight entries per thread (one 16-byte load where the run is whole and aligned)
+    const uint32_t W = prm.W, WW = W * W;                    // eight entries per thread: W is a multiple of 8, a run never leaves its row
     const uint32_t w0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
-    if (w0 >= WW) return;
-    const int16_t* d = prm.occ_dir + (size_t)p * WW + w0;
-    if (w0 + 8u <= WW && ((uintptr_t)d & 15u) == 0) {
-        const uint4 q = *reinterpret_cast<const uint4*>(d);
+    const int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
+    const int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
+    uint32_t need = 0;
+    if (w0 < WW) {
+        const int wy = (int)(w0 / W), x0 = (int)(w0 % W), r = (int)prm.guard_r;
+        // occupancy patches of my eight positions ...
+        const uint4 q = *reinterpret_cast<const uint4*>(occ_dir + w0);
         const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
+        uint32_t own = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-            if (slot >= 0) rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k);
+            if (slot >= 0) { rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k); own |= 1u << k; }
         }
-    } else {
-        for (uint32_t k = 0; k < 8u && w0 + k < WW; ++k) {
-            const int slot = d[k];
-            if (slot >= 0) rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + k);
+        // ... and, for those without a distance-map patch, whether an occupancy patch lies within r patches
+        const uint4 dq = *reinterpret_cast<const uint4*>(dm_dir + w0);
+        const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
+        uint32_t absent = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if ((int)(int16_t)((dw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) < 0) absent |= 1u << k;
+        if (absent) {
+            // presence of occupancy patches in columns x0 - r .. x0 + 7 + r of the rows wy - r .. wy + r, OR-ed over the rows (bit j = column x0 - r + j)
+            uint64_t near = 0;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = wy + dy;
+                if ((uint32_t)y >= W) continue;
+                const int16_t* row = occ_dir + (size_t)y * W;
+                if (dy == 0) near |= (uint64_t)own << r;
+                else {
+                    const uint4 rq = *reinterpret_cast<const uint4*>(row + x0);
+                    const uint32_t rw[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if ((int)(int16_t)((rw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) >= 0) near |= 1ull << (k + r);
+                }
+                for (int j = 0; j < r; ++j) {
+                    const int xl = x0 - r + j, xr = x0 + 8 + j;
+                    if (xl >= 0 && row[xl] >= 0) near |= 1ull << j;
+                    if ((uint32_t)xr < W && row[xr] >= 0) near |= 1ull << (8 + r + j);
+                }
+            }
+            const uint64_t span = (1ull << (2 * r + 1)) - 1ull;
+            for (int k = 0; k < 8; ++k) if (((absent >> k) & 1u) && ((near >> k) & span)) ++need;
+        }
+    }
+    if (need) atomicAdd(prm.guard + 2 * p, need);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(prm.guard + 2 * p + 1, 1u) == gridDim.y - 1) {        // the particle's last workgroup: every count is in
+            const uint32_t total = atomicExch(prm.guard + 2 * p, 0u);
+            prm.guard[2 * p + 1] = 0;
+            if ((uint64_t)prm.counts[2 * p] + total > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
         }
     }
 }
@@ -165,6 +210,8 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     __shared__ uint32_t list_n;
     const int p = first_particle + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // first map-modifying kernel of the update: nothing is touched when the allocation phase failed (the host grows and retries)
+    if (map_update_aborted(prm)) { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicOr(prm.err, ERR_CLEAN_ABORT); return; }
     const int count = prm.counts[2 * p + 1];
     const size_t WW = (size_t)prm.W * prm.W;
     uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;

@@ -39,6 +39,8 @@ inline wsim_tidx wsim_thread_idx() { const wsim::Block* b = wsim::blk(); const u
 #define __builtin_amdgcn_s_sleep(n) wsim::yield()
 #define __builtin_readcyclecounter() wsim::clock()
 #define __syncthreads() wsim::syncthreads()
+#define __threadfence() ((void)0)
+#define __threadfence_block() ((void)0)
 
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }

@@ -133,16 +133,20 @@ def test_parallel_raycast_with_truncation_and_mounted_sensor(F, monkeypatch):
         ctx.close()
 
 
-def test_patch_arenas_grow_on_demand(F):
+@pytest.mark.parametrize("cap,seq_ray", [(96, 0), (8, 0), (8, 1)])
+def test_patch_arenas_grow_on_demand(F, cap, seq_ray):
     """The reference's maps allocate patches without bound (src/sdm/map.cpp:400-411); the device arenas start small here and
-    must be doubled on the way -- maps stay bit-identical to the oracle's, the growth counter moves, resample() still works."""
+    must be doubled on the way -- maps stay bit-identical to the oracle's, the growth counter moves, resample() still works.
+    cap = 8: a SINGLE scan (the first one needs ~55 occupancy / ~70 distance-map patches) asks for far more than is free: the
+    update's allocation phase reports it before any cell is modified, the arenas are doubled and the update runs again
+    (both ray-cast forms)."""
     P, steps = 4, 14
     pts, odom, truth = F.corridor_log(steps, 1080)
     pf = O.PF(O.default_options(particles=P, seed=3))
     pose0 = O.se2(*odom[0])
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
-    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=96, occ_patch_capacity=96))
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=cap, occ_patch_capacity=cap, sequential_raycast=seq_ray))
     ctx.init(pts[0], pose0)
     rng = np.random.default_rng(11)
     for k in range(1, steps + 1):
@@ -161,7 +165,7 @@ def test_patch_arenas_grow_on_demand(F):
         assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
     c = ctx.counters()
     assert c["arena_growths"] >= 1, c
-    assert c["dm_patches"] > 96 * P / 2
+    assert c["dm_patches"] > cap * P / 2
     ctx.close()
 
 

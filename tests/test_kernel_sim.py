@@ -89,3 +89,12 @@ def test_hand_over_to_the_resume_stage_in_the_middle_of_an_update(Fsim_smallq, w
     """First-stage queues of 320 / 80 entries: particles outgrow them while the brushfire runs and are handed, state intact, to the
     resume stage (wave-pair and one-wave first stage)."""
     _run(Fsim_smallq, 2, 2, brushfire_waves=waves)
+
+
+@pytest.mark.parametrize("seq_ray", [0, 1])
+def test_update_that_runs_out_of_patches_is_repeated_after_growth(Fsim, seq_ray):
+    """Arenas of 8 patches against a first scan that needs ~55 / ~70: the allocation phase (hit cells, ray patches, the bound on the
+    distance-map patches still to come) fails BEFORE any cell is modified, the host doubles the arenas and runs the update again --
+    maps bit-exact, several growths, both ray-cast forms."""
+    c = _run(Fsim, 1, 1, dm_patch_capacity=8, occ_patch_capacity=8, sequential_raycast=seq_ray)
+    assert c["arena_growths"] >= 3, c
