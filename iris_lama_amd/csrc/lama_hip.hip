@@ -467,8 +467,7 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
                        c->d_rrec, c->d_rbbox, alloc_only);
     const int rw_seg = count <= 64 ? 8 : 2;
     hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
-    const uint32_t WW = c->W * c->W;
-    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count, (WW / 8 + 255) / 256 + 1), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
     return LAMA_HIP_OK;
 }
 

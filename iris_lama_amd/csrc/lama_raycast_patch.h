@@ -136,65 +136,51 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
 // occupancy patch.  The number of window positions without a distance-map patch but with an occupancy patch that close bounds what
 // is still to come; the last workgroup of the particle compares it with the free slots and raises ERR_DM_CAP BEFORE any map cell
 // is modified, so that the host can grow the arena and run the update again.
+constexpr int RD_MARK_WORDS = (248 * 248 + 31) / 32;       // one bit per window position (window_patches <= 248)
+
 __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle)
 {
+    __shared__ uint32_t mark[RD_MARK_WORDS];                  // window positions within guard_r patches of an occupancy patch
+    __shared__ uint32_t need_s;
     const int p = first_particle + blockIdx.x;
-    const uint32_t W = prm.W, WW = W * W;                    // eight entries per thread: W is a multiple of 8, a run never leaves its row
-    const uint32_t w0 = (blockIdx.y * 256u + threadIdx.x) * 8u;
+    const uint32_t W = prm.W, WW = W * W;
+    const int tid = threadIdx.x, r = (int)prm.guard_r;
     const int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
     const int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
-    uint32_t need = 0;
-    if (w0 < WW) {
-        const int wy = (int)(w0 / W), x0 = (int)(w0 % W), r = (int)prm.guard_r;
-        // occupancy patches of my eight positions ...
+    for (uint32_t i = tid; i < (WW + 31u) / 32u; i += 256u) mark[i] = 0;
+    if (tid == 0) need_s = 0;
+    __syncthreads();
+    // eight directory entries per thread and round (W is a multiple of 8: a run never leaves its row, 16-byte aligned)
+    for (uint32_t w0 = (uint32_t)tid * 8u; w0 < WW; w0 += 256u * 8u) {
         const uint4 q = *reinterpret_cast<const uint4*>(occ_dir + w0);
+        if ((q.x & q.y & q.z & q.w) == 0xFFFFFFFFu) continue;                 // eight absent patches (-1): the common case
         const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
-        uint32_t own = 0;
+        const int wy = (int)(w0 / W), x0 = (int)(w0 % W);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
-            if (slot >= 0) { rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k); own |= 1u << k; }
-        }
-        // ... and, for those without a distance-map patch, whether an occupancy patch lies within r patches
-        const uint4 dq = *reinterpret_cast<const uint4*>(dm_dir + w0);
-        const uint32_t dw[4] = {dq.x, dq.y, dq.z, dq.w};
-        uint32_t absent = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) if ((int)(int16_t)((dw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) < 0) absent |= 1u << k;
-        if (absent) {
-            // presence of occupancy patches in columns x0 - r .. x0 + 7 + r of the rows wy - r .. wy + r, OR-ed over the rows (bit j = column x0 - r + j)
-            uint64_t near = 0;
-            for (int dy = -r; dy <= r; ++dy) {
-                const int y = wy + dy;
-                if ((uint32_t)y >= W) continue;
-                const int16_t* row = occ_dir + (size_t)y * W;
-                if (dy == 0) near |= (uint64_t)own << r;
-                else {
-                    const uint4 rq = *reinterpret_cast<const uint4*>(row + x0);
-                    const uint32_t rw[4] = {rq.x, rq.y, rq.z, rq.w};
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if ((int)(int16_t)((rw[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu) >= 0) near |= 1ull << (k + r);
+            if (slot < 0) continue;
+            rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k);
+            for (int dy = -r; dy <= r; ++dy)
+                for (int dx = -r; dx <= r; ++dx) {
+                    const int x = x0 + k + dx, y = wy + dy;
+                    if ((uint32_t)x < W && (uint32_t)y < W) { const uint32_t n = (uint32_t)y * W + (uint32_t)x; atomicOr(&mark[n >> 5], 1u << (n & 31u)); }
                 }
-                for (int j = 0; j < r; ++j) {
-                    const int xl = x0 - r + j, xr = x0 + 8 + j;
-                    if (xl >= 0 && row[xl] >= 0) near |= 1ull << j;
-                    if ((uint32_t)xr < W && row[xr] >= 0) near |= 1ull << (8 + r + j);
-                }
-            }
-            const uint64_t span = (1ull << (2 * r + 1)) - 1ull;
-            for (int k = 0; k < 8; ++k) if (((absent >> k) & 1u) && ((near >> k) & span)) ++need;
         }
     }
-    if (need) atomicAdd(prm.guard + 2 * p, need);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        if (atomicAdd(prm.guard + 2 * p + 1, 1u) == gridDim.y - 1) {        // the particle's last workgroup: every count is in
-            const uint32_t total = atomicExch(prm.guard + 2 * p, 0u);
-            prm.guard[2 * p + 1] = 0;
-            if ((uint64_t)prm.counts[2 * p] + total > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
+    uint32_t need = 0;
+    for (uint32_t i = tid; i < (WW + 31u) / 32u; i += 256u) {
+        uint32_t m = mark[i];
+        while (m) {
+            const uint32_t n = i * 32u + (uint32_t)(__ffs((int)m) - 1);
+            if (dm_dir[n] < 0) ++need;
+            m &= m - 1u;
         }
     }
+    if (need) atomicAdd(&need_s, need);
+    __syncthreads();
+    if (tid == 0 && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
 }
 
 constexpr int RPT_CHUNK = 512;        // beams tested per round: the records of those that cross the patch wait in LDS

@@ -21,9 +21,9 @@ def q(db, sql):
 
 
 out = [f"# rocprofv3 summary ({tag})", "",
-       "Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu --sweep ''` "
+       f"Command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps {K} --warmup 5 --no-cpu --sweep ''` "
        "(MI355X, gfx950, ROCm 7.2).", "",
-       "## All dispatches (rocprofv3 `top_kernels` view: first scan + 5 warm-up + 30 timed updates)", "",
+       f"## All dispatches (rocprofv3 `top_kernels` view: first scan + 5 warm-up + {K} timed updates; bench.py runs the pass four times: value, kernel brackets, forced resampling, Summary)", "",
        "| kernel | calls | total ms | avg ms | % |", "|---|---:|---:|---:|---:|"]
 tdb = os.path.join(src, "trace", f"{tag}_results.db")
 for name, calls, tot, avg, pct in q(tdb, "select name,total_calls,total_duration,average,percentage from top_kernels"):
