@@ -82,6 +82,7 @@ struct lama_hip_ctx {
     uint32_t* d_qsizes = nullptr;
     uint64_t* d_dbg = nullptr;
     uint32_t* d_slow = nullptr;
+    uint32_t* d_slow_list = nullptr; uint32_t* d_slow_n = nullptr;      // hand-over list of the brushfire's first stage
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; size_t rrec_cap = 0;
@@ -178,7 +179,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
-    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
@@ -487,6 +488,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
+        (void)hipMemsetAsync(c->d_slow_n, 0, 2 * sizeof(uint32_t), c->stream);
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
@@ -534,12 +536,13 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
                                (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
+            const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
             if (count <= 512) {
-                hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
-                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(resume_grid), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
             } else {
-                hipLaunchKernelGGL((k_ray_replay<2048, 2048, false, RP_BLOCK_SMALL>), dim3(count), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
-                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_SMALL>), dim3(count), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_SMALL>), dim3(count), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
+                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_SMALL>), dim3(resume_grid), dim3(RP_BLOCK_SMALL), 0, c->stream, prm, (int)first);
             }
         }
         t.stop();
@@ -555,12 +558,13 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         const bool two_waves = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
         c->ctr.brushfire_mode = c->cfg.brushfire_mode;
         c->ctr.brushfire_waves = two_waves ? 2u : 1u;
+        const unsigned resume_grid = std::min<unsigned>(count, 256u);      // workgroups that walk the hand-over list (usually empty)
         if (two_waves) {
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
-            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         t.stop();
@@ -663,6 +667,8 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
+    CHK(hipMalloc(&c->d_slow_list, 2 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 2 * P * 4));
+    CHK(hipMalloc(&c->d_slow_n, 16));                CHK(hipMemset(c->d_slow_n, 0, 16));
     CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
     CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
@@ -689,7 +695,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -1263,6 +1269,7 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     // obstacles then updating in slices yields the same distance map only if no slice boundary matters -- so a list
     // longer than the queue is rejected instead)
     if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
+    HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
     hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);
     hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);

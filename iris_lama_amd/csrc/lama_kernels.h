@@ -1037,12 +1037,17 @@ __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
-__global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
+// hand particle p to the next stage: the first stage lists it for the resume stage, the resume stage flags it for k_brushfire_slow
+__device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool from_resume)
 {
-    __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
-    const int p = first_particle + blockIdx.x;
-    if (!RESUME && map_update_aborted(prm)) return;      // the update's allocation phase failed: nothing was queued, nothing is touched
+    prm.slow[p] = 1;
+    if (!from_resume) prm.slow_list[atomicAdd(prm.slow_n, 1u)] = (uint32_t)p;
+}
+
+// the brushfire of ONE particle by the calling workgroup (body of k_brushfire)
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+__device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, BfLds<LQ_LDS, RQ_LDS>& sh)
+{
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
@@ -1060,7 +1065,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     if (RESUME && handed == 0) return;
     if (tid == 0) prm.slow[p] = 0;
     if (nl == 0 && nr == 0) return;
-    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) prm.slow[p] = 1; return; }
+    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) bf_hand_over(prm, p, RESUME); return; }
 
     for (int k = tid; k < DC_SIZE; k += nthreads) sh.dc[k] = DC_EMPTY;
     for (uint32_t k = tid; k < nl; k += nthreads) sh.lower[k] = g_lower[k];
@@ -1427,15 +1432,14 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     #undef BF_LOAD_A
     #undef BF_LOAD_B
     #undef BF_POP_WITH_LOADS
-    if (spill) {      // hand the particle over, state intact, to k_brushfire_slow
-        __syncthreads();
+    if (spill) {      // hand the particle over, state intact, to the next stage (the helper wave is past its last LDS access: barrier F, or S0 when it never started)
         for (uint32_t k = lane; k < nl; k += UM_BLOCK) g_lower[k] = sh.lower[k];
         for (uint32_t k = lane; k < nr; k += UM_BLOCK) g_raise[k] = sh.raise[k];
     }
     if (lane == 0) {
         prm.counts[2 * p] = count;
         prm.stats[4 * p + 3] += processed;
-        if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; prm.slow[p] = 1; }
+        if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; bf_hand_over(prm, p, RESUME); }
 #ifdef LAMA_PROFILE_BF
 #ifdef LAMA_PROFILE_BF_MAIN
         for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];
@@ -1443,6 +1447,27 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         for (int k = 0; k < (TW ? 5 : 8); ++k) prm.dbg[8 * p + k] = prof[k];
 #endif
 #endif
+    }
+}
+
+// Stage structure: the first stage (RESUME = false) is a workgroup per particle with small LDS queues.  A particle whose queue does
+// not fit (e.g. the first scan) is handed over -- flag prm.slow[p] and an entry in the hand-over list -- to the resume stage with its
+// big LDS queues (84 KB: one workgroup per CU).  That stage is launched with a SMALL grid whose workgroups walk the list: with an
+// empty list (the normal case) it costs a few microseconds; launched with one workgroup per particle it cost 1.2 ms at 3000
+// particles for doing nothing (12 rounds of one 84 KB workgroup per CU, rocprofv3 r03).
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+__global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
+{
+    __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
+    if (!RESUME) {
+        if (map_update_aborted(prm)) return;             // the update's allocation phase failed: nothing was queued, nothing is touched
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, first_particle + (int)blockIdx.x, sh);
+        return;
+    }
+    const uint32_t n = prm.slow_n[0];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)prm.slow_list[i], sh);
+        __syncthreads();                                 // every wave is done with this particle's LDS before the next one is loaded
     }
 }
 

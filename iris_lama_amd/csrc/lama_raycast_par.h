@@ -32,6 +32,11 @@ namespace lama_dev {
 
 
 constexpr int RP_BLOCK_SMALL = 256, RP_BLOCK_LARGE = 1024;   // k_ray_replay workgroup: 1024 threads while the chip is not full
+#ifdef LAMA_TEST_SMALL_QUEUES       // tests/sim only: a first replay stage so small that a corridor scan is handed to the resume stage
+constexpr int RP_SORT_SMALL = 512;
+#else
+constexpr int RP_SORT_SMALL = 2048; // active visits the first replay stage sorts in LDS (the resume stage: 8192)
+#endif
 
 // ---- directory entry (int16 inside an aligned 32-bit word) with lock-free allocation ----------------------
 // -1 = absent, -2 = being allocated, -3 = allocation failed (arena full), >= 0 = slot (never changes afterwards)
@@ -242,17 +247,18 @@ struct ReplayLds {
 };
 
 // event: (seq << 32) | (is_add << 31) | cellkey
+// the ordered replay of ONE particle's active visits by the calling workgroup (body of k_ray_replay)
 template <int SORT_CAP, int EV_CAP, bool RESUME, int RP_BLOCK>
-__global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int first_particle)
+__device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const int p, ReplayLds<SORT_CAP, EV_CAP>& sh)
 {
-    __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
-    const int p = first_particle + blockIdx.x;
     const uint32_t n = prm.act_count[p];
-    if (map_update_aborted(prm)) return;                      // the allocation phase failed: the maps stay untouched (ERR_CLEAN_ABORT)
     if (RESUME && prm.slow[p] == 0) return;
     if (n > prm.act_cap) return;                              // overflow already reported by act_append
-    if (n > (uint32_t)SORT_CAP) {                             // hand over to the next (bigger) stage
-        if (threadIdx.x == 0) { if (RESUME) atomicOr(prm.err, ERR_QUEUE); else prm.slow[p] = 1; }
+    if (n > (uint32_t)SORT_CAP) {                             // hand over to the next (bigger) stage: flag + list entry
+        if (threadIdx.x == 0) {
+            if (RESUME) atomicOr(prm.err, ERR_QUEUE);
+            else { prm.slow[p] = 1; prm.slow_list[prm.P + atomicAdd(prm.slow_n + 1, 1u)] = (uint32_t)p; }
+        }
         return;
     }
     const size_t WW = (size_t)prm.W * prm.W;
@@ -363,6 +369,22 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
             prm.act_count[p] = 0;
             prm.slow[p] = 0;
         }
+    }
+}
+
+
+// First stage: a workgroup per particle.  Resume stage (128 KB of LDS: one workgroup per CU): a small grid walks the list of the
+// particles the first stage handed over -- usually none (see k_brushfire).
+template <int SORT_CAP, int EV_CAP, bool RESUME, int RP_BLOCK>
+__global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int first_particle)
+{
+    __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
+    if (map_update_aborted(prm)) return;                      // the allocation phase failed: the maps stay untouched (ERR_CLEAN_ABORT)
+    if (!RESUME) { ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, first_particle + (int)blockIdx.x, sh); return; }
+    const uint32_t n = prm.slow_n[1];
+    for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
+        ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, (int)prm.slow_list[prm.P + i], sh);
+        __syncthreads();
     }
 }
 
