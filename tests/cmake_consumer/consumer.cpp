@@ -154,7 +154,7 @@ int main()
         // sharded step, the results do not depend on the number of shards
         {
             lama::PFSlam2D::Options mo = options;
-            mo.gpus = 2; mo.meas_sigma_gain = 0.01;
+            mo.gpus = 2; mo.meas_sigma_gain = 0.01; mo.seed = 42;     // (seed 0 = random_device: two objects would draw different noise)
             lama::PFSlam2D::Options so = mo;
             so.gpus = 1;
             lama::PFSlam2D multi(mo), single(so);

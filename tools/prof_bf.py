@@ -6,7 +6,7 @@ import iris_lama_amd.ffi as F
 F.HIP_LIB = os.environ.get("LAMA_PROF_LIB", F.HIP_LIB)
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 pts, odom, truth = F.corridor_log(12, 1080)
-ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+ctx = F.HipContext(F.default_cfg(particles=P, profile=1, brushfire_waves=int(os.environ.get("LAMA_PROF_WAVES", "0"))))
 ctx.init(pts[0], F.pose_from_xyr(*odom[0]))
 L = F.hip_lib()
 L.lama_hip_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
