@@ -8,7 +8,7 @@ Ps = [int(a) for a in sys.argv[1:]] or [30, 300, 1000, 3000]
 pts, odom, truth = F.corridor_log(14, 1080)
 for P in Ps:
     row = []
-    for waves in (1, 2, 3):
+    for waves in (1, 2):
         ctx = F.HipContext(F.default_cfg(particles=P, profile=1, brushfire_waves=waves))
         ctx.init(pts[0], F.pose_from_xyr(*odom[0]))
         rng = np.random.default_rng(1)
