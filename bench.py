@@ -16,6 +16,7 @@ Launched as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) 
 (torch.distributed.run, rendezvous on 127.0.0.1).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -387,7 +388,8 @@ def main():
                    shipped_particles=int(sum(x["shipped_particles"] for x in xs)), shipped_bytes=int(sum(x["shipped_bytes"] for x in xs)),
                    exchange_ms={"gather_per_step": 1e3 * float(np.mean([x["gather_s"] for x in xs])),
                                 "ship_per_resample": 1e3 * float(np.mean([x["ship_s"] for x in ships])) if ships else 0.0,
-                                "import_per_resample": 1e3 * float(np.mean([x["import_s"] for x in ships])) if ships else 0.0},
+                                "import_per_resample": 1e3 * float(np.mean([x["import_s"] for x in ships])) if ships else 0.0,
+                                "local_copies_per_resample": 1e3 * float(np.mean([x["local_copies_s"] for x in ships])) if ships else 0.0},
                    devices=min(gpus, torch.cuda.device_count()))
         pf.close()
         return out
@@ -421,7 +423,13 @@ def main():
             cpp_multi = run_cpp_multi(P_total, world, K, W)
             cpp_multi_forced = run_cpp_multi(P_total, world, K, W, gain=forced_gain)
             assert cpp_multi_forced["resamples"] > 0 and cpp_multi_forced["shipped_particles"] > 0, cpp_multi_forced
-        torch.distributed.barrier()
+        # the other ranks wait on the rendezvous store (a blocking socket read): a process-group barrier here would park an RCCL
+        # kernel on every other GPU -- or spin on the host with gloo -- underneath the object that rank 0 is timing
+        store = torch.distributed.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("lama_bench_rank0_done", "1")
+        else:
+            store.wait(["lama_bench_rank0_done"], datetime.timedelta(seconds=1800))
 
     if rank != 0:
         return

@@ -196,7 +196,7 @@ public:
     const PFSlam2D* shard(size_t r) const;
     // seconds the last update() spent in the exchange steps of a multi-GPU object: gathering the log-likelihoods, shipping
     // particles between devices (export + peer copy), importing them
-    struct ExchangeTimes { double gather = 0, ship = 0, import_ = 0; uint64_t shipped_particles = 0, shipped_bytes = 0; };
+    struct ExchangeTimes { double gather = 0, ship = 0, import_ = 0, local_copies = 0, phase_begin = 0, phase_maps = 0; uint64_t shipped_particles = 0, shipped_bytes = 0; };
     const ExchangeTimes& exchangeTimes() const { return xt_; }
 
     // Exposed for tests (host logic, identical formulas to src/pf_slam2d.cpp:365-391,511-556)

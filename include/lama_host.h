@@ -78,8 +78,9 @@ int lama_pf_best(const lama_pf* pf);
 int lama_pf_best_pose_xyr(const lama_pf* pf, double* xyr);
 uint32_t lama_pf_num_resamples(const lama_pf* pf);
 /* Options::gpus > 1: seconds the last update spent gathering log-likelihoods / shipping (export + peer copy) / importing particles,
- * particles and bytes shipped between shards by it.  out5 = {gather_s, ship_s, import_s, particles, bytes}.  Returns the number of shards. */
-int lama_pf_exchange_times(const lama_pf* pf, double* out5);
+ * particles and bytes shipped between shards by it.  out8 = {gather_s, ship_s, import_s, particles, bytes, local_copies_s (resample copies
+ * inside a shard), phase_begin_s (motion + scan match on all shards), phase_maps_s (map-update launch + state mirror)}.  Returns the number of shards. */
+int lama_pf_exchange_times(const lama_pf* pf, double* out8);
 /* lama_hip_ctx* of shard r of a gpus > 1 object (NULL when out of range) */
 void* lama_pf_shard_context(const lama_pf* pf, uint32_t r);
 uint64_t lama_pf_memory_usage(const lama_pf* pf);

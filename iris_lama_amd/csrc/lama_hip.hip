@@ -105,6 +105,9 @@ struct lama_hip_ctx {
     double scan_reach = 0.0;          // largest point distance of the resident scan (sensor frame, metres)
     uint32_t visit_bound = 0;         // upper bound of the largest `visited` counter of any frequency cell (see k_occ_max_visited)
     uint32_t* d_scalar = nullptr;
+    // particle shipping: descriptors / gathered blob heads of one batch
+    lama_dev::ShipDesc* d_ship_desc = nullptr; uint8_t* d_ship_heads = nullptr; uint32_t ship_cap = 0;
+    PinVec<lama_dev::ShipDesc> h_ship_desc; PinVec<uint8_t> h_ship_heads;
     uint32_t* d_guard = nullptr;      // [P][2] bound on the distance-map patches an update may still allocate + block ticket (k_occ_reverse_dir)
     // what the last run_update_maps was asked to do: a cleanly aborted update (ERR_CLEAN_ABORT) is run again after the arenas grew
     Affine last_mtf; uint32_t last_first = 0, last_count = 0;
@@ -695,7 +698,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -1382,110 +1385,114 @@ static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
     return 32 + 32 + 2 * WW * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
 }
 
-int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* buf, uint64_t cap, uint64_t* bytes)
+// ---- particle shipping: all outgoing / incoming particles of a resample in one launch each (k_export_particles / k_import_particles)
+static int32_t upload_ship_desc(lama_hip_ctx* c, uint32_t n)
 {
-    if (!c || particle >= c->P) return LAMA_HIP_E_INVALID;
+    if (n > c->ship_cap) {
+        (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads);
+        c->d_ship_desc = nullptr; c->d_ship_heads = nullptr; c->ship_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(n, 64u);
+        HIPCHK(c, hipMalloc(&c->d_ship_desc, sizeof(ShipDesc) * cap));
+        HIPCHK(c, hipMalloc(&c->d_ship_heads, (size_t)BLOB_HEAD * cap));
+        c->ship_cap = cap;
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_ship_desc, c->h_ship_desc.data(), sizeof(ShipDesc) * n, hipMemcpyHostToDevice, c->stream));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_export_particles(lama_hip_ctx* c, uint32_t n, const uint32_t* particles, void* const* bufs, const uint64_t* caps, uint64_t* bytes)
+{
+    if (!c || (n && !particles)) return LAMA_HIP_E_INVALID;
     ENTER(c);
     if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "export before init");
-    const int dmc = c->h_counts[2 * particle], occ = c->h_counts[2 * particle + 1];
-    const uint64_t need = blob_bytes(c, dmc, occ);
-    if (bytes) *bytes = need;
-    if (!buf) return LAMA_HIP_OK;
-    if (cap < need) return fail(c, LAMA_HIP_E_INVALID, "export buffer too small");
+    bool sizes_only = bufs == nullptr;
+    for (uint32_t k = 0; k < n; ++k) {
+        if (particles[k] >= c->P) return LAMA_HIP_E_INVALID;
+        const uint64_t need = blob_bytes(c, c->h_counts[2 * particles[k]], c->h_counts[2 * particles[k] + 1]);
+        if (bytes) bytes[k] = need;
+        if (!sizes_only && (!bufs[k] || !caps || caps[k] < need)) return fail(c, LAMA_HIP_E_INVALID, "export buffer missing or too small");
+    }
+    if (sizes_only || n == 0) return LAMA_HIP_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const ParticleSet& s = c->set[c->cur];
-    const uint64_t WW = (uint64_t)c->W * c->W;
-    const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
-    uint8_t* o = (uint8_t*)buf;
-    // counts + the window origin (patches) the directories refer to + the exporter's upper bound of the `visited` counters (the
-    // importer's uint16 wrap guard must cover the cells this particle brings, see run_update_maps)
-    int32_t hdr[8] = {dmc, occ, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5), (int32_t)c->visit_bound, 0, 0, 0};
-    HIPCHK(c, hipMemcpyAsync(o, &c->h_poses[4 * particle], 32, hipMemcpyHostToDevice, c->stream)); o += 32;
-    HIPCHK(c, hipMemcpyAsync(o, hdr, 32, hipMemcpyHostToDevice, c->stream)); o += 32;
-    auto d2d = [&](const void* src, uint64_t nbytes) -> hipError_t {
-        hipError_t e = nbytes ? hipMemcpyAsync(o, src, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
-        o += nbytes;
-        return e;
-    };
-    HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
-    HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
-    HIPCHK(c, d2d(s.dm_sv + particle * dcap * 1024, (uint64_t)dmc * 2048));
-    HIPCHK(c, d2d(s.dm_obs + particle * dcap * 1024, (uint64_t)dmc * 4096));
-    HIPCHK(c, d2d(s.dm_mask + particle * dcap * 16, (uint64_t)dmc * 128));
-    HIPCHK(c, d2d(s.occ + particle * ocap * 1024, (uint64_t)occ * 4096));
-    HIPCHK(c, d2d(s.occ_mask + particle * ocap * 16, (uint64_t)occ * 128));
+    c->h_ship_desc.resize(n);
+    for (uint32_t k = 0; k < n; ++k) c->h_ship_desc[k] = ShipDesc{(uint8_t*)bufs[k], particles[k], 0, 0, 0};
+    const int32_t rc = upload_ship_desc(c, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_export_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(c->set[c->cur]), (const ShipDesc*)c->d_ship_desc,
+                       (const double*)c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5),
+                       (int32_t)c->visit_bound);
+    HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_export_particle(lama_hip_ctx* c, uint32_t particle, void* buf, uint64_t cap, uint64_t* bytes)
+{
+    if (!buf) return lama_hip_pf_export_particles(c, 1, &particle, nullptr, nullptr, bytes);
+    void* b1 = buf;
+    return lama_hip_pf_export_particles(c, 1, &particle, &b1, &cap, bytes);
+}
+
+int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t* particles, const void* const* bufs, const uint64_t* bytes)
+{
+    if (!c || (n && (!particles || !bufs || !bytes))) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "import before init");
+    if (n == 0) return LAMA_HIP_OK;
+    for (uint32_t k = 0; k < n; ++k) if (particles[k] >= c->P || !bufs[k] || bytes[k] < (uint64_t)BLOB_HEAD) return LAMA_HIP_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // 1. what is coming: the blobs' heads in one copy
+    c->h_ship_desc.resize(n);
+    for (uint32_t k = 0; k < n; ++k) c->h_ship_desc[k] = ShipDesc{(uint8_t*)const_cast<void*>(bufs[k]), particles[k], 0, 0, 0};
+    int32_t rc = upload_ship_desc(c, n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gather_blob_heads, dim3(n), dim3(64), 0, c->stream, (const ShipDesc*)c->d_ship_desc, n, c->d_ship_heads);
+    c->h_ship_heads.resize((size_t)BLOB_HEAD * n);
+    HIPCHK(c, hipMemcpyAsync(c->h_ship_heads.data(), c->d_ship_heads, (size_t)BLOB_HEAD * n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    uint32_t max_dm = 0, max_occ = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        int32_t hdr[8];
+        std::memcpy(hdr, c->h_ship_heads.data() + (size_t)BLOB_HEAD * k + 32, 32);
+        if (hdr[0] < 0 || hdr[1] < 0 || hdr[0] > 32767 || hdr[1] > 32767 || blob_bytes(c, hdr[0], hdr[1]) != bytes[k])
+            return fail(c, LAMA_HIP_E_INVALID, "particle blob does not match this context's geometry");
+        max_dm = std::max<uint32_t>(max_dm, (uint32_t)hdr[0]); max_occ = std::max<uint32_t>(max_occ, (uint32_t)hdr[1]);
+        // the sender's window may sit elsewhere (every shard follows its own particles): the kernel translates the directories
+        c->h_ship_desc[k].wdx = (int32_t)((int64_t)(c->wx0 >> 5) - (int64_t)hdr[2]);
+        c->h_ship_desc[k].wdy = (int32_t)((int64_t)(c->wy0 >> 5) - (int64_t)hdr[3]);
+    }
+    if (max_dm > c->cfg.dm_patch_capacity || max_occ > c->cfg.occ_patch_capacity) {      // the sender's arenas may have grown before ours
+        rc = grow_arenas(c, max_dm, max_occ);
+        if (rc) return rc;
+        if (max_dm > c->cfg.dm_patch_capacity || max_occ > c->cfg.occ_patch_capacity) return fail(c, LAMA_HIP_E_CAPACITY, "incoming particle exceeds the patch limit");
+    }
+    // 2. the copies
+    rc = upload_ship_desc(c, n);
+    if (rc) return rc;
+    ParticleSet& s = c->set[c->cur];
+    HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, s.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_import_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(s), (const ShipDesc*)c->d_ship_desc, (const int32_t*)c->d_oldcounts,
+                       c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, c->d_err);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // 3. host mirrors
+    for (uint32_t k = 0; k < n; ++k) {
+        const uint8_t* head = c->h_ship_heads.data() + (size_t)BLOB_HEAD * k;
+        int32_t hdr[8];
+        std::memcpy(hdr, head + 32, 32);
+        const uint32_t i = particles[k];
+        std::memcpy(&c->h_poses[4 * i], head, 32);
+        c->h_counts[2 * i] = hdr[0]; c->h_counts[2 * i + 1] = hdr[1];
+        // the wrap guard's bound must hold for the counters this particle brings (they may be far above this context's own)
+        c->visit_bound = std::max<uint32_t>(c->visit_bound, (uint32_t)std::min<int32_t>(std::max<int32_t>(hdr[4], 0), 65535));
+    }
     return LAMA_HIP_OK;
 }
 
 int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const void* buf, uint64_t bytes)
 {
-    if (!c || !buf || particle >= c->P || bytes < 64) return LAMA_HIP_E_INVALID;
-    ENTER(c);
-    if (!c->initialised) return fail(c, LAMA_HIP_E_STATE, "import before init");
-    HIPCHK(c, hipSetDevice(c->cfg.device));
-    const uint8_t* in = (const uint8_t*)buf;
-    double pose[4]; int32_t hdr[8];
-    {
-        uint8_t head[64];
-        HIPCHK(c, hipMemcpy(head, in, 64, hipMemcpyDeviceToHost));
-        std::memcpy(pose, head, 32); std::memcpy(hdr, head + 32, 32);
-    }
-    const int dmc = hdr[0], occ = hdr[1];
-    if (dmc >= 0 && occ >= 0 && dmc <= 32767 && occ <= 32767 &&
-        ((uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity)) {
-        const int32_t rcg = grow_arenas(c, (uint32_t)dmc, (uint32_t)occ);        // the sender's arenas may have grown before ours
-        if (rcg) return rcg;
-    }
-    if (dmc < 0 || occ < 0 || (uint32_t)dmc > c->cfg.dm_patch_capacity || (uint32_t)occ > c->cfg.occ_patch_capacity ||
-        blob_bytes(c, dmc, occ) != bytes)
-        return fail(c, LAMA_HIP_E_INVALID, "particle blob does not match this context's geometry");
-    ParticleSet& s = c->set[c->cur];
-    const uint64_t WW = (uint64_t)c->W * c->W;
-    const uint64_t dcap = c->cfg.dm_patch_capacity, ocap = c->cfg.occ_patch_capacity;
-    const int odm = c->h_counts[2 * particle], oocc = c->h_counts[2 * particle + 1];
-    in += 64;
-    auto d2d = [&](void* dst, uint64_t nbytes) -> hipError_t {
-        hipError_t e = nbytes ? hipMemcpyAsync(dst, in, nbytes, hipMemcpyDeviceToDevice, c->stream) : hipSuccess;
-        in += nbytes;
-        return e;
-    };
-    auto zero = [&](void* dst, uint64_t nbytes) -> hipError_t { return nbytes ? hipMemsetAsync(dst, 0, nbytes, c->stream) : hipSuccess; };
-    // the sender's window may sit elsewhere (every shard follows its own particles): translate the directories
-    const int wdx = (int)((int64_t)(c->wx0 >> 5) - (int64_t)hdr[2]), wdy = (int)((int64_t)(c->wy0 >> 5) - (int64_t)hdr[3]);
-    if (wdx == 0 && wdy == 0) {
-        HIPCHK(c, d2d(s.dm_dir + particle * WW, WW * 2));
-        HIPCHK(c, d2d(s.occ_dir + particle * WW, WW * 2));
-    } else {
-        const dim3 grid(1, (unsigned)((WW + 255) / 256));
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, reinterpret_cast<const int16_t*>(in), s.dm_dir + particle * WW, c->W, wdx, wdy, (size_t)0, (size_t)0, c->d_err);
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, reinterpret_cast<const int16_t*>(in + WW * 2), s.occ_dir + particle * WW, c->W, wdx, wdy, (size_t)0, (size_t)0, c->d_err);
-        HIPCHK(c, hipGetLastError());
-        in += 2 * WW * 2;
-    }
-    HIPCHK(c, d2d(s.dm_sv + particle * dcap * 1024, (uint64_t)dmc * 2048));
-    HIPCHK(c, d2d(s.dm_obs + particle * dcap * 1024, (uint64_t)dmc * 4096));
-    HIPCHK(c, d2d(s.dm_mask + particle * dcap * 16, (uint64_t)dmc * 128));
-    HIPCHK(c, d2d(s.occ + particle * ocap * 1024, (uint64_t)occ * 4096));
-    HIPCHK(c, d2d(s.occ_mask + particle * ocap * 16, (uint64_t)occ * 128));
-    if (odm > dmc) {   // keep "unused slot == zero"
-        HIPCHK(c, zero(s.dm_sv + (particle * dcap + dmc) * 1024, (uint64_t)(odm - dmc) * 2048));
-        HIPCHK(c, zero(s.dm_obs + (particle * dcap + dmc) * 1024, (uint64_t)(odm - dmc) * 4096));
-        HIPCHK(c, zero(s.dm_mask + (particle * dcap + dmc) * 16, (uint64_t)(odm - dmc) * 128));
-    }
-    if (oocc > occ) {
-        HIPCHK(c, zero(s.occ + (particle * ocap + occ) * 1024, (uint64_t)(oocc - occ) * 4096));
-        HIPCHK(c, zero(s.occ_mask + (particle * ocap + occ) * 16, (uint64_t)(oocc - occ) * 128));
-    }
-    int32_t cnt[2] = {dmc, occ};
-    HIPCHK(c, hipMemcpyAsync(s.counts + 2 * particle, cnt, 8, hipMemcpyHostToDevice, c->stream));
-    std::memcpy(&c->h_poses[4 * particle], pose, 32);
-    HIPCHK(c, hipMemcpyAsync(c->d_poses + 4 * particle, pose, 32, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->h_counts[2 * particle] = dmc; c->h_counts[2 * particle + 1] = occ;
-    // the wrap guard's bound must hold for the counters this particle brings (they may be far above this context's own)
-    c->visit_bound = std::max<uint32_t>(c->visit_bound, (uint32_t)std::min<int32_t>(std::max<int32_t>(hdr[4], 0), 65535));
-    return LAMA_HIP_OK;
+    const void* b1 = buf;
+    return lama_hip_pf_import_particles(c, 1, &particle, &b1, &bytes);
 }
 
 int32_t lama_hip_blob_alloc(lama_hip_ctx* c, uint64_t bytes, void** buf)

@@ -1819,4 +1819,112 @@ __global__ __launch_bounds__(256) void k_copy_particles(SetPtrs dst, SetPtrs src
     if (plane == 0 && threadIdx.x == 0) { dst.counts[2 * i] = sdm; dst.counts[2 * i + 1] = socc; }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Particle shipping (multi-GPU resampling): ALL outgoing / incoming particles of a resample in one launch each.
+// Blob layout (16-byte aligned): [pose 4 f64][header 8 i32: dm patches, occ patches, window origin x / y in patches, visited bound, 0, 0, 0]
+// [dm_dir W*W i16][occ_dir W*W i16][dm_sv n_dm x 2048 B][dm_obs n_dm x 4096 B][dm_mask n_dm x 128 B][occ n_occ x 4096 B][occ_mask n_occ x 128 B]
+// ------------------------------------------------------------------------------------------------
+constexpr int BLOB_HEAD = 64;
+struct ShipDesc {
+    uint8_t* blob;         // device buffer of the particle's blob
+    uint32_t particle;     // slot in this context
+    int32_t wdx, wdy;      // import: this context's window origin minus the blob's, in patches
+    uint32_t pad;
+};
+
+__device__ inline const uint4* blob_plane(const uint8_t* blob, int plane, size_t WW, int dmc, int occ, size_t& n16)
+{
+    size_t off = BLOB_HEAD;
+    const size_t sz[7] = {WW * 2, WW * 2, (size_t)dmc * 2048, (size_t)dmc * 4096, (size_t)dmc * 128, (size_t)occ * 4096, (size_t)occ * 128};
+    for (int k = 0; k < plane; ++k) off += sz[k];
+    n16 = sz[plane] / 16;
+    return reinterpret_cast<const uint4*>(blob + off);
+}
+
+// grid (n, 7 planes, SHIP_SPLIT): every plane of every outgoing particle in parallel
+constexpr int SHIP_SPLIT = 4;
+__global__ __launch_bounds__(256) void k_export_particles(SetPtrs src, const ShipDesc* __restrict__ desc, const double* __restrict__ poses, uint32_t W,
+                                                           uint32_t dm_cap, uint32_t occ_cap, int32_t wx_patch, int32_t wy_patch, int32_t visit_bound)
+{
+    const ShipDesc d = desc[blockIdx.x];
+    const int j = (int)d.particle, plane = blockIdx.y;
+    const int dmc = src.counts[2 * j], occ = src.counts[2 * j + 1];
+    const size_t WW = (size_t)W * W;
+    size_t n16;
+    uint4* out = const_cast<uint4*>(blob_plane(d.blob, plane, WW, dmc, occ, n16));
+    const uint4* in;
+    switch (plane) {
+    case 0: in = (const uint4*)(src.dm_dir + j * WW); break;
+    case 1: in = (const uint4*)(src.occ_dir + j * WW); break;
+    case 2: in = (const uint4*)(src.dm_sv + (size_t)j * dm_cap * 1024); break;
+    case 3: in = (const uint4*)(src.dm_obs + (size_t)j * dm_cap * 1024); break;
+    case 4: in = (const uint4*)(src.dm_mask + (size_t)j * dm_cap * 16); break;
+    case 5: in = (const uint4*)(src.occ + (size_t)j * occ_cap * 1024); break;
+    default: in = (const uint4*)(src.occ_mask + (size_t)j * occ_cap * 16); break;
+    }
+    for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
+    if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        double* hp = reinterpret_cast<double*>(d.blob);
+        for (int k = 0; k < 4; ++k) hp[k] = poses[4 * j + k];
+        int32_t* hh = reinterpret_cast<int32_t*>(d.blob + 32);
+        hh[0] = dmc; hh[1] = occ; hh[2] = wx_patch; hh[3] = wy_patch; hh[4] = visit_bound; hh[5] = hh[6] = hh[7] = 0;
+    }
+}
+
+// the 64-byte heads of n blobs gathered into one buffer (one device-to-host copy then tells the importer what is coming)
+__global__ __launch_bounds__(64) void k_gather_blob_heads(const ShipDesc* __restrict__ desc, uint32_t n, uint8_t* __restrict__ heads)
+{
+    const uint32_t j = blockIdx.x;
+    if (j >= n || threadIdx.x >= 16) return;
+    reinterpret_cast<uint32_t*>(heads + (size_t)j * BLOB_HEAD)[threadIdx.x] = reinterpret_cast<const uint32_t*>(desc[j].blob)[threadIdx.x];
+}
+
+// grid (n, 7 planes, SHIP_SPLIT).  The directories are translated when the sender's window sits elsewhere (see k_shift_window); slots the
+// destination used before and the incoming particle does not are zeroed ("unused slot == zero"); old_counts = the destination's counts
+// before the import.
+__global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const ShipDesc* __restrict__ desc, const int32_t* __restrict__ old_counts, double* __restrict__ poses,
+                                                           uint32_t W, uint32_t dm_cap, uint32_t occ_cap, int32_t* err)
+{
+    const ShipDesc d = desc[blockIdx.x];
+    const int i = (int)d.particle, plane = blockIdx.y;
+    const int32_t* hh = reinterpret_cast<const int32_t*>(d.blob + 32);
+    const int dmc = hh[0], occ = hh[1];
+    const int odm = old_counts[2 * i], oocc = old_counts[2 * i + 1];
+    const size_t WW = (size_t)W * W;
+    size_t n16;
+    const uint4* in = blob_plane(d.blob, plane, WW, dmc, occ, n16);
+    uint4* out; size_t nzero = 0;
+    switch (plane) {
+    case 0: out = (uint4*)(dst.dm_dir + i * WW); break;
+    case 1: out = (uint4*)(dst.occ_dir + i * WW); break;
+    case 2: out = (uint4*)(dst.dm_sv + (size_t)i * dm_cap * 1024); nzero = odm > dmc ? (size_t)(odm - dmc) * 2048 / 16 : 0; break;
+    case 3: out = (uint4*)(dst.dm_obs + (size_t)i * dm_cap * 1024); nzero = odm > dmc ? (size_t)(odm - dmc) * 4096 / 16 : 0; break;
+    case 4: out = (uint4*)(dst.dm_mask + (size_t)i * dm_cap * 16); nzero = odm > dmc ? (size_t)(odm - dmc) * 128 / 16 : 0; break;
+    case 5: out = (uint4*)(dst.occ + (size_t)i * occ_cap * 1024); nzero = oocc > occ ? (size_t)(oocc - occ) * 4096 / 16 : 0; break;
+    default: out = (uint4*)(dst.occ_mask + (size_t)i * occ_cap * 16); nzero = oocc > occ ? (size_t)(oocc - occ) * 128 / 16 : 0; break;
+    }
+    if (plane < 2 && (d.wdx != 0 || d.wdy != 0)) {
+        const int16_t* sdir = reinterpret_cast<const int16_t*>(in);
+        int16_t* ddir = reinterpret_cast<int16_t*>(out);
+        for (size_t idx = (size_t)blockIdx.z * 256 + threadIdx.x; idx < WW; idx += 256 * SHIP_SPLIT) {
+            const int wy = (int)(idx / W), wx = (int)(idx % W);
+            const int sx = wx + d.wdx, sy = wy + d.wdy;
+            const bool inw = sx >= 0 && sy >= 0 && sx < (int)W && sy < (int)W;
+            ddir[idx] = inw ? sdir[(size_t)sy * W + (size_t)sx] : (int16_t)-1;
+            const int tx = wx - d.wdx, ty = wy - d.wdy;          // where the sender's entry (wx, wy) ends up
+            if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && sdir[idx] >= 0) atomicOr(err, ERR_WINDOW);
+        }
+    } else {
+        for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < nzero; k += 256 * SHIP_SPLIT) out[n16 + k] = z;
+    if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        dst.counts[2 * i] = dmc; dst.counts[2 * i + 1] = occ;
+        const double* hp = reinterpret_cast<const double*>(d.blob);
+        for (int k = 0; k < 4; ++k) poses[4 * i + k] = hp[k];
+    }
+}
+
 } // namespace lama_dev

@@ -112,7 +112,9 @@ class ShardedPF:
 
     # ------------------------------------------------------------------ resample with cross-shard clones
     def _ship(self, idx):
-        """Returns {local slot (global index): blob tensor} for slots whose source lives on another shard."""
+        """Moves every particle that is cloned across shards: ONE export launch on the source rank, ONE message per
+        (source rank, destination rank) pair, and -- in update() -- ONE import launch on the destination rank.
+        Returns (slots, addresses, sizes) of the local slots whose source lives on another shard, or None."""
         P, G = self.P, self.world
         ia = np.asarray(idx, dtype=np.int64)
         src_owner = (ia * G) // P
@@ -120,40 +122,55 @@ class ShardedPF:
         cross = np.nonzero(src_owner != dst_owner)[0]
         transfers = sorted({(int(src_owner[i]), int(dst_owner[i]), int(ia[i])) for i in cross})
         if not transfers:
-            return {}
+            return None
         ctx = self.pf.hip_context()
-        sizes = torch.zeros(len(transfers), dtype=torch.int64, device=self.device)
-        for t, (sr, dr, sp) in enumerate(transfers):
-            if sr == self.rank:
-                sizes[t] = ctx.export_bytes(sp - self.pf.lo)
+        tr = np.asarray(transfers, dtype=np.int64)
+        mine = np.nonzero(tr[:, 0] == self.rank)[0]
+        sizes = torch.zeros(len(transfers), dtype=torch.int64)
+        if len(mine):
+            sizes[torch.from_numpy(mine)] = torch.from_numpy(ctx.export_sizes(tr[mine, 2] - self.pf.lo).astype(np.int64))
+        sizes = sizes.to(self.device)
         dist.all_reduce(sizes, op=dist.ReduceOp.SUM)
-        sizes = sizes.cpu().tolist()
-        ops, bufs = [], {}
+        sizes = sizes.cpu().numpy()
+        # blobs of one (source, destination) pair lie back to back (256-byte aligned) in one message
+        offs = np.zeros(len(transfers), dtype=np.int64)
+        pair_bytes = {}
         for t, (sr, dr, sp) in enumerate(transfers):
-            if sr == self.rank:
-                buf = torch.empty(sizes[t], dtype=torch.uint8, device=self.blob_device)
-                ctx.export_particle(sp - self.pf.lo, buf.data_ptr(), sizes[t])
-                buf = buf.to(self.device)
-                ops.append(dist.P2POp(dist.isend, buf, dr))
-                bufs[("s", t)] = buf
-                self.shipped_particles += 1
-                self.shipped_bytes += sizes[t]
-            elif dr == self.rank:
-                buf = torch.empty(sizes[t], dtype=torch.uint8, device=self.device)
-                ops.append(dist.P2POp(dist.irecv, buf, sr))
-                bufs[(sr, sp)] = buf
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
+            o = pair_bytes.get((sr, dr), 0)
+            offs[t] = o
+            pair_bytes[(sr, dr)] = o + ((int(sizes[t]) + 255) & ~255)
+        msgs, ops = {}, []
+        for (sr, dr), nb in sorted(pair_bytes.items()):
+            if sr == self.rank or dr == self.rank:
+                msgs[(sr, dr)] = torch.empty(nb, dtype=torch.uint8, device=self.blob_device)
+        if len(mine):
+            ptrs = [msgs[(self.rank, int(tr[t, 1]))].data_ptr() + int(offs[t]) for t in mine]
+            ctx.export_particles(tr[mine, 2] - self.pf.lo, ptrs, sizes[mine])
+            self.shipped_particles += len(mine)
+            self.shipped_bytes += int(sizes[mine].sum())
+        for (sr, dr), buf in msgs.items():
+            if buf.device != self.device:
+                buf = msgs[(sr, dr)] = buf.to(self.device)
+            ops.append(dist.P2POp(dist.isend if sr == self.rank else dist.irecv, buf, dr if sr == self.rank else sr))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        incoming = {}
+        where = {(sr, sp): t for t, (sr, dr, sp) in enumerate(transfers) if dr == self.rank}
+        slots, addrs, nbytes, keep = [], [], [], []
         for i in range(self.pf.lo, self.pf.hi):
             src = int(idx[i])
             sr = owner_of(src, P, G)
             if sr != self.rank:
-                incoming[i] = bufs[(sr, src)].to(self.blob_device)
-        return incoming
+                t = where[(sr, src)]
+                buf = msgs[(sr, self.rank)]
+                if buf.device != self.blob_device:
+                    buf = msgs[(sr, self.rank)] = buf.to(self.blob_device)
+                slots.append(i)
+                addrs.append(buf.data_ptr() + int(offs[t]))
+                nbytes.append(int(sizes[t]))
+        keep = [b for (sr, dr), b in msgs.items() if dr == self.rank]       # the buffers stay alive until the import ran
+        return (slots, addrs, nbytes, keep) if slots else None
 
     # ------------------------------------------------------------------ PFSlam2D::update, sharded
     def update(self, pts, odom_xyr, ts=0.0, origin=None, quat=None):
@@ -178,12 +195,11 @@ class ShardedPF:
             self.pf.apply_resample(idx)
             if incoming:
                 t2 = time.perf_counter()
+                slots, addrs, nbytes, _keep = incoming
                 ctx = self.pf.hip_context()
-                for i, buf in incoming.items():
-                    ctx.import_particle(i - self.pf.lo, buf.data_ptr(), buf.numel())
-                    # the host mirror of the pose travels inside the blob; refresh it
-                poses = ctx.get_poses()
-                for i in incoming:
+                ctx.import_particles(np.asarray(slots) - self.pf.lo, addrs, nbytes)
+                poses = ctx.get_poses()                       # the pose travels inside the blob: refresh the host mirror
+                for i in slots:
                     self.pf.set_pose(i, poses[i - self.pf.lo])
                 self.t_import += time.perf_counter() - t2
         self.pf.update_maps()

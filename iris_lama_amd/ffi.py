@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
     "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
     "lama_hip_pf_map_checksums", "lama_hip_match_eval", "lama_hip_match_cell_distances", "lama_hip_match_solve_with",
-    "lama_hip_blob_alloc", "lama_hip_blob_free", "lama_hip_blob_copy",
+    "lama_hip_blob_alloc", "lama_hip_blob_free", "lama_hip_blob_copy", "lama_hip_pf_export_particles", "lama_hip_pf_import_particles",
 ]
 
 _hip = None
@@ -104,6 +104,8 @@ def _bind_hip(L):
         L.lama_hip_match_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp]
         L.lama_hip_pf_export_particle.argtypes = [vp, u32, vp, u64, vp]
         L.lama_hip_pf_import_particle.argtypes = [vp, u32, vp, u64]
+        L.lama_hip_pf_export_particles.argtypes = [vp, u32, vp, vp, vp, vp]
+        L.lama_hip_pf_import_particles.argtypes = [vp, u32, vp, vp, vp]
         L.lama_hip_get_counters.argtypes = [vp, vp]
         L.lama_hip_reset_counters.argtypes = [vp]
         L.lama_hip_map_add_obstacles.argtypes = [vp, u32, vp, u32]
@@ -312,6 +314,28 @@ class HipContext:
 
     def import_particle(self, particle, device_ptr, nbytes):
         self._chk(self.L.lama_hip_pf_import_particle(self.h, particle, C.c_void_p(device_ptr), nbytes))
+
+    def export_sizes(self, particles):
+        """Blob sizes of a batch of particles (host mirror of the patch counts: no device work)."""
+        pa = np.ascontiguousarray(particles, dtype=np.uint32)
+        out = np.zeros(len(pa), dtype=np.uint64)
+        self._chk(self.L.lama_hip_pf_export_particles(self.h, len(pa), _p(pa), None, None, _p(out)))
+        return out
+
+    def export_particles(self, particles, device_ptrs, caps):
+        """All outgoing particles of a resample in one launch (device_ptrs: one buffer address per particle)."""
+        pa = np.ascontiguousarray(particles, dtype=np.uint32)
+        ptrs = np.ascontiguousarray(device_ptrs, dtype=np.uint64)
+        cp = np.ascontiguousarray(caps, dtype=np.uint64)
+        out = np.zeros(len(pa), dtype=np.uint64)
+        self._chk(self.L.lama_hip_pf_export_particles(self.h, len(pa), _p(pa), _p(ptrs), _p(cp), _p(out)))
+        return out
+
+    def import_particles(self, particles, device_ptrs, nbytes):
+        pa = np.ascontiguousarray(particles, dtype=np.uint32)
+        ptrs = np.ascontiguousarray(device_ptrs, dtype=np.uint64)
+        nb = np.ascontiguousarray(nbytes, dtype=np.uint64)
+        self._chk(self.L.lama_hip_pf_import_particles(self.h, len(pa), _p(pa), _p(ptrs), _p(nb)))
 
     def counters(self):
         c = HipCounters()
@@ -583,9 +607,10 @@ class PFSlam2D:
 
     def exchange_times(self):
         """Options::gpus > 1: what the last update spent exchanging (seconds) and shipped between shards."""
-        t = np.zeros(5)
+        t = np.zeros(8)
         n = self.L.lama_pf_exchange_times(self.h, _p(t))
-        return dict(shards=n, gather_s=t[0], ship_s=t[1], import_s=t[2], shipped_particles=int(t[3]), shipped_bytes=int(t[4]))
+        return dict(shards=n, gather_s=t[0], ship_s=t[1], import_s=t[2], shipped_particles=int(t[3]), shipped_bytes=int(t[4]),
+                    local_copies_s=t[5], phase_begin_s=t[6], phase_maps_s=t[7])
 
     def shard_context(self, r):
         """HipContext view of shard r's device context (Options::gpus > 1), None when out of range."""

@@ -68,6 +68,8 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(match_eval, lama_hip_match_eval)
     BIND(match_cell_distances, lama_hip_match_cell_distances)
     BIND(match_solve_with, lama_hip_match_solve_with)
+    BIND(pf_export_particles, lama_hip_pf_export_particles)
+    BIND(pf_import_particles, lama_hip_pf_import_particles)
     BIND(blob_alloc, lama_hip_blob_alloc)
     BIND(blob_free, lama_hip_blob_free)
     BIND(blob_copy, lama_hip_blob_copy)

@@ -42,6 +42,8 @@ struct HipEngine {
     decltype(&lama_hip_match_eval) match_eval = nullptr;
     decltype(&lama_hip_match_cell_distances) match_cell_distances = nullptr;
     decltype(&lama_hip_match_solve_with) match_solve_with = nullptr;
+    decltype(&lama_hip_pf_export_particles) pf_export_particles = nullptr;
+    decltype(&lama_hip_pf_import_particles) pf_import_particles = nullptr;
     decltype(&lama_hip_blob_alloc) blob_alloc = nullptr;
     decltype(&lama_hip_blob_free) blob_free = nullptr;
     decltype(&lama_hip_blob_copy) blob_copy = nullptr;

@@ -122,10 +122,11 @@ lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
 }
 
 void lama_pf_destroy(lama_pf* pf) { delete pf; }
-int lama_pf_exchange_times(const lama_pf* h, double* out5)
+int lama_pf_exchange_times(const lama_pf* h, double* out8)
 {
     const PFSlam2D::ExchangeTimes& x = h->pf->exchangeTimes();
-    out5[0] = x.gather; out5[1] = x.ship; out5[2] = x.import_; out5[3] = (double)x.shipped_particles; out5[4] = (double)x.shipped_bytes;
+    out8[0] = x.gather; out8[1] = x.ship; out8[2] = x.import_; out8[3] = (double)x.shipped_particles; out8[4] = (double)x.shipped_bytes;
+    out8[5] = x.local_copies; out8[6] = x.phase_begin; out8[7] = x.phase_maps;
     return (int)h->pf->numShards();
 }
 void* lama_pf_shard_context(const lama_pf* h, uint32_t r)

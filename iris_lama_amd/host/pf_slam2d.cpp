@@ -14,6 +14,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <thread>
+#include <tuple>
 
 #include "hip_engine.hpp"
 
@@ -228,6 +229,7 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
     std::vector<Phase> ph(G, kNoUpdate);
     g.run([&](uint32_t r) { ph[r] = g.shards[r]->updateBegin(surface, odometry, timestamp); });
     const double t_solved = now_s();
+    xt_.phase_begin = t_solved - t_begin;
     if (first) {                                                 // :185-228
         has_first_scan = true;
         timestamps_.push_back(timestamp);
@@ -277,6 +279,10 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
                 seen[{ds, sp}] = true;
                 xf.push_back(Xfer{ss, ds, sp, 0, 0, 0});
             }
+            // (destination, source, particle) order: the blobs of one (source, destination) pair lie back to back in the source's
+            // staging buffer AND in the destination's, so a pair moves with one copy
+            std::sort(xf.begin(), xf.end(), [](const Xfer& a, const Xfer& b) {
+                return std::tie(a.dst_shard, a.src_shard, a.particle) < std::tie(b.dst_shard, b.src_shard, b.particle); });
         }
         double ts0 = now_s();
         if (!xf.empty()) {
@@ -289,26 +295,32 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
                 x.src_off = out_bytes[x.src_shard]; out_bytes[x.src_shard] += (x.bytes + 255) & ~255ull;
             }
             for (auto& x : xf) { x.dst_off = out_bytes[x.dst_shard] + in_bytes[x.dst_shard]; in_bytes[x.dst_shard] += (x.bytes + 255) & ~255ull; }
-            // every source shard exports its outgoing particles into its buffer (concurrently) ...
+            // every source shard exports its outgoing particles into its buffer: ONE launch per shard, all shards concurrently ...
             g.run([&](uint32_t r) {
                 if (out_bytes[r] + in_bytes[r] == 0) return;
                 g.reserve_stage(r, out_bytes[r] + in_bytes[r]);
                 PFSlam2D& sh = *g.shards[r];
-                for (auto& x : xf) {
-                    if (x.src_shard != r) continue;
-                    uint64_t nb = 0;
-                    const int32_t rc = sh.eng_->pf_export_particle(sh.ctx_, x.particle - sh.lo_, (uint8_t*)g.stage[r] + x.src_off, x.bytes, &nb);
-                    if (rc) sh.fail(rc, "lama_hip_pf_export_particle");
-                }
+                std::vector<uint32_t> parts; std::vector<void*> bufs; std::vector<uint64_t> caps;
+                for (auto& x : xf)
+                    if (x.src_shard == r) { parts.push_back(x.particle - sh.lo_); bufs.push_back((uint8_t*)g.stage[r] + x.src_off); caps.push_back(x.bytes); }
+                if (parts.empty()) return;
+                const int32_t rc = sh.eng_->pf_export_particles(sh.ctx_, (uint32_t)parts.size(), parts.data(), bufs.data(), caps.data(), nullptr);
+                if (rc) sh.fail(rc, "lama_hip_pf_export_particles");
             });
-            // ... and every destination shard pulls its blobs GPU to GPU (hipMemcpyPeerAsync over xGMI between different devices)
+            // ... and every destination shard pulls each source's run of blobs with ONE GPU-to-GPU copy (hipMemcpyPeerAsync over
+            // xGMI between different devices)
             g.run([&](uint32_t r) {
                 PFSlam2D& dsh = *g.shards[r];
-                for (auto& x : xf) {
-                    if (x.dst_shard != r) continue;
-                    PFSlam2D& ssh = *g.shards[x.src_shard];
-                    const int32_t rc = dsh.eng_->blob_copy(dsh.ctx_, (uint8_t*)g.stage[r] + x.dst_off, ssh.ctx_, (const uint8_t*)g.stage[x.src_shard] + x.src_off, x.bytes);
+                for (size_t a = 0; a < xf.size();) {
+                    if (xf[a].dst_shard != r) { ++a; continue; }
+                    size_t b = a;
+                    uint64_t run = 0;
+                    while (b < xf.size() && xf[b].dst_shard == r && xf[b].src_shard == xf[a].src_shard) { run += (xf[b].bytes + 255) & ~255ull; ++b; }
+                    PFSlam2D& ssh = *g.shards[xf[a].src_shard];
+                    const int32_t rc = dsh.eng_->blob_copy(dsh.ctx_, (uint8_t*)g.stage[r] + xf[a].dst_off, ssh.ctx_,
+                                                           (const uint8_t*)g.stage[xf[a].src_shard] + xf[a].src_off, run);
                     if (rc) dsh.fail(rc, "lama_hip_blob_copy");
+                    a = b;
                 }
             });
             for (auto& x : xf) { xt_.shipped_particles += 1; xt_.shipped_bytes += x.bytes; }
@@ -316,20 +328,24 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
         xt_.ship = now_s() - ts0;
         // local copies on every shard, then the imports into the slots whose source was remote
         ts0 = now_s();
+        std::vector<double> local_s(G, 0.0);
         g.run([&](uint32_t r) {
             PFSlam2D& sh = *g.shards[r];
+            const double tl0 = now_s();
             sh.applyResample(idx);
-            bool any = false;
+            local_s[r] = now_s() - tl0;
+            // one import launch for all the slots of this shard whose source was remote (several slots may take the same blob)
+            std::vector<uint32_t> slots; std::vector<const void*> bufs; std::vector<uint64_t> nbytes;
             for (uint32_t i = sh.lo_; i < sh.hi_; ++i) {
                 const uint32_t sp = (uint32_t)idx[i];
                 if (owner(sp) == r) continue;
                 for (auto& x : xf)
-                    if (x.dst_shard == r && x.particle == sp) {
-                        const int32_t rc = sh.eng_->pf_import_particle(sh.ctx_, i - sh.lo_, (const uint8_t*)g.stage[r] + x.dst_off, x.bytes);
-                        if (rc) sh.fail(rc, "lama_hip_pf_import_particle");
-                        any = true;
-                        break;
-                    }
+                    if (x.dst_shard == r && x.particle == sp) { slots.push_back(i - sh.lo_); bufs.push_back((const uint8_t*)g.stage[r] + x.dst_off); nbytes.push_back(x.bytes); break; }
+            }
+            const bool any = !slots.empty();
+            if (any) {
+                const int32_t rc = sh.eng_->pf_import_particles(sh.ctx_, (uint32_t)slots.size(), slots.data(), bufs.data(), nbytes.data());
+                if (rc) sh.fail(rc, "lama_hip_pf_import_particles");
             }
             if (any) {                                           // the pose travels inside the blob: refresh the host mirror
                 std::vector<double> poses((size_t)(sh.hi_ - sh.lo_) * 4);
@@ -339,7 +355,8 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
                     if (owner((uint32_t)idx[i]) != r) sh.particles_[i].pose.state = SE2d::fromArray(&poses[4 * (size_t)(i - sh.lo_)]);
             }
         });
-        xt_.import_ = now_s() - ts0;
+        xt_.local_copies = *std::max_element(local_s.begin(), local_s.end());   // resample copies inside a shard (any pool has them)
+        xt_.import_ = now_s() - ts0 - xt_.local_copies;
         // this object's particle list follows the same permutation (histories included), :561-570
         std::vector<Particle> next(P);
         for (uint32_t i = 0; i < P; ++i) { next[i] = particles_[(uint32_t)idx[i]]; }
@@ -349,6 +366,7 @@ bool PFSlam2D::updateGroup(const PointCloudXYZ::Ptr& surface, const Pose2D& odom
     t0 = now_s();
     g.run([&](uint32_t r) { g.shards[r]->updateMaps(); if (summary) g.shards[r]->syncDevice(); });    // :289-302
     mirrorShards(due[0] != 0);
+    xt_.phase_maps = now_s() - t0;
     if (summary) {
         summary->time_mapping.push_back(now_s() - t0);
         summary->time.push_back(now_s() - t_begin);

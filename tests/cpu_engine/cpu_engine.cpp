@@ -280,6 +280,22 @@ int32_t lama_hip_pf_import_particle(lama_hip_ctx* c, uint32_t particle, const vo
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_pf_export_particles(lama_hip_ctx* c, uint32_t n, const uint32_t* particles, void* const* bufs, const uint64_t* caps, uint64_t* bytes)
+{
+    for (uint32_t k = 0; k < n; ++k) {
+        uint64_t nb = 0;
+        const int32_t rc = lama_hip_pf_export_particle(c, particles[k], bufs ? bufs[k] : nullptr, caps ? caps[k] : 0, &nb);
+        if (rc) return rc;
+        if (bytes) bytes[k] = nb;
+    }
+    return LAMA_HIP_OK;
+}
+int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t* particles, const void* const* bufs, const uint64_t* bytes)
+{
+    for (uint32_t k = 0; k < n; ++k) { const int32_t rc = lama_hip_pf_import_particle(c, particles[k], bufs[k], bytes[k]); if (rc) return rc; }
+    return LAMA_HIP_OK;
+}
+
 // "device" staging buffers of the test double are host memory
 int32_t lama_hip_blob_alloc(lama_hip_ctx*, uint64_t bytes, void** buf) { *buf = std::malloc(bytes); return *buf ? LAMA_HIP_OK : LAMA_HIP_E_HIP; }
 int32_t lama_hip_blob_free(lama_hip_ctx*, void* buf) { std::free(buf); return LAMA_HIP_OK; }

@@ -98,3 +98,44 @@ def test_update_that_runs_out_of_patches_is_repeated_after_growth(Fsim, seq_ray)
     maps bit-exact, several growths, both ray-cast forms."""
     c = _run(Fsim, 1, 1, dm_patch_capacity=8, occ_patch_capacity=8, sequential_raycast=seq_ray)
     assert c["arena_growths"] >= 3, c
+
+
+def test_batched_export_and_import_between_two_contexts(Fsim):
+    """The resample of a sharded pool: all outgoing particles of one context leave in ONE export launch, arrive in another context
+    in ONE import launch (two slots take the same blob), and the receiving context carries on -- maps bit-exact against the oracle
+    that resampled in place."""
+    F, P = Fsim, 3
+    pts, odom, truth = F.corridor_log(2, 1080)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    a = F.HipContext(F.default_cfg(particles=P, device=0))
+    b = F.HipContext(F.default_cfg(particles=P, device=0))
+    a.init(pts[0], pose0)
+    b.init(pts[0], pose0)
+    rng = np.random.default_rng(1)
+    start = np.stack([O.se2_mul(O.se2(*truth[1]), O.se2(*rng.normal(0, [0.05, 0.05, 0.02]))) for _ in range(P)])
+    pf.set_poses(start); pf.stage_set_scan(pts[1]); pf.stage_update_maps()
+    a.set_poses(start); a.update_maps(pts[1])
+    src = np.array([2, 0], dtype=np.uint32)
+    sizes = a.export_sizes(src)
+    bufs = [np.zeros(int(n), dtype=np.uint8) for n in sizes]
+    got = a.export_particles(src, [x.ctypes.data for x in bufs], sizes)
+    assert np.array_equal(got, sizes)
+    for k, p in enumerate(src):                               # the batch writes what the single-particle call writes
+        one = np.zeros(int(sizes[k]), dtype=np.uint8)
+        a.export_particle(int(p), one.ctypes.data, int(sizes[k]))
+        assert np.array_equal(one, bufs[k])
+    b.import_particles([0, 1, 2], [bufs[0].ctypes.data, bufs[0].ctypes.data, bufs[1].ctypes.data], [sizes[0], sizes[0], sizes[1]])
+    pf.stage_resample_with(np.array([2, 2, 0], dtype=np.int32))
+    assert np.array_equal(b.get_poses(), pf.poses())
+    for rnd in range(2):
+        for i in range(P):
+            assert_maps_equal(b.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"round {rnd} occ p{i}")
+            assert_maps_equal(b.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"round {rnd} dm p{i}")
+        if rnd == 0:                                          # ... and the imported particles are live: one more update
+            nxt = np.stack([O.se2_mul(O.se2(*truth[2]), O.se2(*rng.normal(0, [0.05, 0.05, 0.02]))) for _ in range(P)])
+            pf.set_poses(nxt); pf.stage_set_scan(pts[2]); pf.stage_update_maps()
+            b.set_poses(nxt); b.update_maps(pts[2])
+    a.close(); b.close()
