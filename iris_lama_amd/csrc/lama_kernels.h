@@ -1072,6 +1072,11 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, B
     for (uint32_t k = tid; k < nr; k += nthreads) sh.raise[k] = g_raise[k];
     __syncthreads();
     const uint64_t anc = lds_pop_ancestors(lane);
+#ifndef LAMA_WAVE_SIM
+    // Chip full (12 workgroups per CU: three main and three helper waves per SIMD): the issue slots of a SIMD are the scarce
+    // resource and the main wave is the longer chain of the pair (the helper waits for it), so it gets the arbiter's preference.
+    if (TW) { if (tid >= UM_BLOCK) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+#endif
     if (TW && tid >= UM_BLOCK) {
         // helper wave: owns both queues from the hand-over on.  While the raise queue is not empty it is the one popped
         // (dynamic_distance_map.cpp:162-173), then the lower queue (:175-194).
@@ -1461,7 +1466,18 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     if (!RESUME) {
         if (map_update_aborted(prm)) return;             // the update's allocation phase failed: nothing was queued, nothing is touched
+#ifdef LAMA_PROFILE_BF                                   // where and when this particle ran (constant 100 MHz counter)
+        uint64_t rt0; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt0));
+#endif
         bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, first_particle + (int)blockIdx.x, sh);
+#ifdef LAMA_PROFILE_BF
+        if (threadIdx.x == 0) {
+            uint64_t rt1; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt1));
+            uint32_t hw, xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            uint64_t* o = prm.dbg + 8 * (size_t)prm.P + 8 * (size_t)(first_particle + (int)blockIdx.x);
+            o[0] = rt0; o[1] = rt1; o[2] = hw; o[3] = xcc;
+        }
+#endif
         return;
     }
     const uint32_t n = prm.slow_n[0];
