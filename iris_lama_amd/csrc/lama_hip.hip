@@ -85,7 +85,7 @@ struct lama_hip_ctx {
     uint32_t* d_slow_list = nullptr; uint32_t* d_slow_n = nullptr;      // hand-over list of the brushfire's first stage
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
-    lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; size_t rrec_cap = 0;
+    lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
     int32_t* d_rev = nullptr; size_t rev_cap = 0;
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
@@ -457,9 +457,10 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
 {
     const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
     if (need > c->rrec_cap) {
-        (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->rrec_cap = 0;
+        (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->d_rchunk = nullptr; c->rrec_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
         HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
+        HIPCHK(c, hipMalloc(&c->d_rchunk, (size_t)c->P * ((n + 63) / 64) * sizeof(lama_dev::RayChunk)));     // per 64 beams of a particle
         c->rrec_cap = need;
     }
     if (need_rev > c->rev_cap) {
@@ -468,7 +469,7 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
         c->rev_cap = need_rev;
     }
     hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
-                       c->d_rrec, c->d_rbbox, alloc_only);
+                       c->d_rrec, c->d_rbbox, alloc_only, c->d_rchunk);
     const int rw_seg = count <= 64 ? 8 : 2;
     hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
     hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
@@ -538,7 +539,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
-                               (const uint64_t*)c->d_rbbox, (const int32_t*)c->d_rev, (int)n, (int)first);
+                               (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, (int)first);
             const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
             if (count <= 512) {
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
@@ -698,7 +699,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);

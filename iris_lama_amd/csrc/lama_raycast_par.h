@@ -170,13 +170,17 @@ __device__ inline void act_append(const DevParams& prm, int p, uint64_t key)
 // of the cells the ray visits; k_ray_alloc_walk then allocates the occupancy patches the rays cross, so that the patch pass finds
 // every patch in the directory.
 struct RayRec;
-__device__ inline void ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out);
+struct RayChunk;
+constexpr uint64_t RAY_BBOX_EMPTY = 0x0000FFFF0000FFFFull;   // x0 = y0 = 0xFFFF > x1 = y1 = 0
+__device__ inline uint64_t ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out);
+__device__ inline void ray_chunk_record(const DevParams& prm, const BeamGeom& g, uint64_t bb, int lane, RayChunk* chunks, size_t index);
 
 // alloc_only: the beam-sequential ray-cast (k_raycast) follows -- only the allocation phase is wanted here (ray records for the
 // allocation walk, the hit cells' patches); no hit bits, no active-visit list.
 __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* __restrict__ pts, int n,
                                                    const double* __restrict__ tfs, int first_particle,
-                                                   RayRec* __restrict__ rec_out = nullptr, uint64_t* __restrict__ bbox_out = nullptr, int alloc_only = 0)
+                                                   RayRec* __restrict__ rec_out = nullptr, uint64_t* __restrict__ bbox_out = nullptr, int alloc_only = 0,
+                                                   RayChunk* __restrict__ chunk_out = nullptr)
 {
     const int p = first_particle + blockIdx.x;
     const int i = blockIdx.y * 256 + threadIdx.x;
@@ -188,7 +192,9 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
 #pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
     const BeamGeom g = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
-    if (rec_out && live) ray_hits_record(prm, g, p, i, n, rec_out, bbox_out);
+    uint64_t bb = RAY_BBOX_EMPTY;
+    if (rec_out && live) bb = ray_hits_record(prm, g, p, i, n, rec_out, bbox_out);
+    if (chunk_out && (i & ~63) < n) ray_chunk_record(prm, g, bb, lane, chunk_out, (size_t)p * ((n + 63) / 64) + (i >> 6));   // wave-uniform condition
     if (live && g.steps < 0) atomicOr(prm.err, ERR_WINDOW);
     // ray cells of the scan (statistics): one atomic per wave, not one per beam on the particle's single counter
     if (!alloc_only) {

@@ -35,7 +35,19 @@ struct RayRec {
     uint32_t nnf;            // nn | (s0 < 0) << 16 | (s1 < 0) << 17 | valid << 18
     uint64_t magic;
 };
-constexpr uint64_t RAY_BBOX_EMPTY = 0x0000FFFF0000FFFFull;   // x0 = y0 = 0xFFFF > x1 = y1 = 0
+// 64 consecutive beams of one particle (one wave of k_ray_hits): what k_ray_patches needs to skip all of them at once.  All rays of
+// a scan start in the sensor's cell, so the beams of a chunk fan out inside a cone; when the fan is narrower than 180 degrees (a
+// LIDAR's beams come in angular order: 64 of them span a few degrees) the chunk stores its two bounding directions.  A ray's cells
+// lie within half a cell of the segment start -> start + direction, so a patch that -- grown by one cell -- lies strictly clockwise
+// of the clockwise bound (or counter-clockwise of the other one) is not touched by any ray of the chunk.  Nothing depends on the
+// order of the points: a chunk without such a cone (cone = 0) is simply tested beam by beam.
+struct RayChunk {
+    int32_t cwx, cwy;        // direction (cells) of the clockwise-most ray ...
+    int32_t ccwx, ccwy;      // ... and of the counter-clockwise-most one
+    uint64_t bbox;           // union of the rays' boxes (RAY_BBOX_EMPTY: no valid ray in the chunk)
+    uint32_t sxy;            // the common start cell, window-relative: x | y << 16
+    uint32_t cone;           // 1 = every valid ray of the chunk lies between the two directions and starts in (sx, sy)
+};
 
 __device__ inline RayRec ray_rec(const BeamGeom& g)
 {
@@ -75,8 +87,8 @@ __device__ __forceinline__ bool ray_axis_range(int m, bool neg, uint32_t a, uint
     return t_lo <= t_hi;
 }
 
-// what k_ray_hits stores for the patch pass (see k_ray_hits)
-__device__ inline void ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out)
+// what k_ray_hits stores for the patch pass (see k_ray_hits); returns the box of the ray's cells (RAY_BBOX_EMPTY: nothing to visit)
+__device__ inline uint64_t ray_hits_record(const DevParams& prm, const BeamGeom& g, int p, int i, int n, RayRec* rec_out, uint64_t* bbox_out)
 {
     RayRec r = ray_rec(g);
     uint64_t bb = RAY_BBOX_EMPTY;
@@ -92,6 +104,39 @@ __device__ inline void ray_hits_record(const DevParams& prm, const BeamGeom& g, 
     if (!ok) r.nnf &= ~(1u << 18);
     rec_out[(size_t)p * n + i] = r;
     bbox_out[(size_t)p * n + i] = bb;
+    return bb;
+}
+
+// the chunk record of the calling wave (64 consecutive beams; every lane of the wave calls this, `bb` = its ray's box or
+// RAY_BBOX_EMPTY for a lane without a ray)
+__device__ inline void ray_chunk_record(const DevParams& prm, const BeamGeom& g, uint64_t bb, int lane, RayChunk* chunks, size_t index)
+{
+    const bool val = bb != RAY_BBOX_EMPTY;
+    const unsigned long long vm = __ballot(val);
+    uint32_t x0 = (uint32_t)(bb & 0xFFFFu), x1 = (uint32_t)((bb >> 16) & 0xFFFFu), y0 = (uint32_t)((bb >> 32) & 0xFFFFu), y1 = (uint32_t)(bb >> 48);
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t ox0 = (uint32_t)__shfl_xor((int)x0, off, 64), ox1 = (uint32_t)__shfl_xor((int)x1, off, 64);
+        const uint32_t oy0 = (uint32_t)__shfl_xor((int)y0, off, 64), oy1 = (uint32_t)__shfl_xor((int)y1, off, 64);
+        x0 = ox0 < x0 ? ox0 : x0; x1 = ox1 > x1 ? ox1 : x1; y0 = oy0 < y0 ? oy0 : y0; y1 = oy1 > y1 ? oy1 : y1;
+    }
+    const int lf = vm ? __ffsll((long long)vm) - 1 : 0, ll = vm ? 63 - __clzll((long long)vm) : 0;
+    const int dx = g.s0 < 0 ? -(int)g.a0 : (int)g.a0, dy = g.s1 < 0 ? -(int)g.a1 : (int)g.a1;       // |d| < 2^13: products fit 32 bits
+    const int sx = (int)(g.msx - prm.wx0), sy = (int)(g.msy - prm.wy0);
+    const int fx = __shfl(dx, lf, 64), fy = __shfl(dy, lf, 64), lx = __shfl(dx, ll, 64), ly = __shfl(dy, ll, 64);
+    const int fsx = __shfl(sx, lf, 64), fsy = __shfl(sy, lf, 64);
+    const int c_f = fx * dy - fy * dx, c_l = dx * ly - dy * lx;          // cross(first, d), cross(d, last)
+    const bool front = fx * dx + fy * dy > 0 && lx * dx + ly * dy > 0 && sx == fsx && sy == fsy;
+    const bool all_ccw = __ballot(val && !(front && c_f >= 0 && c_l >= 0)) == 0ull;    // first = clockwise end, last = counter-clockwise end
+    const bool all_cw = __ballot(val && !(front && c_f <= 0 && c_l <= 0)) == 0ull;     // a scan that turns the other way
+    if (lane == 0) {
+        RayChunk c;
+        c.bbox = vm ? ((uint64_t)x0 | ((uint64_t)x1 << 16) | ((uint64_t)y0 << 32) | ((uint64_t)y1 << 48)) : RAY_BBOX_EMPTY;
+        c.sxy = ((uint32_t)fsx & 0xFFFFu) | ((uint32_t)fsy << 16);
+        c.cone = (vm && (all_ccw || all_cw)) ? 1u : 0u;
+        c.cwx = all_ccw ? fx : lx; c.cwy = all_ccw ? fy : ly;
+        c.ccwx = all_ccw ? lx : fx; c.ccwy = all_ccw ? ly : fy;
+        chunks[index] = c;
+    }
 }
 
 // allocation walk: afterwards the occupancy patch of every ray cell of the scan exists.  RW_SEG threads per beam (many while the
@@ -183,17 +228,34 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
     if (tid == 0 && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
 }
 
-constexpr int RPT_CHUNK = 512;        // beams tested per round: the records of those that cross the patch wait in LDS
+// developer build (-DLAMA_PROFILE_RAY, tools/prof_ray.py): event counts and per-phase cycles of k_ray_patches, summed over the launch
+// into the spare part of prm.dbg (16 words behind the per-particle blocks)
+#ifdef LAMA_PROFILE_RAY
+#ifdef LAMA_PROFILE_RAY_COUNT         // the event counts cost a device atomic each: a build of its own, its cycles mean nothing
+#define RPC(k, v) atomicAdd((unsigned long long*)(prm.dbg + 16 * (size_t)prm.P + (k)), (unsigned long long)(v))
+#else
+#define RPC(k, v) do {} while (0)
+#endif
+// cycles of thread 0 per phase, kept in registers and stored once per workgroup (the first 64 particles only: 8 words per workgroup
+// behind the 16 event counters)
+#define RPT_T(k) do { if (tid == 0) { const uint64_t t_ = __builtin_readcyclecounter(); tacc[(k) - 8] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define RPC(k, v) do {} while (0)
+#define RPT_T(k) do {} while (0)
+#endif
+constexpr int RPT_CHUNK = 256;        // candidate beams tested per round: the records of those that cross the patch wait in LDS
+constexpr int RPT_WALK = 4;           // lanes that share the cells of one (beam, patch) crossing
 
 __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec* __restrict__ recs, const uint64_t* __restrict__ bbox,
-                                                      const int32_t* __restrict__ rev, int n, int first_particle)
+                                                      const RayChunk* __restrict__ chunks, const int32_t* __restrict__ rev, int n, int first_particle)
 {
+    static_assert(RPT_CHUNK == 256, "one candidate beam per thread and round");
     __shared__ uint32_t cnt[1024];
     __shared__ RayRec lrec[RPT_CHUNK];           // beams of the round that cross the patch ...
     __shared__ uint32_t lbt[RPT_CHUNK];          // ... their step range t_lo | t_hi << 16 ...
     __shared__ uint16_t lbeam[RPT_CHUNK];        // ... and beam index
     __shared__ uint32_t actw[32], newm[32], wrapm[32];
-    __shared__ uint32_t list_n;
+    __shared__ uint32_t list_n[2];               // by round parity: the idle one is cleared while the other one is in use
     const int p = first_particle + blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // first map-modifying kernel of the update: nothing is touched when the allocation phase failed (the host grows and retries)
@@ -203,68 +265,143 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
     const RayRec* prec = recs + (size_t)p * n;
     const uint64_t* pbb = bbox + (size_t)p * n;
-    for (int slot = blockIdx.y; slot < count; slot += gridDim.y) {
-        const uint32_t pidx = (uint32_t)rev[(size_t)p * prm.occ_cap + slot];
+    const int nck = (n + 63) / 64;                                 // <= 32 (LAMA_HIP_MAX_POINTS = 2048)
+    // The kernel is a chain of memory round trips per patch unless they are taken out of the chain: the chunk records do not depend
+    // on the patch (lane c of EVERY wave keeps chunk c in registers: each wave decides for itself which chunks a patch keeps, no
+    // list, no barrier), the directory position of the next patch is fetched one patch ahead, and the cells of the patch, its hit
+    // bits and the records of the first 256 candidate beams are requested together.
+    RayChunk ck;
+    ck.bbox = RAY_BBOX_EMPTY; ck.cone = 0; ck.cwx = ck.cwy = ck.ccwx = ck.ccwy = 0; ck.sxy = 0;
+    if (lane < nck) ck = chunks[(size_t)p * nck + lane];
+    if (tid < 2) list_n[tid] = 0;
+    int slot = blockIdx.y;
+    uint32_t pidx_next = slot < count ? (uint32_t)rev[(size_t)p * prm.occ_cap + slot] : 0u;
+    uint32_t par = 0;                                              // parity of the round
+#ifdef LAMA_PROFILE_RAY
+    uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+#endif
+    __syncthreads();
+    for (; slot < count; slot += gridDim.y) {
+        const uint32_t pidx = pidx_next;
+        if (slot + (int)gridDim.y < count) pidx_next = (uint32_t)rev[(size_t)p * prm.occ_cap + slot + gridDim.y];
         const int px = (int)((pidx % prm.W) * 32u), py = (int)((pidx / prm.W) * 32u);       // window-relative origin of the patch
-        // ---- 1. the patch and the classification of its cells
+#ifdef LAMA_PROFILE_RAY
+        tprev = __builtin_readcyclecounter();
+        ++tacc[5];
+        if (tid == 0) RPC(0, 1);
+#endif
+        // ---- 2a. which chunks of 64 beams can cross the patch at all: the box of the chunk's rays, then its cone
+        bool keep = false;
+        if (lane < nck) {
+            const int x0 = (int)(ck.bbox & 0xFFFFu), x1 = (int)((ck.bbox >> 16) & 0xFFFFu), y0 = (int)((ck.bbox >> 32) & 0xFFFFu), y1 = (int)(ck.bbox >> 48);
+            keep = !(x1 < px || x0 > px + 31 || y1 < py || y0 > py + 31);              // (a chunk without rays has an empty box)
+            if (keep && ck.cone) {
+                const int sx = (int)(ck.sxy & 0xFFFFu), sy = (int)(ck.sxy >> 16);
+                const int ax = px - 1 - sx, bx = px + 32 - sx, ay = py - 1 - sy, by = py + 32 - sy;   // the patch grown by one cell
+                const int a00 = ck.cwx * ay - ck.cwy * ax, a10 = ck.cwx * ay - ck.cwy * bx, a01 = ck.cwx * by - ck.cwy * ax, a11 = ck.cwx * by - ck.cwy * bx;
+                const int b00 = ck.ccwx * ay - ck.ccwy * ax, b10 = ck.ccwx * ay - ck.ccwy * bx, b01 = ck.ccwx * by - ck.ccwy * ax, b11 = ck.ccwx * by - ck.ccwy * bx;
+                if ((a00 < 0 && a10 < 0 && a01 < 0 && a11 < 0) || (b00 > 0 && b10 > 0 && b01 > 0 && b11 > 0)) keep = false;
+            }
+        }
+        const uint32_t km = (uint32_t)__ballot(keep);              // chunks 0 .. 31, the same in every wave
+        const int ncand = __popc(km) * 64;
+        if (tid == 0) RPC(2, __popc(km));
+        // ---- 1. the patch: its cells and hit bits are requested now, classified below (after the candidates' loads are out too)
         uint32_t v[4];
+        uint64_t hw[4];
         const uint64_t* hitw = prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ci = tid + 256 * j;
-            v[j] = occ[(size_t)slot * 1024 + ci];
-            cnt[ci] = 0;
-            const uint32_t o0 = v[j] & 0xFFFFu, v0 = v[j] >> 16;
-            const bool hit = (hitw[ci >> 6] >> (ci & 63)) & 1ull;
-            const bool active = hit || !(v0 == 0 ? o0 == 0 : 4u * o0 < v0);
-            const unsigned long long am = __ballot(active);                // cells 256 j + 64 wave .. + 63
-            if (lane == 0) { actw[8 * j + 2 * wave] = (uint32_t)am; actw[8 * j + 2 * wave + 1] = (uint32_t)(am >> 32); }
-        }
-        if (tid < 32) { newm[tid] = 0; wrapm[tid] = 0; }
-        for (int b0 = 0; b0 < n; b0 += RPT_CHUNK) {
-            if (tid == 0) list_n = 0;
-            __syncthreads();
-            // ---- 2. which beams of the round cross the patch, and in which steps
-            for (int b = b0 + tid; b < n && b < b0 + RPT_CHUNK; b += 256) {
-                const uint64_t bb = pbb[b];
+        for (int j = 0; j < 4; ++j) { v[j] = occ[(size_t)slot * 1024 + tid + 256 * j]; hw[j] = hitw[wave + 4 * j]; }
+        bool has_act = false;
+        for (int c0 = 0; c0 == 0 || c0 < ncand; c0 += RPT_CHUNK, par ^= 1u) {
+            // ---- 2b. which beams of the kept chunks cross the patch, and in which steps: one candidate per thread
+            const int jc = (c0 >> 6) + wave;                       // this wave's candidates are the beams of the jc-th kept chunk
+            int b = -1;
+            if (jc * 64 < ncand) {
+                uint32_t m = km;
+                for (int i = 0; i < jc; ++i) m &= m - 1u;
+                b = (__ffs((int)m) - 1) * 64 + lane;
+                if (b >= n) b = -1;
+            }
+            uint64_t bb = RAY_BBOX_EMPTY;
+            RayRec r;
+            r.msx = r.msy = r.a01 = r.nnf = 0; r.magic = 0;
+            if (b >= 0) { bb = pbb[b]; r = prec[b]; RPC(3, 1); }
+            if (c0 == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ci = tid + 256 * j;
+                    cnt[ci] = 0;
+                    const uint32_t o0 = v[j] & 0xFFFFu, v0 = v[j] >> 16;
+                    const bool hit = (hw[j] >> lane) & 1ull;
+                    const bool active = hit || !(v0 == 0 ? o0 == 0 : 4u * o0 < v0);
+                    const unsigned long long am = __ballot(active);            // cells 256 j + 64 wave .. + 63
+                    if (lane == 0) { actw[8 * j + 2 * wave] = (uint32_t)am; actw[8 * j + 2 * wave + 1] = (uint32_t)(am >> 32); }
+                }
+                if (tid < 32) { newm[tid] = 0; wrapm[tid] = 0; }
+                RPT_T(8);
+            }
+            {
                 const int x0 = (int)(bb & 0xFFFFu), x1 = (int)((bb >> 16) & 0xFFFFu), y0 = (int)((bb >> 32) & 0xFFFFu), y1 = (int)(bb >> 48);
-                if (x1 < px || x0 > px + 31 || y1 < py || y0 > py + 31) continue;      // (an invalid ray has an empty box)
-                const RayRec r = prec[b];
+                bool cross = !(x1 < px || x0 > px + 31 || y1 < py || y0 > py + 31);        // (an invalid ray has an empty box)
+                if (cross) RPC(4, 1);
                 const uint32_t nn = r.nnf & 0xFFFFu, steps = nn - 1u;
-                {   // Every ray cell lies within half a cell of the segment start -> start + (s0 a0, s1 a1) (each axis is the rounded
+                if (cross) {
+                    // Every ray cell lies within half a cell of the segment start -> start + (s0 a0, s1 a1) (each axis is the rounded
                     // position t a / n): a ray whose segment keeps the patch, grown by one cell, strictly on one side cannot touch it
                     const int sx = (int)(r.msx - prm.wx0), sy = (int)(r.msy - prm.wy0);
                     const int dx = ((r.nnf >> 16) & 1u) ? -(int)(r.a01 & 0xFFFFu) : (int)(r.a01 & 0xFFFFu);
                     const int dy = ((r.nnf >> 17) & 1u) ? -(int)(r.a01 >> 16) : (int)(r.a01 >> 16);
                     const int ax = px - 1 - sx, bx = px + 32 - sx, ay = py - 1 - sy, by = py + 32 - sy;
                     const int c00 = dx * ay - dy * ax, c10 = dx * ay - dy * bx, c01 = dx * by - dy * ax, c11 = dx * by - dy * bx;
-                    if ((c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0) || (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0)) continue;
+                    if ((c00 > 0 && c10 > 0 && c01 > 0 && c11 > 0) || (c00 < 0 && c10 < 0 && c01 < 0 && c11 < 0)) cross = false;
                 }
-                uint32_t xl, xh, yl, yh;
-                if (!ray_axis_range((int)(r.msx - prm.wx0), (r.nnf >> 16) & 1u, r.a01 & 0xFFFFu, nn, px, steps, xl, xh)) continue;
-                if (!ray_axis_range((int)(r.msy - prm.wy0), (r.nnf >> 17) & 1u, r.a01 >> 16, nn, py, steps, yl, yh)) continue;
-                const uint32_t tl = xl > yl ? xl : yl, th = xh < yh ? xh : yh;
-                if (tl > th) continue;
-                const uint32_t k = atomicAdd(&list_n, 1u);
-                lrec[k] = r; lbt[k] = tl | (th << 16); lbeam[k] = (uint16_t)b;
-            }
-            __syncthreads();
-            // ---- 3. walk the ranges: eight lanes per beam (a ray crosses at most 33 cells of a patch, a dozen on average)
-            const uint32_t ln = list_n;
-            const int hw = tid >> 3, hl = tid & 7;
-            for (uint32_t e = (uint32_t)hw; e < ln; e += 32u) {
-                const RayRec r = lrec[e];
-                const uint32_t b = lbeam[e], tl = lbt[e] & 0xFFFFu, th = lbt[e] >> 16;
-                for (uint32_t t = tl + (uint32_t)hl; t <= th; t += 8u) {
-                    uint32_t rx, ry;
-                    ray_cell(r, prm.wx0, prm.wy0, t, rx, ry);
-                    if ((int)(rx & ~31u) != px || (int)(ry & ~31u) != py) continue;     // cannot happen: the range is exact
-                    const uint32_t ci = (rx & 31u) | ((ry & 31u) << 5);
-                    if ((actw[ci >> 5] >> (ci & 31u)) & 1u) act_append(prm, p, act_key(rx, ry, b, t));
-                    else atomicAdd(&cnt[ci], 1u);
+                if (cross) {
+                    RPC(5, 1);
+                    uint32_t xl = 0, xh = 0, yl = 0, yh = 0;
+                    cross = ray_axis_range((int)(r.msx - prm.wx0), (r.nnf >> 16) & 1u, r.a01 & 0xFFFFu, nn, px, steps, xl, xh) &&
+                            ray_axis_range((int)(r.msy - prm.wy0), (r.nnf >> 17) & 1u, r.a01 >> 16, nn, py, steps, yl, yh);
+                    const uint32_t tl = xl > yl ? xl : yl, th = xh < yh ? xh : yh;
+                    if (cross && tl <= th) {
+                        const uint32_t k = atomicAdd(&list_n[par], 1u);
+                        lrec[k] = r; lbt[k] = tl | (th << 16); lbeam[k] = (uint16_t)b;
+                        RPC(6, 1); RPC(7, th - tl + 1u);
+                    }
                 }
             }
             __syncthreads();
+            RPT_T(10);
+            if (c0 == 0) has_act = __ballot(actw[lane & 31] != 0u) != 0ull;        // most patches of free space have no active cell at all
+            if (tid == 0) list_n[par ^ 1u] = 0;
+            // ---- 3. walk the ranges: RPT_WALK lanes per crossing, each a contiguous stretch of its steps in the incremental form of
+            // Map::computeRay (k_j = floor((2 t a_j + n) / (2 n)) steps made by axis j, rem_j the remainder: every step adds 2 a_j
+            // and carries at 2 n -- the closed form is evaluated once per lane, not once per cell)
+            const uint32_t ln = list_n[par];
+            const int hq = tid / RPT_WALK, hl = tid % RPT_WALK;
+            for (uint32_t e = (uint32_t)hq; e < ln; e += 256u / RPT_WALK) {
+                const uint32_t tl = lbt[e] & 0xFFFFu, len = (lbt[e] >> 16) - tl + 1u;
+                const uint32_t t0 = tl + (len * (uint32_t)hl) / RPT_WALK, t1 = tl + (len * (uint32_t)(hl + 1)) / RPT_WALK;     // [t0, t1)
+                if (t0 >= t1) continue;
+                const RayRec q = lrec[e];
+                const uint32_t qb = lbeam[e];
+                const uint32_t a0 = q.a01 & 0xFFFFu, a1 = q.a01 >> 16, nn = q.nnf & 0xFFFFu, n2 = 2u * nn;
+                const uint32_t k0 = (uint32_t)(((uint64_t)(2u * t0 * a0 + nn) * q.magic) >> 42), k1 = (uint32_t)(((uint64_t)(2u * t0 * a1 + nn) * q.magic) >> 42);
+                uint32_t rem0 = 2u * t0 * a0 + nn - k0 * n2, rem1 = 2u * t0 * a1 + nn - k1 * n2;
+                const bool neg0 = (q.nnf >> 16) & 1u, neg1 = (q.nnf >> 17) & 1u;
+                const uint32_t rx = neg0 ? q.msx - prm.wx0 - k0 : q.msx - prm.wx0 + k0, ry = neg1 ? q.msy - prm.wy0 - k1 : q.msy - prm.wy0 + k1;
+                if ((int)(rx & ~31u) != px || (int)(ry & ~31u) != py) continue;             // cannot happen: the range is exact
+                int ci = (int)((rx & 31u) | ((ry & 31u) << 5));                             // the cell inside the patch; a step moves it by +-1 / +-32
+                const int d0 = neg0 ? -1 : 1, d1 = neg1 ? -32 : 32;
+                for (uint32_t t = t0; t < t1; ++t) {
+                    const uint32_t cu = (uint32_t)ci & 1023u;
+                    if (has_act && ((actw[cu >> 5] >> (cu & 31u)) & 1u)) act_append(prm, p, act_key((uint32_t)px + (cu & 31u), (uint32_t)py + (cu >> 5), qb, t));
+                    else atomicAdd(&cnt[cu], 1u);
+                    rem0 += 2u * a0; if (rem0 >= n2) { rem0 -= n2; ci += d0; }
+                    rem1 += 2u * a1; if (rem1 >= n2) { rem1 -= n2; ci += d1; }
+                }
+            }
+            __syncthreads();
+            RPT_T(11);
         }
         // ---- 4. visited += count, one coalesced write of the cells that changed
 #pragma unroll
@@ -289,7 +426,14 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
             if (wm) atomicOr((unsigned long long*)(prm.occ_mask + ((size_t)p * prm.occ_cap + slot) * 16 + tid), (unsigned long long)wm);
         }
         __syncthreads();
+        RPT_T(12);
     }
+#ifdef LAMA_PROFILE_RAY
+    if (tid == 0 && blockIdx.x < 64) {
+        uint64_t* o = prm.dbg + 16 * (size_t)prm.P + 16 + 8 * ((size_t)blockIdx.x * gridDim.y + blockIdx.y);
+        for (int k = 0; k < 8; ++k) o[k] = tacc[k];
+    }
+#endif
 }
 
 } // namespace lama_dev
