@@ -70,6 +70,7 @@ struct Block {
 };
 
 inline Block*& blk() { static Block* b = nullptr; return b; }
+inline std::function<void()>& deadlock_hook() { static std::function<void()> h; return h; }     // set by a debug build of the code under test
 inline std::vector<char*>& stack_pool() { static std::vector<char*> p; return p; }
 
 inline unsigned tid() { return blk()->fibers[blk()->cur].tid; }
@@ -117,6 +118,7 @@ inline int wave_sync(int site, uint64_t operand, bool pred)
     } else {
         const uint64_t g = w.gen;
         while (w.gen == g) yield();
+        ++blk()->progress;              // released: what this lane does next (e.g. set a flag another wave polls) is progress too
     }
     return par;
 }
@@ -185,7 +187,7 @@ inline void syncthreads()
     ++b->bar_arrived;
     ++b->progress;
     if (b->bar_arrived == b->bar_live) { b->bar_arrived = 0; ++b->bar_gen; }
-    else { const uint64_t g = b->bar_gen; while (b->bar_gen == g) yield(); }
+    else { const uint64_t g = b->bar_gen; while (b->bar_gen == g) yield(); ++b->progress; }
 }
 
 inline uint64_t clock() { return blk()->switches; }
@@ -258,6 +260,7 @@ inline void launch(dim3s grid, dim3s block, std::function<void()> body)
                 for (size_t wv = 0; wv < b.waves.size(); ++wv)
                     std::fprintf(stderr, "wave_sim: wave %zu: %d of %d live lanes wait at the cross-lane operation of source line %d\n", wv, b.waves[wv].arrived, b.waves[wv].live, b.waves[wv].site);
                 std::fprintf(stderr, "wave_sim: workgroup barrier: %d of %d arrived\n", b.bar_arrived, b.bar_live);
+                if (deadlock_hook()) deadlock_hook()();
                 die("deadlock: no fiber of the workgroup can make progress");
             }
         }

@@ -1119,6 +1119,50 @@ def test_randomized_rooms_maps_bit_exact(F, seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("order", ["reversed", "shuffled", "two_sweeps", "ragged"])
+def test_point_order_is_free_for_the_ray_cast(F, order):
+    """k_ray_patches skips whole chunks of 64 consecutive beams by their cone and box; the cone exists only when the beams of a
+    chunk fan out in angular order.  The reference accepts ANY point order (PointCloudXYZ is just a list): clockwise scans, shuffled
+    points, two sweeps in one cloud and beam counts that are no multiple of 64 must all give the oracle's maps bit for bit."""
+    rng = np.random.default_rng(77)
+    kind = {"R": 7.0, "coef": [(m, rng.uniform(0.02, 0.12), rng.uniform(0, 2 * np.pi)) for m in (2, 3, 5, 7)]}
+    n_beams = {"ragged": 333}.get(order, 720)
+    P = 3
+
+    def reorder(sc):
+        if order == "reversed":
+            return sc[::-1].copy()
+        if order == "shuffled":
+            return sc[rng.permutation(len(sc))]
+        if order == "two_sweeps":
+            return np.concatenate([sc[0::2], sc[1::2]])
+        return sc
+
+    base = np.array([0.4, -0.3, 0.7])
+    pf = O.PF(O.default_options(particles=P, seed=5))
+    scan0 = reorder(_random_room_scan(rng, base, n_beams, kind))
+    pose0 = O.se2(*base)
+    pf.set_prior(pose0)
+    assert pf.update(scan0, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024))
+    ctx.init(scan0, pose0)
+    for k in range(3):
+        truth = base + np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3)])
+        scan = reorder(_random_room_scan(rng, truth, n_beams, kind))
+        poses = np.stack([O.se2(*(truth + rng.normal(0, [0.02, 0.02, 0.01]))) for _ in range(P)])
+        pf.set_poses(poses)
+        pf.stage_set_scan(scan)
+        pf.stage_update_maps()
+        ctx.set_poses(poses)
+        ctx.update_maps(scan)
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"{order} scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"{order} scan {k} dm p{i}")
+        base = truth
+    assert ctx.counters()["parallel_raycast_scans"] == 4
+    ctx.close()
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_randomized_rooms_scan_match_parity(F, seed):
     """Scan matching in random rooms: from start poses up to 15 cm / 5 deg off, device and oracle must reach the same pose

@@ -139,3 +139,24 @@ def test_batched_export_and_import_between_two_contexts(Fsim):
             pf.set_poses(nxt); pf.stage_set_scan(pts[2]); pf.stage_update_maps()
             b.set_poses(nxt); b.update_maps(pts[2])
     a.close(); b.close()
+
+
+def test_shuffled_points_on_the_simulator(Fsim):
+    """A point cloud in random order: the chunks of 64 beams have no cone, the patch kernel tests them beam by beam."""
+    F = Fsim
+    pts, odom, truth = F.corridor_log(1, 360)
+    rng = np.random.default_rng(4)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=1, seed=3))
+    pf.set_prior(pose0)
+    s0 = pts[0][rng.permutation(len(pts[0]))]
+    pf.update(s0, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=1, device=0))
+    ctx.init(s0, pose0)
+    s1 = pts[1][rng.permutation(len(pts[1]))]
+    start = O.se2(*truth[1])[None]
+    pf.set_poses(start); pf.stage_set_scan(s1); pf.stage_update_maps()
+    ctx.set_poses(start); ctx.update_maps(s1)
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), pf.occ(0).dump(), OCC_FIELDS, "occ")
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), pf.dm(0).dump(), DM_FIELDS, "dm")
+    ctx.close()
