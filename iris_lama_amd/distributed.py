@@ -152,8 +152,9 @@ class ShardedPF:
             if buf.device != self.device:
                 buf = msgs[(sr, dr)] = buf.to(self.device)
             ops.append(dist.P2POp(dist.isend if sr == self.rank else dist.irecv, buf, dr if sr == self.rank else sr))
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
+        if ops:                                               # (a rank that neither sends nor receives in this resample has none)
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
         where = {(sr, sp): t for t, (sr, dr, sp) in enumerate(transfers) if dr == self.rank}
