@@ -1,6 +1,7 @@
 """ctypes bindings of include/lama_hip.h and include/lama_host.h."""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -63,6 +64,17 @@ HIP_SYMBOLS = [
 _hip = None
 
 
+def _torch_runtime_first():
+    """A process that also uses PyTorch-ROCm must load torch's HIP runtime FIRST: torch bundles its own libamdhip64, and when
+    /opt/rocm's copy (which liblama_hip.so links) is already loaded, torch.cuda finds "no HIP GPUs" afterwards (measured on the
+    MI355X box; the other order works: liblama_hip.so then binds to the copy torch brought).  Importing torch is enough; done
+    before the device library is loaded -- directly or through liblama_host.so -- whenever torch is installed."""
+    if "torch" not in sys.modules and not os.environ.get("LAMA_NO_TORCH_PRELOAD"):
+        import importlib.util
+        if importlib.util.find_spec("torch") is not None:
+            import torch  # noqa: F401
+
+
 def hip_lib():
     """Load liblama_hip.so (raises if it has not been built: there is no fallback path)."""
     global _hip
@@ -70,6 +82,7 @@ def hip_lib():
         if not os.path.exists(HIP_LIB):
             raise LamaError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        _torch_runtime_first()
         L = C.CDLL(HIP_LIB)
         _bind_hip(L)
         _hip = L
@@ -355,6 +368,7 @@ def host_lib():
     if _host is None:
         if not os.path.exists(HOST_LIB):
             raise LamaError(f"{HOST_LIB} is missing: run `make -C iris_lama_amd host`")
+        _torch_runtime_first()                                # (the host library loads liblama_hip.so when a device object is created)
         L = C.CDLL(HOST_LIB)
         L.lama_corridor_generate.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lama_corridor_generate.restype = C.c_int

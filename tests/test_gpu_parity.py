@@ -228,6 +228,43 @@ def test_particle_blob_between_contexts_with_different_windows(F):
     a.close(); b.close()
 
 
+def test_batched_import_grows_the_receiving_arenas(F):
+    """A shard whose arenas are still small receives particles from a shard whose arenas have grown: the batched import enlarges
+    the receiver first (all slots keep their maps), several slots take the same blob, and the receiver carries on updating."""
+    import torch
+    pts, odom, truth = F.corridor_log(4, 1080)
+    pose0 = O.se2(*odom[0])
+    P = 3
+    pf = O.PF(O.default_options(particles=P, seed=2))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    a = F.HipContext(F.default_cfg(particles=P))                                             # default arenas
+    b = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=8, occ_patch_capacity=8))  # grows on demand
+    a.init(pts[0], pose0)
+    b.init(pts[0], pose0)
+    rng = np.random.default_rng(3)
+    for k in (1, 2):
+        start = np.stack([O.se2_mul(O.se2(*truth[k]), O.se2(*rng.normal(0, [0.05, 0.05, 0.02]))) for _ in range(P)])
+        pf.set_poses(start); pf.stage_set_scan(pts[k]); pf.stage_update_maps()
+        a.set_poses(start); a.update_maps(pts[k])
+    src = np.array([2, 0], dtype=np.uint32)
+    sizes = a.export_sizes(src)
+    bufs = [torch.empty(int(n), dtype=torch.uint8, device="cuda") for n in sizes]
+    assert np.array_equal(a.export_particles(src, [x.data_ptr() for x in bufs], sizes), sizes)
+    b.import_particles([0, 1, 2], [bufs[0].data_ptr(), bufs[0].data_ptr(), bufs[1].data_ptr()], [sizes[0], sizes[0], sizes[1]])
+    pf.stage_resample_with(np.array([2, 2, 0], dtype=np.int32))
+    assert np.array_equal(b.get_poses(), pf.poses())
+    for rnd in range(2):
+        for i in range(P):
+            assert_maps_equal(b.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"round {rnd} occ p{i}")
+            assert_maps_equal(b.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"round {rnd} dm p{i}")
+        if rnd == 0:
+            nxt = np.stack([O.se2_mul(O.se2(*truth[3]), O.se2(*rng.normal(0, [0.05, 0.05, 0.02]))) for _ in range(P)])
+            pf.set_poses(nxt); pf.stage_set_scan(pts[3]); pf.stage_update_maps()
+            b.set_poses(nxt); b.update_maps(pts[3])
+    a.close(); b.close()
+
+
 def test_visited_counter_wrap_inside_a_scan(F):
     """uint16 `visited` wraps silently in the reference (src/sdm/frequency_occupancy_map.cpp:65-74).  The parallel ray-cast adds
     a scan's visits in any order, which is only the same thing while no counter wraps INSIDE a scan: 2000 beams down one corridor
