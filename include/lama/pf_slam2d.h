@@ -9,9 +9,10 @@
 //     throws std::runtime_error when the device library or a GPU is missing);
 //   * what must replay the host RNG stays on the host, statement for statement: drawFromMotion (:365-391),
 //     normalize (:511-535), systematic-resampling indices (:537-556), std::mt19937 seeded like random.cpp;
-//   * Particle::dm / Particle::occ are not host objects any more; getDistanceMap()/getOccupancyMap() are
-//     replaced by downloadDistanceMap()/downloadOccupancyMap() which return the best particle's patches in the
-//     reference's record formats (see INTEGRATION.md for rebuilding a host lama::Map from them);
+//   * the particles' maps live in HBM: Particle::dm / Particle::occ are not host members any more.  getOccupancyMap() /
+//     getDistanceMap() (the best particle's, as in the reference) and getParticleOccupancyMap(i) / getParticleDistanceMap(i)
+//     (any particle's: what Particle::occ / Particle::dm gave) return host SNAPSHOTS with the const map API of lama/sdm_maps.h;
+//     download*Map() return the same patches as raw arrays in the reference's record formats;
 //   * Options gains `gpu_device`, `shard_rank`, `shard_world`, ..., `gpus` at the END (aggregate/default use is unchanged).
 //     With gpus > 1 ONE object drives several GPUs from C++ (a host thread per device, peer copies for cross-shard clones):
 //     update() stays the whole step, nothing else changes for the consumer.
@@ -83,7 +84,7 @@ public:
         uint32_t shard_rank = 0;
         uint32_t shard_world = 1;
         bool profile = false;              // bracket kernels with hipEvents (see lama_hip_get_counters)
-        uint32_t brushfire_mode = 0;       // 0 exact (default), 1 level-synchronous canonical tie rule, 2 exact level by level (lama_hip.h)
+        uint32_t brushfire_mode = 0;       // 0 exact (default, bit-identical to the reference), 1 level-synchronous canonical tie rule (opt-in, NOT bit-identical; lama_hip.h)
         // Device map storage (0 = the device library's defaults).  The reference's maps are unbounded (src/sdm/map.cpp:400-411);
         // here the patch arenas GROW on demand (doubled whenever a particle uses more than half of them) and the map window
         // (window_patches x 1.6 m at 0.05 m: default 128 = 204.8 m, at most 248) FOLLOWS the robot; only a mapped area larger
@@ -133,6 +134,14 @@ public:
     // cells: 10240 B (distance_t) or 4096 B (frequency) per patch, masks: 16 x uint64 per patch.
     bool downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
     bool downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    // Any particle's maps (the reference's public Particle::dm / Particle::occ, include/lama/pf_slam2d.h:83-84): the same arrays
+    // for particle i, and host snapshots with the const map API (valid until they are released; they do not follow later
+    // updates).  false / nullptr before the first scan, for i >= particles, or when particle i lives on another PROCESS' shard
+    // (a gpus > 1 object reaches all of its shards).
+    bool downloadParticleDistanceMap(size_t i, std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    bool downloadParticleOccupancyMap(size_t i, std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const;
+    std::shared_ptr<const FrequencyOccupancyMap> getParticleOccupancyMap(size_t i) const;
+    std::shared_ptr<const DynamicDistanceMap> getParticleDistanceMap(size_t i) const;
     // the same as lama::sdm::HostMap, ready for sdm::write (the reference's .sdm file) / sdm::export_to_png
     bool downloadDistanceMap(sdm::HostMap& m) const
     {

@@ -40,10 +40,13 @@ typedef struct lama_pf lama_pf;
 
 void lama_pf_default_options(lama_pf_options* o);
 
-/* Device library used by PFSlam2D objects created afterwards.  Default (path == NULL or never called):
- * liblama_hip.so next to liblama_host.so.  The test-suite points this at an oracle-backed test double to
- * exercise the host/multi-rank logic on machines without a GPU; the product never calls it. */
+#ifdef LAMA_TESTING
+/* ONLY in a host library compiled with -DLAMA_TESTING (the test-suite builds its own copy, tests/cpu_engine/Makefile); the
+ * shipped liblama_host.so neither declares nor exports it (tests/test_cabi.py asserts that) and always binds liblama_hip.so
+ * next to itself.  Device library used by the objects created afterwards (NULL = liblama_hip.so): the test-suite points it at
+ * an oracle-backed test double to exercise the host / multi-rank logic on machines without a GPU. */
 int lama_host_set_engine_library(const char* path);
+#endif
 /* Path of the device library bound to `pf` (so callers can assert that the HIP library is the one in use). */
 const char* lama_pf_engine_origin(const lama_pf* pf);
 

@@ -8,6 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "lib", "liblama_hip.so")
 HOST_LIB = os.path.join(_HERE, "lib", "liblama_host.so")
+_PRODUCT_HOST_LIB = HOST_LIB
 
 MAP_DISTANCE, MAP_OCCUPANCY = 0, 1
 
@@ -70,9 +71,12 @@ def _torch_runtime_first():
     MI355X box; the other order works: liblama_hip.so then binds to the copy torch brought).  Importing torch is enough; done
     before the device library is loaded -- directly or through liblama_host.so -- whenever torch is installed."""
     if "torch" not in sys.modules and not os.environ.get("LAMA_NO_TORCH_PRELOAD"):
-        import importlib.util
-        if importlib.util.find_spec("torch") is not None:
-            import torch  # noqa: F401
+        try:
+            import importlib.util
+            if importlib.util.find_spec("torch") is not None:
+                import torch  # noqa: F401
+        except Exception:      # torch is optional: a broken install must not make liblama_hip.so unloadable (set LAMA_NO_TORCH_PRELOAD=1
+            pass               # to skip the import altogether, e.g. for pure-ctypes users who never touch torch)
 
 
 def hip_lib():
@@ -401,7 +405,7 @@ class PFOptions(C.Structure):
 
 
 HOST_SYMBOLS = [
-    "lama_corridor_generate", "lama_pf_default_options", "lama_host_set_engine_library", "lama_pf_engine_origin",
+    "lama_corridor_generate", "lama_pf_default_options", "lama_pf_engine_origin",
     "lama_pf_create", "lama_pf_destroy", "lama_pf_last_error", "lama_pf_set_prior", "lama_pf_update",
     "lama_pf_update_begin", "lama_pf_local_range", "lama_pf_local_loglik", "lama_pf_plan_resample",
     "lama_pf_apply_resample", "lama_pf_update_maps", "lama_pf_device_context", "lama_pf_get_poses",
@@ -428,7 +432,7 @@ HOST_SYMBOLS = [
 def _bind_host(L):
     vp, i32, u32, d = C.c_void_p, C.c_int32, C.c_uint32, C.c_double
     sig = {
-        "lama_pf_default_options": (None, [vp]), "lama_host_set_engine_library": (i32, [C.c_char_p]),
+        "lama_pf_default_options": (None, [vp]),
         "lama_pf_engine_origin": (C.c_char_p, [vp]), "lama_pf_create": (vp, [vp, vp, i32]),
         "lama_pf_destroy": (None, [vp]), "lama_pf_last_error": (C.c_char_p, [vp]),
         "lama_pf_set_prior": (None, [vp, d, d, d]), "lama_pf_update": (i32, [vp, vp, u32, vp, vp, vp, d]),
@@ -493,11 +497,15 @@ def _hostlib():
     return L
 
 
-def set_engine_library(path):
-    """Testing hook: bind a different implementation of the device C-ABI (None = liblama_hip.so)."""
-    rc = _hostlib().lama_host_set_engine_library(path.encode() if path else None)
-    if rc != 0:
-        raise LamaError(f"cannot bind engine library {path}")
+def use_host_library(path=None):
+    """Load the host C-ABI (include/lama_host.h) from `path` instead of iris_lama_amd/lib/liblama_host.so (None = back to the
+    product library).  The product never calls this; the test-suite loads its own -DLAMA_TESTING build of the same sources
+    (tests/_testhost.py), the only build that can bind anything but liblama_hip.so.  Objects created before the switch keep
+    working only as long as no call is made through them afterwards: switch between, not during, uses."""
+    global _host, _host_bound, HOST_LIB
+    HOST_LIB = path or _PRODUCT_HOST_LIB
+    _host = None
+    _host_bound = False
 
 
 def pf_options(**kw):

@@ -12,9 +12,13 @@ HipEngine::~HipEngine()
     // the library stays loaded for the life of the process (HIP runtimes do not like dlclose)
 }
 
+#ifdef LAMA_TESTING      // the test-suite's host library only (tests/cpu_engine/Makefile): the shipped liblama_host.so has no such hook
 static std::shared_ptr<HipEngine> g_override;
 void setEngineOverride(std::shared_ptr<HipEngine> e) { g_override = std::move(e); }
-std::shared_ptr<HipEngine> engineOverride() { return g_override; }
+std::shared_ptr<HipEngine> defaultEngine() { return g_override ? g_override : loadHipEngine(); }
+#else
+std::shared_ptr<HipEngine> defaultEngine() { return loadHipEngine(); }
+#endif
 
 static std::string siblingPath()
 {

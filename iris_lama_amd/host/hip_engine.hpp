@@ -1,6 +1,7 @@
 // hip_engine.hpp -- run-time binding of the device C-ABI (include/lama_hip.h) for the host classes.
-// The table can also be filled by a caller (tests inject a CPU engine to exercise the multi-rank logic on
-// machines without a GPU); the default loader only ever binds liblama_hip.so and throws if it cannot.
+// The loader only ever binds liblama_hip.so and throws if it cannot.  (A host library compiled with -DLAMA_TESTING -- the
+// test-suite's own build, never the shipped one -- can be pointed at another implementation of the C-ABI, so that the
+// multi-rank host logic is exercised on machines without a GPU.)
 #pragma once
 
 #include <memory>
@@ -54,8 +55,12 @@ struct HipEngine {
 // std::runtime_error if the library or any symbol is missing.
 std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path = std::string());
 
-// Engine override used by the next PFSlam2D constructed in this process (nullptr = default loader).
+// The engine a newly constructed host object binds: liblama_hip.so through loadHipEngine().
+std::shared_ptr<HipEngine> defaultEngine();
+#ifdef LAMA_TESTING
+// Test builds of the host library only (-DLAMA_TESTING, tests/cpu_engine/Makefile): an engine that the objects constructed
+// afterwards bind instead (nullptr = default loader).  The shipped liblama_host.so is compiled without it.
 void setEngineOverride(std::shared_ptr<HipEngine> e);
-std::shared_ptr<HipEngine> engineOverride();
+#endif
 
 } // namespace lama

@@ -84,6 +84,7 @@ void lama_pf_default_options(lama_pf_options* o)
     o->create_summary = 1; o->gpu_device = 0; o->shard_rank = 0; o->shard_world = 1; o->profile = 0;
 }
 
+#ifdef LAMA_TESTING      // test builds of the host library only; the shipped liblama_host.so does not export this
 int lama_host_set_engine_library(const char* path)
 {
     try {
@@ -94,6 +95,7 @@ int lama_host_set_engine_library(const char* path)
         return -1;
     }
 }
+#endif
 
 lama_pf* lama_pf_create(const lama_pf_options* o, char* err, int errcap)
 {

@@ -25,7 +25,7 @@ void scan_arrays(const PointCloudXYZ& s, std::vector<double>& pts, double o[3], 
 
 LidarOdometry2D::LidarOdometry2D(const Options& o) : opt_(o)              // src/lidar_odometry_2d.cpp:42-52
 {
-    eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+    eng_ = defaultEngine();
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = 1;

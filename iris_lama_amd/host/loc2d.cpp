@@ -84,7 +84,7 @@ void Loc2D::ensureContext()
 {
     if (ctx_) return;
     if (!distance_map) throw std::runtime_error("lama::Loc2D: Init() must be called first");
-    eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+    eng_ = defaultEngine();
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = 1;

@@ -116,7 +116,7 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
         if ((uint32_t)options_.gpus > options_.particles) throw std::runtime_error("lama::PFSlam2D: more GPUs than particles");
         // all shards replay the same host random stream: settle the seed first (0 = random_device, src/pf_slam2d.cpp:131-134)
         if (options_.seed == 0) options_.seed = std::random_device()() | 1u;
-        eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+        eng_ = defaultEngine();
         int32_t ndev = 0;
         if (eng_->device_count(&ndev) != 0 || ndev <= 0)
             throw std::runtime_error("lama::PFSlam2D: no usable MI355X / HIP device; there is no CPU fallback");
@@ -140,7 +140,7 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
     hi_ = (uint32_t)(((r + 1) * P + G - 1) / G);
     if (hi_ <= lo_) throw std::runtime_error("lama::PFSlam2D: more shards than particles");
 
-    eng_ = engineOverride() ? engineOverride() : loadHipEngine();
+    eng_ = defaultEngine();
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = hi_ - lo_;
@@ -649,22 +649,54 @@ static bool download(const HipEngine* e, lama_hip_ctx* ctx, uint32_t particle, i
     return e->pf_download_map(ctx, particle, kind, n, ids.data(), cells.data(), masks.data(), &got) == 0 && got == n;
 }
 
+// Any particle's maps (the reference's public Particle::dm / Particle::occ, include/lama/pf_slam2d.h:83-84) in the reference's
+// record formats.  False before the first scan, for i >= P, or when particle i lives on another process' shard.
+bool PFSlam2D::downloadParticleDistanceMap(size_t i, std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{
+    if (!has_first_scan || i >= particles_.size()) return false;
+    if (group_) return ownerOf((uint32_t)i)->downloadParticleDistanceMap(i, ids, cells, masks);
+    if (!ownsParticle((uint32_t)i)) return false;
+    return download(eng_.get(), ctx_, (uint32_t)i - lo_, LAMA_HIP_MAP_DISTANCE, 10, ids, cells, masks);
+}
+
+bool PFSlam2D::downloadParticleOccupancyMap(size_t i, std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
+{
+    if (!has_first_scan || i >= particles_.size()) return false;
+    if (group_) return ownerOf((uint32_t)i)->downloadParticleOccupancyMap(i, ids, cells, masks);
+    if (!ownsParticle((uint32_t)i)) return false;
+    return download(eng_.get(), ctx_, (uint32_t)i - lo_, LAMA_HIP_MAP_OCCUPANCY, 4, ids, cells, masks);
+}
+
+// the best particle's (its replicated weights name the same best particle on every shard)
 bool PFSlam2D::downloadDistanceMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
 {
-    if (!has_first_scan) return false;
-    const size_t b = getBestParticleIdx();
-    if (group_) return ownerOf((uint32_t)b)->downloadDistanceMap(ids, cells, masks);     // its replicated weights name the same best particle
-    if (!ownsParticle((uint32_t)b)) return false;
-    return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_DISTANCE, 10, ids, cells, masks);
+    return has_first_scan && downloadParticleDistanceMap(getBestParticleIdx(), ids, cells, masks);
 }
 
 bool PFSlam2D::downloadOccupancyMap(std::vector<uint64_t>& ids, std::vector<uint8_t>& cells, std::vector<uint64_t>& masks) const
 {
-    if (!has_first_scan) return false;
-    const size_t b = getBestParticleIdx();
-    if (group_) return ownerOf((uint32_t)b)->downloadOccupancyMap(ids, cells, masks);
-    if (!ownsParticle((uint32_t)b)) return false;
-    return download(eng_.get(), ctx_, (uint32_t)b - lo_, LAMA_HIP_MAP_OCCUPANCY, 4, ids, cells, masks);
+    return has_first_scan && downloadParticleOccupancyMap(getBestParticleIdx(), ids, cells, masks);
+}
+
+std::shared_ptr<const FrequencyOccupancyMap> PFSlam2D::getParticleOccupancyMap(size_t i) const
+{
+    sdm::HostMap m;
+    m.kind = sdm::kFrequencyOccupancyMap; m.resolution = options_.resolution;
+    if (!downloadParticleOccupancyMap(i, m.ids, m.cells, m.masks)) return nullptr;
+    return std::make_shared<const FrequencyOccupancyMap>(std::move(m));
+}
+
+std::shared_ptr<const DynamicDistanceMap> PFSlam2D::getParticleDistanceMap(size_t i) const
+{
+    sdm::HostMap m;
+    m.kind = sdm::kDistanceMap; m.resolution = options_.resolution;
+    const uint32_t r = (uint32_t)std::ceil(options_.l2_max * (1.0 / options_.resolution));    // DynamicDistanceMap::setMaxDistance :149-153
+    m.max_sqdist = r * r;
+    if (!downloadParticleDistanceMap(i, m.ids, m.cells, m.masks)) return nullptr;
+    auto dm = std::make_shared<DynamicDistanceMap>(std::move(m));
+    const PFSlam2D* o = ownerOf((uint32_t)i);
+    dm->bindDevice(o->eng_, o->ctx_, (uint32_t)i - o->lo_);
+    return dm;
 }
 
 // src/pf_slam2d.cpp:49-104 (same buckets; plain loops instead of Eigen::Map)

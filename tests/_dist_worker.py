@@ -19,7 +19,8 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
 
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if engine_path:
-        F.set_engine_library(engine_path)
+        import _testhost                 # test double of the device C-ABI: needs the test-suite's own -DLAMA_TESTING host build
+        _testhost.set_engine_library(engine_path)
     pts, odom, _ = F.corridor_log(steps, beams)
     opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=0)
     pf = ShardedPF(opts, device=torch.device("cpu") if backend == "gloo" else None)

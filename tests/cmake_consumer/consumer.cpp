@@ -147,6 +147,20 @@ int main()
             so.robust_cost.reset(new lama::HuberWeight(0.1));
             try { lama::Solve(so, problem); return 9; } catch (const std::invalid_argument&) {}   // no device kernel: must refuse
         }
+        // ANY particle's maps, what the reference's public Particle::occ / Particle::dm give (include/lama/pf_slam2d.h:83-84): the best
+        // particle's snapshot equals getOccupancyMap() cell for cell, another particle's map is a map of its own
+        {
+            const size_t best = slam.getBestParticleIdx(), other = (best + 1) % slam.getParticles().size();
+            std::shared_ptr<const lama::FrequencyOccupancyMap> pb = slam.getParticleOccupancyMap(best), po = slam.getParticleOccupancyMap(other);
+            std::shared_ptr<const lama::DynamicDistanceMap> db = slam.getParticleDistanceMap(best), dother = slam.getParticleDistanceMap(other);
+            if (!pb || !po || !db || !dother || slam.getParticleOccupancyMap(slam.getParticles().size())) return 40;
+            size_t diff = 0, cells = 0, other_free = 0;
+            map->visit_all_cells([&](const lama::Vector3ui& c) { ++cells; if (map->isFree(c) != pb->isFree(c) || map->isOccupied(c) != pb->isOccupied(c)) ++diff; });
+            po->visit_all_cells([&](const lama::Vector3ui& c) { if (po->isFree(c)) ++other_free; });
+            if (diff != 0 || cells == 0 || other_free < 1000 || pb->patches() != map->patches()) return 41;
+            if (db->distance(lama::Vector3d(1.0, 2.0, 0.0)) != dm->distance(lama::Vector3d(1.0, 2.0, 0.0)) || dother->patches() == 0) return 42;
+            std::printf("per-particle maps: particle %zu (best) == getOccupancyMap(), particle %zu has %zu free cells\n", best, other, other_free);
+        }
         uint64_t occmem = 0, dmmem = 0;
         if (slam.getMemoryUsage(occmem, dmmem) != occmem + dmmem || occmem == 0 || dmmem == 0 || slam.getMemoryUsage() == 0) return 6;
         slam.saveOccImage("/tmp/lama_consumer_occ.png");

@@ -3,7 +3,7 @@
 // Purpose: exercise the HOST-side logic of the product (lama::PFSlam2D orchestration, RNG replay, sharding,
 // the torch.distributed driver and its particle shipping) on machines without a GPU, e.g. the world_size-2
 // gloo tests.  It lives under tests/, links the oracle, and is never shipped, built or loaded by the product:
-// it is only reachable through lama_host_set_engine_library(), which only the test-suite calls.
+// it is only reachable through lama_host_set_engine_library(), which exists only in the test-suite's own -DLAMA_TESTING build of the host library.
 // "Device buffers" of export/import are plain host pointers here.
 #include <cstdlib>
 #include <cstring>

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared(header, prefix):
     src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef LAMA_TESTING.*?#endif", "", src, flags=re.S)      # declared for the test-suite's own build only
     return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", src)))
 
 
@@ -38,11 +39,26 @@ def test_host_library_exports_header_symbols():
 def test_product_fails_loudly_without_gpu():
     if F.device_count() > 0:
         pytest.skip("a GPU is present")
-    F.set_engine_library(None)
+    F.use_host_library(None)
     with pytest.raises(F.LamaError, match="no CPU fallback"):
         F.PFSlam2D(F.pf_options(particles=4, seed=1))
     with pytest.raises(F.LamaError):
         F.HipContext(F.default_cfg(particles=4))
+
+
+def test_shipped_host_library_has_no_engine_override():
+    """the hook that binds another implementation of the device C-ABI exists only in the test-suite's own
+    -DLAMA_TESTING build of the host sources; the shipped liblama_host.so neither exports it nor contains the override."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "iris_lama_amd"), "host"], check=True)
+    L = C.CDLL(F._PRODUCT_HOST_LIB)
+    assert not hasattr(L, "lama_host_set_engine_library")
+    syms = subprocess.run(["nm", "-D", "--defined-only", F._PRODUCT_HOST_LIB], check=True, capture_output=True, text=True).stdout
+    assert "set_engine_library" not in syms and "setEngineOverride" not in syms and "g_override" not in syms
+    assert "defaultEngine" in syms
+    import _testhost
+    _testhost.build()
+    T = C.CDLL(_testhost.TEST_HOST)
+    assert hasattr(T, "lama_host_set_engine_library")
 
 
 def test_product_does_not_reference_oracle():

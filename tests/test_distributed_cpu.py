@@ -19,7 +19,8 @@ from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
 from _dist_worker import run
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CPU_ENGINE = os.path.join(HERE, "cpu_engine", "_build", "liblama_cpu_engine.so")
+import _testhost
+from _testhost import CPU_ENGINE
 
 
 def _free_port():
@@ -81,7 +82,7 @@ def test_multi_gpu_object_equals_single_process_oracle(gpus, P):
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpu_engine")], check=True)
     steps, beams, gain = 10, 360, 0.01
     pts, odom, _ = F.corridor_log(steps, beams)
-    F.set_engine_library(CPU_ENGINE)
+    _testhost.set_engine_library(CPU_ENGINE)
     try:
         pf = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, gpus=gpus))
         assert pf.engine_origin().endswith("liblama_cpu_engine.so")
@@ -111,4 +112,4 @@ def test_multi_gpu_object_equals_single_process_oracle(gpus, P):
                 assert_maps_equal(ctx.download_map(j, F.MAP_OCCUPANCY), o.occ(lo + j).dump(), OCC_FIELDS, f"occ p{lo + j}")
         pf.close()
     finally:
-        F.set_engine_library(None)
+        _testhost.set_engine_library(None)

@@ -9,18 +9,18 @@ import numpy as np
 import pytest
 
 import _oracle as O
+import _testhost
 import iris_lama_amd.ffi as F
+from _testhost import CPU_ENGINE
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CPU_ENGINE = os.path.join(HERE, "cpu_engine", "_build", "liblama_cpu_engine.so")
 
 
 @pytest.fixture(scope="module", autouse=True)
 def cpu_engine():
-    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpu_engine")], check=True)
-    F.set_engine_library(CPU_ENGINE)
+    _testhost.set_engine_library(CPU_ENGINE)      # builds tests/cpu_engine, switches ffi to the -DLAMA_TESTING host build
     yield
-    F.set_engine_library(None)
+    _testhost.set_engine_library(None)
 
 
 @pytest.mark.parametrize("P,gain,expect_resample", [(10, 3.0, False), (12, 0.01, True)])
