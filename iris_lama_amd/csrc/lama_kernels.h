@@ -880,6 +880,7 @@ struct BfLds {
     uint32_t cmd_r;        // raise-queue length at the hand-over
     uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
     uint32_t cmd;          // lower-queue length at the hand-over, or BF_CMD_EXIT
+    uint64_t dummy[2][64]; // per wave and lane: absorbs the LDS stores of lanes without work (an address select instead of an exec mask)
 };
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
@@ -978,6 +979,142 @@ __device__ __forceinline__ void lds_push(uint64_t* h, uint32_t& size, uint64_t v
     LAMA_LOCKSTEP();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the wave-pair brushfire as (nearly) straight-line code.
+//
+// Measured on the MI355X (tools/ubench/issue_costs.hip, profiles/r04_issue_costs_single_wave.txt), one wave alone on a SIMD:
+// a dependent VALU or SALU instruction issues every 4-5 cycles, but every hand-over from the vector to the scalar side costs
+// ~18 cycles on top (v_cmp -> s_cbranch_vccz 28 cycles NOT taken, 44 taken; v_readfirstlane -> s_add -> v_mov 28), an
+// exec-masked region `s_and_saveexec / s_cbranch_execz / s_or exec` 46-52 cycles whether it is entered or skipped, against 13
+// for v_cmp + v_add + v_cndmask.  The round-3 kernel executed 52 branches per pop (SQ_INSTS_BRANCH, profiles/r04_sq_brushfire_
+// before.txt) -- the compiler's lowering of `if (lane has work) load / store` -- which is where its "12 cycles per
+// instruction" came from.  This form keeps control flow wave-uniform and rare:
+//   * loads and stores of lanes without work are not masked off, they go through BUFFER instructions with an offset beyond the
+//     buffer's extent: the hardware drops such a store and returns 0 for such a load -- exactly the "absent cell reads as zero"
+//     semantics of the map (a raw buffer resource per plane of the particle's arena);
+//   * LDS stores of lanes without work go to a per-lane dummy slot (an address select instead of an exec mask);
+//   * everything a pop can need only rarely -- a directory-cache miss, a patch allocation, the second load round of a tie, a
+//     stale queue entry, a cell outside the window -- is detected by ONE ballot and handled by the general code (the round-3
+//     loop body, kept as it was); the speculative path stores nothing before that test;
+//   * the heap pop of the helper wave is a fixed number of predicated rounds instead of a data-dependent loop.
+// The sequence of heap operations and of map stores is the sequential one, as before: results stay bit-identical.
+// ------------------------------------------------------------------------------------------------
+#ifdef LAMA_WAVE_SIM       // tests/sim: host stand-ins with the same out-of-range semantics
+struct BufRsrc { uint8_t* base; uint32_t bytes; };
+__device__ __forceinline__ BufRsrc buf_make(void* p, uint32_t bytes) { return BufRsrc{(uint8_t*)p, bytes}; }
+__device__ __forceinline__ uint32_t buf_load_u16(const BufRsrc& r, uint32_t off) { uint16_t v = 0; if (off <= r.bytes - 2u && off < r.bytes) std::memcpy(&v, r.base + off, 2); return v; }
+__device__ __forceinline__ uint32_t buf_load_u32(const BufRsrc& r, uint32_t off) { uint32_t v = 0; if (off <= r.bytes - 4u && off < r.bytes) std::memcpy(&v, r.base + off, 4); return v; }
+__device__ __forceinline__ void buf_store_u16(const BufRsrc& r, uint32_t off, uint32_t v) { if (off <= r.bytes - 2u && off < r.bytes) { const uint16_t w = (uint16_t)v; std::memcpy(r.base + off, &w, 2); } }
+__device__ __forceinline__ void buf_store_u32(const BufRsrc& r, uint32_t off, uint32_t v) { if (off <= r.bytes - 4u && off < r.bytes) std::memcpy(r.base + off, &v, 4); }
+__device__ __forceinline__ void buf_or_u64(const BufRsrc& r, uint32_t off, uint64_t v) { if (off <= r.bytes - 8u && off < r.bytes) { uint64_t w; std::memcpy(&w, r.base + off, 8); w |= v; std::memcpy(r.base + off, &w, 8); } }
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m, int lane) { return (uint32_t)__popcll(m & ((1ull << lane) - 1ull)); }
+#else
+using BufRsrc = __amdgpu_buffer_rsrc_t;
+// raw buffer (stride 0, offsets checked against `bytes`); 0x00020000 = the gfx9 / CDNA default word 3 (32-bit untyped data)
+__device__ __forceinline__ BufRsrc buf_make(void* p, uint32_t bytes) { return __builtin_amdgcn_make_buffer_rsrc(p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ uint32_t buf_load_u16(BufRsrc r, uint32_t off) { return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(r, (int)off, 0, 0); }
+__device__ __forceinline__ uint32_t buf_load_u32(BufRsrc r, uint32_t off) { return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0); }
+__device__ __forceinline__ void buf_store_u16(BufRsrc r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, (int)off, 0, 0); }
+__device__ __forceinline__ void buf_store_u32(BufRsrc r, uint32_t off, uint32_t v) { __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)off, 0, 0); }
+// (no builtin for the 64-bit OR.  The s_nop covers "VALU writes SGPR -> VMEM reads that SGPR: 5 wait states": the compiler's hazard
+// recogniser does not look inside inline assembly, and when it has spilled the resource to VGPR lanes it restores it with
+// v_readlane right in front of this instruction -- found on the device: the atomic went elsewhere, mask words were lost)
+__device__ __forceinline__ void buf_or_u64(BufRsrc r, uint32_t off, uint64_t v) { asm volatile("s_nop 4\n\tbuffer_atomic_or_x2 %0, %1, %2, 0 offen" :: "v"(v), "v"(off), "s"(r) : "memory"); }
+__device__ __forceinline__ uint32_t lane_rank(unsigned long long m, int) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+#endif
+constexpr uint32_t BUF_OOB = 0x7FFFFFF0u;      // a byte offset beyond any plane of a particle's arena (<= 134 MB)
+
+// pop() of the LDS heap h[0, size) by the helper wave, NR predicated rounds of the 5-level subtree walk of lds_sift_topdown (two
+// cover a heap of 1024 entries, three one of 8192) and the lone-left-child step, no data-dependent branch: same final array as
+// std::pop_heap.  The entry that ends up at the root is stored to *root_out (LDS) by whichever lane holds it -- nothing is read
+// back across lanes.  `dummy`: 64 LDS words that absorb the stores of lanes without work.
+template <int NR>
+__device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const int lane, const uint64_t anc, uint64_t* root_out, uint64_t* dummy)
+{
+    --size;
+    const uint32_t len = size;
+    if (len == 0) return;
+    const uint64_t value = h[len];                                   // the re-inserted last entry
+    const uint64_t tailc = h[len - 1];                               // the lone left child, if the hole ends above it
+    const uint32_t vprio = heap_prio(value);
+    const uint32_t lim = (len - 1) / 2;                              // nodes below `lim` have both children
+    const int d = 31 - __clz(lane + 1);
+    const bool is_left = (lane & 1) != 0;
+    const bool inner = lane >= 1 && lane < 63;
+    uint32_t H = 0;
+    bool stopped = false;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const uint32_t idx = (H << d) + (uint32_t)lane;              // lane L: the node at relative position L below H
+        const uint32_t left = is_left ? idx : idx - 1;
+        const uint32_t parent = (left - 1) >> 1;
+        const bool cand = !stopped && inner && parent < lim;
+        const uint32_t la = cand ? left : 1u;
+        const uint64_t vl = h[la], vr = h[la + 1];
+        const bool take_left = heap_prio(vr) > heap_prio(vl);        // __adjust_heap: right unless comp(right, left)
+        const bool step_to_me = cand && (is_left == take_left);
+        const unsigned long long okm = __ballot(step_to_me);
+        const bool onpath = cand && (okm & anc) == anc;
+        const uint64_t mine = is_left ? vl : vr;
+        const bool moves = onpath && !(heap_prio(mine) > vprio);
+        const unsigned long long pathm = __ballot(onpath), mvm = __ballot(moves);
+        LAMA_LOCKSTEP();
+        uint64_t* dst = moves ? h + parent : dummy + lane;
+        *dst = mine;
+        if (r == 0) {                                                // the new root: the child that moved up, else the re-inserted entry
+            const bool child_root = (lane == 1 || lane == 2) && moves;
+            const bool value_root = lane == 0 && (mvm & 6ull) == 0ull;
+            uint64_t* rd = (child_root || value_root) ? root_out : dummy + lane;
+            *rd = lane == 0 ? value : mine;
+        }
+        const int rel = 63 - __clzll((long long)(mvm | 1ull));       // deepest moved entry: its old slot is the new hole
+        const uint32_t Hn = (H << (31 - __clz(rel + 1))) + (uint32_t)rel;
+        H = mvm ? Hn : H;
+        stopped = stopped || (mvm != pathm);
+        LAMA_LOCKSTEP();
+    }
+    // the hole has a lone left child, the array's last entry
+    const bool up = !stopped && (len & 1u) == 0u && H == (len - 2) / 2 && heap_prio(tailc) <= vprio;
+    {
+        uint64_t* dst = (up && lane == 0) ? h + H : dummy + lane;
+        *dst = tailc;
+        uint64_t* rd = (up && H == 0 && lane == 0) ? root_out : dummy + lane;
+        *rd = tailc;
+    }
+    H = up ? len - 1 : H;
+    {
+        uint64_t* dst = lane == 0 ? h + H : dummy + lane;
+        *dst = value;
+    }
+    LAMA_LOCKSTEP();
+}
+
+// push_heap of the mailbox entries ent[0 .. cnt) (cnt <= 4, in order) by the helper wave: one gather of all would-be parents; when
+// no new entry has to move up (the normal case in a Dijkstra wave) they are appended, which is what the sequential push_heap calls
+// would have done; else those calls are replayed one by one.
+__device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t* cnt_p, const int lane, uint64_t* dummy)
+{
+    const uint32_t l4 = (uint32_t)lane & 3u;
+    const uint64_t entry = ent[l4];                                  // count, entries and would-be parents: ONE LDS round trip
+    const uint32_t pos = n + l4;
+    const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
+    const uint32_t cnt_v = *cnt_p;
+    const bool mine = (uint32_t)lane < cnt_v;
+    const bool up = mine && pprio > heap_prio(entry);
+    const unsigned long long upm = __ballot(up);
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
+    if (cnt == 0) return;
+    if (n >= 4 && upm == 0ull) {
+        uint64_t* dst = mine ? heap + pos : dummy + lane;
+        *dst = entry;
+        n += cnt;
+        LAMA_LOCKSTEP();
+        return;
+    }
+    #pragma unroll 1
+    for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
+}
+
 // push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
 // entries has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply appended, exactly
 // what the sequential push_heap calls would have done.  Returns true if the entries were appended unmoved.
@@ -1046,8 +1183,9 @@ __device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool f
 
 // the brushfire of ONE particle by the calling workgroup (body of k_brushfire)
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
-__device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, BfLds<LQ_LDS, RQ_LDS>& sh)
+__device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_any, BfLds<LQ_LDS, RQ_LDS>& sh)
 {
+    const int p = __builtin_amdgcn_readfirstlane(p_any);      // wave-uniform (the resume stage reads it from the hand-over list): scalar base addresses
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
@@ -1081,7 +1219,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, B
         // helper wave: owns both queues from the hand-over on.  While the raise queue is not empty it is the one popped
         // (dynamic_distance_map.cpp:162-173), then the lower queue (:175-194).
         __syncthreads();                                       // S0: heaps consistent
-        uint32_t hnl = sh.cmd, hnr = sh.cmd_r;
+        uint32_t hnl = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cmd), hnr = (uint32_t)__builtin_amdgcn_readfirstlane((int)sh.cmd_r);
         if (hnl == BF_CMD_EXIT) return;
 #ifdef LAMA_PROFILE_BF
         uint64_t hp[3] = {0, 0, 0};
@@ -1090,48 +1228,18 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, B
 #else
         #define HFT(k) do {} while (0)
 #endif
-        // push_heap of `cnt` (<= 4) mailbox entries.  Fast path: one gather of all parents; if none of the new entries
-        // has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply appended,
-        // exactly what the sequential push_heap calls would have done.
-        auto pushes = [&](uint64_t* heap, uint32_t& n, const uint64_t* ent, uint32_t cnt_v) {
-            const uint32_t l4 = (uint32_t)lane & 3u;
-            const uint64_t entry = ent[l4];                    // count, entries and would-be parents: ONE LDS round trip
-            const uint32_t pos = n + l4;
-            const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
-            const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
-            if (!cnt) return;
-            bool done = false;
-            if (n >= 4) {
-                const bool mine = (uint32_t)lane < cnt;
-                const bool up = mine && pprio > heap_prio(entry);
-                if (__ballot(up) == 0) {
-                    if (mine) heap[pos] = entry;
-                    n += cnt;
-                    done = true;
-                    LAMA_LOCKSTEP();
-                }
-            }
-            if (!done) {
-                #pragma unroll 1
-                for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
-            }
-        };
+        constexpr int NR = LQ_LDS > 1024 ? 3 : 2;              // rounds of lds_pop_flat: 5 heap levels each
+        uint64_t* const dmy = sh.dummy[1];
         for (uint32_t it = 0;; ++it) {
             const uint32_t b = it & 1u;
             const bool ph_r = hnr > 0;
-            if (ph_r) {
-                const uint64_t root_ = lds_pop_topdown(sh.raise, hnr, lane, anc);
-                if (lane == 0 && hnr > 0) sh.topq[b] = root_;
-            } else {
-                const uint64_t root_ = lds_pop_topdown(sh.lower, hnl, lane, anc);
-                if (lane == 0 && hnl > 0) sh.topq[b] = root_;
-            }
+            if (ph_r) lds_pop_flat<NR>(sh.raise, hnr, lane, anc, &sh.topq[b], dmy);
+            else lds_pop_flat<NR>(sh.lower, hnl, lane, anc, &sh.topq[b], dmy);
             HFT(0);
             lds_barrier();                                     // D
             HFT(1);
-            const uint32_t cr = sh.pr_n[b], cl = sh.pl_n[b];
-            if (ph_r) pushes(sh.raise, hnr, sh.pr_e[b], cr);   // raise() is the only producer of raise entries
-            pushes(sh.lower, hnl, sh.pl_e[b], cl);
+            if (ph_r) lds_push_flat(sh.raise, hnr, sh.pr_e[b], &sh.pr_n[b], lane, dmy);   // raise() is the only producer of raise entries
+            lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
             HFT(2);
             const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
             if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
@@ -1292,6 +1400,223 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p, B
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
 
+    // ---- lower wave of the wave pair (round 4: speculative straight-line pop, general code for the rare cases) ---- :175-194
+    if (TW) {
+        BFT(7);                                                    // (profiling build: everything before the lower wave)
+        uint64_t* const dmy = sh.dummy[0];
+        const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
+        const bool is_oc = lane == 5, role = lane < 6;
+
+        // The general pop: the reference's statements with every rare case (cache miss, patch allocation, stale entry, second
+        // load round of a tie, window error).  Leaves the entries to push in the mailbox and returns how many.
+        auto general_pop = [&](const uint64_t e, bool& over_out, uint64_t& entry_out) -> uint32_t {
+            over_out = false; entry_out = 0;
+            const int rx = q_rx(e), ry = q_ry(e);
+            // ONE load round: lanes 0..4 their own cell, lane 5 the obstacle cell the entry says the popped cell points to
+            const int x = rx + (is_oc ? q_ox(e) : ddx), y = ry + (is_oc ? q_oy(e) : ddy);
+            const bool inwin = (uint32_t)x < prm.WC && (uint32_t)y < prm.WC;
+            const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
+            const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
+            int slot = (role && inwin) ? dc.lookup(pidx) : -1;
+            uint16_t s = 0; uint32_t ob = 0;
+            if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) ob = obs[slot * 1024 + (int)ci]; }
+            const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
+            const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
+            uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)s, 5);
+            if (obs_x(cob) != q_ox(e) || obs_y(cob) != q_oy(e)) {
+                // stale entry (the cell was overwritten after it was queued): fetch the obstacle cell it points to now
+                const int ox2 = rx + obs_x(cob), oy2 = ry + obs_y(cob);
+                uint16_t t = 0;
+                if ((uint32_t)ox2 < prm.WC && (uint32_t)oy2 < prm.WC) {
+                    const int os2 = dc.lookup(((uint32_t)oy2 >> 5) * prm.W + ((uint32_t)ox2 >> 5));
+                    if (os2 >= 0) t = sv[os2 * 1024 + (int)(((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5))];
+                }
+                cos_ = t;
+            }
+            // :183-192  valid, its obstacle still has sqdist 0 (valid NOT tested), and lower() :283 still queued
+            const bool fire = (cs & SV_VALID) && (cos_ & SV_SQMASK) == 0 && (cs & SV_QUEUED);
+            if (!fire) return 0u;
+            const int cox = obs_x(cob), coy = obs_y(cob);
+            const int obx = rx + cox, oby = ry + coy;
+            const bool away = is_nb && !(ddx * cox > 0 || ddy * coy > 0);             // :296
+            if (away && !inwin) atomicOr(prm.err, ERR_WINDOW);
+            const bool nb = away && inwin;
+            const bool fresh = nb && slot < 0;
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            const bool nbok = nb && slot >= 0;
+            if (nbok) {
+                const uint64_t bit = 1ull << (ci & 63);
+                if (fresh || !(s & (SV_VALID | SV_QUEUED))) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);   // see raise()
+            }
+            const int qx = x - obx, qy = y - oby;
+            const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
+            const uint32_t cmp = (s & SV_VALID) ? (uint32_t)(s & SV_SQMASK) : prm.max_sqdist;
+            bool over = nbok && new_sq < cmp;
+            const bool tie = nbok && !over && new_sq == (uint32_t)(s & SV_SQMASK);     // :311-317
+            if (__ballot(tie)) {
+                // the neighbour's own obstacle cell: usually the very cell the popped cell points to, whose state lane 5 holds
+                const int ox = x + obs_x(ob), oy = y + obs_y(ob);
+                const bool same = ox == obx && oy == oby;
+                uint16_t os = cos_;
+                if (__ballot(tie && !same)) {
+                    if (tie && !same) {
+                        os = 0;
+                        if ((uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) {
+                            const int oslot = dc.lookup(((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5));
+                            if (oslot >= 0) os = sv[oslot * 1024 + (int)(((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))];
+                        }
+                    }
+                }
+                if (tie && (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0))) over = true;
+            }
+            if (over) {
+                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
+            }
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
+            const unsigned long long om = __ballot(over);
+            over_out = over; entry_out = q_entry(new_sq, x, y, obx - x, oby - y);
+            if (over) sh.pl_e[tw_it & 1u][__popcll(om & ((1ull << lane) - 1ull))] = entry_out;
+            return (uint32_t)__popcll(om);
+        };
+
+        while (tw_running && nl > 0) {
+            const uint64_t e = e_next;                                     // the same value in every lane
+            ++processed;
+            --nl;                                                          // the helper wave pops
+            uint32_t cnt = 0;
+            bool general;
+            bool over = false;                                             // lanes 0..3: my neighbour is lowered and pushed ...
+            uint64_t entry = 0;                                            // ... as this queue entry
+            {
+                // ---- speculative loads: every lane its role's cell through the directory cache, absent / foreign lanes out of range
+                const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+                const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
+                const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
+                const int x = rx + (is_oc ? eox : ddx), y = ry + (is_oc ? eoy : ddy);
+                const bool inwin = ((uint32_t)x < prm.WC) & ((uint32_t)y < prm.WC);
+                const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
+                const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
+                const uint32_t dv = sh.dc[dc.index(inwin ? pidx : 0u)];
+                const bool hit = inwin & ((dv >> 16) == pidx) & (dv != DC_EMPTY);
+                const int slot = (int)(int16_t)(dv & 0xFFFFu);
+                const bool have = role & hit & (slot >= 0);
+                const bool unknown = role & !hit;                           // not cached / outside the window: general code
+                const uint32_t coff = (uint32_t)slot * 1024u + ci;
+                const uint32_t s = buf_load_u16(rsv, have ? coff * 2u : BUF_OOB);
+                const uint32_t ob = buf_load_u32(robs, have ? coff * 4u : BUF_OOB);
+                const unsigned long long unk = __ballot(unknown);
+                BFT(0);
+                // the popped cell, and the obstacle cell it pointed to when it was queued
+                const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)s, 4);
+                const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
+                const uint32_t cos_ = (uint32_t)__builtin_amdgcn_readlane((int)s, 5);
+                const int cox = obs_x(cob), coy = obs_y(cob);
+                const bool stale = (cox != q_ox(e)) | (coy != q_oy(e));
+                const bool fire0 = ((cs & SV_VALID) != 0u) & ((cs & SV_QUEUED) != 0u);      // :183, lower() :283
+                general = (unk != 0ull) | (fire0 & stale);
+                BFT(1);
+#ifdef LAMA_PROFILE_BF_COUNT
+                prof[2] += unk != 0ull ? 1 : 0; prof[3] += (fire0 & stale) ? 1 : 0; prof[6] += (fire0 & ((cos_ & SV_SQMASK) == 0u)) ? 1 : 0;
+#endif
+                if (!general & fire0 & ((cos_ & SV_SQMASK) == 0u)) {         // :191 (valid NOT tested)
+                    const int obx = rx + cox, oby = ry + coy;
+                    const bool away = is_nb & !((ddx * cox > 0) | (ddy * coy > 0));            // :296
+                    const bool nbok = away & (slot >= 0);
+                    const int qx = x - obx, qy = y - oby;
+                    const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
+                    const uint32_t ssq = s & SV_SQMASK;
+                    const bool svalid = (s & SV_VALID) != 0u;
+                    const uint32_t cmp = svalid ? ssq : prm.max_sqdist;
+                    const bool lt = nbok & (new_sq < cmp);
+                    const bool tie = nbok & !lt & (new_sq == ssq);                            // :311-317
+                    const bool same = (x + obs_x(ob) == obx) & (y + obs_y(ob) == oby);      // the neighbour points at the same obstacle: lane 5 holds it
+                    // a tie whose obstacle cell is another one than mine: a second load round (about one pop in six)
+                    const bool tie_other = tie & !same;
+                    uint32_t os = cos_;                                                        // the state of the neighbour's obstacle cell
+                    bool miss2 = false;
+                    if (__ballot(tie_other) != 0ull) {
+                        const int ox = x + obs_x(ob), oy = y + obs_y(ob);
+                        const bool oin = tie_other & ((uint32_t)ox < prm.WC) & ((uint32_t)oy < prm.WC);
+                        const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);
+                        const uint32_t odv = sh.dc[dc.index(oin ? opidx : 0u)];
+                        const bool ohit = oin & ((odv >> 16) == opidx) & (odv != DC_EMPTY);
+                        const int oslot = (int)(int16_t)(odv & 0xFFFFu);
+                        miss2 = oin & !ohit;                                                   // not cached: general code
+                        const uint32_t ooff = ((uint32_t)oslot * 1024u + (((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))) * 2u;
+                        const uint32_t os2 = buf_load_u16(rsv, (ohit & (oslot >= 0)) ? ooff : BUF_OOB);   // outside the window / absent: reads as 0
+                        os = tie_other ? os2 : os;
+                    }
+#ifdef LAMA_PROFILE_BF_COUNT
+                    prof[4] += __ballot(away & (slot < 0)) ? 1 : 0; prof[5] += __ballot(tie_other) ? 1 : 0;
+#endif
+                    // rare: a patch to allocate, a directory entry that is not cached
+                    if (__builtin_expect(__ballot((away & (slot < 0)) | miss2) != 0ull, 0)) {
+                        general = true;
+                    } else {
+                        over = lt | (tie & (!svalid | !(((os & SV_VALID) != 0u) & ((os & SV_SQMASK) == 0u))));     // :311-317
+                        // get() of the examined neighbours: the Container mask bit of a flag-less cell (raise() has the argument)
+                        const bool need_bit = nbok & ((s & (SV_VALID | SV_QUEUED)) == 0u);
+                        buf_or_u64(rmask, need_bit ? ((uint32_t)slot * 16u + (ci >> 6)) * 8u : BUF_OOB, 1ull << (ci & 63u));
+                        // neighbours that are lowered, and the popped cell's is_queued (:329): one store instruction
+                        const uint32_t nsv = is_cur ? (cs & ~(uint32_t)SV_QUEUED) : (uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK);
+                        buf_store_u16(rsv, (over | is_cur) ? coff * 2u : BUF_OOB, nsv);
+                        buf_store_u32(robs, over ? coff * 4u : BUF_OOB, pack_obs(obx - x, oby - y));
+                        const unsigned long long om = __ballot(over);
+                        entry = q_entry(new_sq, x, y, obx - x, oby - y);
+                        const uint32_t rank = lane_rank(om, lane) & 3u;
+                        uint64_t* dst = over ? &sh.pl_e[tw_it & 1u][rank] : dmy + lane;
+                        *dst = entry;
+                        cnt = (uint32_t)__popcll(om);
+                    }
+                }
+            }
+            BFT(2);
+#ifdef LAMA_PROFILE_BF_COUNT
+            prof[0] += 1; prof[1] += general ? 1 : 0;
+#endif
+            if (__builtin_expect(general, 0)) cnt = general_pop(e, over, entry);
+            BFT(3);
+            // ---- hand-over: the push list is in the mailbox.  My own best push -- smallest (priority, neighbour index) -- by a
+            // minimum over the quad of neighbour lanes (DPP), before the helper is met: push_heap lifts an entry above its parent only
+            // if the parent's priority is strictly greater, so a pushed entry becomes the root iff its priority is smaller than the
+            // root's, the first of the smallest ones; the next top follows from the root the helper saw after pop() and that entry.
+            {
+                const uint32_t b_ = tw_it & 1u;
+                uint32_t key = over ? ((heap_prio(entry) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu;
+                uint32_t blo = (uint32_t)entry, bhi = (uint32_t)(entry >> 32);
+#define BF_QUAD_MIN(CTRL)                                                                                              \
+                {                                                                                                      \
+                    const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, 0xF, 0xF, false); \
+                    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp((int)blo, (int)blo, CTRL, 0xF, 0xF, false); \
+                    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp((int)bhi, (int)bhi, CTRL, 0xF, 0xF, false); \
+                    const bool t_ = k2 < key;                                                                          \
+                    key = t_ ? k2 : key; blo = t_ ? l2 : blo; bhi = t_ ? h2 : bhi;                                     \
+                }
+                BF_QUAD_MIN(0xB1)                                  // quad_perm [1,0,3,2]
+                BF_QUAD_MIN(0x4E)                                  // quad_perm [2,3,0,1]
+#undef BF_QUAD_MIN
+                const uint32_t okey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
+                uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)(dmy + lane);
+                *np = cnt;
+                BFT_MAIN(5);
+                lds_barrier();                                     // D
+                BFT_MAIN(6);
+                const uint64_t root_ = sh.topq[b_];
+                const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)root_), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(root_ >> 32));
+                const bool have_root = nl > 0;
+                const bool own_wins = (okey != 0xFFFFFFFFu) & (!have_root | ((okey >> 2) < (rhi >> 16)));
+                e_next = own_wins ? (((uint64_t)ohi << 32) | olo) : (((uint64_t)rhi << 32) | rlo);
+                nl += cnt;
+                spill = nl + 4 > (uint32_t)LQ_LDS;
+                tw_running = !spill && nl > 0;
+                ++tw_it;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            BFT(4);
+        }
+    }
     // ---- lower wave ------------------------------------------------------------------------- :175-194
 #ifdef LAMA_PROFILE_BF_MAIN
     BFT(0);

@@ -10,11 +10,12 @@ ctx = F.HipContext(F.default_cfg(particles=P, profile=1, brushfire_waves=int(os.
 ctx.init(pts[0], F.pose_from_xyr(*odom[0]))
 L = F.hip_lib()
 L.lama_hip_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
-names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "H:pop", "H:wait_D", "H:pushes"]
+# round 4 (wave pair, straight-line lower loop): main-wave buckets of the lower wave, then the helper wave's
+names = ["lookup+issue_loads", "wait_loads+decide0", "decide+commit", "general_pop", "tail(+barrier)", "H:pop", "H:wait_D", "H:pushes"]
 if os.environ.get("LAMA_PROF_MAIN"):   # -DLAMA_PROFILE_BF_MAIN build: all eight buckets belong to the main wave
-    names = ["top", "issue_loads", "heap_pop", "wait_loads+bcast", "decide", "handover+pre_D", "post_D", "wait_D"]
+    names = ["lookup+issue_loads", "wait_loads+decide0", "decide+commit", "general_pop", "post_D", "pre_D", "wait_D", "before_lower(raise)"]
 if os.environ.get("LAMA_PROF_COUNT"):  # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_COUNT build: event counts of the lower wave
-    names = ["lower_pops", "fire", "stale_entry", "tie", "tie_other_obstacle", "pushes", "-", "-"]
+    names = ["lower_pops", "general_pops", "g:cache_miss", "g:stale", "g:alloc", "g:tie_other", "fired", "-"]
 for k in range(1, 13):
     poses = np.tile(F.pose_from_xyr(*truth[k]), (P, 1))
     ctx.set_poses(poses)
@@ -26,8 +27,8 @@ for k in range(1, 13):
     pops = c["bf_cells"] / P
     if os.environ.get("LAMA_PROF_COUNT"):
         j = int(np.argmax(d[:, 0]))
-        print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:6])))
+        print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:7])))
         continue
-    tot = d[0][:5].sum()
+    tot = d[0][:5].sum() if not os.environ.get("LAMA_PROF_MAIN") else d[0][:7].sum()
     print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms raycast {c['ms_raycast']:.3f} ms  cycles/pop {tot / max(pops,1):.0f} :: " +
           " ".join(f"{n}={d[0][i] / max(pops,1):.0f}" for i, n in enumerate(names)))
