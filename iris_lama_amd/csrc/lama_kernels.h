@@ -866,6 +866,15 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 #else
 #define BFT_MAIN(k) do {} while (0)
 #endif
+#ifdef LAMA_PROFILE_BF_FINE            // developer build: eight consecutive sections of the straight-line lower pop (replaces the buckets above)
+#undef BFT
+#undef BFT_MAIN
+#define BFT(k) do {} while (0)
+#define BFT_MAIN(k) do {} while (0)
+#define BFF(k) do { const uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tprev; tprev = t_; } while (0)
+#else
+#define BFF(k) do {} while (0)
+#endif
 
 template <int LQ, int RQ>
 struct BfLds {
@@ -1022,6 +1031,20 @@ __device__ __forceinline__ void buf_store_u32(BufRsrc r, uint32_t off, uint32_t 
 __device__ __forceinline__ void buf_or_u64(BufRsrc r, uint32_t off, uint64_t v) { asm volatile("s_nop 4\n\tbuffer_atomic_or_x2 %0, %1, %2, 0 offen" :: "v"(v), "v"(off), "s"(r) : "memory"); }
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m, int) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 #endif
+// A value the optimiser must take as it is, in a vector register: lane predicates kept as 0 / ~0 words stay on the VALU (v_and /
+// v_or) instead of becoming wave masks that are combined on the scalar unit -- a vector -> scalar hand-over per operation.
+#ifdef LAMA_WAVE_SIM
+__device__ __forceinline__ uint32_t opq(uint32_t x) { return x; }
+#else
+__device__ __forceinline__ uint32_t opq(uint32_t x) { asm("" : "+v"(x)); return x; }
+#endif
+// 0 / ~0 words of the unsigned comparisons a < b and a <= b, for operands below 2^31
+__device__ __forceinline__ uint32_t m_lt(uint32_t a, uint32_t b) { return opq((uint32_t)((int32_t)(opq(a) - b) >> 31)); }
+__device__ __forceinline__ uint32_t m_le(uint32_t a, uint32_t b) { return ~m_lt(b, a); }
+// ... of v != 0 for any word, of a > 0 for a signed word (|a| < 2^31), and the select (m ? a : b) -- one v_bfi_b32
+__device__ __forceinline__ uint32_t m_nz(uint32_t v) { return opq((uint32_t)((int32_t)(opq(v) | (0u - v)) >> 31)); }
+__device__ __forceinline__ uint32_t m_pos(int32_t a) { return opq((uint32_t)((int32_t)(0u - (uint32_t)opq((uint32_t)a)) >> 31)); }
+__device__ __forceinline__ uint32_t m_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
 constexpr uint32_t BUF_OOB = 0x7FFFFFF0u;      // a byte offset beyond any plane of a particle's arena (<= 134 MB)
 
 // pop() of the LDS heap h[0, size) by the helper wave, NR predicated rounds of the 5-level subtree walk of lds_sift_topdown (two
@@ -1031,50 +1054,58 @@ constexpr uint32_t BUF_OOB = 0x7FFFFFF0u;      // a byte offset beyond any plane
 template <int NR>
 __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const int lane, const uint64_t anc, uint64_t* root_out, uint64_t* dummy)
 {
+    // Lane predicates are 0 / ~0 words combined with integer arithmetic: as `bool`s the compiler keeps them as wave masks in scalar
+    // registers and every v_cmp -> s_and -> v_cndmask chain is a vector -> scalar hand-over (~18 cycles each, a dozen per round).
     --size;
     const uint32_t len = size;
     if (len == 0) return;
     const uint64_t value = h[len];                                   // the re-inserted last entry
     const uint64_t tailc = h[len - 1];                               // the lone left child, if the hole ends above it
     const uint32_t vprio = heap_prio(value);
-    const uint32_t lim = (len - 1) / 2;                              // nodes below `lim` have both children
+    const uint32_t lim = (len - 1) >> 1;                             // nodes below `lim` have both children
     const int d = 31 - __clz(lane + 1);
-    const bool is_left = (lane & 1) != 0;
-    const bool inner = lane >= 1 && lane < 63;
+    const uint32_t leftm = (lane & 1) ? 0xFFFFFFFFu : 0u;            // odd relative positions are left children
+    const uint32_t innerm = (lane >= 1 && lane < 63) ? 0xFFFFFFFFu : 0u;
+    const uint32_t anc_lo = (uint32_t)anc, anc_hi = (uint32_t)(anc >> 32);
     uint32_t H = 0;
-    bool stopped = false;
+    uint32_t go = 0xFFFFFFFFu;                                       // wave-uniform: the descent has not stopped
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const uint32_t idx = (H << d) + (uint32_t)lane;              // lane L: the node at relative position L below H
-        const uint32_t left = is_left ? idx : idx - 1;
-        const uint32_t parent = (left - 1) >> 1;
-        const bool cand = !stopped && inner && parent < lim;
-        const uint32_t la = cand ? left : 1u;
+        const uint32_t lm1 = idx - 2u - leftm;                       // (left child of my parent) - 1: idx - 1 for a left child, idx - 2 for a right one
+        const uint32_t parent = lm1 >> 1;
+        const uint32_t cand = opq(innerm & go & m_lt(parent, lim));  // my parent has both children
+        const uint32_t la = 1u + (lm1 & cand);
         const uint64_t vl = h[la], vr = h[la + 1];
-        const bool take_left = heap_prio(vr) > heap_prio(vl);        // __adjust_heap: right unless comp(right, left)
-        const bool step_to_me = cand && (is_left == take_left);
-        const unsigned long long okm = __ballot(step_to_me);
-        const bool onpath = cand && (okm & anc) == anc;
-        const uint64_t mine = is_left ? vl : vr;
-        const bool moves = onpath && !(heap_prio(mine) > vprio);
-        const unsigned long long pathm = __ballot(onpath), mvm = __ballot(moves);
+        const uint32_t pl = opq((uint32_t)(vl >> 32)) >> 16, pr = opq((uint32_t)(vr >> 32)) >> 16;
+        const uint32_t take_left = m_lt(pl, pr);                     // __adjust_heap: right unless prio(right) > prio(left)
+        const uint32_t step = opq(cand & ~(take_left ^ leftm));      // it steps to me
+        const unsigned long long okm = __ballot(step != 0u);
+        const uint32_t offpath = opq((((uint32_t)okm & anc_lo) ^ anc_lo) | (((uint32_t)(okm >> 32) & anc_hi) ^ anc_hi));   // 0: all my ancestors were stepped to
+        const uint32_t onpath = opq(offpath == 0u ? cand : 0u);
+        const uint64_t mine = leftm ? vl : vr;
+        const uint32_t pm = leftm ? pl : pr;
+        const uint32_t moves = opq(onpath & m_le(pm, vprio));        // prio(mine) <= prio(value)
+        const unsigned long long pathm = __ballot(onpath != 0u), mvm = __ballot(moves != 0u);
         LAMA_LOCKSTEP();
         uint64_t* dst = moves ? h + parent : dummy + lane;
         *dst = mine;
         if (r == 0) {                                                // the new root: the child that moved up, else the re-inserted entry
-            const bool child_root = (lane == 1 || lane == 2) && moves;
-            const bool value_root = lane == 0 && (mvm & 6ull) == 0ull;
-            uint64_t* rd = (child_root || value_root) ? root_out : dummy + lane;
-            *rd = lane == 0 ? value : mine;
+            const uint32_t l0m = lane == 0 ? 0xFFFFFFFFu : 0u, l12m = (lane == 1 || lane == 2) ? 0xFFFFFFFFu : 0u;
+            const uint32_t nochild = (mvm & 6ull) == 0ull ? 0xFFFFFFFFu : 0u;
+            const uint32_t sel = opq((l0m & nochild) | (l12m & moves));
+            uint64_t* rd = sel ? root_out : dummy + lane;
+            const uint64_t rv = l0m ? value : mine;
+            *rd = rv;
         }
         const int rel = 63 - __clzll((long long)(mvm | 1ull));       // deepest moved entry: its old slot is the new hole
         const uint32_t Hn = (H << (31 - __clz(rel + 1))) + (uint32_t)rel;
         H = mvm ? Hn : H;
-        stopped = stopped || (mvm != pathm);
+        go = (mvm != pathm) ? 0u : go;
         LAMA_LOCKSTEP();
     }
     // the hole has a lone left child, the array's last entry
-    const bool up = !stopped && (len & 1u) == 0u && H == (len - 2) / 2 && heap_prio(tailc) <= vprio;
+    const bool up = go != 0u && (len & 1u) == 0u && H == (len - 2) / 2 && heap_prio(tailc) <= vprio;
     {
         uint64_t* dst = (up && lane == 0) ? h + H : dummy + lane;
         *dst = tailc;
@@ -1406,6 +1437,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         uint64_t* const dmy = sh.dummy[0];
         const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
         const bool is_oc = lane == 5, role = lane < 6;
+        const uint32_t rolem = role ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
 
         // The general pop: the reference's statements with every rare case (cache miss, patch allocation, stale entry, second
         // load round of a tie, window error).  Leaves the entries to push in the mailbox and returns how many.
@@ -1489,85 +1521,95 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             bool over = false;                                             // lanes 0..3: my neighbour is lowered and pushed ...
             uint64_t entry = 0;                                            // ... as this queue entry
             {
-                // ---- speculative loads: every lane its role's cell through the directory cache, absent / foreign lanes out of range
+                // ---- speculative loads: every lane its role's cell through the directory cache, absent / foreign lanes out of range.
+                // Lane predicates are 0 / ~0 words (see lds_pop_flat); what is wave-uniform stays in scalar registers.
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
                 const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
                 const int x = rx + (is_oc ? eox : ddx), y = ry + (is_oc ? eoy : ddy);
-                const bool inwin = ((uint32_t)x < prm.WC) & ((uint32_t)y < prm.WC);
+                const uint32_t inwin = opq(((uint32_t)x < prm.WC && (uint32_t)y < prm.WC) ? 0xFFFFFFFFu : 0u);
                 const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
                 const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
-                const uint32_t dv = sh.dc[dc.index(inwin ? pidx : 0u)];
-                const bool hit = inwin & ((dv >> 16) == pidx) & (dv != DC_EMPTY);
-                const int slot = (int)(int16_t)(dv & 0xFFFFu);
-                const bool have = role & hit & (slot >= 0);
-                const bool unknown = role & !hit;                           // not cached / outside the window: general code
-                const uint32_t coff = (uint32_t)slot * 1024u + ci;
-                const uint32_t s = buf_load_u16(rsv, have ? coff * 2u : BUF_OOB);
-                const uint32_t ob = buf_load_u32(robs, have ? coff * 4u : BUF_OOB);
-                const unsigned long long unk = __ballot(unknown);
-                BFT(0);
+                const uint32_t dv = sh.dc[dc.index(pidx & inwin)];
+                // (an empty cache word has the tag 0xFFFF: no window position has it)
+                const uint32_t hit = opq(inwin & ~m_nz((dv >> 16) ^ pidx));
+                const uint32_t slotw = (uint32_t)(int)(int16_t)(dv & 0xFFFFu);
+                const uint32_t absent = opq((uint32_t)((int32_t)slotw >> 31));                // cached "no such patch"
+                const uint32_t have = opq(rolem & hit & ~absent);
+                const uint32_t unknown = opq(rolem & ~hit);                                   // not cached / outside the window: general code
+                const uint32_t coff = (slotw << 10) | ci;
+                const uint32_t s = buf_load_u16(rsv, m_sel(have, coff * 2u, BUF_OOB));
+                const uint32_t ob = buf_load_u32(robs, m_sel(have, coff * 4u, BUF_OOB));
+                const unsigned long long unk = __ballot(unknown != 0u);
+                BFT(0); BFF(0);
                 // the popped cell, and the obstacle cell it pointed to when it was queued
                 const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)s, 4);
                 const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
                 const uint32_t cos_ = (uint32_t)__builtin_amdgcn_readlane((int)s, 5);
                 const int cox = obs_x(cob), coy = obs_y(cob);
-                const bool stale = (cox != q_ox(e)) | (coy != q_oy(e));
+                const bool stale = (cox != eox) | (coy != eoy);
                 const bool fire0 = ((cs & SV_VALID) != 0u) & ((cs & SV_QUEUED) != 0u);      // :183, lower() :283
                 general = (unk != 0ull) | (fire0 & stale);
-                BFT(1);
+                BFT(1); BFF(1);
 #ifdef LAMA_PROFILE_BF_COUNT
                 prof[2] += unk != 0ull ? 1 : 0; prof[3] += (fire0 & stale) ? 1 : 0; prof[6] += (fire0 & ((cos_ & SV_SQMASK) == 0u)) ? 1 : 0;
 #endif
-                if (!general & fire0 & ((cos_ & SV_SQMASK) == 0u)) {         // :191 (valid NOT tested)
+                if (__builtin_expect(!general, 1) && fire0 && (cos_ & SV_SQMASK) == 0u) {   // :191 (valid NOT tested)
                     const int obx = rx + cox, oby = ry + coy;
-                    const bool away = is_nb & !((ddx * cox > 0) | (ddy * coy > 0));            // :296
-                    const bool nbok = away & (slot >= 0);
+                    const uint32_t away = opq(nbm & ~(m_pos(ddx * cox) | m_pos(ddy * coy)));          // :296
+                    const uint32_t nbok = away & ~absent;
                     const int qx = x - obx, qy = y - oby;
                     const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
                     const uint32_t ssq = s & SV_SQMASK;
-                    const bool svalid = (s & SV_VALID) != 0u;
-                    const uint32_t cmp = svalid ? ssq : prm.max_sqdist;
-                    const bool lt = nbok & (new_sq < cmp);
-                    const bool tie = nbok & !lt & (new_sq == ssq);                            // :311-317
-                    const bool same = (x + obs_x(ob) == obx) & (y + obs_y(ob) == oby);      // the neighbour points at the same obstacle: lane 5 holds it
-                    // a tie whose obstacle cell is another one than mine: a second load round (about one pop in six)
-                    const bool tie_other = tie & !same;
-                    uint32_t os = cos_;                                                        // the state of the neighbour's obstacle cell
-                    bool miss2 = false;
-                    if (__ballot(tie_other) != 0ull) {
+                    const uint32_t svalid = opq((uint32_t)((int32_t)(s << 16) >> 31));                // bit 15
+                    const uint32_t cmp = m_sel(svalid, ssq, prm.max_sqdist);
+                    const uint32_t lt = opq(nbok & m_lt(new_sq, cmp));
+                    const uint32_t tie = opq(nbok & ~lt & ~m_nz(new_sq ^ ssq));                       // :311-317
+                    // the neighbour points at another obstacle than mine (lane 5 holds mine): a second load round, one pop in six
+                    const uint32_t other = m_nz((uint32_t)((x + obs_x(ob)) ^ obx) | (uint32_t)((y + obs_y(ob)) ^ oby));
+                    const uint32_t tie_other = opq(tie & other);
+                    const uint32_t alloc = away & absent;                                            // a patch to allocate: general code
+                    const bool clive = ((cos_ & SV_VALID) != 0u);                                     // my obstacle cell is a live obstacle ((cos_ & SQMASK) == 0 here)
+                    uint32_t dead = clive ? 0u : 0xFFFFFFFFu;                                        // per lane: the neighbour's obstacle cell is not one
+                    uint32_t miss2 = 0u;
+                    BFF(2);
+                    if (__builtin_expect(__ballot((tie_other | alloc) != 0u) != 0ull, 0)) {
                         const int ox = x + obs_x(ob), oy = y + obs_y(ob);
-                        const bool oin = tie_other & ((uint32_t)ox < prm.WC) & ((uint32_t)oy < prm.WC);
+                        const uint32_t oin = opq((tie_other != 0u && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) ? 0xFFFFFFFFu : 0u);
                         const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);
-                        const uint32_t odv = sh.dc[dc.index(oin ? opidx : 0u)];
-                        const bool ohit = oin & ((odv >> 16) == opidx) & (odv != DC_EMPTY);
-                        const int oslot = (int)(int16_t)(odv & 0xFFFFu);
-                        miss2 = oin & !ohit;                                                   // not cached: general code
-                        const uint32_t ooff = ((uint32_t)oslot * 1024u + (((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5))) * 2u;
-                        const uint32_t os2 = buf_load_u16(rsv, (ohit & (oslot >= 0)) ? ooff : BUF_OOB);   // outside the window / absent: reads as 0
-                        os = tie_other ? os2 : os;
+                        const uint32_t odv = sh.dc[dc.index(opidx & oin)];
+                        const uint32_t ohit = opq(oin & ~m_nz((odv >> 16) ^ opidx));
+                        const uint32_t oslot = (uint32_t)(int)(int16_t)(odv & 0xFFFFu);
+                        miss2 = opq((oin & ~ohit) | alloc);                                   // not cached, or a patch to allocate: general code
+                        const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
+                        const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
+                        const uint32_t olive = opq((uint32_t)((int32_t)(os2 << 16) >> 31) & ~m_nz(os2 & SV_SQMASK));
+                        dead = m_sel(tie_other, ~olive, dead);
                     }
 #ifdef LAMA_PROFILE_BF_COUNT
-                    prof[4] += __ballot(away & (slot < 0)) ? 1 : 0; prof[5] += __ballot(tie_other) ? 1 : 0;
+                    prof[4] += __ballot(alloc != 0u) ? 1 : 0; prof[5] += __ballot(tie_other != 0u) ? 1 : 0;
 #endif
-                    // rare: a patch to allocate, a directory entry that is not cached
-                    if (__builtin_expect(__ballot((away & (slot < 0)) | miss2) != 0ull, 0)) {
+                    if (__builtin_expect(__ballot(miss2 != 0u) != 0ull, 0)) {
                         general = true;
                     } else {
-                        over = lt | (tie & (!svalid | !(((os & SV_VALID) != 0u) & ((os & SV_SQMASK) == 0u))));     // :311-317
+                        BFF(3);
+                        const uint32_t overm = opq(lt | (tie & (~svalid | dead)));                    // :308-317
+                        over = overm != 0u;
                         // get() of the examined neighbours: the Container mask bit of a flag-less cell (raise() has the argument)
-                        const bool need_bit = nbok & ((s & (SV_VALID | SV_QUEUED)) == 0u);
-                        buf_or_u64(rmask, need_bit ? ((uint32_t)slot * 16u + (ci >> 6)) * 8u : BUF_OOB, 1ull << (ci & 63u));
+                        const uint32_t need_bit = nbok & ~m_nz(s & (uint32_t)(SV_VALID | SV_QUEUED));
+                        buf_or_u64(rmask, m_sel(need_bit, ((slotw << 4) + (ci >> 6)) * 8u, BUF_OOB), 1ull << (ci & 63u));
                         // neighbours that are lowered, and the popped cell's is_queued (:329): one store instruction
-                        const uint32_t nsv = is_cur ? (cs & ~(uint32_t)SV_QUEUED) : (uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK);
-                        buf_store_u16(rsv, (over | is_cur) ? coff * 2u : BUF_OOB, nsv);
-                        buf_store_u32(robs, over ? coff * 4u : BUF_OOB, pack_obs(obx - x, oby - y));
-                        const unsigned long long om = __ballot(over);
+                        const uint32_t nsv = m_sel(curm, cs & ~(uint32_t)SV_QUEUED, (uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK));
+                        buf_store_u16(rsv, m_sel(overm | curm, coff * 2u, BUF_OOB), nsv);
+                        buf_store_u32(robs, m_sel(overm, coff * 4u, BUF_OOB), pack_obs(obx - x, oby - y));
+                        BFF(4);
+                        const unsigned long long om = __ballot(overm != 0u);
                         entry = q_entry(new_sq, x, y, obx - x, oby - y);
                         const uint32_t rank = lane_rank(om, lane) & 3u;
-                        uint64_t* dst = over ? &sh.pl_e[tw_it & 1u][rank] : dmy + lane;
+                        uint64_t* dst = overm ? &sh.pl_e[tw_it & 1u][rank] : dmy + lane;
                         *dst = entry;
                         cnt = (uint32_t)__popcll(om);
+                        BFF(5);
                     }
                 }
             }
@@ -1600,7 +1642,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
                 uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)(dmy + lane);
                 *np = cnt;
-                BFT_MAIN(5);
+                BFT_MAIN(5); BFF(6);
                 lds_barrier();                                     // D
                 BFT_MAIN(6);
                 const uint64_t root_ = sh.topq[b_];
@@ -1614,7 +1656,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 ++tw_it;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            BFT(4);
+            BFT(4); BFF(7);
         }
     }
     // ---- lower wave ------------------------------------------------------------------------- :175-194

@@ -14,6 +14,8 @@ L.lama_hip_debug_cycles.argtypes = [C.c_void_p, C.c_void_p]
 names = ["lookup+issue_loads", "wait_loads+decide0", "decide+commit", "general_pop", "tail(+barrier)", "H:pop", "H:wait_D", "H:pushes"]
 if os.environ.get("LAMA_PROF_MAIN"):   # -DLAMA_PROFILE_BF_MAIN build: all eight buckets belong to the main wave
     names = ["lookup+issue_loads", "wait_loads+decide0", "decide+commit", "general_pop", "post_D", "pre_D", "wait_D", "before_lower(raise)"]
+if os.environ.get("LAMA_PROF_FINE"):   # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_FINE build
+    names = ["f0:lookup+issue", "f1:wait+decide0", "f2:valu_decide", "f3:rare_ballot+branch", "f4:atomic+stores", "f5:mailbox", "f6:tail_pre_D", "f7:barrier+post_D"]
 if os.environ.get("LAMA_PROF_COUNT"):  # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_COUNT build: event counts of the lower wave
     names = ["lower_pops", "general_pops", "g:cache_miss", "g:stale", "g:alloc", "g:tie_other", "fired", "-"]
 for k in range(1, 13):
@@ -29,6 +31,6 @@ for k in range(1, 13):
         j = int(np.argmax(d[:, 0]))
         print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:7])))
         continue
-    tot = d[0][:5].sum() if not os.environ.get("LAMA_PROF_MAIN") else d[0][:7].sum()
+    tot = d[0][:5].sum() if not os.environ.get("LAMA_PROF_MAIN") else (d[0][:8].sum() if os.environ.get("LAMA_PROF_FINE") else d[0][:7].sum())
     print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms raycast {c['ms_raycast']:.3f} ms  cycles/pop {tot / max(pops,1):.0f} :: " +
           " ".join(f"{n}={d[0][i] / max(pops,1):.0f}" for i, n in enumerate(names)))
