@@ -396,7 +396,8 @@ def main():
 
     def effective_modes(c):
         return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"],
-                "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"]}
+                "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"],
+                "brushfire_handovers": c["brushfire_handovers"], "replay_handovers": c["replay_handovers"]}
 
     # `value` comes from a pass WITHOUT the per-kernel hipEvent brackets (they cost two extra device-to-host copies and four
     # event records per step); the kernel breakdown and the roofline durations come from a second pass of the same K steps

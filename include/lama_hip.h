@@ -275,7 +275,11 @@ typedef struct lama_hip_counters {
     uint32_t brushfire_waves;   /* exact brushfire of the last map update: 2 = wave pair per particle, 1 = one wave per particle */
     uint64_t sequential_raycast_scans;  /* map updates whose ray-cast ran beam by beam (k_raycast)                           */
     uint64_t parallel_raycast_scans;    /* map updates whose ray-cast ran in the parallel, patch-centric form                */
-    uint32_t reserved0, reserved1;
+    uint32_t brushfire_handovers;       /* particle updates whose brushfire queue outgrew the first stage's LDS window (1020 entries) and
+                                           were finished by the resume stage (sum since the last reset).  Such an update is one long
+                                           serial chain: at 3000 particles one of them (13.9 ms) is what made the resume kernel's MEAN
+                                           1.2 ms in the round-3 profile while its median is 5 us (profiles/r04_timeline_3000_before.txt) */
+    uint32_t replay_handovers;          /* the same for the ordered replay of the parallel ray-cast (more than 2048 order-sensitive visits) */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

@@ -92,6 +92,7 @@ struct lama_hip_ctx {
     PinVec<uint64_t> h_stats;
     PinVec<double> h_tfs, h_pts;
     PinVec<int32_t> h_err;
+    PinVec<uint32_t> h_slow_n;        // hand-over counts of the last map update (brushfire, ordered replay)
     double* d_tfs = nullptr;
     double* d_loglik = nullptr; int32_t* d_iters = nullptr;
     // d_poses | d_loglik | d_iters | d_err are carved out of ONE allocation so that a scan match brings all of its results
@@ -113,6 +114,9 @@ struct lama_hip_ctx {
     Affine last_mtf; uint32_t last_first = 0, last_count = 0;
     bool last_guarded = false;        // the update went through the parallel ray-cast (its allocation phase precedes every modification)
     int recover_depth = 0;
+    bool unguarded_retry = false;     // the arenas are at their hard limit and the guard's bound did not fit: run the update without it
+    // host-side effects of a map update that a repeated pass (recover_update) must not apply twice
+    uint32_t saved_visit_bound = 0; lama_hip_counters saved_ctr;
     bool pending_maps = false;        // lama_hip_pf_update_maps_begin queued work whose status has not been collected yet
     PinVec<double> h_poses;           // host mirror of the particle poses (source of truth between calls)
     PinVec<int32_t> h_counts;         // host mirror of counts of the current set (refreshed after map updates)
@@ -241,7 +245,9 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
         HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+    if (maps) { c->h_slow_n.resize(2); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1]; }
     if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
     if (e != 0) {
@@ -333,8 +339,18 @@ int32_t recover_update(lama_hip_ctx* c, int32_t e)
 {
     const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
     const uint32_t ndc = (e & ERR_DM_CAP) ? std::min<uint32_t>(2 * dc, 32767u) : dc, noc = (e & ERR_OCC_CAP) ? std::min<uint32_t>(2 * oc, 32767u) : oc;
-    if (ndc == dc && noc == oc) return LAMA_HIP_E_CAPACITY;
+    // at the hard limit the distance-map guard (an upper bound) must not be what fails the update: repeat it unguarded -- once
+    const bool at_limit = ndc == dc && noc == oc;
+    if (at_limit && (c->unguarded_retry || !(e & ERR_DM_CAP) || (e & ERR_OCC_CAP))) return LAMA_HIP_E_CAPACITY;
     ++c->recover_depth;
+    c->unguarded_retry = at_limit;
+    // the aborted pass changed nothing on the device; undo what it did on the host (wrap-guard bound, scan / launch counters)
+    c->visit_bound = c->saved_visit_bound;
+    {
+        const lama_hip_counters now = c->ctr;
+        c->ctr = c->saved_ctr;
+        c->ctr.arena_growths = now.arena_growths; c->ctr.dm_patches = now.dm_patches; c->ctr.occ_patches = now.occ_patches;
+    }
     DevParams prm = make_params(c, c->cur);
     const size_t WW = (size_t)c->W * c->W;
     hipLaunchKernelGGL(k_update_cleanup, dim3(c->P, (unsigned)((WW + 255) / 256)), dim3(256), 0, c->stream, prm);
@@ -349,7 +365,7 @@ int32_t recover_update(lama_hip_ctx* c, int32_t e)
     if (rc == LAMA_HIP_OK) rc = run_update_maps(c, c->last_n, c->last_mtf, c->last_first, c->last_count);
     if (rc == LAMA_HIP_OK) rc = check_device_errors(c, true, false);
     --c->recover_depth;
-    if (rc == LAMA_HIP_OK) c->ctr.arena_growths += 0;      // (resize_arenas counted the growth)
+    c->unguarded_retry = false;
     return rc;
 }
 
@@ -472,7 +488,11 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
                        c->d_rrec, c->d_rbbox, alloc_only, c->d_rchunk);
     const int rw_seg = count <= 64 ? 8 : 2;
     hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
-    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->d_rev, (int)first);
+    double far = c->scan_reach;                                   // no cell further than truncated_range from the sensor is touched
+    if (c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
+    const int reach_cells = (int)std::ceil(far * c->scale) + 2;
+    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->d_rev, (int)first, (const double*)c->d_tfs, reach_cells,
+                       c->unguarded_retry ? 1 : 0);
     return LAMA_HIP_OK;
 }
 
@@ -483,6 +503,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         if (rcw) return rcw;
     }
     c->last_mtf = mtf; c->last_first = first; c->last_count = count;
+    if (c->recover_depth == 0) { c->saved_visit_bound = c->visit_bound; c->saved_ctr = c->ctr; }
     PinVec<double>& tfs = c->h_tfs;
     tfs.resize((size_t)c->P * 12);
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
@@ -1475,7 +1496,9 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     hipLaunchKernelGGL(k_import_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(s), (const ShipDesc*)c->d_ship_desc, (const int32_t*)c->d_oldcounts,
                        c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, c->d_err);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // the import itself reports what it could not place (a patch of the sender's window outside this one: ERR_WINDOW) -- not the
+    // next, unrelated call on the context
+    { const int32_t ri = check_device_errors(c); if (ri) return ri; }
     // 3. host mirrors
     for (uint32_t k = 0; k < n; ++k) {
         const uint8_t* head = c->h_ship_heads.data() + (size_t)BLOB_HEAD * k;

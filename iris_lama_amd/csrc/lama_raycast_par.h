@@ -8,7 +8,7 @@
 //   k_ray_hits   (thread / beam)   : the hit cells of this scan are flagged (one bit per cell) and queued as
 //                                    "active" visits;
 //   k_ray_patches (workgroup / occupancy patch, lama_raycast_patch.h; the round-1 beam-centric form with LDS-aggregated
-//                                    atomics is kept for reference in tools/research/k_ray_visits.h):
+//                                    atomics is in the history: tools/research/README.md):
 //                                    every free-cell visit (beam, t) in parallel.  A visit is INERT when its cell
 //                                    is not hit in this scan and is already free (4*occupied < visited: a miss can
 //                                    never raise an event, src/sdm/frequency_occupancy_map.cpp:65-74) or brand new

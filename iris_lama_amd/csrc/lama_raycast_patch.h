@@ -178,12 +178,17 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
 // The same pass closes the ALLOCATION phase of the update: every occupancy patch the scan touches exists by now (k_ray_hits,
 // k_ray_alloc_walk), and every distance-map patch the update can allocate -- first misses and hits in those patches, the
 // brushfire's neighbours at most sqrt(max_sqdist) + 1 cells from a changed obstacle -- lies within `guard_r` patches of an
-// occupancy patch.  The number of window positions without a distance-map patch but with an occupancy patch that close bounds what
-// is still to come; the last workgroup of the particle compares it with the free slots and raises ERR_DM_CAP BEFORE any map cell
-// is modified, so that the host can grow the arena and run the update again.
+// occupancy patch THE SCAN CAN TOUCH: one whose patch meets the box sensor +- (largest point distance + 2 cells) (counting
+// around every occupancy patch of the map, free space far behind the robot included, doubled the arenas of all particles without
+// need in open environments).  The number of window positions without a distance-map patch but with such an occupancy patch that
+// close bounds what is still to come; the particle's workgroup compares it with the free slots and raises ERR_DM_CAP BEFORE any
+// map cell is modified, so that the host can grow the arena and run the update again.  (`guard_off`: the arenas are at their hard
+// limit and the bound did not fit -- the update runs unguarded, as it did before the guard existed: it fails only if it REALLY
+// runs out of patches.)
 constexpr int RD_MARK_WORDS = (248 * 248 + 31) / 32;       // one bit per window position (window_patches <= 248)
 
-__global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle)
+__global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle,
+                                                          const double* __restrict__ tfs /*[P][12]*/, int reach_cells, int guard_off)
 {
     __shared__ uint32_t mark[RD_MARK_WORDS];                  // window positions within guard_r patches of an occupancy patch
     __shared__ uint32_t need_s;
@@ -194,6 +199,9 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
     const int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
     for (uint32_t i = tid; i < (WW + 31u) / 32u; i += 256u) mark[i] = 0;
     if (tid == 0) need_s = 0;
+    // the patches the scan can touch: sensor origin (tf.translation(), src/pf_slam2d.cpp:452) +- reach, window-relative patch units
+    const int scx = (int)(w2m(prm, tfs[12 * (size_t)p + 9]) - prm.wx0), scy = (int)(w2m(prm, tfs[12 * (size_t)p + 10]) - prm.wy0);
+    const int bx0 = (scx - reach_cells) >> 5, bx1 = (scx + reach_cells) >> 5, by0 = (scy - reach_cells) >> 5, by1 = (scy + reach_cells) >> 5;
     __syncthreads();
     // eight directory entries per thread and round (W is a multiple of 8: a run never leaves its row, 16-byte aligned)
     for (uint32_t w0 = (uint32_t)tid * 8u; w0 < WW; w0 += 256u * 8u) {
@@ -206,6 +214,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
             if (slot < 0) continue;
             rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k);
+            if (x0 + k < bx0 || x0 + k > bx1 || wy < by0 || wy > by1) continue;       // out of the scan's reach: nothing changes there
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
                     const int x = x0 + k + dx, y = wy + dy;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
     }
     if (need) atomicAdd(&need_s, need);
     __syncthreads();
-    if (tid == 0 && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
+    if (tid == 0 && !guard_off && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
 }
 
 // developer build (-DLAMA_PROFILE_RAY, tools/prof_ray.py): event counts and per-phase cycles of k_ray_patches, summed over the launch

@@ -532,6 +532,7 @@ PFSlam2D::Phase PFSlam2D::updateBegin(const PointCloudXYZ::Ptr& surface, const P
 
 bool PFSlam2D::planResample(const double* all_loglik, std::vector<int32_t>& sample_idx)
 {
+    if (group_) throw std::runtime_error("lama::PFSlam2D: the step-wise API belongs to single shards; an object with Options::gpus > 1 runs the whole step in update()");
     const uint32_t P = options_.particles;
     const double t0 = now_s();
     for (uint32_t i = 0; i < P; ++i) {                                      // :434-436
@@ -548,6 +549,7 @@ bool PFSlam2D::planResample(const double* all_loglik, std::vector<int32_t>& samp
 
 void PFSlam2D::applyResample(const std::vector<int32_t>& sample_idx)
 {
+    if (group_) throw std::runtime_error("lama::PFSlam2D: the step-wise API belongs to single shards; an object with Options::gpus > 1 runs the whole step in update()");
     const uint32_t P = options_.particles;
     const double t0 = now_s();
     std::vector<Particle> next(P);
@@ -572,6 +574,7 @@ void PFSlam2D::applyResample(const std::vector<int32_t>& sample_idx)
 
 void PFSlam2D::updateMaps()
 {
+    if (group_) throw std::runtime_error("lama::PFSlam2D: the step-wise API belongs to single shards; an object with Options::gpus > 1 runs the whole step in update()");
     const double t0 = now_s();
     dropMapViews();
     const uint32_t n = (uint32_t)(pts_.size() / 3);

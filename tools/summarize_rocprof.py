@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn the rocprofv3 (ROCm 7.2, rocpd SQLite) outputs of tools/profile_r01.sh into the committed summaries:
+"""Turn the rocprofv3 (ROCm 7.2, rocpd SQLite) outputs of tools/profile_round.sh into the committed summaries:
   profiles/<tag>_rocprof_stats.md      per-kernel time (all dispatches, and the last K = timed-region dispatches)
   profiles/pmc_brushfire.json          HBM traffic per launch of the dominant kernel (read by bench.py)
 FETCH_SIZE / WRITE_SIZE are in KiB; per MI355X_MICROARCH.md (HBM section) FETCH_SIZE on gfx950 counts 128-B requests
