@@ -6,12 +6,17 @@
 
 A "step" is one PFSlam2D::update() (predict, scan-match, normalise, resample if due, map update) of ALL particles
 on one 1080-beam scan.  N = 1: BASELINE.json configs[1] (PFSlam2D, 30 particles, 1080 beams, one MI355X).
-N > 1: BASELINE.json configs[2] -- the 3000 particles of configs[2] sharded in contiguous blocks over N processes, one per GPU
-(STRONG scaling: the pool is fixed, 3000 / N particles per GPU); the per-scan exchange is an all-gather of the log-likelihoods
-(RCCL) plus particle shipping over xGMI when a resample clones across shards.  Besides the default options the sharded run is
-repeated with a measurement gain that makes the 3000-particle filter resample (meas_sigma_gain = 1e-4); that
-variant must resample and ship particles (asserted) and reports the time spent in the all-gather and in shipping per step.
-The N = 1 line carries the single-GPU rate at 3000 particles ("other_particle_counts"), the base of the N > 1 values.
+N > 1: BASELINE.json configs[2] -- the 3000 particles of configs[2] sharded in contiguous blocks over the N GPUs (STRONG scaling:
+the pool is fixed, 3000 / N particles per GPU).  `value` of such a line is the PRODUCT path of a multi-GPU node: ONE
+lama::PFSlam2D object with Options::gpus = N (C++: a host thread and a device context per GPU, the log-likelihoods gathered in
+host memory, clones shipped GPU to GPU with peer copies), run by rank 0 while the other ranks have released their devices.  The
+one-process-per-GPU driver (iris_lama_amd/distributed.py over torch.distributed: an RCCL all-gather of the log-likelihoods plus
+particle shipping over xGMI), timed with the barrier / max-over-ranks bracket, is reported beside it ("torch_distributed_ranks"),
+and so are: the same pool unsharded on one GPU ("single_gpu_same_pool", the base of the curve), one GPU's share alone on one GPU
+("strong_scaling_ceiling": what no sharding can beat -- a particle's exact brushfire is a serial chain), the WEAK-scaling run (the
+3000-particle pool on every GPU, "weak_scaling"), and a variant whose measurement gain makes the filter resample
+(meas_sigma_gain = 1e-4, SURVEY 8(d): it must resample and ship particles -- asserted -- and reports the exchange times).
+The N = 1 line carries the single-GPU rate at 3000 particles ("other_particle_counts").
 Launched as plain `python bench.py --gpus N` (no WORLD_SIZE in the environment) it spawns the N ranks itself
 (torch.distributed.run, rendezvous on 127.0.0.1).  Prints ONE JSON line on rank 0.
 """
@@ -415,15 +420,23 @@ def main():
     if world > 1:
         assert resample_run["resamples"] > 0, "the forced-resample variant did not resample"
         assert resample_run["shipped_particles"] > 0 and resample_run["shipped_bytes"] > 0, "no particle crossed a shard boundary"
-    single, cpp_multi, cpp_multi_forced = None, None, None
+    single, cpp_multi, cpp_multi_forced, weak, share = None, None, None, None, None
     if world > 1:
         # base of the strong-scaling figure: the same pool on ONE GPU (rank 0's), unsharded; then the same pool as one C++ object
-        # over all N devices (lama::PFSlam2D, Options::gpus = N); the other ranks have released their contexts and wait
+        # over all N devices (lama::PFSlam2D, Options::gpus = N: the PRODUCT path of a multi-GPU node -- it is what `value` reports);
+        # the other ranks have released their contexts and wait
         if rank == 0:
             single = run(P_total, K, W, profile=False, sharded=False)
+            # one GPU's share of the pool alone on one GPU: the step time no amount of sharding can beat (the brushfire chain of a
+            # particle does not shrink with the shard) -> predicted ceiling of the strong-scaling curve
+            share = run(max(P_total // world, 1), K, W, profile=False, sharded=False)
             cpp_multi = run_cpp_multi(P_total, world, K, W)
             cpp_multi_forced = run_cpp_multi(P_total, world, K, W, gain=forced_gain)
             assert cpp_multi_forced["resamples"] > 0 and cpp_multi_forced["shipped_particles"] > 0, cpp_multi_forced
+            # weak scaling: the single-GPU pool (3000 particles) on EVERY GPU (one device for all shards: its share instead)
+            per_gpu = P_total if torch.cuda.device_count() >= world else max(P_total // world, 1)
+            weak = run_cpp_multi(per_gpu * world, world, K, W)
+            weak["particles_per_gpu"] = per_gpu
         # the other ranks wait on the rendezvous store (a blocking socket read): a process-group barrier here would park an RCCL
         # kernel on every other GPU -- or spin on the host with gloo -- underneath the object that rank 0 is timing
         store = torch.distributed.distributed_c10d._get_default_store()
@@ -438,7 +451,7 @@ def main():
     result = {
         "metric": "particle-scans/sec", "value": main_run["value"], "unit": "particle-scans/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": main_run["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"PFSlam2D {P_total} particles" + (f" ({P_total // world}/GPU, fixed pool sharded over {world} GPUs)" if world > 1 else "") +
                                ", 1080-beam synthetic corridor log "
                                f"(SURVEY.md 8(d)), res 0.05 m, patch 32, l2_max 0.5, GN+Cauchy(0.15), seed 42",
@@ -455,6 +468,24 @@ def main():
     if world == 1:
         result["summary_buckets_ms_per_update"] = run(P_total, K, W, summary=True)["buckets_ms"]
     else:
+        # `value` of a multi-GPU line is the product path: ONE lama::PFSlam2D object with Options::gpus = N (C++: a host thread
+        # and a device context per GPU, the log-likelihoods gathered in host memory, clones shipped GPU to GPU).  The
+        # one-process-per-GPU driver over torch.distributed / RCCL (iris_lama_amd/distributed.py), timed with the barrier /
+        # max-over-ranks bracket, stands beside it.
+        result["scaling"] = "strong"
+        result["torch_distributed_ranks"] = {"value": main_run["value"], "ms_per_step": main_run["ms_per_step"],
+                                             "exchange_ms_per_step": main_run["exchange_ms_per_step"],
+                                             "note": "one process per GPU, all-gather of the log-likelihoods over the process group, barrier + max over ranks"}
+        result["value"], result["ms_per_step"] = cpp_multi["value"], cpp_multi["ms_per_step"]
+        result["value_source"] = f"lama::PFSlam2D, Options::gpus = {world} (one process, {cpp_multi['devices']} device(s)), run by rank 0"
+        result["strong_scaling_ceiling"] = {"particles_per_gpu": max(P_total // world, 1), "ms_per_step_of_one_share_alone": share["ms_per_step"],
+                                            "ceiling_speedup": single["ms_per_step"] / share["ms_per_step"],
+                                            "note": "step time of the unsharded pool / step time of ONE GPU's share alone on one GPU: no exchange, "
+                                                    "no imbalance -- the curve cannot rise above it, because a particle's exact brushfire is a serial chain"}
+        result["weak_scaling"] = {"particles_per_gpu": weak["particles_per_gpu"], "particles": weak["particles_per_gpu"] * world,
+                                  "value": weak["value"], "ms_per_step": weak["ms_per_step"], "exchange_ms": weak["exchange_ms"],
+                                  "single_gpu_base": {"particles": P_total, "value": single["value"], "ms_per_step": single["ms_per_step"]} if weak["particles_per_gpu"] == P_total else None,
+                                  "note": "the same C++ object with the single-GPU pool on every GPU (fixed work per GPU)"}
         result["exchange_ms_per_step"] = main_run["exchange_ms_per_step"]
         result["single_gpu_same_pool"] = {"value": single["value"], "ms_per_step": single["ms_per_step"],
                                           "note": f"the same {P_total} particles unsharded on one GPU (rank 0's), same steps: the base of the strong-scaling figure"}

@@ -151,6 +151,9 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* ctx, uint32_t particle, int32_t k
 int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* ctx, const double* pts_xyz, uint32_t n,
                                       const double* sensor_origin3, const double* sensor_quat_wxyz);
 int32_t lama_hip_sync(lama_hip_ctx* ctx);
+/* HIP device ordinal the context lives on (cfg.device); < 0 for a null context.  Lets a caller of a multi-GPU object check
+ * that its shards really sit on distinct devices. */
+int32_t lama_hip_ctx_device(const lama_hip_ctx* ctx);
 
 /* Patch bookkeeping for transient maps (LidarOdometry2D::updateMaps, src/lidar_odometry_2d.cpp:128-199):
  *   lama_hip_pf_patch_ids     : Map::visit_all_patches -- the reference patch indices (Map::m2p) of the allocated patches;

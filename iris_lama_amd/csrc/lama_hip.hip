@@ -865,6 +865,8 @@ int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* c, const double* pts, uint32
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_ctx_device(const lama_hip_ctx* c) { return c ? c->cfg.device : -1; }
+
 int32_t lama_hip_sync(lama_hip_ctx* c)
 {
     if (!c) return LAMA_HIP_E_INVALID;

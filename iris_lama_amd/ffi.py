@@ -57,7 +57,7 @@ HIP_SYMBOLS = [
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
-    "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync",
+    "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync", "lama_hip_ctx_device",
     "lama_hip_pf_map_checksums", "lama_hip_match_eval", "lama_hip_match_cell_distances", "lama_hip_match_solve_with",
     "lama_hip_blob_alloc", "lama_hip_blob_free", "lama_hip_blob_copy", "lama_hip_pf_export_particles", "lama_hip_pf_import_particles",
 ]
@@ -116,6 +116,8 @@ def _bind_hip(L):
         L.lama_hip_pf_update_maps.argtypes = [vp, vp, u32, vp, vp]
         L.lama_hip_pf_update_maps_begin.argtypes = [vp, vp, u32, vp, vp]
         L.lama_hip_sync.argtypes = [vp]
+        L.lama_hip_ctx_device.argtypes = [vp]
+        L.lama_hip_ctx_device.restype = C.c_int32
         L.lama_hip_pf_map_patches.argtypes = [vp, u32, i32, vp]
         L.lama_hip_pf_download_map.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
         L.lama_hip_match_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp]
@@ -269,6 +271,10 @@ class HipContext:
 
     def sync(self):
         self._chk(self.L.lama_hip_sync(self.h))
+
+    def device(self):
+        """HIP device ordinal of the context."""
+        return int(self.L.lama_hip_ctx_device(self.h))
 
     def map_checksums(self, kind):
         """One 64-bit checksum per particle of its distance / occupancy map (patch set, cells, masks), computed on the device."""

@@ -17,12 +17,14 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
     import iris_lama_amd.ffi as F
     from iris_lama_amd.distributed import ShardedPF
 
+    if backend == "nccl":                # one process per GPU: RCCL binds the process' current device
+        torch.cuda.set_device(gpu)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if engine_path:
         import _testhost                 # test double of the device C-ABI: needs the test-suite's own -DLAMA_TESTING host build
         _testhost.set_engine_library(engine_path)
     pts, odom, _ = F.corridor_log(steps, beams)
-    opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=0)
+    opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=gpu)
     pf = ShardedPF(opts, device=torch.device("cpu") if backend == "gloo" else None)
     pf.set_prior(*odom[0])
     hist = []
@@ -39,7 +41,7 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
         for i in range(pf.pf.lo, pf.pf.hi):
             maps[i] = (ctx.download_map(i - pf.pf.lo, F.MAP_DISTANCE), ctx.download_map(i - pf.pf.lo, F.MAP_OCCUPANCY))
     res = dict(lo=pf.pf.lo, hi=pf.pf.hi, hist=hist, maps=maps, sums=sums, resamples=pf.pf.num_resamples(), shipped=pf.shipped_particles,
-               origin=pf.pf.engine_origin())
+               origin=pf.pf.engine_origin(), device=ctx.device(), backend=pf.backend)
     with open(os.path.join(out_dir, f"rank{rank}.pkl"), "wb") as f:
         pickle.dump(res, f)
     dist.barrier()

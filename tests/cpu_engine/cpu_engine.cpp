@@ -192,6 +192,7 @@ int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* c, const double* pts, uint32
     return update_maps_impl(c, pts, n, origin, quat);
 }
 int32_t lama_hip_sync(lama_hip_ctx*) { return LAMA_HIP_OK; }
+int32_t lama_hip_ctx_device(const lama_hip_ctx* c) { return c ? 0 : -1; }
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
 {

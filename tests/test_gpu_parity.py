@@ -404,21 +404,23 @@ def test_sharded_two_ranks_one_gpu_gloo(F):
     h.close()
 
 
-@pytest.mark.parametrize("world", [4, 8])
-def test_config3_split_partition_invariance(F, world):
-    """BASELINE configs[2]: 3000 particles in G = 4 / 8 contiguous shards (750 / 375 per shard -- the 8-GPU split), here as G
-    processes on ONE device over gloo, with a small meas_sigma_gain so that the filter resamples and clones cross shard
-    borders.  Every shard must agree with a single-shard run of the same library bit for bit: poses, weights, resampling
-    decisions, and a device-side checksum of every particle's maps."""
+def _visible_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.0001):
+    """`world` processes, one shard each (on the HIP devices `devices[r]`), against a single-shard run of the same library: poses,
+    weights, resampling decisions and a device-side checksum of every particle's maps must agree bit for bit."""
     import os, pickle, tempfile
     import torch.multiprocessing as mp
     from test_distributed_cpu import _free_port
     from _dist_worker import run
-    P, steps, beams, gain = 3000, 5, 1080, 0.0001
+    beams = 1080
     out = tempfile.mkdtemp()
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=run, args=(r, world, port, "gloo", None, P, steps, beams, gain, out, 0, True)) for r in range(world)]
+    procs = [ctx.Process(target=run, args=(r, world, port, backend, None, P, steps, beams, gain, out, devices[r], True)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
@@ -426,6 +428,7 @@ def test_config3_split_partition_invariance(F, world):
         assert p.exitcode == 0
     res = [pickle.load(open(os.path.join(out, f"rank{r}.pkl"), "rb")) for r in range(world)]
     assert [(r["lo"], r["hi"]) for r in res] == [(k * P // world, (k + 1) * P // world) for k in range(world)]
+    assert [r["device"] for r in res] == list(devices) and all(r["backend"] == backend for r in res)
     assert len({r["resamples"] for r in res}) == 1 and res[0]["resamples"] > 0
     assert sum(r["shipped"] for r in res) > 0, "no clone crossed a shard border: the test would not exercise the shipping"
     pts, odom, _ = F.corridor_log(steps, beams)
@@ -445,17 +448,34 @@ def test_config3_split_partition_invariance(F, world):
     h.close()
 
 
-@pytest.mark.parametrize("gpus,P,gain", [(2, 30, 0.01), (3, 301, 0.001), (8, 3000, 0.0001)])
-def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
-    """lama::PFSlam2D with Options::gpus > 1 (one process, a host thread + device context per shard, here all on the one device of
-    the box): update() is the whole sharded step in C++ -- no Python, no process group.  With a gain that makes the filter resample
-    and clone across shard borders it must agree with the gpus = 1 object bit for bit: poses, weights, Neff, best particle,
-    resampling decisions and a device-side checksum of every particle's maps.  (8, 3000) is BASELINE configs[2]'s split."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_config3_split_partition_invariance(F, world):
+    """BASELINE configs[2]: 3000 particles in G = 4 / 8 contiguous shards (750 / 375 per shard -- the 8-GPU split), here as G
+    processes on ONE device over gloo, with a small meas_sigma_gain so that the filter resamples and clones cross shard
+    borders.  Every shard must agree with a single-shard run of the same library bit for bit: poses, weights, resampling
+    decisions, and a device-side checksum of every particle's maps."""
+    _partition_invariance(F, world, "gloo", [0] * world)
+
+
+def test_config3_on_distinct_devices_over_rccl(F):
+    """The same on REAL devices when the box has them (auto-skipped on a one-GPU box): one process per GPU, min(8, visible)
+    ranks over `nccl` (= RCCL: the all-gather of the log-likelihoods and the batched isend / irecv of the particle blobs run
+    device to device over xGMI), against the single-shard run."""
+    n = min(8, _visible_gpus())
+    if n < 2:
+        pytest.skip("one visible device: RCCL with several ranks needs one GPU per rank (the sharding itself runs in test_config3_split_partition_invariance)")
+    _partition_invariance(F, n, "nccl", list(range(n)))
+
+
+def _multi_gpu_object_vs_one_shard(F, gpus, P, gain, distinct_devices=False):
     steps = 6 if P >= 3000 else 12
     pts, odom, _ = F.corridor_log(steps, 1080)
     a = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
     b = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, gpus=gpus))
     assert b.engine_origin().endswith("liblama_hip.so")
+    devs = [b.shard_context(r).device() for r in range(gpus)]
+    if distinct_devices:
+        assert sorted(devs) == list(range(gpus)), devs            # shard r on HIP device r: peer copies really cross devices
     a.set_prior(*odom[0]); b.set_prior(*odom[0])
     shipped = 0
     for k in range(steps + 1):
@@ -474,6 +494,24 @@ def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
         assert np.array_equal(np.concatenate([b.shard_context(r).map_checksums(kind) for r in range(gpus)]), ca.map_checksums(kind))
     assert np.array_equal(a.best_pose_xyr(), b.best_pose_xyr())
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("gpus,P,gain", [(2, 30, 0.01), (3, 301, 0.001), (8, 3000, 0.0001)])
+def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
+    """lama::PFSlam2D with Options::gpus > 1 (one process, a host thread + device context per shard; on a one-GPU box all of them
+    on that device): update() is the whole sharded step in C++ -- no Python, no process group.  With a gain that makes the filter
+    resample and clone across shard borders it must agree with the gpus = 1 object bit for bit: poses, weights, Neff, best particle,
+    resampling decisions and a device-side checksum of every particle's maps.  (8, 3000) is BASELINE configs[2]'s split."""
+    _multi_gpu_object_vs_one_shard(F, gpus, P, gain)
+
+
+def test_multi_gpu_object_on_distinct_devices(F):
+    """The same object with one shard per REAL device (auto-skipped on a one-GPU box): Options::gpus = min(8, visible devices),
+    3000 particles -- the clones that cross a shard border travel with hipMemcpyPeerAsync between different GPUs."""
+    n = min(8, _visible_gpus())
+    if n < 2:
+        pytest.skip("one visible device: the shards of the object would share it (covered by test_multi_gpu_object_is_bit_identical_to_one_shard)")
+    _multi_gpu_object_vs_one_shard(F, n, 3000, 0.0001, distinct_devices=True)
 
 
 @pytest.mark.parametrize("seq_ray", [2, 1])
