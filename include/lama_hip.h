@@ -66,7 +66,9 @@ typedef struct lama_hip_cfg {
     double truncated_ray;        /* Options::truncated_ray                                        */
     double truncated_range;      /* Options::truncated_range                                      */
     int32_t device;              /* HIP device ordinal                                            */
-    uint32_t window_patches;     /* side of the square map window in patches (default 128 = 204.8 m; multiple of 8, <= 248) */
+    uint32_t window_patches;     /* INITIAL side of the square map window in patches (default 128 = 204.8 m; a multiple of 8).  The window
+                                    follows the robot and GROWS (re-allocated at least half as large again) when the mapped area
+                                    outgrows it, up to 1016 patches = 1.6 km at 0.05 m; only a wider map is LAMA_HIP_E_WINDOW */
     uint32_t dm_patch_capacity;  /* DM patches per particle to start with (default 256).  The reference's maps are unbounded; here the
                                     arenas grow on demand: doubled whenever a particle has filled more than half of one, and a
                                     map update that needs more patches than are free reports that BEFORE it modifies any cell
@@ -283,6 +285,8 @@ typedef struct lama_hip_counters {
                                            serial chain: at 3000 particles one of them (13.9 ms) is what made the resume kernel's MEAN
                                            1.2 ms in the round-3 profile while its median is 5 us (profiles/r04_timeline_3000_before.txt) */
     uint32_t replay_handovers;          /* the same for the ordered replay of the parallel ray-cast (more than 2048 order-sensitive visits) */
+    uint32_t window_patches;            /* current side of the map window in patches (it grows with the mapped area, up to 1016)            */
+    uint32_t window_growths;            /* times the window directories were re-allocated with a larger side                                */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

@@ -114,6 +114,8 @@ struct lama_hip_ctx {
     Affine last_mtf; uint32_t last_first = 0, last_count = 0;
     bool last_guarded = false;        // the update went through the parallel ray-cast (its allocation phase precedes every modification)
     int recover_depth = 0;
+    // the box of everything that can be mapped so far, absolute patch coordinates (ensure_window)
+    int64_t mbx0 = 0, mbx1 = 0, mby0 = 0, mby1 = 0; bool mb_valid = false;
     bool unguarded_retry = false;     // the arenas are at their hard limit and the guard's bound did not fit: run the update without it
     // host-side effects of a map update that a repeated pass (recover_update) must not apply twice
     uint32_t saved_visit_bound = 0; lama_hip_counters saved_ctr;
@@ -257,7 +259,7 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             const int32_t rr = recover_update(c, e);
             if (rr != LAMA_HIP_E_CAPACITY) return rr;      // done (or another error); E_CAPACITY: the arenas are at their limit
         }
-        if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (raise cfg.window_patches)");
+        if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (the mapped area is wider than 1016 patches)");
         if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
         if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
         if (e & ERR_QUEUE) return fail(c, LAMA_HIP_E_CAPACITY, "brushfire queue full (raise cfg.queue_capacity)");
@@ -417,11 +419,84 @@ void resolve_timers(lama_hip_ctx* c)      // call after the stream has been sync
     c->ctr.launches_update_maps = c->ctr.launches_raycast;
 }
 
-// The reference's maps have no extent (src/sdm/map.cpp:400-411); the device window has one, but it MOVES: before a map update
-// the window must hold every cell the scan can touch from any particle of the range (pose +- scan reach).  If it does not, the
-// window is moved to hold that box -- a patch-granular shift of the two directories of every particle (k_shift_window; the other
-// particle set's directories are the scratch destination, then the pointers are swapped).  Only a map whose extent exceeds the
-// window side remains an error.
+// The reference's maps have no extent (src/sdm/map.cpp:400-411); the device window has one, but it MOVES and (round 4) GROWS.  The
+// host keeps the box of everything that can be mapped so far -- the union, over all updates, of pose +- scan reach of every
+// particle, in absolute patch coordinates (a superset of the mapped area; imported particles bring their sender's).  Before a map
+// update (and before an import) the window must hold that box:
+//   * it fits the window side: the window is moved by the smallest patch-granular step that holds it (plus a little slack in the
+//     direction of the move) -- a permutation of the two directories of every particle (k_shift_window; the other particle set's
+//     directories are the scratch destination, then the pointers are swapped);
+//   * it does not: the directories are re-allocated with a larger side (at least half as large again, a multiple of 8, at most
+//     LAMA_HIP_MAX_WINDOW = 1016 patches = 1.6 km at 0.05 m) and re-tiled by the same kernel; arenas, cells and slots are untouched.
+// Only a map wider than 1016 patches remains LAMA_HIP_E_WINDOW (the kernels report what really falls outside).
+constexpr int64_t LAMA_HIP_MAX_WINDOW = 1016;
+
+int32_t regrid_window(lama_hip_ctx* c, uint32_t newW, int64_t nox, int64_t noy)
+{
+    const int64_t ox = c->wx0 >> 5, oy = c->wy0 >> 5;
+    const int dx = (int)(nox - ox), dy = (int)(noy - oy);
+    const size_t WW = (size_t)c->W * c->W, nWW = (size_t)newW * newW, P = c->P;
+    if (!c->initialised && newW == c->W) { c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32); return LAMA_HIP_OK; }   // nothing mapped yet
+    ParticleSet& a = c->set[c->cur];
+    ParticleSet& b = c->set[1 - c->cur];
+    if (newW == c->W) {
+        const dim3 grid((unsigned)P, (unsigned)((WW + 255) / 256));
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, b.dm_dir, c->W, c->W, dx, dy, WW, WW, c->d_err);
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, b.occ_dir, c->W, c->W, dx, dy, WW, WW, c->d_err);
+        HIPCHK(c, hipGetLastError());
+        std::swap(a.dm_dir, b.dm_dir);
+        std::swap(a.occ_dir, b.occ_dir);
+    } else {
+        int16_t* nd[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+        for (int k = 0; k < 2; ++k)
+            for (int m = 0; m < 2; ++m) {
+                HIPCHK(c, hipMalloc(&nd[k][m], P * nWW * 2));
+                HIPCHK(c, hipMemsetAsync(nd[k][m], 0xFF, P * nWW * 2, c->stream));
+            }
+        const dim3 grid((unsigned)P, (unsigned)((std::max(WW, nWW) + 255) / 256));
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, nd[c->cur][0], c->W, newW, dx, dy, WW, nWW, c->d_err);
+        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, nd[c->cur][1], c->W, newW, dx, dy, WW, nWW, c->d_err);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k < 2; ++k) {
+            (void)hipFree(c->set[k].dm_dir); (void)hipFree(c->set[k].occ_dir);
+            c->set[k].dm_dir = nd[k][0]; c->set[k].occ_dir = nd[k][1];
+        }
+        c->W = newW; c->WC = newW * 32; c->cfg.window_patches = newW;
+        c->ctr.window_growths += 1;
+    }
+    c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32);
+    c->ctr.window_shifts += 1;
+    c->ctr.window_patches = c->W;
+    return LAMA_HIP_OK;
+}
+
+// the window must hold the box [x0, x1] x [y0, y1] (absolute patches): union it into the mapped box, then move / grow the window
+int32_t ensure_window(lama_hip_ctx* c, int64_t x0, int64_t x1, int64_t y0, int64_t y1)
+{
+    if (!c->mb_valid) { c->mbx0 = x0; c->mbx1 = x1; c->mby0 = y0; c->mby1 = y1; c->mb_valid = true; }
+    else { c->mbx0 = std::min(c->mbx0, x0); c->mbx1 = std::max(c->mbx1, x1); c->mby0 = std::min(c->mby0, y0); c->mby1 = std::max(c->mby1, y1); }
+    const int64_t ox = c->wx0 >> 5, oy = c->wy0 >> 5, W = c->W;
+    if (std::getenv("LAMA_HIP_DEBUG_WINDOW")) std::fprintf(stderr, "ensure_window: box x [%ld, %ld] y [%ld, %ld] mapped x [%ld, %ld] y [%ld, %ld] window x [%ld, %ld) y [%ld, %ld)\n", (long)x0, (long)x1, (long)y0, (long)y1, (long)c->mbx0, (long)c->mbx1, (long)c->mby0, (long)c->mby1, (long)ox, (long)(ox + W), (long)oy, (long)(oy + W));
+    if (c->mbx0 >= ox && c->mbx1 < ox + W && c->mby0 >= oy && c->mby1 < oy + W) return LAMA_HIP_OK;
+    const int64_t span = std::max(c->mbx1 - c->mbx0 + 1, c->mby1 - c->mby0 + 1);
+    int64_t newW = W;
+    if (span > W) newW = std::min<int64_t>(LAMA_HIP_MAX_WINDOW, std::max<int64_t>((span + 8 + 7) / 8 * 8, (W + W / 2 + 7) / 8 * 8));
+    // what the (new) window must hold: the whole mapped box when it fits, else at least this call's box (the kernels then report
+    // what really falls outside: LAMA_HIP_E_WINDOW)
+    int64_t hx0 = c->mbx0, hx1 = c->mbx1, hy0 = c->mby0, hy1 = c->mby1;
+    if (span > newW) { hx0 = x0; hx1 = x1; hy0 = y0; hy1 = y1; if (x1 - x0 + 1 > newW || y1 - y0 + 1 > newW) return LAMA_HIP_OK; }
+    auto place = [&](int64_t o, int64_t lo, int64_t hi) {
+        const int64_t a = hi - newW + 1, b = lo;              // admissible origins: a <= origin <= b
+        int64_t no = std::min(std::max(o, a), b);
+        if (no > o) no = std::min(no + 4, b); else if (no < o) no = std::max(no - 4, a);
+        return no;
+    };
+    const int64_t nox = c->initialised ? place(ox, hx0, hx1) : (hx0 + hx1 + 1) / 2 - newW / 2;
+    const int64_t noy = c->initialised ? place(oy, hy0, hy1) : (hy0 + hy1 + 1) / 2 - newW / 2;
+    return regrid_window(c, (uint32_t)newW, nox, noy);
+}
+
 int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t count)
 {
     // no cell further than truncated_range from the sensor is touched (src/pf_slam2d.cpp:470-476): "no return" readings far
@@ -436,35 +511,7 @@ int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t 
         ylo = std::min(ylo, y - reach); yhi = std::max(yhi, y + reach);
     }
     auto patch = [&](double w) { return (int64_t)std::floor((c->scale * w + c->off) / 32.0); };
-    const int64_t pxlo = patch(xlo), pxhi = patch(xhi), pylo = patch(ylo), pyhi = patch(yhi);
-    const int64_t ox = c->wx0 >> 5, oy = c->wy0 >> 5, W = c->W;
-    if (std::getenv("LAMA_HIP_DEBUG_WINDOW")) std::fprintf(stderr, "fit_window: reach %.2f box x [%ld, %ld] y [%ld, %ld] window x [%ld, %ld) y [%ld, %ld)\n", reach, (long)pxlo, (long)pxhi, (long)pylo, (long)pyhi, (long)ox, (long)(ox + W), (long)oy, (long)(oy + W));
-    if (pxlo >= ox && pxhi < ox + W && pylo >= oy && pyhi < oy + W) return LAMA_HIP_OK;
-    if (pxhi - pxlo + 1 > W || pyhi - pylo + 1 > W) return LAMA_HIP_OK;      // cannot hold the box: the kernels report what really falls outside
-    // the smallest move that holds the box (keeps as much of the mapped area inside as possible), plus a few patches of slack in
-    // the direction of the move so that the next scans do not shift again
-    auto place = [&](int64_t o, int64_t lo, int64_t hi) {
-        const int64_t a = hi - W + 1, b = lo;                 // admissible origins: a <= origin <= b
-        int64_t no = std::min(std::max(o, a), b);
-        if (no > o) no = std::min(no + 4, b); else if (no < o) no = std::max(no - 4, a);
-        return no;
-    };
-    const int64_t nox = c->initialised ? place(ox, pxlo, pxhi) : (pxlo + pxhi + 1) / 2 - W / 2;
-    const int64_t noy = c->initialised ? place(oy, pylo, pyhi) : (pylo + pyhi + 1) / 2 - W / 2;
-    const int dx = (int)(nox - ox), dy = (int)(noy - oy);
-    if (!c->initialised) { c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32); return LAMA_HIP_OK; }   // nothing mapped yet
-    ParticleSet& a = c->set[c->cur];
-    ParticleSet& b = c->set[1 - c->cur];
-    const size_t WW = (size_t)c->W * c->W;
-    const dim3 grid(c->P, (unsigned)((WW + 255) / 256));
-    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, b.dm_dir, c->W, dx, dy, WW, WW, c->d_err);
-    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, b.occ_dir, c->W, dx, dy, WW, WW, c->d_err);
-    HIPCHK(c, hipGetLastError());
-    std::swap(a.dm_dir, b.dm_dir);
-    std::swap(a.occ_dir, b.occ_dir);
-    c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32);
-    c->ctr.window_shifts += 1;
-    return LAMA_HIP_OK;
+    return ensure_window(c, patch(xlo), patch(xhi), patch(ylo), patch(yhi));
 }
 
 // allocation phase of a map update (ray records, hit cells' patches, the patches the rays cross, the bound on the distance-map patches
@@ -517,8 +564,8 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
-        // in 11 bits (act_key): scans with more points go beam by beam
-        if (!sequential && (n > 2048u || (uint64_t)n + 4096u > c->cfg.active_capacity)) sequential = true;
+        // in 13 bits (act_key) and k_ray_patches keeps one 64-beam chunk per lane: scans with more than 4096 points go beam by beam
+        if (!sequential && (n > 4096u || (uint64_t)n + 4096u > c->cfg.active_capacity)) sequential = true;
         // a uint16 `visited` counter that wraps INSIDE a scan makes the order of the visits matter (k_occ_max_visited)
         if (!sequential && (uint64_t)c->visit_bound + n >= 65536u) {
             uint32_t m = 0;
@@ -645,7 +692,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // configuration only (cfg.brushfire_mode = 1, the one variant that is NOT bit-identical to the reference, must be asked for
     // by the caller), and lama_hip_get_counters reports what actually ran.
     if (cfg.brushfire_mode > 1 || cfg.brushfire_waves > 2) return LAMA_HIP_E_INVALID;
-    if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > 248 ||
+    if (cfg.particles == 0 || cfg.patch_size != 32 || !(cfg.resolution > 0) || cfg.window_patches > (uint32_t)LAMA_HIP_MAX_WINDOW ||
         (cfg.window_patches & 7) || cfg.dm_patch_capacity > 32767 || cfg.occ_patch_capacity > 32767 ||
         cfg.queue_capacity < (uint32_t)LQ_BIG)
         return LAMA_HIP_E_INVALID;
@@ -656,6 +703,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     c->cfg = cfg;
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
+    c->ctr.window_patches = c->W;
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
     // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)
@@ -1254,9 +1302,17 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     if (!c || !cells_xy || n == 0 || particle >= c->P) return LAMA_HIP_E_INVALID;
     ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    {   // the window must hold the listed cells and what the brushfire reaches from them (it is centred / moved / grown for that)
+        const int64_t r = (int64_t)(((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u);
+        int64_t x0 = INT64_MAX, x1 = INT64_MIN, y0 = INT64_MAX, y1 = INT64_MIN;
+        for (uint32_t i = 0; i < n; ++i) {
+            const int64_t px = cells_xy[2 * i] >> 5, py = cells_xy[2 * i + 1] >> 5;
+            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+        const int32_t rw = ensure_window(c, x0 - r, x1 + r, y0 - r, y1 + r);
+        if (rw) return rw;
+    }
     if (!c->initialised) {
-        c->wx0 = ((cells_xy[0] >> 5) - c->W / 2) * 32;
-        c->wy0 = ((cells_xy[1] >> 5) - c->W / 2) * 32;
         for (uint32_t p = 0; p < c->P; ++p) { c->h_poses[4 * p] = 1.0; c->h_poses[4 * p + 1] = 0.0; c->h_poses[4 * p + 2] = 0.0; c->h_poses[4 * p + 3] = 0.0; }
         HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
         c->initialised = true;
@@ -1402,11 +1458,21 @@ static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double
     return LAMA_HIP_OK;
 }
 
-// Particle blob layout: [pose 4 f64][counts 2 i32][dm_dir][occ_dir][dm_sv used][dm_obs used][dm_mask used][occ used][occ_mask used]
-static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ)
+// Particle blob layout: [pose 4 f64][header 8 i32][dm_dir][occ_dir][dm_sv used][dm_obs used][dm_mask used][occ used][occ_mask used]
+// (the directories in the SENDER's window side W: windows grow independently, the header carries the side)
+static uint64_t blob_bytes_w(uint64_t W, int dmc, int occ)
 {
-    const uint64_t WW = (uint64_t)c->W * c->W;
-    return 32 + 32 + 2 * WW * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
+    return 32 + 32 + 2 * W * W * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
+}
+static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ) { return blob_bytes_w(c->W, dmc, occ); }
+
+// the extent of this context's mapped box inside its window (lo | hi << 16 in patches; the whole window when nothing is known)
+static int32_t mapped_box_rel(const lama_hip_ctx* c, int axis)
+{
+    const int64_t o = (axis == 0 ? c->wx0 : c->wy0) >> 5, W = c->W;
+    int64_t lo = 0, hi = W - 1;
+    if (c->mb_valid) { lo = std::min(std::max((axis == 0 ? c->mbx0 : c->mby0) - o, (int64_t)0), W - 1); hi = std::min(std::max((axis == 0 ? c->mbx1 : c->mby1) - o, (int64_t)0), W - 1); }
+    return (int32_t)((uint32_t)lo | ((uint32_t)hi << 16));
 }
 
 // ---- particle shipping: all outgoing / incoming particles of a resample in one launch each (k_export_particles / k_import_particles)
@@ -1444,7 +1510,7 @@ int32_t lama_hip_pf_export_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     if (rc) return rc;
     hipLaunchKernelGGL(k_export_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(c->set[c->cur]), (const ShipDesc*)c->d_ship_desc,
                        (const double*)c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5),
-                       (int32_t)c->visit_bound);
+                       (int32_t)c->visit_bound, mapped_box_rel(c, 0), mapped_box_rel(c, 1));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return LAMA_HIP_OK;
@@ -1478,10 +1544,19 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     for (uint32_t k = 0; k < n; ++k) {
         int32_t hdr[8];
         std::memcpy(hdr, c->h_ship_heads.data() + (size_t)BLOB_HEAD * k + 32, 32);
-        if (hdr[0] < 0 || hdr[1] < 0 || hdr[0] > 32767 || hdr[1] > 32767 || blob_bytes(c, hdr[0], hdr[1]) != bytes[k])
+        if (hdr[0] < 0 || hdr[1] < 0 || hdr[0] > 32767 || hdr[1] > 32767 || hdr[5] < 8 || hdr[5] > (int32_t)LAMA_HIP_MAX_WINDOW || (hdr[5] & 7) ||
+            blob_bytes_w((uint64_t)hdr[5], hdr[0], hdr[1]) != bytes[k])
             return fail(c, LAMA_HIP_E_INVALID, "particle blob does not match this context's geometry");
         max_dm = std::max<uint32_t>(max_dm, (uint32_t)hdr[0]); max_occ = std::max<uint32_t>(max_occ, (uint32_t)hdr[1]);
-        // the sender's window may sit elsewhere (every shard follows its own particles): the kernel translates the directories
+        // every shard's window follows (and grows with) its own particles: this one must hold what the sender has mapped
+        const int64_t sx = hdr[2], sy = hdr[3];
+        rc = ensure_window(c, sx + (hdr[6] & 0xFFFF), sx + ((uint32_t)hdr[6] >> 16), sy + (hdr[7] & 0xFFFF), sy + ((uint32_t)hdr[7] >> 16));
+        if (rc) return rc;
+    }
+    for (uint32_t k = 0; k < n; ++k) {
+        int32_t hdr[8];
+        std::memcpy(hdr, c->h_ship_heads.data() + (size_t)BLOB_HEAD * k + 32, 32);
+        // the sender's window sits elsewhere: the kernel translates the directories
         c->h_ship_desc[k].wdx = (int32_t)((int64_t)(c->wx0 >> 5) - (int64_t)hdr[2]);
         c->h_ship_desc[k].wdy = (int32_t)((int64_t)(c->wy0 >> 5) - (int64_t)hdr[3]);
     }
@@ -1593,6 +1668,7 @@ int32_t lama_hip_reset_counters(lama_hip_ctx* c)
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->ctr.dm_patches = old.dm_patches; c->ctr.occ_patches = old.occ_patches;
     c->ctr.brushfire_mode = old.brushfire_mode; c->ctr.brushfire_waves = old.brushfire_waves;
+    c->ctr.window_patches = c->W;
     return LAMA_HIP_OK;
 }
 

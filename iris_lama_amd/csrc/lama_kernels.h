@@ -614,23 +614,29 @@ __global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int par
 constexpr uint32_t DC_EMPTY = 0xFFFFFFFFu;
 constexpr int DC_SIZE = 512;
 
-// direct-mapped LDS cache of window-directory entries: (pidx << 16) | uint16(slot), XOR-folded index
+// direct-mapped LDS cache of window-directory entries, XOR-folded index.  A word holds ((pidx >> 3) << 15) | (slot + 1): the low
+// three bits of pidx are implied by the index (the fold XORs them with higher bits of pidx, all of which the tag holds), 17 tag bits
+// cover windows up to 1016 x 1016 patches (round 4: the window grows with the map), slot + 1 in 15 bits (0 = no such patch).  An
+// empty word carries a tag no window position has.
 struct DirCache {
     uint32_t* e;
     const int16_t* dir;
     uint32_t W;
     // pidx = wy * W + wx with W a multiple of 8: (pidx & 7) = wx & 7; fold the rest without a division
-    __device__ inline uint32_t index(uint32_t pidx) const { return (pidx ^ (pidx >> 9) ^ (pidx >> 5)) & (DC_SIZE - 1); }
+    __device__ static inline uint32_t index(uint32_t pidx) { return (pidx ^ (pidx >> 9) ^ (pidx >> 5)) & (DC_SIZE - 1); }
+    __device__ static inline uint32_t pack(uint32_t pidx, int slot) { return ((pidx >> 3) << 15) | (uint32_t)(slot < 0 ? 0 : slot + 1); }
+    __device__ static inline bool hit(uint32_t v, uint32_t pidx) { return (v >> 15) == (pidx >> 3); }
+    __device__ static inline int slot_of(uint32_t v) { return (int)(v & 0x7FFFu) - 1; }
     __device__ inline int lookup(uint32_t pidx) const
     {
         const uint32_t k = index(pidx);
         const uint32_t v = e[k];
-        if ((v >> 16) == pidx && v != DC_EMPTY) return (int)(int16_t)(v & 0xFFFFu);
+        if (hit(v, pidx)) return slot_of(v);
         const int slot = dir[pidx];
-        e[k] = (pidx << 16) | (uint32_t)(uint16_t)(int16_t)slot;
-        return slot;
+        e[k] = pack(pidx, slot);
+        return slot < 0 ? -1 : slot;
     }
-    __device__ inline void update(uint32_t pidx, int slot) const { e[index(pidx)] = (pidx << 16) | (uint32_t)(uint16_t)(int16_t)slot; }
+    __device__ inline void update(uint32_t pidx, int slot) const { e[index(pidx)] = pack(pidx, slot); }
 };
 
 // Wave-cooperative "non-const Map::get" patch lookup (src/sdm/map.cpp:371-412): every lane with `want`
@@ -1531,9 +1537,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
                 const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
                 const uint32_t dv = sh.dc[dc.index(pidx & inwin)];
-                // (an empty cache word has the tag 0xFFFF: no window position has it)
-                const uint32_t hit = opq(inwin & ~m_nz((dv >> 16) ^ pidx));
-                const uint32_t slotw = (uint32_t)(int)(int16_t)(dv & 0xFFFFu);
+                // (an empty cache word has a tag no window position has)
+                const uint32_t hit = opq(inwin & ~m_nz((dv >> 15) ^ (pidx >> 3)));
+                const uint32_t slotw = (dv & 0x7FFFu) - 1u;
                 const uint32_t absent = opq((uint32_t)((int32_t)slotw >> 31));                // cached "no such patch"
                 const uint32_t have = opq(rolem & hit & ~absent);
                 const uint32_t unknown = opq(rolem & ~hit);                                   // not cached / outside the window: general code
@@ -1578,8 +1584,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         const uint32_t oin = opq((tie_other != 0u && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) ? 0xFFFFFFFFu : 0u);
                         const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);
                         const uint32_t odv = sh.dc[dc.index(opidx & oin)];
-                        const uint32_t ohit = opq(oin & ~m_nz((odv >> 16) ^ opidx));
-                        const uint32_t oslot = (uint32_t)(int)(int16_t)(odv & 0xFFFFu);
+                        const uint32_t ohit = opq(oin & ~m_nz((odv >> 15) ^ (opidx >> 3)));
+                        const uint32_t oslot = (odv & 0x7FFFu) - 1u;
                         miss2 = opq((oin & ~ohit) | alloc);                                   // not cached, or a patch to allocate: general code
                         const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
                         const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
@@ -2118,17 +2124,22 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
 // and patches live in per-particle arenas, so moving the window only permutes directory entries.  A patch that would leave
 // the window means the map no longer fits it: ERR_WINDOW (nothing is dropped silently).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_shift_window(const int16_t* __restrict__ src, int16_t* __restrict__ dst, uint32_t W, int dx, int dy,
+__global__ __launch_bounds__(256) void k_shift_window(const int16_t* __restrict__ src, int16_t* __restrict__ dst, uint32_t Ws, uint32_t Wd, int dx, int dy,
                                                        size_t src_stride, size_t dst_stride, int32_t* err)
 {
+    // (round 4) source and destination windows may differ in size: the window GROWS when the mapped area outgrows it
     const uint32_t p = blockIdx.x, idx = blockIdx.y * 256u + threadIdx.x;
-    if (idx >= W * W) return;
-    const int wy = (int)(idx / W), wx = (int)(idx % W);
-    const int sx = wx + dx, sy = wy + dy;
-    const bool in = sx >= 0 && sy >= 0 && sx < (int)W && sy < (int)W;
-    dst[p * dst_stride + idx] = in ? src[p * src_stride + (size_t)sy * W + (size_t)sx] : (int16_t)-1;
-    const int tx = wx - dx, ty = wy - dy;                  // where the old entry (wx, wy) ends up
-    if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && src[p * src_stride + idx] >= 0) atomicOr(err, ERR_WINDOW);
+    if (idx < Wd * Wd) {
+        const int wy = (int)(idx / Wd), wx = (int)(idx % Wd);
+        const int sx = wx + dx, sy = wy + dy;
+        const bool in = sx >= 0 && sy >= 0 && sx < (int)Ws && sy < (int)Ws;
+        dst[p * dst_stride + idx] = in ? src[p * src_stride + (size_t)sy * Ws + (size_t)sx] : (int16_t)-1;
+    }
+    if (idx < Ws * Ws) {
+        const int wy = (int)(idx / Ws), wx = (int)(idx % Ws);
+        const int tx = wx - dx, ty = wy - dy;                  // where the old entry (wx, wy) ends up
+        if (!(tx >= 0 && ty >= 0 && tx < (int)Wd && ty < (int)Wd) && src[p * src_stride + idx] >= 0) atomicOr(err, ERR_WINDOW);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2228,7 +2239,8 @@ __device__ inline const uint4* blob_plane(const uint8_t* blob, int plane, size_t
 // grid (n, 7 planes, SHIP_SPLIT): every plane of every outgoing particle in parallel
 constexpr int SHIP_SPLIT = 4;
 __global__ __launch_bounds__(256) void k_export_particles(SetPtrs src, const ShipDesc* __restrict__ desc, const double* __restrict__ poses, uint32_t W,
-                                                           uint32_t dm_cap, uint32_t occ_cap, int32_t wx_patch, int32_t wy_patch, int32_t visit_bound)
+                                                           uint32_t dm_cap, uint32_t occ_cap, int32_t wx_patch, int32_t wy_patch, int32_t visit_bound,
+                                                           int32_t bbox_x, int32_t bbox_y)
 {
     const ShipDesc d = desc[blockIdx.x];
     const int j = (int)d.particle, plane = blockIdx.y;
@@ -2251,7 +2263,8 @@ __global__ __launch_bounds__(256) void k_export_particles(SetPtrs src, const Shi
         double* hp = reinterpret_cast<double*>(d.blob);
         for (int k = 0; k < 4; ++k) hp[k] = poses[4 * j + k];
         int32_t* hh = reinterpret_cast<int32_t*>(d.blob + 32);
-        hh[0] = dmc; hh[1] = occ; hh[2] = wx_patch; hh[3] = wy_patch; hh[4] = visit_bound; hh[5] = hh[6] = hh[7] = 0;
+        // [5] the sender's window side, [6] / [7] the extent of its mapped area inside that window (lo | hi << 16, patches)
+        hh[0] = dmc; hh[1] = occ; hh[2] = wx_patch; hh[3] = wy_patch; hh[4] = visit_bound; hh[5] = (int32_t)W; hh[6] = bbox_x; hh[7] = bbox_y;
     }
 }
 
@@ -2274,9 +2287,10 @@ __global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const Shi
     const int32_t* hh = reinterpret_cast<const int32_t*>(d.blob + 32);
     const int dmc = hh[0], occ = hh[1];
     const int odm = old_counts[2 * i], oocc = old_counts[2 * i + 1];
-    const size_t WW = (size_t)W * W;
+    const uint32_t Ws = (uint32_t)hh[5];                         // the sender's window side (windows grow independently)
+    const size_t WW = (size_t)W * W, WWs = (size_t)Ws * Ws;
     size_t n16;
-    const uint4* in = blob_plane(d.blob, plane, WW, dmc, occ, n16);
+    const uint4* in = blob_plane(d.blob, plane, WWs, dmc, occ, n16);
     uint4* out; size_t nzero = 0;
     switch (plane) {
     case 0: out = (uint4*)(dst.dm_dir + i * WW); break;
@@ -2287,17 +2301,21 @@ __global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const Shi
     case 5: out = (uint4*)(dst.occ + (size_t)i * occ_cap * 1024); nzero = oocc > occ ? (size_t)(oocc - occ) * 4096 / 16 : 0; break;
     default: out = (uint4*)(dst.occ_mask + (size_t)i * occ_cap * 16); nzero = oocc > occ ? (size_t)(oocc - occ) * 128 / 16 : 0; break;
     }
-    if (plane < 2 && (d.wdx != 0 || d.wdy != 0)) {
+    if (plane < 2 && (d.wdx != 0 || d.wdy != 0 || Ws != W)) {
         const int16_t* sdir = reinterpret_cast<const int16_t*>(in);
         int16_t* ddir = reinterpret_cast<int16_t*>(out);
         for (size_t idx = (size_t)blockIdx.z * 256 + threadIdx.x; idx < WW; idx += 256 * SHIP_SPLIT) {
             const int wy = (int)(idx / W), wx = (int)(idx % W);
             const int sx = wx + d.wdx, sy = wy + d.wdy;
-            const bool inw = sx >= 0 && sy >= 0 && sx < (int)W && sy < (int)W;
-            ddir[idx] = inw ? sdir[(size_t)sy * W + (size_t)sx] : (int16_t)-1;
+            const bool inw = sx >= 0 && sy >= 0 && sx < (int)Ws && sy < (int)Ws;
+            ddir[idx] = inw ? sdir[(size_t)sy * Ws + (size_t)sx] : (int16_t)-1;
+        }
+        for (size_t idx = (size_t)blockIdx.z * 256 + threadIdx.x; idx < WWs; idx += 256 * SHIP_SPLIT) {
+            const int wy = (int)(idx / Ws), wx = (int)(idx % Ws);
             const int tx = wx - d.wdx, ty = wy - d.wdy;          // where the sender's entry (wx, wy) ends up
             if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && sdir[idx] >= 0) atomicOr(err, ERR_WINDOW);
         }
+        n16 = WW * 2 / 16;                                       // (what this plane occupies in the DESTINATION: nothing is zeroed behind it)
     } else {
         for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
     }

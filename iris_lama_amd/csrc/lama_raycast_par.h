@@ -152,10 +152,12 @@ __device__ inline BeamGeom beam_geometry(const DevParams& prm, const double* T, 
     return g;
 }
 
-// active-visit key: (cellkey << 24) | seq, cellkey = ry << 13 | rx, seq = beam << 13 | t  (t = 0: the hit)
+// active-visit key: (cellkey << 26) | seq, cellkey = ry << 15 | rx (window-relative cell: 15 bits each, a window of up to 1016
+// patches), seq = beam << 13 | t (13 bits each: scans of up to 8192 points, rays of up to 8191 cells; t = 0: the hit)
+constexpr int ACT_SEQ_BITS = 26, ACT_XY_BITS = 15;
 __device__ inline uint64_t act_key(uint32_t rx, uint32_t ry, uint32_t beam, uint32_t t)
 {
-    return ((uint64_t)((ry << 13) | rx) << 24) | (uint64_t)((beam << 13) | t);
+    return ((uint64_t)((ry << ACT_XY_BITS) | rx) << ACT_SEQ_BITS) | (uint64_t)((beam << 13) | t);
 }
 
 __device__ inline void act_append(const DevParams& prm, int p, uint64_t key)
@@ -287,9 +289,9 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
     // ---- per-cell replay in the reference's visit order (one thread per active cell) ----
     for (uint32_t i = threadIdx.x; i < n; i += RP_BLOCK) {
         const uint64_t k0 = sh.keys[i];
-        const uint32_t ck = (uint32_t)(k0 >> 24);
-        if (i > 0 && (uint32_t)(sh.keys[i - 1] >> 24) == ck) continue;      // not the first visit of its cell
-        const uint32_t rx = ck & 8191u, ry = ck >> 13;
+        const uint32_t ck = (uint32_t)(k0 >> ACT_SEQ_BITS);
+        if (i > 0 && (uint32_t)(sh.keys[i - 1] >> ACT_SEQ_BITS) == ck) continue;      // not the first visit of its cell
+        const uint32_t rx = ck & 32767u, ry = ck >> ACT_XY_BITS;
         const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
         const uint64_t bit = 1ull << (ci & 63);
         const int slot = occ_dir[pidx];                                     // allocated by k_ray_hits / k_ray_alloc_walk
@@ -302,8 +304,8 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         uint16_t s = 0;
         for (uint32_t j = i; j < n; ++j) {
             const uint64_t kj = sh.keys[j];
-            if ((uint32_t)(kj >> 24) != ck) break;
-            const uint32_t seq = (uint32_t)(kj & 0xFFFFFFu);
+            if ((uint32_t)(kj >> ACT_SEQ_BITS) != ck) break;
+            const uint32_t seq = (uint32_t)(kj & 0x3FFFFFFu);
             const bool is_hit = (seq & 8191u) == 0;
             bool changed;
             if (is_hit) {                                                   // setOccupied (frequency_occupancy_map.cpp:81-91)
@@ -361,8 +363,8 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
             const bool is_add = act && ((e >> 31) & 1ull);
             const bool is_rem = act && !is_add;
             const unsigned long long ma = __ballot(is_add), mr = __ballot(is_rem);
-            const uint32_t ck = (uint32_t)(e & 0x3FFFFFFu);
-            const int rx = (int)(ck & 8191u), ry = (int)(ck >> 13);
+            const uint32_t ck = (uint32_t)(e & 0x3FFFFFFFu);                 // (bit 31: add; the cell key has 30 bits)
+            const int rx = (int)(ck & 32767u), ry = (int)(ck >> ACT_XY_BITS);
             const unsigned long long lt = (1ull << lane) - 1ull;
             if (is_add) { const uint32_t k = nadd + (uint32_t)__popcll(ma & lt); if (k < prm.qcap) q_lower[k] = q_entry(0, rx, ry); else atomicOr(prm.err, ERR_QUEUE); }
             if (is_rem) { const uint32_t k = nrem + (uint32_t)__popcll(mr & lt); if (k < prm.qcap) q_raise[k] = q_entry(0, rx, ry); else atomicOr(prm.err, ERR_QUEUE); }

@@ -185,23 +185,31 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
 // map cell is modified, so that the host can grow the arena and run the update again.  (`guard_off`: the arenas are at their hard
 // limit and the bound did not fit -- the update runs unguarded, as it did before the guard existed: it fails only if it REALLY
 // runs out of patches.)
-constexpr int RD_MARK_WORDS = (248 * 248 + 31) / 32;       // one bit per window position (window_patches <= 248)
+__device__ inline int imin(int a, int b) { return a < b ? a : b; }
+__device__ inline int imax(int a, int b) { return a > b ? a : b; }
+constexpr int RD_MARK_SIDE = 256;                            // the marked region (scan box grown by guard_r) is at most this many patches wide
+constexpr int RD_MARK_WORDS = RD_MARK_SIDE * RD_MARK_SIDE / 32;
 
 __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle,
                                                           const double* __restrict__ tfs /*[P][12]*/, int reach_cells, int guard_off)
 {
-    __shared__ uint32_t mark[RD_MARK_WORDS];                  // window positions within guard_r patches of an occupancy patch
+    __shared__ uint32_t mark[RD_MARK_WORDS];                  // positions of the region within guard_r patches of an occupancy patch in reach
     __shared__ uint32_t need_s;
     const int p = first_particle + blockIdx.x;
     const uint32_t W = prm.W, WW = W * W;
     const int tid = threadIdx.x, r = (int)prm.guard_r;
     const int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
     const int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
-    for (uint32_t i = tid; i < (WW + 31u) / 32u; i += 256u) mark[i] = 0;
-    if (tid == 0) need_s = 0;
     // the patches the scan can touch: sensor origin (tf.translation(), src/pf_slam2d.cpp:452) +- reach, window-relative patch units
     const int scx = (int)(w2m(prm, tfs[12 * (size_t)p + 9]) - prm.wx0), scy = (int)(w2m(prm, tfs[12 * (size_t)p + 10]) - prm.wy0);
-    const int bx0 = (scx - reach_cells) >> 5, bx1 = (scx + reach_cells) >> 5, by0 = (scy - reach_cells) >> 5, by1 = (scy + reach_cells) >> 5;
+    const int bx0 = imax((scx - reach_cells) >> 5, 0), bx1 = imin((scx + reach_cells) >> 5, (int)W - 1);
+    const int by0 = imax((scy - reach_cells) >> 5, 0), by1 = imin((scy + reach_cells) >> 5, (int)W - 1);
+    // the marked region: that box grown by guard_r, clipped to the window; too large for the bitmap -> no bound (as guard_off)
+    const int mx0 = imax(bx0 - r, 0), my0 = imax(by0 - r, 0), mw = imin(bx1 + r, (int)W - 1) - mx0 + 1, mh = imin(by1 + r, (int)W - 1) - my0 + 1;
+    const bool bounded = mw > 0 && mh > 0 && mw <= RD_MARK_SIDE && mh <= RD_MARK_SIDE;
+    const uint32_t nbits = bounded ? (uint32_t)(mw * mh) : 0u;
+    for (uint32_t i = tid; i < (nbits + 31u) / 32u; i += 256u) mark[i] = 0;
+    if (tid == 0) need_s = 0;
     __syncthreads();
     // eight directory entries per thread and round (W is a multiple of 8: a run never leaves its row, 16-byte aligned)
     for (uint32_t w0 = (uint32_t)tid * 8u; w0 < WW; w0 += 256u * 8u) {
@@ -214,27 +222,28 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
             if (slot < 0) continue;
             rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k);
-            if (x0 + k < bx0 || x0 + k > bx1 || wy < by0 || wy > by1) continue;       // out of the scan's reach: nothing changes there
+            if (!bounded || x0 + k < bx0 || x0 + k > bx1 || wy < by0 || wy > by1) continue;       // out of the scan's reach: nothing changes there
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
-                    const int x = x0 + k + dx, y = wy + dy;
-                    if ((uint32_t)x < W && (uint32_t)y < W) { const uint32_t n = (uint32_t)y * W + (uint32_t)x; atomicOr(&mark[n >> 5], 1u << (n & 31u)); }
+                    const int x = x0 + k + dx - mx0, y = wy + dy - my0;
+                    if ((uint32_t)x < (uint32_t)mw && (uint32_t)y < (uint32_t)mh) { const uint32_t n = (uint32_t)y * (uint32_t)mw + (uint32_t)x; atomicOr(&mark[n >> 5], 1u << (n & 31u)); }
                 }
         }
     }
     __syncthreads();
     uint32_t need = 0;
-    for (uint32_t i = tid; i < (WW + 31u) / 32u; i += 256u) {
+    for (uint32_t i = tid; i < (nbits + 31u) / 32u; i += 256u) {
         uint32_t m = mark[i];
         while (m) {
             const uint32_t n = i * 32u + (uint32_t)(__ffs((int)m) - 1);
-            if (dm_dir[n] < 0) ++need;
+            const uint32_t wx = (uint32_t)mx0 + n % (uint32_t)mw, wy = (uint32_t)my0 + n / (uint32_t)mw;
+            if (dm_dir[wy * W + wx] < 0) ++need;
             m &= m - 1u;
         }
     }
     if (need) atomicAdd(&need_s, need);
     __syncthreads();
-    if (tid == 0 && !guard_off && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
+    if (tid == 0 && bounded && !guard_off && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
 }
 
 // developer build (-DLAMA_PROFILE_RAY, tools/prof_ray.py): event counts and per-phase cycles of k_ray_patches, summed over the launch
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
     const RayRec* prec = recs + (size_t)p * n;
     const uint64_t* pbb = bbox + (size_t)p * n;
-    const int nck = (n + 63) / 64;                                 // <= 32 (LAMA_HIP_MAX_POINTS = 2048)
+    const int nck = (n + 63) / 64;                                 // <= 64: lane c of a wave holds chunk c (scans of up to 4096 points)
     // The kernel is a chain of memory round trips per patch unless they are taken out of the chain: the chunk records do not depend
     // on the patch (lane c of EVERY wave keeps chunk c in registers: each wave decides for itself which chunks a patch keeps, no
     // list, no barrier), the directory position of the next patch is fetched one patch ahead, and the cells of the patch, its hit
@@ -312,9 +321,9 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
                 if ((a00 < 0 && a10 < 0 && a01 < 0 && a11 < 0) || (b00 > 0 && b10 > 0 && b01 > 0 && b11 > 0)) keep = false;
             }
         }
-        const uint32_t km = (uint32_t)__ballot(keep);              // chunks 0 .. 31, the same in every wave
-        const int ncand = __popc(km) * 64;
-        if (tid == 0) RPC(2, __popc(km));
+        const unsigned long long km = __ballot(keep);              // chunks 0 .. 63, the same in every wave
+        const int ncand = __popcll(km) * 64;
+        if (tid == 0) RPC(2, __popcll(km));
         // ---- 1. the patch: its cells and hit bits are requested now, classified below (after the candidates' loads are out too)
         uint32_t v[4];
         uint64_t hw[4];
@@ -327,9 +336,9 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
             const int jc = (c0 >> 6) + wave;                       // this wave's candidates are the beams of the jc-th kept chunk
             int b = -1;
             if (jc * 64 < ncand) {
-                uint32_t m = km;
-                for (int i = 0; i < jc; ++i) m &= m - 1u;
-                b = (__ffs((int)m) - 1) * 64 + lane;
+                unsigned long long m = km;
+                for (int i = 0; i < jc; ++i) m &= m - 1ull;
+                b = (__ffsll((long long)m) - 1) * 64 + lane;
                 if (b >= n) b = -1;
             }
             uint64_t bb = RAY_BBOX_EMPTY;

@@ -43,7 +43,8 @@ class HipCounters(C.Structure):
                 ("ms_eval_batch", C.c_double), ("launches_eval_batch", C.c_uint64), ("arena_growths", C.c_uint64), ("window_shifts", C.c_uint64), ("wrap_guard_scans", C.c_uint64),
                 ("brushfire_mode", C.c_uint32), ("brushfire_waves", C.c_uint32),
                 ("sequential_raycast_scans", C.c_uint64), ("parallel_raycast_scans", C.c_uint64),
-                ("brushfire_handovers", C.c_uint32), ("replay_handovers", C.c_uint32)]
+                ("brushfire_handovers", C.c_uint32), ("replay_handovers", C.c_uint32),
+                ("window_patches", C.c_uint32), ("window_growths", C.c_uint32)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

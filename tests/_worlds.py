@@ -58,3 +58,40 @@ def open_corridor_scan(x, y, yaw, beams=360, fov=np.deg2rad(270.0), max_range=12
         if 0.2 < r <= max_range:
             out.append((r * np.cos(phi), r * np.sin(phi), 0.0))
     return np.array(out)
+
+
+def long_corridor_segments(length=460.0, width=4.0, pillar_every=4.0):
+    """Wall segments (S, 4) = x0, y0, x1, y1 of a closed corridor [0, length] x [0, width] with square pillars (0.4 m) every
+    `pillar_every` metres alternating between y = 0.8 and y = width - 0.8 (the SURVEY 8(d) corridor, made long)."""
+    segs = [(0.0, 0.0, length, 0.0), (length, 0.0, length, width), (length, width, 0.0, width), (0.0, width, 0.0, 0.0)]
+    k = 0
+    cx = 5.0
+    while cx < length - 1.0:
+        cy = 0.8 if k % 2 == 0 else width - 0.8
+        xa, xb, ya, yb = cx - 0.2, cx + 0.2, cy - 0.2, cy + 0.2
+        segs += [(xa, ya, xb, ya), (xb, ya, xb, yb), (xb, yb, xa, yb), (xa, yb, xa, ya)]
+        cx += pillar_every
+        k += 1
+    return np.array(segs)
+
+
+def segment_world_scan(segs, x, y, yaw, beams=1080, fov=np.deg2rad(270.0), max_range=30.0, noise=None):
+    """Sensor-frame points (n, 3) of a 2-D scanner at (x, y, yaw) in a world of wall segments: one point per beam that hits a wall
+    within max_range (beams without a return are dropped, as iris_lama_ros drops out-of-range readings)."""
+    phi = -fov / 2 + fov * np.arange(beams) / (beams - 1)
+    dx, dy = np.cos(yaw + phi)[:, None], np.sin(yaw + phi)[:, None]
+    near = (np.minimum(segs[:, 0], segs[:, 2]) < x + max_range) & (np.maximum(segs[:, 0], segs[:, 2]) > x - max_range)
+    s = segs[near]
+    ex, ey = (s[:, 2] - s[:, 0])[None, :], (s[:, 3] - s[:, 1])[None, :]
+    ax, ay = (s[:, 0] - x)[None, :], (s[:, 1] - y)[None, :]
+    den = dx * ey - dy * ex
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = (ax * ey - ay * ex) / den           # along the beam
+        u = (ax * dy - ay * dx) / den           # along the segment
+    ok = (np.abs(den) > 1e-12) & (t > 0.05) & (u >= 0.0) & (u <= 1.0)
+    t = np.where(ok, t, np.inf)
+    r = t.min(axis=1)
+    if noise is not None:
+        r = r + noise
+    keep = np.isfinite(r) & (r <= max_range)
+    return np.stack([r[keep] * np.cos(phi[keep]), r[keep] * np.sin(phi[keep]), np.zeros(keep.sum())], axis=1)

@@ -207,6 +207,45 @@ def test_map_window_follows_the_robot(F):
     ctx.close()
 
 
+def test_map_extent_is_not_limited_by_the_window_450m(F):
+    """the reference allocates patches anywhere (src/sdm/map.cpp:400-411).  One particle is driven 450 m down a
+    generated corridor (460 m x 4 m, pillars every 4 m, a 1080-beam 270-degree scanner with 30 m range: beams without a return are
+    dropped, so the scans are ragged): the device window starts at 128 patches (204.8 m), must GROW past the old limit of 248
+    patches, the arenas grow with the map, and the maps stay bit-identical to the oracle's."""
+    from _worlds import long_corridor_segments, segment_world_scan
+    P, dist, step = 1, 450.0, 0.75
+    n_scans = int(dist / step)
+    segs = long_corridor_segments()
+    rng = np.random.default_rng(77)
+
+    def scan_at(k):
+        x, y, yaw = 2.0 + step * k, 2.0 + 0.3 * np.sin(0.05 * k), 0.04 * np.sin(0.11 * k)
+        return O.se2(x, y, yaw), segment_world_scan(segs, x, y, yaw, noise=rng.normal(0.0, 0.01, 1080))
+    pose0, scan0 = scan_at(0)
+    pf = O.PF(O.default_options(particles=P, seed=5))
+    pf.set_prior(pose0)
+    assert pf.update(scan0, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P))
+    ctx.init(scan0, pose0)
+    for k in range(1, n_scans + 1):
+        pose, scan = scan_at(k)
+        pf.set_poses(pose[None, :]); pf.stage_set_scan(scan); pf.stage_update_maps()
+        ctx.set_poses(pose[None, :]); ctx.update_maps(scan)
+        if k in (150, 400):          # on the way
+            assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), pf.occ(0).dump(), OCC_FIELDS, f"scan {k} occ")
+    c = ctx.counters()
+    assert c["window_growths"] >= 1 and c["window_patches"] > 280, c          # 450 m + sensor reach = more than 280 patches of 1.6 m
+    assert c["arena_growths"] >= 1
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), pf.occ(0).dump(), OCC_FIELDS, "occ after 450 m")
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), pf.dm(0).dump(), DM_FIELDS, "dm after 450 m")
+    # scan matching on the grown window sees the map
+    pose, scan = scan_at(n_scans)
+    g_poses, g_ll, g_it = ctx.scan_match(scan)
+    pf.stage_set_scan(scan); pf.set_weights(w=np.zeros(P), ws=np.zeros(P)); pf.stage_scan_match()
+    assert np.abs(g_poses - pf.poses()).max() <= 1e-6
+    ctx.close()
+
+
 def test_particle_blob_between_contexts_with_different_windows(F):
     """Every shard's window follows its own particles, so a shipped particle may come from a window that sits elsewhere: the blob
     carries its origin and the importer translates the directories -- the imported particle's maps are the exported ones."""
@@ -1026,11 +1065,16 @@ def test_limits_fail_loudly_with_status_codes(F):
     truncation (include/lama_hip.h status codes); full patch arenas grow, too many order-sensitive visits go beam by beam."""
     pts, odom, truth = F.corridor_log(1, 1080)
     pose0 = O.se2(*odom[0])
-    # window of 8 patches = 12.8 m: the 28 m corridor does not fit
+    # a window of 8 patches = 12.8 m does not hold the 28 m corridor: since round 4 the window GROWS (the reference's maps have no
+    # extent) -- same maps as from the default window
     ctx = F.HipContext(F.default_cfg(particles=2, window_patches=8))
-    with pytest.raises(F.LamaError, match=r"status -\d+: .*window"):
-        ctx.init(pts[0], pose0)
-    ctx.close()
+    ref = F.HipContext(F.default_cfg(particles=2))
+    ctx.init(pts[0], pose0); ref.init(pts[0], pose0)
+    cw = ctx.counters()
+    assert cw["window_growths"] >= 1 and cw["window_patches"] > 8 and ref.counters()["window_growths"] == 0
+    for kind, fields in ((F.MAP_DISTANCE, DM_FIELDS), (F.MAP_OCCUPANCY, OCC_FIELDS)):
+        assert_maps_equal(ctx.download_map(1, kind), ref.download_map(1, kind), fields, "grown window")
+    ctx.close(); ref.close()
     # 4 patches per particle used to be an error; since round 3 an update that needs more patches than are free says so before it
     # modifies anything, the arenas are doubled and the update runs again (the reference's maps just allocate)
     for small in (dict(dm_patch_capacity=4), dict(occ_patch_capacity=4)):
@@ -1043,7 +1087,7 @@ def test_limits_fail_loudly_with_status_codes(F):
     ctx = F.HipContext(F.default_cfg(particles=2, active_capacity=64, sequential_raycast=2))
     ctx.init(pts[0], pose0)
     ctx.close()
-    for bad in (dict(patch_size=16), dict(window_patches=252), dict(resolution=0.0), dict(l2_max=10.0)):
+    for bad in (dict(patch_size=16), dict(window_patches=252), dict(window_patches=1024), dict(resolution=0.0), dict(l2_max=10.0)):
         with pytest.raises(F.LamaError, match="lama_hip_ctx_create failed"):
             F.HipContext(F.default_cfg(particles=2, **bad))
     # calls before init / with bad arguments
@@ -1054,7 +1098,7 @@ def test_limits_fail_loudly_with_status_codes(F):
     with pytest.raises(F.LamaError):
         ctx.download_map(5, F.MAP_DISTANCE)          # particle out of range
     # a map update that was only queued reports its error at the next synchronising call
-    far = np.tile(O.se2(500.0, 2.0, 0.0), (2, 1))    # 500 m away: outside the 204.8 m window
+    far = np.tile(O.se2(3000.0, 2.0, 0.0), (2, 1))   # 3 km away: the mapped area would be wider than the largest window (1016 patches = 1.6 km)
     ctx.set_poses(far)
     ctx.update_maps_begin(pts[0])                    # returns before the kernels have run
     with pytest.raises(F.LamaError, match=r"deferred from lama_hip_pf_update_maps_begin.*window"):
