@@ -1282,6 +1282,71 @@ def test_point_order_is_free_for_the_ray_cast(F, order):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_beams,parallel", [(4096, True), (3000, True), (5000, False)])
+def test_scans_with_thousands_of_points(F, n_beams, parallel):
+    """scans with more than 2,048 points used to drop silently to the one-wave ray-cast.  The visit key now carries the
+    beam index in 13 bits and k_ray_patches keeps 64 chunk records per wave: up to 4,096 points stay on the parallel, patch-centric
+    form (asserted through the counters); beyond that the beam-sequential form takes over.  Bit-exact either way."""
+    rng = np.random.default_rng(5)
+    kind = {"R": 6.0, "coef": [(m, rng.uniform(0.02, 0.1), rng.uniform(0, 2 * np.pi)) for m in (2, 3, 5)]}
+    P = 2
+    base = np.array([0.2, 0.1, -0.4])
+    pf = O.PF(O.default_options(particles=P, seed=5))
+    scan0 = _random_room_scan(rng, base, n_beams, kind)
+    pose0 = O.se2(*base)
+    pf.set_prior(pose0)
+    assert pf.update(scan0, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, dm_patch_capacity=1024, occ_patch_capacity=1024))
+    ctx.init(scan0, pose0)
+    for k in range(2):
+        truth = base + np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), rng.uniform(-0.2, 0.2)])
+        scan = _random_room_scan(rng, truth, n_beams, kind)
+        poses = np.stack([O.se2(*(truth + rng.normal(0, [0.02, 0.02, 0.01]))) for _ in range(P)])
+        pf.set_poses(poses); pf.stage_set_scan(scan); pf.stage_update_maps()
+        ctx.set_poses(poses); ctx.update_maps(scan)
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"{n_beams} beams scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"{n_beams} beams scan {k} dm p{i}")
+        base = truth
+    c = ctx.counters()
+    assert (c["parallel_raycast_scans"], c["sequential_raycast_scans"]) == ((3, 0) if parallel else (0, 3)), c
+    ctx.close()
+
+
+def test_dynamic_scene_moving_box(F):
+    """every GPU world so far was static (removals came from pose noise only).  Here a 1 m box crosses a 10 m room,
+    0.2 m per scan for 20 scans, in front of a standing scanner: every scan frees the cells the box left (removeObstacle -> long
+    raise waves that clear and re-lower whole disks) and occupies new ones.  Occupancy and distance maps bit-exact after every scan."""
+    from _worlds import segment_world_scan
+    P = 2
+    room = [(-5.0, -5.0, 5.0, -5.0), (5.0, -5.0, 5.0, 5.0), (5.0, 5.0, -5.0, 5.0), (-5.0, 5.0, -5.0, -5.0)]
+
+    def world(k):
+        bx = -3.0 + 0.2 * k
+        box = [(bx, 1.0, bx + 1.0, 1.0), (bx + 1.0, 1.0, bx + 1.0, 2.0), (bx + 1.0, 2.0, bx, 2.0), (bx, 2.0, bx, 1.0)]
+        return np.array(room + box)
+    rng = np.random.default_rng(3)
+    pose = O.se2(0.0, -1.0, np.pi / 2)
+    scan0 = segment_world_scan(world(0), 0.0, -1.0, np.pi / 2, beams=1080, max_range=30.0, noise=rng.normal(0.0, 0.005, 1080))
+    pf = O.PF(O.default_options(particles=P, seed=5))
+    pf.set_prior(pose)
+    assert pf.update(scan0, pose)
+    ctx = F.HipContext(F.default_cfg(particles=P))
+    ctx.init(scan0, pose)
+    raise_pops = 0
+    for k in range(1, 21):
+        scan = segment_world_scan(world(k), 0.0, -1.0, np.pi / 2, beams=1080, max_range=30.0, noise=rng.normal(0.0, 0.005, 1080))
+        poses = _perturbed(rng, pose, P, sxy=0.004, sth=0.001)
+        pf.set_poses(poses); pf.stage_set_scan(scan); pf.stage_update_maps()
+        ctx.set_poses(poses); ctx.reset_counters(); ctx.update_maps(scan)
+        raise_pops += ctx.counters()["bf_cells"]
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    assert raise_pops > 20 * P * 500                 # the brushfire really had work (a static scene settles to a few hundred cells per scan)
+    ctx.close()
+
+
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_randomized_rooms_scan_match_parity(F, seed):
     """Scan matching in random rooms: from start poses up to 15 cm / 5 deg off, device and oracle must reach the same pose
