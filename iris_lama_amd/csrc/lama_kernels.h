@@ -1267,20 +1267,28 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #endif
         constexpr int NR = LQ_LDS > 1024 ? 3 : 2;              // rounds of lds_pop_flat: 5 heap levels each
         uint64_t* const dmy = sh.dummy[1];
-        for (uint32_t it = 0;; ++it) {
+        uint32_t it = 0;
+        bool hstop = false;
+        while (hnr > 0) {                                      // raise phase: pops of the raise queue, pushes into both
             const uint32_t b = it & 1u;
-            const bool ph_r = hnr > 0;
-            if (ph_r) lds_pop_flat<NR>(sh.raise, hnr, lane, anc, &sh.topq[b], dmy);
-            else lds_pop_flat<NR>(sh.lower, hnl, lane, anc, &sh.topq[b], dmy);
+            lds_pop_flat<NR>(sh.raise, hnr, lane, anc, &sh.topq[b], dmy);
+            lds_barrier();                                     // D
+            lds_push_flat(sh.raise, hnr, sh.pr_e[b], &sh.pr_n[b], lane, dmy);   // raise() is the only producer of raise entries
+            lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
+            ++it;
+            if (hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS) || (hnr == 0 && hnl == 0)) { hstop = true; break; }   // the main wave takes the same decision
+            if (hnr == 0) lds_barrier();                       // X: phase switch, the main wave reads lower[0] after the pushes
+        }
+        if (!hstop && hnl > 0) for (;;) {                      // lower phase
+            const uint32_t b = it & 1u;
+            lds_pop_flat<NR>(sh.lower, hnl, lane, anc, &sh.topq[b], dmy);
             HFT(0);
             lds_barrier();                                     // D
             HFT(1);
-            if (ph_r) lds_push_flat(sh.raise, hnr, sh.pr_e[b], &sh.pr_n[b], lane, dmy);   // raise() is the only producer of raise entries
             lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
             HFT(2);
-            const bool sp = hnl + 4 > (uint32_t)LQ_LDS || (hnr > 0 && hnr + 4 > (uint32_t)RQ_LDS);
-            if (sp || (hnr == 0 && hnl == 0)) break;           // the main wave takes the same decision
-            if (ph_r && hnr == 0) lds_barrier();               // X: phase switch, the main wave reads lower[0] after the pushes
+            ++it;
+            if (hnl - 1u >= (uint32_t)LQ_LDS - 4u) break;      // empty, or about to outgrow the LDS window
         }
 #ifdef LAMA_PROFILE_BF
 #ifndef LAMA_PROFILE_BF_MAIN
@@ -1518,7 +1526,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             return (uint32_t)__popcll(om);
         };
 
-        while (tw_running && nl > 0) {
+        if (tw_running && nl > 0) for (;;) {
             const uint64_t e = e_next;                                     // the same value in every lane
             ++processed;
             --nl;                                                          // the helper wave pops
@@ -1657,12 +1665,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const bool own_wins = (okey != 0xFFFFFFFFu) & (!have_root | ((okey >> 2) < (rhi >> 16)));
                 e_next = own_wins ? (((uint64_t)ohi << 32) | olo) : (((uint64_t)rhi << 32) | rlo);
                 nl += cnt;
-                spill = nl + 4 > (uint32_t)LQ_LDS;
-                tw_running = !spill && nl > 0;
                 ++tw_it;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             BFT(4); BFF(7);
+            // the queue is empty, or would outgrow its LDS window (the helper wave takes the same decision): one scalar test
+            if (nl - 1u >= (uint32_t)LQ_LDS - 4u) { spill = nl != 0u; tw_running = false; break; }
         }
     }
     // ---- lower wave ------------------------------------------------------------------------- :175-194
