@@ -1585,7 +1585,6 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     const uint32_t alloc = away & absent;                                            // a patch to allocate: general code
                     const bool clive = ((cos_ & SV_VALID) != 0u);                                     // my obstacle cell is a live obstacle ((cos_ & SQMASK) == 0 here)
                     uint32_t dead = clive ? 0u : 0xFFFFFFFFu;                                        // per lane: the neighbour's obstacle cell is not one
-                    uint32_t miss2 = 0u;
                     BFF(2);
                     if (__builtin_expect(__ballot((tie_other | alloc) != 0u) != 0ull, 0)) {
                         const int ox = x + obs_x(ob), oy = y + obs_y(ob);
@@ -1594,18 +1593,17 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         const uint32_t odv = sh.dc[dc.index(opidx & oin)];
                         const uint32_t ohit = opq(oin & ~m_nz((odv >> 15) ^ (opidx >> 3)));
                         const uint32_t oslot = (odv & 0x7FFFu) - 1u;
-                        miss2 = opq((oin & ~ohit) | alloc);                                   // not cached, or a patch to allocate: general code
                         const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
                         const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
                         const uint32_t olive = opq((uint32_t)((int32_t)(os2 << 16) >> 31) & ~m_nz(os2 & SV_SQMASK));
                         dead = m_sel(tie_other, ~olive, dead);
+                        // rare among the rare: a directory entry that is not cached, or a patch to allocate: general code
+                        general = __ballot(((oin & ~ohit) | alloc) != 0u) != 0ull;
                     }
 #ifdef LAMA_PROFILE_BF_COUNT
                     prof[4] += __ballot(alloc != 0u) ? 1 : 0; prof[5] += __ballot(tie_other != 0u) ? 1 : 0;
 #endif
-                    if (__builtin_expect(__ballot(miss2 != 0u) != 0ull, 0)) {
-                        general = true;
-                    } else {
+                    if (__builtin_expect(!general, 1)) {
                         BFF(3);
                         const uint32_t overm = opq(lt | (tie & (~svalid | dead)));                    // :308-317
                         over = overm != 0u;
