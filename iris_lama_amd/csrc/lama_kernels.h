@@ -1075,6 +1075,9 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
     const uint32_t anc_lo = (uint32_t)anc, anc_hi = (uint32_t)(anc >> 32);
     uint32_t H = 0;
     uint32_t go = 0xFFFFFFFFu;                                       // wave-uniform: the descent has not stopped
+    uint64_t mine0 = 0;                                              // first round: what lanes 1 / 2 moved to the root ...
+    uint32_t root_child = 0;                                         // ... if they did (per lane) ...
+    bool root_value = true;                                          // ... else the re-inserted entry is the new root (wave-uniform)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const uint32_t idx = (H << d) + (uint32_t)lane;              // lane L: the node at relative position L below H
@@ -1096,32 +1099,28 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
         LAMA_LOCKSTEP();
         uint64_t* dst = moves ? h + parent : dummy + lane;
         *dst = mine;
-        if (r == 0) {                                                // the new root: the child that moved up, else the re-inserted entry
-            const uint32_t l0m = lane == 0 ? 0xFFFFFFFFu : 0u, l12m = (lane == 1 || lane == 2) ? 0xFFFFFFFFu : 0u;
-            const uint32_t nochild = (mvm & 6ull) == 0ull ? 0xFFFFFFFFu : 0u;
-            const uint32_t sel = opq((l0m & nochild) | (l12m & moves));
-            uint64_t* rd = sel ? root_out : dummy + lane;
-            const uint64_t rv = l0m ? value : mine;
-            *rd = rv;
-        }
+        if (r == 0) { mine0 = mine; root_child = opq(((lane == 1 || lane == 2) ? 0xFFFFFFFFu : 0u) & moves); root_value = (mvm & 6ull) == 0ull; }
         const int rel = 63 - __clzll((long long)(mvm | 1ull));       // deepest moved entry: its old slot is the new hole
         const uint32_t Hn = (H << (31 - __clz(rel + 1))) + (uint32_t)rel;
         H = mvm ? Hn : H;
         go = (mvm != pathm) ? 0u : go;
         LAMA_LOCKSTEP();
     }
-    // the hole has a lone left child, the array's last entry
+    // the hole has a lone left child, the array's last entry (rare: only when the descent ran to the very end of the array)
     const bool up = go != 0u && (len & 1u) == 0u && H == (len - 2) / 2 && heap_prio(tailc) <= vprio;
-    {
-        uint64_t* dst = (up && lane == 0) ? h + H : dummy + lane;
-        *dst = tailc;
-        uint64_t* rd = (up && H == 0 && lane == 0) ? root_out : dummy + lane;
-        *rd = tailc;
+    if (up) {
+        if (lane == 0) { h[H] = tailc; if (H == 0) *root_out = tailc; }
+        root_value = root_value && H != 0;
+        H = len - 1;
+        LAMA_LOCKSTEP();
     }
-    H = up ? len - 1 : H;
+    // ONE store for what is left: the re-inserted entry into the hole (lane 0), and the new root for the main wave -- the child
+    // that moved up in the first round (lane 1 or 2 still holds it) or the re-inserted entry itself (lane 3)
     {
-        uint64_t* dst = lane == 0 ? h + H : dummy + lane;
-        *dst = value;
+        const uint32_t l0 = lane == 0 ? 0xFFFFFFFFu : 0u, l3 = (lane == 3 && root_value) ? 0xFFFFFFFFu : 0u;
+        uint64_t* dst = l0 ? h + H : ((l3 | root_child) ? root_out : dummy + lane);
+        const uint64_t v = root_child ? mine0 : value;
+        *dst = v;
     }
     LAMA_LOCKSTEP();
 }

@@ -99,6 +99,32 @@ __global__ __launch_bounds__(64) void k_single(Res* out, const uint32_t* __restr
     // 34: ds_read2_b64 dependent chain (the heap's pair load)
     { uint32_t p = 8; uint64_t* l64 = (uint64_t*)lds; BEGIN(); for (int i = 0; i < 64; ++i) { const uint64_t a = l64[(p & 1022u)], b = l64[(p & 1022u) + 1]; p = (uint32_t)(a + b); asm volatile("" : "+v"(p)); } END(); x += p; }
 
+    // ---- round 4 additions: the sequences the brushfire's straight-line pop is made of
+    // 35: 64 x (v_readlane -> VALU reads that SGPR)
+    BEGIN(); asm volatile(".rept 64\n v_readlane_b32 %1, %0, 4\n s_nop 0\n v_add_u32 %0, %1, %0\n .endr" : "+v"(x), "+s"(s)); END();
+    // 36: 64 x (s_add -> VALU reads that SGPR)
+    BEGIN(); asm volatile(".rept 64\n s_add_u32 %1, %1, 1\n v_add_u32 %0, %1, %0\n .endr" : "+v"(x), "+s"(s) :: "scc"); END();
+    // 37: 64 x (v_sub ; v_ashrrev 31 ; v_and)  mask arithmetic, dependent
+    BEGIN(); asm volatile(".rept 64\n v_sub_u32 %1, %0, %2\n v_ashrrev_i32 %1, 31, %1\n v_and_b32 %0, %1, %0\n v_add_u32 %0, 3, %0\n .endr" : "+v"(x), "+v"(y) : "v"(z)); END();
+    // 38: 64 x (v_cmp -> sgpr pair ; v_and with that SGPR as data) incl. the 2 wait states the compiler inserts
+    BEGIN(); asm volatile(".rept 64\n v_cmp_ne_u32 s[20:21], 0, %0\n s_nop 1\n v_and_b32 %1, s20, %0\n v_add_u32 %0, %1, %0\n .endr" : "+v"(x), "+v"(y) :: "s20", "s21"); END();
+    // 39: 64 x (v_cmp -> sgpr pair ; v_cndmask with that mask)
+    BEGIN(); asm volatile(".rept 64\n v_cmp_ne_u32 s[20:21], 0, %0\n v_cndmask_b32 %1, 1, %0, s[20:21]\n v_add_u32 %0, %1, %0\n .endr" : "+v"(x), "+v"(y) :: "s20", "s21"); END();
+    // 40: 16 x (4 buffer-less global stores to distinct lines, then 16 dependent VALU) : does store issue stall the VALU?
+    { uint32_t* gp = grw + 1024 + lane; BEGIN(); for (int i = 0; i < 16; ++i) { gp[0] = x; gp[64] = x; gp[128] = x; gp[192] = x; asm volatile(".rept 16\n v_add_u32 %0, %0, 1\n .endr" : "+v"(x)); } END(); }
+    // 41: the same 16 x 16 VALU without stores
+    BEGIN(); for (int i = 0; i < 16; ++i) { asm volatile(".rept 16\n v_add_u32 %0, %0, 1\n .endr" : "+v"(x)); } END();
+    // 42: 16 x (1 global atomic-or x2 to distinct words, 16 VALU)
+    { unsigned long long* ap = (unsigned long long*)(grw + 2048) + lane; BEGIN(); for (int i = 0; i < 16; ++i) { atomicOr(ap + 64 * (i & 3), 1ull << i); asm volatile(".rept 16\n v_add_u32 %0, %0, 1\n .endr" : "+v"(x)); } END(); }
+    // 43: 16 x (ds_write_b64 ; 16 VALU)
+    { uint64_t* l64 = (uint64_t*)lds; BEGIN(); for (int i = 0; i < 16; ++i) { l64[64 + lane] = x; asm volatile(".rept 16\n v_add_u32 %0, %0, 1\n .endr" : "+v"(x) :: "memory"); } END(); }
+    // 44: 16 x (global load L1-resident -> wait -> 3 readlane -> s_ logic -> v_) the head of a pop
+    { uint32_t p = 0; BEGIN(); for (int i = 0; i < 16; ++i) { p = gro[64 + ((p + lane) & 63u)]; const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)p, 4), b = (uint32_t)__builtin_amdgcn_readlane((int)p, 5); p = (a & 7u) + (b & 3u) + (uint32_t)lane; asm volatile("" : "+v"(p)); } END(); x += p; }
+    // 45: 64 x DPP quad_perm step with select (the own-best minimum): mov_dpp, s_nop, min, cmp, cndmask
+    BEGIN(); asm volatile(".rept 64\n v_mov_b32_dpp %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_cmp_lt_u32 vcc, %1, %0\n v_cndmask_b32 %0, %0, %1, vcc\n v_add_u32 %0, %0, 1\n .endr" : "+v"(x), "+v"(y) :: "vcc"); END();
+    // 46: 64 x v_readfirstlane -> s_cmp -> s_cselect (no VALU consumer): cost of pulling a uniform value to the scalar side
+    BEGIN(); asm volatile(".rept 64\n v_readfirstlane_b32 %1, %0\n s_cmp_eq_u32 %1, 0\n s_cselect_b32 %1, 1, 2\n v_add_u32 %0, 1, %0\n .endr" : "+v"(x), "+s"(s) :: "scc"); END();
+
     if (lane == 0) { grw[0] = x + y + z + w + s; out->cyc[63] = (uint64_t)k; }
 }
 
@@ -204,8 +230,12 @@ int main()
         "64 global chase, L1-resident ring", "64 global chase, 8 MB (L2/MALL)", "64 scalar-load chase (s_load)",
         "32 global store -> nt load back", "32 volatile store -> load back", "64 global stores + wait", "64 global atomic_or + wait",
         "64 s_memtime", "64 x readlane->s_cmp->s_cselect->v_add", "64 x v_cmp->s_and exec->s_cselect->v_add", "64 dependent v_mul_lo_u32",
-        "64 dependent v_mul_i32_i24", "64 dependent v_lshlrev_b64", "64 ds_read2_b64 pair chase"};
-    const int per[] = {1, 256, 256, 256, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64};
+        "64 dependent v_mul_i32_i24", "64 dependent v_lshlrev_b64", "64 ds_read2_b64 pair chase",
+        "64 x v_readlane -> (s_nop) -> v_add reads SGPR", "64 x s_add -> v_add reads SGPR", "64 x v_sub,v_ashr,v_and,v_add masks", "64 x v_cmp->sgpr, nop, v_and sgpr data, v_add",
+        "64 x v_cmp->sgpr, v_cndmask, v_add", "16 x (4 global stores + 16 VALU)", "16 x 16 VALU (no stores)", "16 x (atomic_or_x2 + 16 VALU)", "16 x (ds_write_b64 + 16 VALU)",
+        "16 x load->wait->2 readlane->s_and->v_add", "64 x dpp mov, cmp, cndmask, add", "64 x readfirstlane, s_cmp, s_cselect, v_add"};
+    const int per[] = {1, 256, 256, 256, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 64, 32, 32, 64, 64, 64, 64, 64, 64, 64, 64, 64,
+                       64, 64, 64, 64, 64, 16, 16, 16, 16, 16, 64, 64};
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(k_single, dim3(1), dim3(64), 0, 0, d_res, d_ro, d_rw, NCH);
         hipLaunchKernelGGL(k_pair, dim3(1), dim3(128), 0, 0, d_res2, d_rw);
@@ -215,7 +245,7 @@ int main()
     hipMemcpy(&r2, d_res2, sizeof(Res), hipMemcpyDeviceToHost);
     printf("# single wave, cycles (s_memtime) -- total, minus timer overhead, per item\n");
     const uint64_t ovh = r.cyc[0];
-    for (int i = 0; i < (int)r.cyc[63] && i < 35; ++i)
+    for (int i = 0; i < (int)r.cyc[63] && i < 47; ++i)
         printf("%2d %-46s total %8llu  per %8.1f\n", i, names[i], (unsigned long long)r.cyc[i], (double)((long long)r.cyc[i] - (long long)ovh) / per[i]);
     const char* n2[] = {"256 s_barrier (2 waves)", "128 LDS hand-over round trips with 2 barriers each", "128 LDS hand-over round trips, polling",
                         "128 round trips, polling + s_sleep 1", "1024 dependent v_add beside a polling partner"};
