@@ -1531,6 +1531,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             --nl;                                                          // the helper wave pops
             uint32_t cnt = 0;
             bool general;
+            uint32_t floor_sq = 0;                                         // every push of this pop has a priority above this
             bool over = false;                                             // lanes 0..3: my neighbour is lowered and pushed ...
             uint64_t entry = 0;                                            // ... as this queue entry
             {
@@ -1568,6 +1569,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 prof[2] += unk != 0ull ? 1 : 0; prof[3] += (fire0 & stale) ? 1 : 0; prof[6] += (fire0 & ((cos_ & SV_SQMASK) == 0u)) ? 1 : 0;
 #endif
                 if (__builtin_expect(!general, 1) && fire0 && (cos_ & SV_SQMASK) == 0u) {   // :191 (valid NOT tested)
+                    floor_sq = cs & SV_SQMASK;                                           // lower() :303: candidates of cells further from the obstacle
                     const int obx = rx + cox, oby = ry + coy;
                     const uint32_t away = opq(nbm & ~(m_pos(ddx * cox) | m_pos(ddy * coy)));          // :296
                     const uint32_t nbok = away & ~absent;
@@ -1630,27 +1632,15 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #endif
             if (__builtin_expect(general, 0)) cnt = general_pop(e, over, entry);
             BFT(3);
-            // ---- hand-over: the push list is in the mailbox.  My own best push -- smallest (priority, neighbour index) -- by a
-            // minimum over the quad of neighbour lanes (DPP), before the helper is met: push_heap lifts an entry above its parent only
-            // if the parent's priority is strictly greater, so a pushed entry becomes the root iff its priority is smaller than the
-            // root's, the first of the smallest ones; the next top follows from the root the helper saw after pop() and that entry.
+            // ---- hand-over: the push list is in the mailbox; meet the helper (its pop is done) and derive the next top from the root
+            // it saw after pop() and my own pushes: push_heap lifts an entry above its parent only if the parent's priority is
+            // strictly greater, so a pushed entry becomes the root iff its priority is smaller than the root's, the first of the
+            // smallest ones.  Every push of this pop has a priority above `floor_sq` (lower() only offers distances larger than the
+            // popped cell's): while the root's priority is not above floor_sq + 1 -- the normal case inside a priority level -- no
+            // push can win and the root is the next top; else my best push (smallest (priority, neighbour index): a minimum over
+            // the quad of neighbour lanes, DPP) is compared with it.
             {
                 const uint32_t b_ = tw_it & 1u;
-                uint32_t key = over ? ((heap_prio(entry) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu;
-                uint32_t blo = (uint32_t)entry, bhi = (uint32_t)(entry >> 32);
-#define BF_QUAD_MIN(CTRL)                                                                                              \
-                {                                                                                                      \
-                    const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, 0xF, 0xF, false); \
-                    const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp((int)blo, (int)blo, CTRL, 0xF, 0xF, false); \
-                    const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp((int)bhi, (int)bhi, CTRL, 0xF, 0xF, false); \
-                    const bool t_ = k2 < key;                                                                          \
-                    key = t_ ? k2 : key; blo = t_ ? l2 : blo; bhi = t_ ? h2 : bhi;                                     \
-                }
-                BF_QUAD_MIN(0xB1)                                  // quad_perm [1,0,3,2]
-                BF_QUAD_MIN(0x4E)                                  // quad_perm [2,3,0,1]
-#undef BF_QUAD_MIN
-                const uint32_t okey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
-                const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
                 uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)(dmy + lane);
                 *np = cnt;
                 BFT_MAIN(5); BFF(6);
@@ -1659,8 +1649,25 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint64_t root_ = sh.topq[b_];
                 const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)root_), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(root_ >> 32));
                 const bool have_root = nl > 0;
-                const bool own_wins = (okey != 0xFFFFFFFFu) & (!have_root | ((okey >> 2) < (rhi >> 16)));
-                e_next = own_wins ? (((uint64_t)ohi << 32) | olo) : (((uint64_t)rhi << 32) | rlo);
+                e_next = ((uint64_t)rhi << 32) | rlo;
+                if (__builtin_expect(cnt > 0 && (!have_root || (rhi >> 16) > floor_sq + 1u), 0)) {
+                    uint32_t key = over ? ((heap_prio(entry) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu;
+                    uint32_t blo = (uint32_t)entry, bhi = (uint32_t)(entry >> 32);
+#define BF_QUAD_MIN(CTRL)                                                                                              \
+                    {                                                                                                  \
+                        const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, 0xF, 0xF, false); \
+                        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp((int)blo, (int)blo, CTRL, 0xF, 0xF, false); \
+                        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp((int)bhi, (int)bhi, CTRL, 0xF, 0xF, false); \
+                        const bool t_ = k2 < key;                                                                      \
+                        key = t_ ? k2 : key; blo = t_ ? l2 : blo; bhi = t_ ? h2 : bhi;                                 \
+                    }
+                    BF_QUAD_MIN(0xB1)                              // quad_perm [1,0,3,2]
+                    BF_QUAD_MIN(0x4E)                              // quad_perm [2,3,0,1]
+#undef BF_QUAD_MIN
+                    const uint32_t okey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                    const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
+                    if (!have_root || (okey >> 2) < (rhi >> 16)) e_next = ((uint64_t)ohi << 32) | olo;
+                }
                 nl += cnt;
                 ++tw_it;
             }
