@@ -1571,7 +1571,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 if (__builtin_expect(!general, 1) && fire0 && (cos_ & SV_SQMASK) == 0u) {   // :191 (valid NOT tested)
                     floor_sq = cs & SV_SQMASK;                                           // lower() :303: candidates of cells further from the obstacle
                     const int obx = rx + cox, oby = ry + coy;
-                    const uint32_t away = opq(nbm & ~(m_pos(ddx * cox) | m_pos(ddy * coy)));          // :296
+                    const uint32_t away = opq(nbm & ~m_pos(ddx * cox + ddy * coy));                     // :296 (one of ddx, ddy is 0)
                     const uint32_t nbok = away & ~absent;
                     const int qx = x - obx, qy = y - oby;
                     const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
@@ -1581,7 +1581,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     const uint32_t lt = opq(nbok & m_lt(new_sq, cmp));
                     const uint32_t tie = opq(nbok & ~lt & ~m_nz(new_sq ^ ssq));                       // :311-317
                     // the neighbour points at another obstacle than mine (lane 5 holds mine): a second load round, one pop in six
-                    const uint32_t other = m_nz((uint32_t)((x + obs_x(ob)) ^ obx) | (uint32_t)((y + obs_y(ob)) ^ oby));
+                    const uint32_t my_obs = pack_obs(obx - x, oby - y);                                // what I would store: my obstacle seen from the neighbour
+                    const uint32_t other = m_nz(ob ^ my_obs);
                     const uint32_t tie_other = opq(tie & other);
                     const uint32_t alloc = away & absent;                                            // a patch to allocate: general code
                     const bool clive = ((cos_ & SV_VALID) != 0u);                                     // my obstacle cell is a live obstacle ((cos_ & SQMASK) == 0 here)
@@ -1614,11 +1615,11 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         // neighbours that are lowered, and the popped cell's is_queued (:329): one store instruction
                         const uint32_t nsv = m_sel(curm, cs & ~(uint32_t)SV_QUEUED, (uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK));
                         buf_store_u16(rsv, m_sel(overm | curm, coff * 2u, BUF_OOB), nsv);
-                        buf_store_u32(robs, m_sel(overm, coff * 4u, BUF_OOB), pack_obs(obx - x, oby - y));
+                        buf_store_u32(robs, m_sel(overm, coff * 4u, BUF_OOB), my_obs);
                         BFF(4);
                         const unsigned long long om = __ballot(overm != 0u);
                         entry = q_entry(new_sq, x, y, obx - x, oby - y);
-                        const uint32_t rank = lane_rank(om, lane) & 3u;
+                        const uint32_t rank = opq(lane_rank(om, lane) & 3u);                         // (opaque: computed for every lane, no exec-masked region)
                         uint64_t* dst = overm ? &sh.pl_e[tw_it & 1u][rank] : dmy + lane;
                         *dst = entry;
                         cnt = (uint32_t)__popcll(om);
