@@ -1051,6 +1051,11 @@ __device__ __forceinline__ uint32_t m_le(uint32_t a, uint32_t b) { return ~m_lt(
 __device__ __forceinline__ uint32_t m_nz(uint32_t v) { return opq((uint32_t)((int32_t)(opq(v) | (0u - v)) >> 31)); }
 __device__ __forceinline__ uint32_t m_pos(int32_t a) { return opq((uint32_t)((int32_t)(0u - (uint32_t)opq((uint32_t)a)) >> 31)); }
 __device__ __forceinline__ uint32_t m_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }
+#ifdef LAMA_WAVE_SIM
+__device__ __forceinline__ uint32_t bf_mul24(uint32_t a, uint32_t b) { return a * b; }
+#else
+__device__ __forceinline__ uint32_t bf_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }       // v_mul_u32_u24 / v_mad_u32_u24: full rate
+#endif
 constexpr uint32_t BUF_OOB = 0x7FFFFFF0u;      // a byte offset beyond any plane of a particle's arena (<= 134 MB)
 
 // pop() of the LDS heap h[0, size) by the helper wave, NR predicated rounds of the 5-level subtree walk of lds_sift_topdown (two
@@ -1541,8 +1546,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
                 const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
                 const int x = rx + (is_oc ? eox : ddx), y = ry + (is_oc ? eoy : ddy);
-                const uint32_t inwin = opq(((uint32_t)x < prm.WC && (uint32_t)y < prm.WC) ? 0xFFFFFFFFu : 0u);
-                const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
+                const uint32_t mxy = (uint32_t)x > (uint32_t)y ? (uint32_t)x : (uint32_t)y;
+                const uint32_t inwin = opq(mxy < prm.WC ? 0xFFFFFFFFu : 0u);
+                const uint32_t pidx = bf_mul24((uint32_t)y >> 5, prm.W) + ((uint32_t)x >> 5);     // (24-bit multiply: both factors < 2^11)
                 const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
                 const uint32_t dv = sh.dc[dc.index(pidx & inwin)];
                 // (an empty cache word has a tag no window position has)
@@ -1591,9 +1597,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     if (__builtin_expect(__ballot((tie_other | alloc) != 0u) != 0ull, 0)) {
                         const int ox = x + obs_x(ob), oy = y + obs_y(ob);
                         const uint32_t oin = opq((tie_other != 0u && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) ? 0xFFFFFFFFu : 0u);
-                        const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);
+                        const uint32_t opidx = bf_mul24((uint32_t)oy >> 5, prm.W) + ((uint32_t)ox >> 5);
                         const uint32_t odv = sh.dc[dc.index(opidx & oin)];
-                        const uint32_t ohit = opq(oin & ~m_nz((odv >> 15) ^ (opidx >> 3)));
+                        const uint32_t ohit = opq((odv >> 15) == (opidx >> 3) ? oin : 0u);
                         const uint32_t oslot = (odv & 0x7FFFu) - 1u;
                         const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
                         const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
