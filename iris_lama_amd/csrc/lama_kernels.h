@@ -882,6 +882,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 #define BFF(k) do {} while (0)
 #endif
 
+constexpr int BF_DUMMY = 8;   // dummy slots per wave (lane & 7): 64 of them cost the 12th workgroup of a CU (LDS is granted in 1,280-byte blocks)
 template <int LQ, int RQ>
 struct BfLds {
     uint64_t lower[LQ];
@@ -895,7 +896,7 @@ struct BfLds {
     uint32_t cmd_r;        // raise-queue length at the hand-over
     uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
     uint32_t cmd;          // lower-queue length at the hand-over, or BF_CMD_EXIT
-    uint64_t dummy[2][64]; // per wave and lane: absorbs the LDS stores of lanes without work (an address select instead of an exec mask)
+    uint64_t dummy[2][BF_DUMMY]; // per wave: absorbs the LDS stores of lanes without work (an address select instead of an exec mask)
 };
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
@@ -1061,7 +1062,7 @@ constexpr uint32_t BUF_OOB = 0x7FFFFFF0u;      // a byte offset beyond any plane
 // pop() of the LDS heap h[0, size) by the helper wave, NR predicated rounds of the 5-level subtree walk of lds_sift_topdown (two
 // cover a heap of 1024 entries, three one of 8192) and the lone-left-child step, no data-dependent branch: same final array as
 // std::pop_heap.  The entry that ends up at the root is stored to *root_out (LDS) by whichever lane holds it -- nothing is read
-// back across lanes.  `dummy`: 64 LDS words that absorb the stores of lanes without work.
+// back across lanes.  `dummy`: this lane's LDS word that absorbs its stores when it has no work.
 template <int NR>
 __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const int lane, const uint64_t anc, uint64_t* root_out, uint64_t* dummy)
 {
@@ -1102,7 +1103,7 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
         const uint32_t moves = opq(onpath & m_le(pm, vprio));        // prio(mine) <= prio(value)
         const unsigned long long pathm = __ballot(onpath != 0u), mvm = __ballot(moves != 0u);
         LAMA_LOCKSTEP();
-        uint64_t* dst = moves ? h + parent : dummy + lane;
+        uint64_t* dst = moves ? h + parent : dummy;
         *dst = mine;
         if (r == 0) { mine0 = mine; root_child = opq(((lane == 1 || lane == 2) ? 0xFFFFFFFFu : 0u) & moves); root_value = (mvm & 6ull) == 0ull; }
         const int rel = 63 - __clzll((long long)(mvm | 1ull));       // deepest moved entry: its old slot is the new hole
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
     // that moved up in the first round (lane 1 or 2 still holds it) or the re-inserted entry itself (lane 3)
     {
         const uint32_t l0 = lane == 0 ? 0xFFFFFFFFu : 0u, l3 = (lane == 3 && root_value) ? 0xFFFFFFFFu : 0u;
-        uint64_t* dst = l0 ? h + H : ((l3 | root_child) ? root_out : dummy + lane);
+        uint64_t* dst = l0 ? h + H : ((l3 | root_child) ? root_out : dummy);
         const uint64_t v = root_child ? mine0 : value;
         *dst = v;
     }
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const
     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
     if (cnt == 0) return;
     if (n >= 4 && upm == 0ull) {
-        uint64_t* dst = mine ? heap + pos : dummy + lane;
+        uint64_t* dst = mine ? heap + pos : dummy;
         *dst = entry;
         n += cnt;
         LAMA_LOCKSTEP();
@@ -1270,7 +1271,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         #define HFT(k) do {} while (0)
 #endif
         constexpr int NR = LQ_LDS > 1024 ? 3 : 2;              // rounds of lds_pop_flat: 5 heap levels each
-        uint64_t* const dmy = sh.dummy[1];
+        uint64_t* const dmy = sh.dummy[1] + (lane & (BF_DUMMY - 1));
         uint32_t it = 0;
         bool hstop = false;
         while (hnr > 0) {                                      // raise phase: pops of the raise queue, pushes into both
@@ -1452,7 +1453,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     // ---- lower wave of the wave pair (round 4: speculative straight-line pop, general code for the rare cases) ---- :175-194
     if (TW) {
         BFT(7);                                                    // (profiling build: everything before the lower wave)
-        uint64_t* const dmy = sh.dummy[0];
+        uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
         const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
         const bool is_oc = lane == 5, role = lane < 6;
         const uint32_t rolem = role ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
@@ -1626,7 +1627,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         const unsigned long long om = __ballot(overm != 0u);
                         entry = q_entry(new_sq, x, y, obx - x, oby - y);
                         const uint32_t rank = opq(lane_rank(om, lane) & 3u);                         // (opaque: computed for every lane, no exec-masked region)
-                        uint64_t* dst = overm ? &sh.pl_e[tw_it & 1u][rank] : dmy + lane;
+                        uint64_t* dst = overm ? &sh.pl_e[tw_it & 1u][rank] : dmy;
                         *dst = entry;
                         cnt = (uint32_t)__popcll(om);
                         BFF(5);
@@ -1648,7 +1649,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             // the quad of neighbour lanes, DPP) is compared with it.
             {
                 const uint32_t b_ = tw_it & 1u;
-                uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)(dmy + lane);
+                uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)dmy;
                 *np = cnt;
                 BFT_MAIN(5); BFF(6);
                 lds_barrier();                                     // D
