@@ -246,6 +246,75 @@ __device__ inline void bitonic_sort(uint64_t* a, uint32_t m)
     }
 }
 
+// The same sort with E keys per thread held in registers (m = RP_BLOCK * E keys; key i lives in thread i / E, register i % E).  A
+// bitonic network exchanges key i with key i ^ j; bit b of the index is used by log2(m) - b stages, so the bits that are used most
+// are the cheapest here: the low log2(E) bits are register-to-register (no memory at all), the next six are lanes of one wave (a
+// cross-lane move, no barrier), and only the top bits -- 3 of the 66 stages for 2,048 keys on 256 threads -- go through LDS with a
+// barrier pair.  The LDS form above pays two LDS reads, two conditional writes and a barrier for every one of the 66 stages.
+template <int RP_BLOCK, int E>
+__device__ inline void bitonic_sort_regs(uint64_t* a)
+{
+    constexpr uint32_t M = (uint32_t)RP_BLOCK * E;
+    const uint32_t base = threadIdx.x * (uint32_t)E;
+    uint64_t x[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) x[r] = a[base + r];
+    for (uint32_t k = 2; k <= M; k <<= 1) {
+        uint32_t j = k >> 1;
+        for (; j >= 64u * E; j >>= 1) {                        // partners in another wave: through LDS
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < E; ++r) a[base + r] = x[r];
+            __syncthreads();
+            const uint32_t pb = base ^ j;
+            const bool keep_min = ((base & j) == 0) == ((base & k) == 0);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint64_t y = a[pb + r];
+                x[r] = ((y < x[r]) == keep_min) ? y : x[r];
+            }
+        }
+        for (; j >= (uint32_t)E; j >>= 1) {                    // partners in another lane of this wave
+            const int lj = (int)(j / (uint32_t)E);
+            const bool keep_min = ((base & j) == 0) == ((base & k) == 0);
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint64_t y = __shfl_xor(x[r], lj, 64);
+                x[r] = ((y < x[r]) == keep_min) ? y : x[r];
+            }
+        }
+#pragma unroll
+        for (int jr = E / 2; jr > 0; jr >>= 1) {               // partners in this thread's registers
+            if ((uint32_t)jr >= k) continue;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                if (r & jr) continue;
+                const bool up = ((base + (uint32_t)r) & k) == 0;
+                const uint64_t lo = x[r], hi = x[r | jr];
+                const bool sw = (lo > hi) == up;
+                x[r] = sw ? hi : lo; x[r | jr] = sw ? lo : hi;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < E; ++r) a[base + r] = x[r];
+    __syncthreads();
+}
+
+// sorts the first `m` keys of `a` (m a power of two; the caller padded with ~0): the register form whenever a thread's share fits
+// eight register pairs, else (the resume stage's 8,192 keys on 256 threads) the LDS form.  Returns with the keys in LDS, barrier done.
+template <int RP_BLOCK>
+__device__ inline void sort_keys(uint64_t* a, uint32_t m)
+{
+    if (m < (uint32_t)RP_BLOCK) { if (m > 1) bitonic_sort<RP_BLOCK>(a, m); }
+    else if (m == (uint32_t)RP_BLOCK) bitonic_sort_regs<RP_BLOCK, 1>(a);
+    else if (m == 2u * RP_BLOCK) bitonic_sort_regs<RP_BLOCK, 2>(a);
+    else if (m == 4u * RP_BLOCK) bitonic_sort_regs<RP_BLOCK, 4>(a);
+    else if (m == 8u * RP_BLOCK) bitonic_sort_regs<RP_BLOCK, 8>(a);
+    else bitonic_sort<RP_BLOCK>(a, m);
+}
+
 template <int SORT_CAP, int EV_CAP>
 struct ReplayLds {
     uint64_t keys[SORT_CAP];
@@ -284,7 +353,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
     for (uint32_t i = threadIdx.x; i < m; i += RP_BLOCK) sh.keys[i] = i < n ? src[i] : ~0ull;
     if (threadIdx.x == 0) { sh.ev_n = 0; sh.nadd = 0; sh.nrem = 0; }
     __syncthreads();
-    if (m > 1) bitonic_sort<RP_BLOCK>(sh.keys, m);
+    sort_keys<RP_BLOCK>(sh.keys, m);
 
     // ---- per-cell replay in the reference's visit order (one thread per active cell) ----
     for (uint32_t i = threadIdx.x; i < n; i += RP_BLOCK) {
