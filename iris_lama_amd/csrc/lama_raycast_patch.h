@@ -140,8 +140,12 @@ __device__ inline void ray_chunk_record(const DevParams& prm, const BeamGeom& g,
 }
 
 // allocation walk: afterwards the occupancy patch of every ray cell of the scan exists.  RW_SEG threads per beam (many while the
-// chip is not full: short chains; few when it is: fewer threads to launch), each walks one stretch of the ray (one directory read
-// per patch change; the lock-free CAS only runs for a missing patch).
+// chip is not full: short chains; few when it is: fewer threads to launch), each takes one stretch [t0, t1] of the ray's steps.
+// Round 4: the stretch is walked PATCH BY PATCH, not cell by cell.  Map::computeRay (src/sdm/map.cpp:198-227) puts step t of axis j
+// at start_j + s_j * floor((2 t a_j + n) / (2 n)): both coordinates are monotone in t and move by at most one cell per step, so the
+// patch changes exactly at the steps where an axis makes its k-th move for a k that takes it across a multiple of 32 -- the first
+// such step is t = ceil((2 n k - n) / (2 a_j)).  Two merged sequences of such steps (one division per patch boundary) replace ~20
+// cell steps per patch; one directory read per patch, the lock-free CAS only for a missing one.
 __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const RayRec* __restrict__ recs, int n, int first_particle, int RW_SEG)
 {
     const int p = first_particle + blockIdx.x;
@@ -155,20 +159,24 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
     const size_t WW = (size_t)prm.W * prm.W;
     int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
     if (t0 > t1) return;
-    // Map::computeRay (src/sdm/map.cpp:198-227) in its incremental form from step t0 on: k_j = floor((2 t a_j + n) / (2 n)) steps
-    // made by axis j, rem_j the remainder; every step adds 2 a_j and carries at 2 n
-    const uint32_t a0 = r.a01 & 0xFFFFu, a1 = r.a01 >> 16, nn = r.nnf & 0xFFFFu, n2 = 2u * nn;
-    uint32_t k0 = (uint32_t)(((uint64_t)(2u * t0 * a0 + nn) * r.magic) >> 42), k1 = (uint32_t)(((uint64_t)(2u * t0 * a1 + nn) * r.magic) >> 42);
-    uint32_t rem0 = 2u * t0 * a0 + nn - k0 * n2, rem1 = 2u * t0 * a1 + nn - k1 * n2;
+    const uint32_t a0 = r.a01 & 0xFFFFu, a1 = r.a01 >> 16, nn = r.nnf & 0xFFFFu;
+    const uint32_t k0 = (uint32_t)(((uint64_t)(2u * t0 * a0 + nn) * r.magic) >> 42), k1 = (uint32_t)(((uint64_t)(2u * t0 * a1 + nn) * r.magic) >> 42);
     const bool neg0 = (r.nnf >> 16) & 1u, neg1 = (r.nnf >> 17) & 1u;
     const uint32_t bx = r.msx - prm.wx0, by = r.msy - prm.wy0;
-    uint32_t last = 0xFFFFFFFFu;
-    for (uint32_t t = t0; t <= t1; ++t) {
-        const uint32_t rx = neg0 ? bx - k0 : bx + k0, ry = neg1 ? by - k1 : by + k1;
-        const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5);
-        if (pidx != last) { (void)dir_get_or_alloc(occ_dir, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err); last = pidx; }
-        rem0 += 2u * a0; if (rem0 >= n2) { rem0 -= n2; ++k0; }
-        rem1 += 2u * a1; if (rem1 >= n2) { rem1 -= n2; ++k1; }
+    const uint32_t rx = neg0 ? bx - k0 : bx + k0, ry = neg1 ? by - k1 : by + k1;          // the cell of step t0
+    uint32_t X = rx >> 5, Y = ry >> 5;
+    // the number of moves after which the axis stands in the next patch, and the first step at which it has made them (n < 8192
+    // and k <= a < 8192: the products fit 32 bits); an axis that never gets there: no such step
+    uint32_t kx = neg0 ? k0 + (rx & 31u) + 1u : k0 + 32u - (rx & 31u), ky = neg1 ? k1 + (ry & 31u) + 1u : k1 + 32u - (ry & 31u);
+    auto step_of = [nn](uint32_t k, uint32_t a) { return k > a ? 0xFFFFFFFFu : (2u * nn * k - nn + 2u * a - 1u) / (2u * a); };
+    uint32_t tx = step_of(kx, a0), ty = step_of(ky, a1);
+    (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+    for (;;) {
+        const uint32_t t = tx < ty ? tx : ty;
+        if (t > t1) break;
+        if (tx == t) { X = neg0 ? X - 1u : X + 1u; kx += 32u; tx = step_of(kx, a0); }
+        if (ty == t) { Y = neg1 ? Y - 1u : Y + 1u; ky += 32u; ty = step_of(ky, a1); }
+        (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
     }
 }
 
