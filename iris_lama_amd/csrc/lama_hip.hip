@@ -538,7 +538,7 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
     }
     hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
                        c->d_rrec, c->d_rbbox, alloc_only, c->d_rchunk);
-    const int rw_seg = count <= 64 ? 8 : 2;
+    const int rw_seg = count <= 64 ? 4 : 1;
     hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
     double far = c->scan_reach;                                   // no cell further than truncated_range from the sensor is touched
     if (c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);

@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
         const unsigned long long km = __ballot(keep);              // chunks 0 .. 63, the same in every wave
         const int ncand = __popcll(km) * 64;
         if (tid == 0) RPC(2, __popcll(km));
+        if (km == 0ull) continue;                                  // a patch out of this scan's reach (the same decision in every wave): untouched
         // ---- 1. the patch: its cells and hit bits are requested now, classified below (after the candidates' loads are out too)
         uint32_t v[4];
         uint64_t hw[4];
