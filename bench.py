@@ -129,6 +129,17 @@ def cpu_baseline(pts, odom, P, updates, warm, bytes_only=False):
     return cores, res
 
 
+def chain_spread(cc, particles):
+    """A particle's exact brushfire is ONE serial chain of pops, so a map update lasts as long as the longest chain of the pool:
+    mean chain, mean over the updates of the longest one, and the pace of that longest chain (brushfire time / its pops)."""
+    n = max(cc["launches_brushfire"], 1)
+    mean = cc["bf_cells"] / (particles * n)
+    longest = cc["bf_longest_chain_sum"] / n
+    return {"mean_pops_per_particle": round(mean, 1), "mean_longest_chain_pops": round(longest, 1),
+            "longest_over_mean": round(longest / mean, 2) if mean else None,
+            "us_per_pop_of_the_longest_chain": round(cc["ms_brushfire"] / n * 1e3 / longest, 3) if longest else None}
+
+
 def next_rows(F, with_cpu=True):
     """Informational timings of the SURVEY 8(f) rows that run on the device (never part of `value`)."""
     import numpy as np
@@ -464,6 +475,7 @@ def main():
                                "brushfire": c["ms_brushfire"] / max(c["launches_brushfire"], 1),
                                "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0,
                                "measured_in": "second pass of the same steps with hipEvent brackets on (ms_per_step there: %.4f)" % prof_run["ms_per_step"]},
+        "brushfire_chains": chain_spread(c, P_total // world),
     }
     if world == 1:
         result["summary_buckets_ms_per_update"] = run(P_total, K, W, summary=True)["buckets_ms"]
@@ -568,7 +580,8 @@ def main():
                              "update_maps_ms": cc["ms_update_maps"] / max(cc["launches_update_maps"], 1),
                              "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1),
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
-                             "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1)}
+                             "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1),
+                             "brushfire_chains": chain_spread(cc, P)}
             if base and "bytes" in base:       # same log, same per-particle footprint: the P = 30 byte counts apply
                 bf_s = cc["ms_brushfire"] / max(cc["launches_brushfire"], 1) * 1e-3
                 extra[str(P)]["roofline_frac_brushfire"] = base["bytes"]["brushfire"] * P / bf_s / 1e9 / HBM_PEAK_GBS

@@ -287,6 +287,10 @@ typedef struct lama_hip_counters {
     uint32_t replay_handovers;          /* the same for the ordered replay of the parallel ray-cast (more than 2048 order-sensitive visits) */
     uint32_t window_patches;            /* current side of the map window in patches (it grows with the mapped area, up to 1016)            */
     uint32_t window_growths;            /* times the window directories were re-allocated with a larger side                                */
+    uint64_t bf_longest_chain_sum;      /* sum over map updates of the LARGEST brushfire cell count of a single particle: a particle's exact
+                                           brushfire is one serial chain, so a map update lasts as long as its longest chain --
+                                           bf_longest_chain_sum / map updates against bf_cells / (particles x map updates) is the spread   */
+    uint64_t bf_longest_chain_last;     /* the largest per-particle count of the last map update                                           */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

@@ -274,10 +274,11 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             dm += c->h_counts[2 * p]; oc += c->h_counts[2 * p + 1];
         }
         c->ctr.dm_patches = dm; c->ctr.occ_patches = oc;
-        if (maps && std::getenv("LAMA_HIP_DEBUG_TAIL")) {           // developer aid: how uneven the brushfire chains of this update were
+        if (maps) {                                                  // the update lasted as long as its longest chain
             uint64_t mx = 0, sum = 0; uint32_t arg = 0;
             for (uint32_t p = 0; p < c->P; ++p) { sum += st[4 * p + 3]; if (st[4 * p + 3] > mx) { mx = st[4 * p + 3]; arg = p; } }
-            std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire);
+            c->ctr.bf_longest_chain_sum += mx; c->ctr.bf_longest_chain_last = mx;
+            if (std::getenv("LAMA_HIP_DEBUG_TAIL")) std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire);
         }
         if (maps) return grow_arenas(c);
     }

@@ -1270,13 +1270,16 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #else
         #define HFT(k) do {} while (0)
 #endif
-        constexpr int NR = LQ_LDS > 1024 ? 3 : 2;              // rounds of lds_pop_flat: 5 heap levels each
+        // rounds of lds_pop_flat, 5 heap levels each: two reach the bottom of a heap of up to 2,047 entries (levels 0 .. 10), three
+        // that of 8,192.  The resume stage's big queues are mostly far from full: it takes the third round only when the heap needs it.
+        constexpr int NR = LQ_LDS > 2047 ? 3 : 2;
+        #define BF_HELPER_POP(H, N, B) do { if (NR == 3 && (N) > 2047u) lds_pop_flat<3>(H, N, lane, anc, &sh.topq[B], dmy); else lds_pop_flat<2>(H, N, lane, anc, &sh.topq[B], dmy); } while (0)
         uint64_t* const dmy = sh.dummy[1] + (lane & (BF_DUMMY - 1));
         uint32_t it = 0;
         bool hstop = false;
         while (hnr > 0) {                                      // raise phase: pops of the raise queue, pushes into both
             const uint32_t b = it & 1u;
-            lds_pop_flat<NR>(sh.raise, hnr, lane, anc, &sh.topq[b], dmy);
+            BF_HELPER_POP(sh.raise, hnr, b);
             lds_barrier();                                     // D
             lds_push_flat(sh.raise, hnr, sh.pr_e[b], &sh.pr_n[b], lane, dmy);   // raise() is the only producer of raise entries
             lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
@@ -1286,7 +1289,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         }
         if (!hstop && hnl > 0) for (;;) {                      // lower phase
             const uint32_t b = it & 1u;
-            lds_pop_flat<NR>(sh.lower, hnl, lane, anc, &sh.topq[b], dmy);
+            BF_HELPER_POP(sh.lower, hnl, b);
             HFT(0);
             lds_barrier();                                     // D
             HFT(1);
@@ -1301,6 +1304,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #endif
 #endif
         #undef HFT
+        #undef BF_HELPER_POP
         __syncthreads();                                       // F: last pushes applied
         return;
     }
