@@ -886,7 +886,7 @@ constexpr int BF_DUMMY = 8;   // dummy slots per wave (lane & 7): 64 of them cos
 template <int LQ, int RQ>
 struct BfLds {
     uint64_t lower[LQ];
-    uint64_t raise[RQ];
+    uint64_t raise[RQ];    // directly behind `lower`: once the raise queue is empty (lower phase) the lower heap of the wave pair may grow into it
     uint32_t dc[DC_SIZE];
     // TW mailboxes (double buffered by iteration parity)
     uint64_t pl_e[2][4];   // main -> helper: the entries to push into the LOWER queue, in neighbour order
@@ -1252,6 +1252,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     for (uint32_t k = tid; k < nr; k += nthreads) sh.raise[k] = g_raise[k];
     __syncthreads();
     const uint64_t anc = lds_pop_ancestors(lane);
+    // lower phase of the wave pair: the raise queue is empty for good (lower() never raises) and lies directly behind the lower heap in
+    // LDS -- the heap may grow into it (first stage: 1,280 entries instead of 1,024 before the particle is handed over; the big stage
+    // keeps its own limit, which is what cfg.queue_capacity is checked against)
+    constexpr uint32_t LOWER_CAP = RESUME ? (uint32_t)LQ_LDS : (uint32_t)(LQ_LDS + RQ_LDS);
 #ifndef LAMA_WAVE_SIM
     // Chip full (12 workgroups per CU: three main and three helper waves per SIMD): the issue slots of a SIMD are the scarce
     // resource and the main wave is the longer chain of the pair (the helper waits for it), so it gets the arbiter's preference.
@@ -1296,7 +1300,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
             HFT(2);
             ++it;
-            if (hnl - 1u >= (uint32_t)LQ_LDS - 4u) break;      // empty, or about to outgrow the LDS window
+            if (hnl - 1u >= LOWER_CAP - 4u) break;   // empty, or about to outgrow the LDS window (in the lower phase the idle raise queue behind it is part of it)
         }
 #ifdef LAMA_PROFILE_BF
 #ifndef LAMA_PROFILE_BF_MAIN
@@ -1686,7 +1690,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             BFT(4); BFF(7);
             // the queue is empty, or would outgrow its LDS window (the helper wave takes the same decision): one scalar test
-            if (nl - 1u >= (uint32_t)LQ_LDS - 4u) { spill = nl != 0u; tw_running = false; break; }
+            if (nl - 1u >= LOWER_CAP - 4u) { spill = nl != 0u; tw_running = false; break; }
         }
     }
     // ---- lower wave ------------------------------------------------------------------------- :175-194
@@ -1835,7 +1839,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     #undef BF_LOAD_B
     #undef BF_POP_WITH_LOADS
     if (spill) {      // hand the particle over, state intact, to the next stage (the helper wave is past its last LDS access: barrier F, or S0 when it never started)
-        for (uint32_t k = lane; k < nl; k += UM_BLOCK) g_lower[k] = sh.lower[k];
+        const uint64_t* lq = sh.lower;                   // (may run on into sh.raise: the lower phase of the wave pair uses both, see BfLds)
+        for (uint32_t k = lane; k < nl; k += UM_BLOCK) g_lower[k] = lq[k];
         for (uint32_t k = lane; k < nr; k += UM_BLOCK) g_raise[k] = sh.raise[k];
     }
     if (lane == 0) {
