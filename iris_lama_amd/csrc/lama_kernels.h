@@ -885,18 +885,20 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
 constexpr int BF_DUMMY = 8;   // dummy slots per wave (lane & 7): 64 of them cost the 12th workgroup of a CU (LDS is granted in 1,280-byte blocks)
 template <int LQ, int RQ>
 struct BfLds {
-    uint64_t lower[LQ];
-    uint64_t raise[RQ];    // directly behind `lower`: once the raise queue is empty (lower phase) the lower heap of the wave pair may grow into it
-    uint32_t dc[DC_SIZE];
+    // the small, hot fields first: a DS instruction's immediate offset reaches 64 KB, and the resume stage's queues alone are 80 KB --
+    // behind them every mailbox / cache access needed its address computed in a register
     // TW mailboxes (double buffered by iteration parity)
     uint64_t pl_e[2][4];   // main -> helper: the entries to push into the LOWER queue, in neighbour order
-    uint32_t pl_n[2];      //                 and how many
     uint64_t pr_e[2][4];   // main -> helper: the entries raise() pushes into the RAISE queue
+    uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
+    uint64_t dummy[2][BF_DUMMY]; // per wave: absorbs the LDS stores of lanes without work (an address select instead of an exec mask)
+    uint32_t pl_n[2];      //                 and how many
     uint32_t pr_n[2];
     uint32_t cmd_r;        // raise-queue length at the hand-over
-    uint64_t topq[2];      // helper -> main: the heap's root after pop() (before the pushes)
     uint32_t cmd;          // lower-queue length at the hand-over, or BF_CMD_EXIT
-    uint64_t dummy[2][BF_DUMMY]; // per wave: absorbs the LDS stores of lanes without work (an address select instead of an exec mask)
+    uint32_t dc[DC_SIZE];
+    uint64_t lower[LQ];
+    uint64_t raise[RQ];    // directly behind `lower`: once the raise queue is empty (lower phase) the lower heap of the wave pair may grow into it
 };
 constexpr uint32_t BF_CMD_EXIT = 0xFFFFFFFFu;
 
@@ -1134,27 +1136,32 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
 // push_heap of the mailbox entries ent[0 .. cnt) (cnt <= 4, in order) by the helper wave: one gather of all would-be parents; when
 // no new entry has to move up (the normal case in a Dijkstra wave) they are appended, which is what the sequential push_heap calls
 // would have done; else those calls are replayed one by one.
-__device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t* cnt_p, const int lane, uint64_t* dummy)
+// FLAG: bit 31 of the count word is the main wave's "this was the last iteration" (pop budget, see bf_particle); returns the word.
+template <bool FLAG = false>
+__device__ __forceinline__ uint32_t lds_push_flat(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t* cnt_p, const int lane, uint64_t* dummy)
 {
     const uint32_t l4 = (uint32_t)lane & 3u;
     const uint64_t entry = ent[l4];                                  // count, entries and would-be parents: ONE LDS round trip
     const uint32_t pos = n + l4;
     const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
-    const uint32_t cnt_v = *cnt_p;
+    const uint32_t cnt_w = *cnt_p;
+    const uint32_t cnt_v = FLAG ? (cnt_w & 0x7FFFFFFFu) : cnt_w;
     const bool mine = (uint32_t)lane < cnt_v;
     const bool up = mine && pprio > heap_prio(entry);
     const unsigned long long upm = __ballot(up);
-    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
-    if (cnt == 0) return;
+    const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_w);
+    const uint32_t cnt = FLAG ? (word & 0x7FFFFFFFu) : word;
+    if (cnt == 0) return word;
     if (n >= 4 && upm == 0ull) {
         uint64_t* dst = mine ? heap + pos : dummy;
         *dst = entry;
         n += cnt;
         LAMA_LOCKSTEP();
-        return;
+        return word;
     }
     #pragma unroll 1
     for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
+    return word;
 }
 
 // push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
@@ -1224,7 +1231,12 @@ __device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool f
 }
 
 // the brushfire of ONE particle by the calling workgroup (body of k_brushfire)
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+// BUDGET (first stage of the wave pair on a full chip): a map update lasts as long as the LONGEST chain of the pool, and that chain
+// runs a quarter slower while it shares its CU with eleven other wave pairs -- and a particle whose queue outgrew the first stage
+// waits for all of it to end.  With a pop budget (the host derives it from the previous update's chain lengths so that few chains
+// exceed it) a workgroup that reaches it takes a ticket; the first prm.budget_cap of them hand their particle over, state intact,
+// exactly like a queue overflow: the first stage ends early and the few long chains continue in the resume stage, one per CU.
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool BUDGET = false>
 __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_any, BfLds<LQ_LDS, RQ_LDS>& sh)
 {
     const int p = __builtin_amdgcn_readfirstlane(p_any);      // wave-uniform (the resume stage reads it from the hand-over list): scalar base addresses
@@ -1297,9 +1309,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             HFT(0);
             lds_barrier();                                     // D
             HFT(1);
-            lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
+            const uint32_t word = lds_push_flat<BUDGET>(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
             HFT(2);
             ++it;
+            if (BUDGET && (word >> 31)) break;                 // the main wave stops here (pop budget): so do I
             if (hnl - 1u >= LOWER_CAP - 4u) break;   // empty, or about to outgrow the LDS window (in the lower phase the idle raise queue behind it is part of it)
         }
 #ifdef LAMA_PROFILE_BF
@@ -1397,12 +1410,140 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             ++tw_it;                                                                                        \
         }
 
-    // ---- raise wave ------------------------------------------------------------------------- :162-173
-    while (TW ? (tw_running && nr > 0) : (nr > 0)) {
+    // ---- raise wave of the wave pair (round 4: the same straight-line form as the lower wave below) ---------- :162-173, raise() :244-279
+    // Lanes 0..3: the four neighbours, lane 4: the popped cell, lane 5: the obstacle cell the popped cell pointed to when it was queued
+    // (raise entries carry that offset since round 4; the reference's entries have none and the heap only orders by distance) --
+    // inside a raise wave most neighbours point to that very cell, so its state answers "is my obstacle still one?" without the second,
+    // dependent load round; a neighbour that points elsewhere gets it (one ballot).  Rare cases -- a cell that is not cached, a
+    // patch to allocate, a neighbour whose obstacle cell is another neighbour (raise() handles them in order) -- take the general code.
+    if (TW) {
+        uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
+        const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
+        const bool is_oc = lane == 5;
+        const uint32_t rolem = lane < 6 ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
+
+        // the general raise pop: the reference's statements with every rare case; leaves the entries to push in the two mailboxes
+        auto general_raise = [&](const uint64_t e, uint32_t& cnt_r, uint32_t& cnt_l, uint64_t& entry_r, uint32_t& rm_out) {
+            const int rx = q_rx(e), ry = q_ry(e);
+            BF_LOAD_A()
+            BF_LOAD_B()
+            if (is_nb && !inwin) atomicOr(prm.err, ERR_WINDOW);
+            const bool nb = is_nb && inwin;
+            const bool fresh = nb && slot < 0;
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            const bool nbok = nb && slot >= 0;
+            if (nbok) {
+                const uint64_t bit = 1ull << (ci & 63);
+                if (fresh || !(s & (SV_VALID | SV_QUEUED))) atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
+            }
+            const bool cand = nbok && !(s & SV_QUEUED) && (s & SV_VALID);        // :253
+            bool ovalid = (os & SV_VALID) != 0;
+            bool clear = cand && !ovalid;
+            #pragma unroll 1
+            for (int i = 0; i < 3; ++i) {                                        // neighbour i is handled before j > i
+                const int cxi = __builtin_amdgcn_readlane(x, i), cyi = __builtin_amdgcn_readlane(y, i);
+                const bool ci_clear = __builtin_amdgcn_readlane((int)clear, i) != 0;
+                if (lane > i && lane < 4 && cand && ci_clear && ox == cxi && oy == cyi) { ovalid = false; clear = true; }
+            }
+            const bool to_raise = cand && !ovalid, to_lower = cand && ovalid;    // :262-272
+            const uint32_t rm = (uint32_t)__ballot(to_raise) & 15u, lm = (uint32_t)__ballot(to_lower) & 15u;
+            const uint32_t below = (1u << lane) - 1u;
+            entry_r = q_entry((uint32_t)(s & SV_SQMASK), x, y, obs_x(ob), obs_y(ob));
+            if (to_raise) sh.pr_e[tw_it & 1u][__popc(rm & below)] = entry_r;
+            if (to_lower) sh.pl_e[tw_it & 1u][__popc(lm & below)] = entry_r;
+            cnt_r = (uint32_t)__popc(rm); cnt_l = (uint32_t)__popc(lm); rm_out = rm;
+            if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0u; }
+            if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
+        };
+
+        while (tw_running && nr > 0) {
+            const uint64_t e = e_next;
+            ++processed;
+#ifdef LAMA_PROFILE_BF_COUNT
+            prof[7] += 1;
+#endif
+            --nr;                                                          // the helper wave pops
+            uint32_t cnt_r = 0, cnt_l = 0, rm = 0;
+            uint64_t entry = 0;
+            bool general;
+            {
+                const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
+                const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
+                const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
+                const int obx = rx + eox, oby = ry + eoy;                  // the obstacle cell the popped cell pointed to
+                const int x = is_oc ? obx : rx + ddx, y = is_oc ? oby : ry + ddy;
+                const uint32_t mxy = (uint32_t)x > (uint32_t)y ? (uint32_t)x : (uint32_t)y;
+                const uint32_t inwin = opq(mxy < prm.WC ? 0xFFFFFFFFu : 0u);
+                const uint32_t pidx = bf_mul24((uint32_t)y >> 5, prm.W) + ((uint32_t)x >> 5);
+                const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
+                const uint32_t dv = sh.dc[dc.index(pidx & inwin)];
+                const uint32_t hit = opq(inwin & ~m_nz((dv >> 15) ^ (pidx >> 3)));
+                const uint32_t slotw = (dv & 0x7FFFu) - 1u;
+                const uint32_t absent = opq((uint32_t)((int32_t)slotw >> 31));
+                const uint32_t have = opq(rolem & hit & ~absent);
+                const uint32_t coff = (slotw << 10) | ci;
+                const uint32_t s = buf_load_u16(rsv, m_sel(have, coff * 2u, BUF_OOB));
+                const uint32_t ob = buf_load_u32(robs, m_sel(have, coff * 4u, BUF_OOB));
+                // general code: a role cell that is not cached or outside the window, a neighbour (or the popped cell) without a patch
+                const uint32_t rare0 = (rolem & ~hit) | ((nbm | curm) & hit & absent);
+                // :253  neighbours that are valid and not queued
+                const uint32_t svalid = opq((uint32_t)((int32_t)(s << 16) >> 31)), squeued = opq((uint32_t)((int32_t)(s << 17) >> 31));
+                const uint32_t cand = opq(nbm & svalid & ~squeued);
+                // the neighbour's obstacle cell: the one lane 5 holds, or another one (second round)
+                const int ox = x + obs_x(ob), oy = y + obs_y(ob);
+                const uint32_t same = ~(m_nz((uint32_t)(ox ^ obx)) | m_nz((uint32_t)(oy ^ oby)));
+                const uint32_t other = opq(cand & ~same);
+                // raise() handles the neighbours in order: one whose obstacle cell is an EARLIER neighbour sees what that one became --
+                // only possible when the offset points at a cell next to the popped one: general code
+                const int ax = ox - rx, ay = oy - ry;
+                const uint32_t adj = cand & ~m_nz((uint32_t)(ax * ax + ay * ay) ^ 1u);
+                const unsigned long long rarem = __ballot((rare0 | adj) != 0u);
+                const uint32_t cos_ = (uint32_t)__builtin_amdgcn_readlane((int)s, 5);
+                uint32_t ovalid = (cos_ & SV_VALID) ? 0xFFFFFFFFu : 0u;   // (lanes whose obstacle cell is lane 5's)
+                general = rarem != 0ull;
+                if (!general && __builtin_expect(__ballot(other != 0u) != 0ull, 0)) {
+                    const uint32_t oin = opq((other != 0u && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC) ? 0xFFFFFFFFu : 0u);
+                    const uint32_t opidx = bf_mul24((uint32_t)oy >> 5, prm.W) + ((uint32_t)ox >> 5);
+                    const uint32_t odv = sh.dc[dc.index(opidx & oin)];
+                    const uint32_t ohit = opq((odv >> 15) == (opidx >> 3) ? oin : 0u);
+                    const uint32_t oslot = (odv & 0x7FFFu) - 1u;
+                    const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
+                    const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
+                    ovalid = m_sel(other, (uint32_t)((int32_t)(os2 << 16) >> 31), ovalid);
+                    general = __ballot((oin & ~ohit) != 0u) != 0ull;       // its directory entry is not cached
+                }
+                if (__builtin_expect(!general, 1)) {
+                    const uint32_t to_raise = opq(cand & ~ovalid), to_lower = opq(cand & ovalid);       // :262-272
+                    // get() of the four neighbours: the Container mask bit of a flag-less cell
+                    const uint32_t need_bit = nbm & ~(svalid | squeued);
+                    buf_or_u64(rmask, m_sel(need_bit, ((slotw << 4) + (ci >> 6)) * 8u, BUF_OOB), 1ull << (ci & 63u));
+                    // raised: is_queued only, obstacle cleared; lowered: is_queued added; the popped cell: is_queued removed (:278)
+                    const uint32_t nsv = m_sel(to_raise, (uint32_t)SV_QUEUED, m_sel(curm, s & ~(uint32_t)SV_QUEUED, s | (uint32_t)SV_QUEUED));
+                    buf_store_u16(rsv, m_sel(to_raise | to_lower | curm, coff * 2u, BUF_OOB), nsv);
+                    buf_store_u32(robs, m_sel(to_raise, coff * 4u, BUF_OOB), 0u);
+                    const unsigned long long rmm = __ballot(to_raise != 0u), lmm = __ballot(to_lower != 0u);
+                    entry = q_entry(s & SV_SQMASK, x, y, obs_x(ob), obs_y(ob));
+                    const uint32_t rank_r = opq(lane_rank(rmm, lane) & 3u), rank_l = opq(lane_rank(lmm, lane) & 3u);
+                    uint64_t* dst = to_raise ? &sh.pr_e[tw_it & 1u][rank_r] : (to_lower ? &sh.pl_e[tw_it & 1u][rank_l] : dmy);
+                    *dst = entry;
+                    cnt_r = (uint32_t)__popcll(rmm); cnt_l = (uint32_t)__popcll(lmm); rm = (uint32_t)rmm & 15u;
+                }
+            }
+            if (__builtin_expect(general, 0)) general_raise(e, cnt_r, cnt_l, entry, rm);
+            BF_TW_TAIL(true, nr, cnt_r, cnt_l, entry, rm)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        }
+    }
+    // ---- raise wave, one-wave form ------------------------------------------------------------ :162-173
+    while (!TW && nr > 0) {
         if (!TW && (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS)) { spill = true; break; }
         const uint64_t e = TW ? e_next : sh.raise[0];    // priority_queue::top(); the cell loads below are in
         const int rx = q_rx(e), ry = q_ry(e);            // flight while pop() sifts the heap in LDS
         ++processed;
+#ifdef LAMA_PROFILE_BF_COUNT
+        prof[7] += 1;
+#endif
         BF_POP_WITH_LOADS(sh.raise, nr)
         // neighbours: get() = allocate + mask bit (all four)
         if (is_nb && !inwin) atomicOr(prm.err, ERR_WINDOW);
@@ -1539,10 +1680,18 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             return (uint32_t)__popcll(om);
         };
 
+        uint32_t budget = BUDGET ? prm.pop_budget : 0xFFFFFFFFu;
         if (tw_running && nl > 0) for (;;) {
             const uint64_t e = e_next;                                     // the same value in every lane
             ++processed;
             --nl;                                                          // the helper wave pops
+            uint32_t stopbit = 0;
+            if (BUDGET && __builtin_expect(tw_it >= budget, 0)) {          // once per particle: a ticket to the resume stage, or none
+                uint32_t t = 0;
+                if (lane == 0) t = atomicAdd(prm.slow_n + 2, 1u);
+                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+                if (t < prm.budget_cap) stopbit = 0x80000000u; else budget = 0xFFFFFFFFu;
+            }
             uint32_t cnt = 0;
             bool general;
             uint32_t floor_sq = 0;                                         // every push of this pop has a priority above this
@@ -1658,7 +1807,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             {
                 const uint32_t b_ = tw_it & 1u;
                 uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)dmy;
-                *np = cnt;
+                *np = BUDGET ? (cnt | stopbit) : cnt;
                 BFT_MAIN(5); BFF(6);
                 lds_barrier();                                     // D
                 BFT_MAIN(6);
@@ -1690,7 +1839,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             BFT(4); BFF(7);
             // the queue is empty, or would outgrow its LDS window (the helper wave takes the same decision): one scalar test
-            if (nl - 1u >= LOWER_CAP - 4u) { spill = nl != 0u; tw_running = false; break; }
+            if (nl - 1u >= LOWER_CAP - 4u || (BUDGET && stopbit != 0u)) { spill = nl != 0u; tw_running = false; break; }
         }
     }
     // ---- lower wave ------------------------------------------------------------------------- :175-194
@@ -1862,7 +2011,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 // big LDS queues (84 KB: one workgroup per CU).  That stage is launched with a SMALL grid whose workgroups walk the list: with an
 // empty list (the normal case) it costs a few microseconds; launched with one workgroup per particle it cost 1.2 ms at 3000
 // particles for doing nothing (12 rounds of one 84 KB workgroup per CU, rocprofv3 r03).
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool BUDGET = false>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
@@ -1871,7 +2020,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #ifdef LAMA_PROFILE_BF                                   // where and when this particle ran (constant 100 MHz counter)
         uint64_t rt0; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt0));
 #endif
-        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, first_particle + (int)blockIdx.x, sh);
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW, BUDGET>(prm, first_particle + (int)blockIdx.x, sh);
 #ifdef LAMA_PROFILE_BF
         if (threadIdx.x == 0) {
             uint64_t rt1; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt1));

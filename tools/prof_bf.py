@@ -17,9 +17,13 @@ if os.environ.get("LAMA_PROF_MAIN"):   # -DLAMA_PROFILE_BF_MAIN build: all eight
 if os.environ.get("LAMA_PROF_FINE"):   # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_FINE build
     names = ["f0:lookup+issue", "f1:wait+decide0", "f2:valu_decide", "f3:rare_ballot+branch", "f4:atomic+stores", "f5:mailbox", "f6:tail_pre_D", "f7:barrier+post_D"]
 if os.environ.get("LAMA_PROF_COUNT"):  # -DLAMA_PROFILE_BF_MAIN -DLAMA_PROFILE_BF_COUNT build: event counts of the lower wave
-    names = ["lower_pops", "general_pops", "g:cache_miss", "g:stale", "g:alloc", "g:tie_other", "fired", "-"]
+    names = ["lower_pops", "general_pops", "g:cache_miss", "g:stale", "g:alloc", "g:tie_other", "fired", "raise_pops"]
+noise = float(os.environ.get("LAMA_PROF_NOISE", "0"))      # pose noise (m; rad = a third of it): particles that disagree with their maps raise as well
+rng = np.random.default_rng(1)
 for k in range(1, 13):
     poses = np.tile(F.pose_from_xyr(*truth[k]), (P, 1))
+    if noise > 0:
+        poses = np.stack([F.pose_from_xyr(*(truth[k] + rng.normal(0, [noise, noise, noise / 3]))) for _ in range(P)])
     ctx.set_poses(poses)
     ctx.reset_counters()
     ctx.update_maps(pts[k])
@@ -29,8 +33,11 @@ for k in range(1, 13):
     pops = c["bf_cells"] / P
     if os.environ.get("LAMA_PROF_COUNT"):
         j = int(np.argmax(d[:, 0]))
-        print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:7])))
+        print(f"scan {k}: pops/particle {pops:.0f} (max lower pops {d[j][0]}) brushfire {c['ms_brushfire']:.3f} ms :: " + " ".join(f"{n}={d[j][i]}" for i, n in enumerate(names[:8])))
         continue
+    if os.environ.get("LAMA_PROF_MAIN") and not os.environ.get("LAMA_PROF_FINE"):
+        j = int(np.argmax(d[:, :8].sum(axis=1)))
+        print(f"scan {k}: slowest particle {j}: main-wave cycles total {d[j][:8].sum()} of which before the lower wave (raise phase) {d[j][7]}  brushfire {c['ms_brushfire']:.3f} ms")
     tot = d[0][:5].sum() if not os.environ.get("LAMA_PROF_MAIN") else (d[0][:8].sum() if os.environ.get("LAMA_PROF_FINE") else d[0][:7].sum())
     print(f"scan {k}: pops/particle {pops:.0f} brushfire {c['ms_brushfire']:.3f} ms raycast {c['ms_raycast']:.3f} ms  cycles/pop {tot / max(pops,1):.0f} :: " +
           " ".join(f"{n}={d[0][i] / max(pops,1):.0f}" for i, n in enumerate(names)))
