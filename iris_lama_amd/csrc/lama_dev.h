@@ -81,9 +81,7 @@ struct DevParams {
     uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
     uint32_t* slow;        // [P] 1 = a stage handed this particle to the next (bigger / slower) stage
     uint32_t* slow_list;   // [2][P] particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
-    uint32_t* slow_n;      // [3]    ... and how many ([0] brushfire, [1] replay); [2]: pop-budget tickets taken in this update
-    uint32_t pop_budget;   //        first brushfire stage, budget form: pops after which a workgroup asks for a ticket to the resume stage ...
-    uint32_t budget_cap;   //        ... and how many tickets there are
+    uint32_t* slow_n;      // [2]    ... and how many
     uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
     uint32_t* act_count;   // [P]
     uint64_t* occ_hit;     // [P][occ_cap][16] one bit per occupancy cell: hit in the current scan (all zero between scans)

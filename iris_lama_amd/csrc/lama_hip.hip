@@ -83,8 +83,6 @@ struct lama_hip_ctx {
     uint64_t* d_dbg = nullptr;
     uint32_t* d_slow = nullptr;
     uint32_t* d_slow_list = nullptr; uint32_t* d_slow_n = nullptr;      // hand-over list of the brushfire's first stage
-    uint32_t pop_budget = 0, budget_cap = 0;                            // pop budget of the brushfire's first stage (0: none), from the previous update's chains
-    bool budget_forced = false;                                         // LAMA_HIP_BF_BUDGET=pops,cap (tests / experiments)
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
@@ -190,7 +188,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
-    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.pop_budget = c->pop_budget; p.budget_cap = c->budget_cap;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
@@ -280,21 +278,6 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             uint64_t mx = 0, sum = 0; uint32_t arg = 0;
             for (uint32_t p = 0; p < c->P; ++p) { sum += st[4 * p + 3]; if (st[4 * p + 3] > mx) { mx = st[4 * p + 3]; arg = p; } }
             c->ctr.bf_longest_chain_sum += mx; c->ctr.bf_longest_chain_last = mx;
-            // Pop budget of the next update's first brushfire stage (k_brushfire, BUDGET): on a full chip (>= 4 wave pairs per CU) the
-            // few longest chains are moved to the resume stage, where each has a CU to itself, once they have done 1.1 times the
-            // pops of the previous update's (tickets)-th longest chain -- so that about that many ask for a ticket.
-            if (!c->budget_forced) {
-                c->pop_budget = 0; c->budget_cap = 0;
-                if (c->P >= 1024 && mx > 0) {
-                    const uint32_t tickets = std::min<uint32_t>(192u, c->P / 16u);
-                    std::vector<uint64_t> v(c->P);
-                    for (uint32_t p = 0; p < c->P; ++p) v[p] = st[4 * p + 3];
-                    std::nth_element(v.begin(), v.begin() + (c->P - tickets), v.end());
-                    const uint64_t kth = v[c->P - tickets];
-                    c->pop_budget = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kth + kth / 10, 1024), 0x7FFFFFFFull);
-                    c->budget_cap = tickets;
-                }
-            }
             if (std::getenv("LAMA_HIP_DEBUG_TAIL")) std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire);
         }
         if (maps) return grow_arenas(c);
@@ -583,7 +566,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        (void)hipMemsetAsync(c->d_slow_n, 0, 3 * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->d_slow_n, 0, 2 * sizeof(uint32_t), c->stream);
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
@@ -655,13 +638,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         c->ctr.brushfire_waves = two_waves ? 2u : 1u;
         const unsigned resume_grid = std::min<unsigned>(count, 256u);      // workgroups that walk the hand-over list (usually empty)
         if (two_waves) {
-            if (prm.pop_budget) {
-                // budget form: the longest chains leave the first stage early and continue, one per CU, in a second pass of the SAME
-                // small-queue kernel over the hand-over list (what does not fit its queues is passed on to the big stage as before)
-                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-            }
-            else hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
         } else {
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
@@ -733,11 +710,6 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->ctr.window_patches = c->W;
-    if (const char* bb = std::getenv("LAMA_HIP_BF_BUDGET")) {     // "pops,tickets": fixed pop budget of the first brushfire stage (tests, experiments); "0": never
-        unsigned bp = 0, bc = 0;
-        const int nf = std::sscanf(bb, "%u,%u", &bp, &bc);
-        if (nf >= 1) { c->budget_forced = true; c->pop_budget = bp; c->budget_cap = nf == 2 ? bc : 0u; }
-    }
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
     // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)

@@ -1136,32 +1136,27 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
 // push_heap of the mailbox entries ent[0 .. cnt) (cnt <= 4, in order) by the helper wave: one gather of all would-be parents; when
 // no new entry has to move up (the normal case in a Dijkstra wave) they are appended, which is what the sequential push_heap calls
 // would have done; else those calls are replayed one by one.
-// FLAG: bit 31 of the count word is the main wave's "this was the last iteration" (pop budget, see bf_particle); returns the word.
-template <bool FLAG = false>
-__device__ __forceinline__ uint32_t lds_push_flat(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t* cnt_p, const int lane, uint64_t* dummy)
+__device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t* cnt_p, const int lane, uint64_t* dummy)
 {
     const uint32_t l4 = (uint32_t)lane & 3u;
     const uint64_t entry = ent[l4];                                  // count, entries and would-be parents: ONE LDS round trip
     const uint32_t pos = n + l4;
     const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
-    const uint32_t cnt_w = *cnt_p;
-    const uint32_t cnt_v = FLAG ? (cnt_w & 0x7FFFFFFFu) : cnt_w;
+    const uint32_t cnt_v = *cnt_p;
     const bool mine = (uint32_t)lane < cnt_v;
     const bool up = mine && pprio > heap_prio(entry);
     const unsigned long long upm = __ballot(up);
-    const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_w);
-    const uint32_t cnt = FLAG ? (word & 0x7FFFFFFFu) : word;
-    if (cnt == 0) return word;
+    const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
+    if (cnt == 0) return;
     if (n >= 4 && upm == 0ull) {
         uint64_t* dst = mine ? heap + pos : dummy;
         *dst = entry;
         n += cnt;
         LAMA_LOCKSTEP();
-        return word;
+        return;
     }
     #pragma unroll 1
     for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
-    return word;
 }
 
 // push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
@@ -1231,12 +1226,7 @@ __device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool f
 }
 
 // the brushfire of ONE particle by the calling workgroup (body of k_brushfire)
-// BUDGET (first stage of the wave pair on a full chip): a map update lasts as long as the LONGEST chain of the pool, and that chain
-// runs a quarter slower while it shares its CU with eleven other wave pairs -- and a particle whose queue outgrew the first stage
-// waits for all of it to end.  With a pop budget (the host derives it from the previous update's chain lengths so that few chains
-// exceed it) a workgroup that reaches it takes a ticket; the first prm.budget_cap of them hand their particle over, state intact,
-// exactly like a queue overflow: the first stage ends early and the few long chains continue in the resume stage, one per CU.
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool BUDGET = false>
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_any, BfLds<LQ_LDS, RQ_LDS>& sh)
 {
     const int p = __builtin_amdgcn_readfirstlane(p_any);      // wave-uniform (the resume stage reads it from the hand-over list): scalar base addresses
@@ -1309,10 +1299,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             HFT(0);
             lds_barrier();                                     // D
             HFT(1);
-            const uint32_t word = lds_push_flat<BUDGET>(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
+            lds_push_flat(sh.lower, hnl, sh.pl_e[b], &sh.pl_n[b], lane, dmy);
             HFT(2);
             ++it;
-            if (BUDGET && (word >> 31)) break;                 // the main wave stops here (pop budget): so do I
             if (hnl - 1u >= LOWER_CAP - 4u) break;   // empty, or about to outgrow the LDS window (in the lower phase the idle raise queue behind it is part of it)
         }
 #ifdef LAMA_PROFILE_BF
@@ -1531,7 +1520,46 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 }
             }
             if (__builtin_expect(general, 0)) general_raise(e, cnt_r, cnt_l, entry, rm);
-            BF_TW_TAIL(true, nr, cnt_r, cnt_l, entry, rm)
+            // ---- hand-over (see the lower wave): both counts in one LDS store, meet the helper, next top = the raise heap's root after
+            // pop() unless one of my own raise pushes beats it -- push_heap lifts an entry above its parent only if the parent's
+            // priority is strictly greater, so the first of my smallest pushes becomes the root iff its priority is smaller than the
+            // root's.  (A raise wave's pushes are not ordered against the popped cell: no shortcut as in the lower wave.)
+            {
+                const uint32_t b_ = tw_it & 1u;
+                uint32_t* np = lane == 0 ? &sh.pr_n[b_] : (lane == 1 ? &sh.pl_n[b_] : (uint32_t*)dmy);
+                *np = lane == 0 ? cnt_r : cnt_l;
+                lds_barrier();                                     // D
+                const uint64_t root_ = sh.topq[b_];
+                const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)root_), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(root_ >> 32));
+                const bool have_root = nr > 0;
+                uint64_t cand_ = ((uint64_t)rhi << 32) | rlo;
+                if (cnt_r > 0) {
+                    uint32_t key = (lane < 4 && ((rm >> lane) & 1u)) ? ((heap_prio(entry) << 2) | (uint32_t)lane) : 0xFFFFFFFFu;
+                    uint32_t blo = (uint32_t)entry, bhi = (uint32_t)(entry >> 32);
+#define BF_QUAD_MIN(CTRL)                                                                                              \
+                    {                                                                                                  \
+                        const uint32_t k2 = (uint32_t)__builtin_amdgcn_update_dpp((int)key, (int)key, CTRL, 0xF, 0xF, false); \
+                        const uint32_t l2 = (uint32_t)__builtin_amdgcn_update_dpp((int)blo, (int)blo, CTRL, 0xF, 0xF, false); \
+                        const uint32_t h2 = (uint32_t)__builtin_amdgcn_update_dpp((int)bhi, (int)bhi, CTRL, 0xF, 0xF, false); \
+                        const bool t_ = k2 < key;                                                                      \
+                        key = t_ ? k2 : key; blo = t_ ? l2 : blo; bhi = t_ ? h2 : bhi;                                 \
+                    }
+                    BF_QUAD_MIN(0xB1)                              // quad_perm [1,0,3,2]
+                    BF_QUAD_MIN(0x4E)                              // quad_perm [2,3,0,1]
+#undef BF_QUAD_MIN
+                    const uint32_t okey = (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+                    const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
+                    if (!have_root || (okey >> 2) < (rhi >> 16)) cand_ = ((uint64_t)ohi << 32) | olo;
+                }
+                nr += cnt_r; nl += cnt_l;
+                spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
+                tw_running = !spill && (nr > 0 || nl > 0);
+                if (tw_running) {
+                    if (nr == 0) { lds_barrier(); /* X: the helper has applied the pushes */ e_next = sh.lower[0]; }
+                    else e_next = cand_;
+                }
+                ++tw_it;
+            }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
     }
@@ -1680,18 +1708,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             return (uint32_t)__popcll(om);
         };
 
-        uint32_t budget = BUDGET ? prm.pop_budget : 0xFFFFFFFFu;
         if (tw_running && nl > 0) for (;;) {
             const uint64_t e = e_next;                                     // the same value in every lane
             ++processed;
             --nl;                                                          // the helper wave pops
-            uint32_t stopbit = 0;
-            if (BUDGET && __builtin_expect(tw_it >= budget, 0)) {          // once per particle: a ticket to the resume stage, or none
-                uint32_t t = 0;
-                if (lane == 0) t = atomicAdd(prm.slow_n + 2, 1u);
-                t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-                if (t < prm.budget_cap) stopbit = 0x80000000u; else budget = 0xFFFFFFFFu;
-            }
             uint32_t cnt = 0;
             bool general;
             uint32_t floor_sq = 0;                                         // every push of this pop has a priority above this
@@ -1807,7 +1827,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             {
                 const uint32_t b_ = tw_it & 1u;
                 uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)dmy;
-                *np = BUDGET ? (cnt | stopbit) : cnt;
+                *np = cnt;
                 BFT_MAIN(5); BFF(6);
                 lds_barrier();                                     // D
                 BFT_MAIN(6);
@@ -1839,7 +1859,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             BFT(4); BFF(7);
             // the queue is empty, or would outgrow its LDS window (the helper wave takes the same decision): one scalar test
-            if (nl - 1u >= LOWER_CAP - 4u || (BUDGET && stopbit != 0u)) { spill = nl != 0u; tw_running = false; break; }
+            if (nl - 1u >= LOWER_CAP - 4u) { spill = nl != 0u; tw_running = false; break; }
         }
     }
     // ---- lower wave ------------------------------------------------------------------------- :175-194
@@ -2011,7 +2031,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 // big LDS queues (84 KB: one workgroup per CU).  That stage is launched with a SMALL grid whose workgroups walk the list: with an
 // empty list (the normal case) it costs a few microseconds; launched with one workgroup per particle it cost 1.2 ms at 3000
 // particles for doing nothing (12 rounds of one 84 KB workgroup per CU, rocprofv3 r03).
-template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW, bool BUDGET = false>
+template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
@@ -2020,7 +2040,7 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #ifdef LAMA_PROFILE_BF                                   // where and when this particle ran (constant 100 MHz counter)
         uint64_t rt0; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt0));
 #endif
-        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW, BUDGET>(prm, first_particle + (int)blockIdx.x, sh);
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, first_particle + (int)blockIdx.x, sh);
 #ifdef LAMA_PROFILE_BF
         if (threadIdx.x == 0) {
             uint64_t rt1; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(rt1));

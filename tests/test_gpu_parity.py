@@ -46,16 +46,6 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
     _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode)
 
 
-def test_pop_budget_of_the_first_brushfire_stage(F, monkeypatch):
-    """On a full chip the first brushfire stage runs with a pop budget: the few longest chains take a ticket and continue in the
-    resume stage, one per CU (k_brushfire BUDGET).  Forced here on 16 particles with a budget of 300 pops and 5 tickets: five
-    particles per update are handed over in the middle of their lower wave, the others ask, get no ticket and finish in place --
-    scan match and maps as exact as without it."""
-    monkeypatch.setenv("LAMA_HIP_BF_BUDGET", "300,5")
-    c = _stagewise(F, 16, 6, 0, 2, 0)
-    assert c["brushfire_handovers"] >= 5 * 6, c
-
-
 def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)

@@ -91,15 +91,6 @@ def test_hand_over_to_the_resume_stage_in_the_middle_of_an_update(Fsim_smallq, w
     _run(Fsim_smallq, 2, 2, brushfire_waves=waves)
 
 
-def test_pop_budget_moves_long_chains_to_the_resume_stage(Fsim, monkeypatch):
-    """Pop budget of the wave pair's first stage (k_brushfire BUDGET: on a full chip the longest chains continue in the resume stage,
-    one per CU): with a budget of 150 pops and one ticket, one of the two particles is handed over in the middle of its lower wave,
-    the other one asks for a ticket, gets none and finishes where it is -- maps bit-exact either way."""
-    monkeypatch.setenv("LAMA_HIP_BF_BUDGET", "150,1")
-    c = _run(Fsim, 2, 2)
-    assert c["brushfire_handovers"] >= 2 and c["brushfire_waves"] == 2, c
-
-
 @pytest.mark.parametrize("seq_ray", [0, 1])
 def test_update_that_runs_out_of_patches_is_repeated_after_growth(Fsim, seq_ray):
     """Arenas of 8 patches against a first scan that needs ~55 / ~70: the allocation phase (hit cells, ray patches, the bound on the
