@@ -1088,6 +1088,8 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
     bool root_value = true;                                          // ... else the re-inserted entry is the new root (wave-uniform)
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
+        // (a later round is skipped -- one scalar branch -- when the descent has stopped or the heap ends above its levels)
+        if (r > 0 && (go == 0u || ((H << 1) + 1u) >= len)) break;
         const uint32_t idx = (H << d) + (uint32_t)lane;              // lane L: the node at relative position L below H
         const uint32_t lm1 = idx - 2u - leftm;                       // (left child of my parent) - 1: idx - 1 for a left child, idx - 2 for a right one
         const uint32_t parent = lm1 >> 1;
