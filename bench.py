@@ -413,7 +413,8 @@ def main():
     def effective_modes(c):
         return {"brushfire_mode": c["brushfire_mode"], "brushfire_waves": c["brushfire_waves"],
                 "sequential_raycast_scans": c["sequential_raycast_scans"], "parallel_raycast_scans": c["parallel_raycast_scans"],
-                "brushfire_handovers": c["brushfire_handovers"], "replay_handovers": c["replay_handovers"]}
+                "brushfire_handovers": c["brushfire_handovers"], "replay_handovers": c["replay_handovers"],
+                "brushfire_routed": c["brushfire_routed"]}
 
     # `value` comes from a pass WITHOUT the per-kernel hipEvent brackets (they cost two extra device-to-host copies and four
     # event records per step); the kernel breakdown and the roofline durations come from a second pass of the same K steps
@@ -581,7 +582,8 @@ def main():
                              "raycast_ms": cc["ms_raycast"] / max(cc["launches_raycast"], 1),
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1),
-                             "brushfire_chains": chain_spread(cc, P)}
+                             "brushfire_chains": chain_spread(cc, P), "brushfire_handovers": cc["brushfire_handovers"],
+                             "brushfire_routed": cc["brushfire_routed"]}
             if base and "bytes" in base:       # same log, same per-particle footprint: the P = 30 byte counts apply
                 bf_s = cc["ms_brushfire"] / max(cc["launches_brushfire"], 1) * 1e-3
                 extra[str(P)]["roofline_frac_brushfire"] = base["bytes"]["brushfire"] * P / bf_s / 1e9 / HBM_PEAK_GBS

@@ -291,6 +291,8 @@ typedef struct lama_hip_counters {
                                            brushfire is one serial chain, so a map update lasts as long as its longest chain --
                                            bf_longest_chain_sum / map updates against bf_cells / (particles x map updates) is the spread   */
     uint64_t bf_longest_chain_last;     /* the largest per-particle count of the last map update                                           */
+    uint64_t brushfire_routed;          /* particle updates whose brushfire ran in the big-queue stage from the start, beside the first stage:
+                                           their obstacle-event count (known before the brushfire starts) marked them as the long chains   */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);

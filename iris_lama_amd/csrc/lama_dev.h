@@ -80,8 +80,9 @@ struct DevParams {
     uint64_t* q_raise;     // [P][qcap]
     uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
     uint32_t* slow;        // [P] 1 = a stage handed this particle to the next (bigger / slower) stage
-    uint32_t* slow_list;   // [2][P] particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
-    uint32_t* slow_n;      // [2]    ... and how many
+    uint32_t* slow_list;   // [3][P] ([2]: the routed particles) particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
+    uint32_t* slow_n;      // [3]    ... and how many; [2]: particles routed to the big-queue stage before the brushfire started (k_bf_route)
+    uint8_t* heavy;        // [P]    1 = routed: the first brushfire stage skips the particle (nullptr: routing is off)
     uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
     uint32_t* act_count;   // [P]
     uint64_t* occ_hit;     // [P][occ_cap][16] one bit per occupancy cell: hit in the current scan (all zero between scans)

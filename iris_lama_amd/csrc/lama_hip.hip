@@ -83,6 +83,10 @@ struct lama_hip_ctx {
     uint64_t* d_dbg = nullptr;
     uint32_t* d_slow = nullptr;
     uint32_t* d_slow_list = nullptr; uint32_t* d_slow_n = nullptr;      // hand-over list of the brushfire's first stage
+    // routing of the long brushfire chains (k_bf_route): second stream + events for the big-queue stage that runs beside the first one
+    uint8_t* d_heavy = nullptr;
+    hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
+    uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
@@ -188,7 +192,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
-    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.heavy = nullptr;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
@@ -247,9 +251,9 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
         HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-    if (maps) { c->h_slow_n.resize(2); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
+    if (maps) { c->h_slow_n.resize(3); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1]; }
+    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1]; c->ctr.brushfire_routed += c->h_slow_n[2]; }
     if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
     if (e != 0) {
@@ -566,7 +570,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        (void)hipMemsetAsync(c->d_slow_n, 0, 2 * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->d_slow_n, 0, 3 * sizeof(uint32_t), c->stream);
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
@@ -637,12 +641,29 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
         c->ctr.brushfire_mode = c->cfg.brushfire_mode;
         c->ctr.brushfire_waves = two_waves ? 2u : 1u;
         const unsigned resume_grid = std::min<unsigned>(count, 256u);      // workgroups that walk the hand-over list (usually empty)
+        // the long chains are known before they start (k_bf_route): they go to the big-queue stage on a second stream, beside the
+        // first stage (which skips them), instead of outgrowing it half-way and waiting for it to end
+        const bool route = two_waves && count >= c->route_min_count && c->route_cap > 0;
         if (two_waves) {
-            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
-            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first);
+            if (route) {
+                // The big-queue workgroups (84 KB of LDS each) must be placed BEFORE the first stage fills every CU's LDS, or they wait
+                // for a third of it to finish: their kernel follows k_bf_route directly in this stream, the first stage goes to the
+                // second stream behind an event -- the cross-queue signal is what makes it the later dispatch.
+                prm.heavy = c->d_heavy;
+                hipLaunchKernelGGL(k_bf_route, dim3(1), dim3(256), 0, c->stream, prm, (int)first, (int)count, c->route_min_events, c->route_percent, c->route_cap);
+                HIPCHK(c, hipEventRecord(c->ev_route, c->stream));
+                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(std::min<unsigned>(c->route_cap, 256u)), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 1);
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_route, 0));
+                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream2, prm, (int)first, 0);
+                HIPCHK(c, hipEventRecord(c->ev_heavy, c->stream2));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_heavy, 0));
+            } else {
+                hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 0);
+            }
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 0);
         } else {
-            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
-            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+            hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 0);
+            hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 0);
         }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         t.stop();
@@ -710,6 +731,10 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->ctr.window_patches = c->W;
+    if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
+        unsigned a = 0, b = 0, pc = 0, d = 0;
+        if (std::sscanf(rr, "%u,%u,%u,%u", &a, &b, &pc, &d) == 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); }
+    }
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
     // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)
@@ -746,7 +771,10 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
-    CHK(hipMalloc(&c->d_slow_list, 2 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 2 * P * 4));
+    CHK(hipMalloc(&c->d_slow_list, 3 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 3 * P * 4));
+    CHK(hipMalloc(&c->d_heavy, P));                  CHK(hipMemset(c->d_heavy, 0, P));
+    CHK(hipStreamCreate(&c->stream2));
+    CHK(hipEventCreateWithFlags(&c->ev_route, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
     CHK(hipMalloc(&c->d_slow_n, 16));                CHK(hipMemset(c->d_slow_n, 0, 16));
     CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
     CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
@@ -774,7 +802,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -782,6 +810,9 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->ev_route) (void)hipEventDestroy(c->ev_route);
+    if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
     delete c;
 }
 
@@ -1360,8 +1391,8 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
     HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
-    hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);
-    hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle);
+    hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
+    hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
     hipLaunchKernelGGL(k_brushfire_slow, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
     HIPCHK(c, hipGetLastError());
     int32_t rc = check_device_errors(c, true, false);

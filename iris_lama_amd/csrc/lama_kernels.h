@@ -1232,6 +1232,7 @@ template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_any, BfLds<LQ_LDS, RQ_LDS>& sh)
 {
     const int p = __builtin_amdgcn_readfirstlane(p_any);      // wave-uniform (the resume stage reads it from the hand-over list): scalar base addresses
+    if (!RESUME && prm.heavy != nullptr && prm.heavy[p] != 0) return;   // routed to the big-queue stage, which runs beside this one (k_bf_route)
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
@@ -2033,8 +2034,42 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 // big LDS queues (84 KB: one workgroup per CU).  That stage is launched with a SMALL grid whose workgroups walk the list: with an
 // empty list (the normal case) it costs a few microseconds; launched with one workgroup per particle it cost 1.2 ms at 3000
 // particles for doing nothing (12 rounds of one 84 KB workgroup per CU, rocprofv3 r03).
+// A map update lasts as long as the LONGEST brushfire chain of the pool, and how long a particle's chain will be is known before it
+// starts: it is proportional to the number of obstacle events the ray-cast queued (typical particles of the corridor log: 30-55
+// events, ~2,000 pops; the ones whose pose has drifted: 70-300 events, 6,000-13,000 pops -- and those are also the ones whose queue
+// outgrows the first stage, after which they used to wait for ALL of it to end).  k_bf_route (one workgroup) marks the particles
+// with more than 1.5 times the pool's mean number of events (at most `cap`) and lists them; the host launches the big-queue stage
+// for that list on a second stream BESIDE the first stage, which skips them: the long chains start at once, one per CU.
+__global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_particle, int count, uint32_t min_events, uint32_t percent, uint32_t cap)
+{
+    __shared__ uint32_t part[256];
+    const int tid = threadIdx.x;
+    if (map_update_aborted(prm)) { for (int i = tid; i < count; i += 256) prm.heavy[first_particle + i] = 0; return; }
+    uint32_t sum = 0;
+    for (int i = tid; i < count; i += 256) { const int p = first_particle + i; sum += prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]; }
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) part[tid] += part[tid + off]; __syncthreads(); }
+    const uint32_t mean = part[0] / (uint32_t)count;
+    const uint32_t scaled = (uint32_t)(((uint64_t)mean * percent) / 100u);
+    const uint32_t thr = scaled > min_events ? scaled : min_events;
+    for (int i = tid; i < count; i += 256) {
+        const int p = first_particle + i;
+        const uint32_t q = prm.qsizes[2 * p] + prm.qsizes[2 * p + 1];
+        uint8_t h = 0;
+        if (q > thr) {
+            const uint32_t k = atomicAdd(prm.slow_n + 2, 1u);
+            if (k < cap) { h = 1; prm.slow[p] = 1; prm.slow_list[2 * (size_t)prm.P + k] = (uint32_t)p; }
+        }
+        prm.heavy[p] = h;
+    }
+    __syncthreads();
+    if (tid == 0 && prm.slow_n[2] > cap) prm.slow_n[2] = cap;         // (more candidates than places: the others stay in the first stage)
+}
+
+// `routed` (resume stages only): walk the list of the routed particles (k_bf_route) instead of the first stage's hand-over list
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
-__global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle)
+__global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle, int routed = 0)
 {
     __shared__ BfLds<LQ_LDS, RQ_LDS> sh;
     if (!RESUME) {
@@ -2053,9 +2088,10 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #endif
         return;
     }
-    const uint32_t n = prm.slow_n[0];
+    const uint32_t n = routed ? prm.slow_n[2] : prm.slow_n[0];
+    const uint32_t* list = prm.slow_list + (routed ? 2 * (size_t)prm.P : 0);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)prm.slow_list[i], sh);
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)list[i], sh);
         __syncthreads();                                 // every wave is done with this particle's LDS before the next one is loaded
     }
 }

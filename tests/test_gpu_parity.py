@@ -46,6 +46,19 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
     _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode)
 
 
+@pytest.mark.parametrize("route", ["1,0,110,8", "1,0,0,256", "1000000,0,150,64"])
+def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
+    """k_bf_route: particles with many more obstacle events than the pool's mean are the long brushfire chains; they run in the
+    big-queue stage on a second stream beside the first stage, which skips them.  Forced on 40 particles: (a) threshold 110 % of the
+    mean, 8 places; (b) everybody over the threshold, more candidates than places; (c) routing off -- bit-exact maps in all three."""
+    monkeypatch.setenv("LAMA_HIP_BF_ROUTE", route)
+    c = _stagewise(F, 40, 6, 0, 2, 0)
+    if route.startswith("1,"):
+        assert c["brushfire_routed"] > 0, c
+    else:
+        assert c["brushfire_routed"] == 0, c
+
+
 def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)

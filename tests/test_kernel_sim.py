@@ -91,6 +91,15 @@ def test_hand_over_to_the_resume_stage_in_the_middle_of_an_update(Fsim_smallq, w
     _run(Fsim_smallq, 2, 2, brushfire_waves=waves)
 
 
+def test_long_chains_are_routed_to_the_big_queue_stage(Fsim, monkeypatch):
+    """k_bf_route: the particles with the most obstacle events go to the big-queue brushfire stage before the first stage starts
+    (which skips them).  Forced here on two particles (threshold = 90 % of the mean, one place): in every update one of the two
+    runs its whole brushfire in the big-queue stage -- maps bit-exact."""
+    monkeypatch.setenv("LAMA_HIP_BF_ROUTE", "1,0,90,1")
+    c = _run(Fsim, 2, 2)
+    assert c["brushfire_routed"] >= 2 and c["brushfire_waves"] == 2, c
+
+
 @pytest.mark.parametrize("seq_ray", [0, 1])
 def test_update_that_runs_out_of_patches_is_repeated_after_growth(Fsim, seq_ray):
     """Arenas of 8 patches against a first scan that needs ~55 / ~70: the allocation phase (hit cells, ray patches, the bound on the
