@@ -117,7 +117,8 @@ __device__ inline bool so2_normalize(double& c, double& s)
 __device__ inline SE2 se2_exp_mul(const double h[3], const SE2& st, bool& ok)
 {
     const double theta = h[2];
-    double ec = cos(theta), es = sin(theta);
+    double ec, es;
+    sincos(theta, &es, &ec);                    // (one range reduction for both: the step runs on a single lane)
     ok = so2_normalize(ec, es) && ok;
     double a, b;   // sin(theta)/theta, (1-cos(theta))/theta
     if (fabs(theta) < 1e-10) {
@@ -144,7 +145,8 @@ __device__ inline SE2 se2_exp_mul(const double h[3], const SE2& st, bool& ok)
 __device__ inline Affine scan_tf(const SE2& st, const Affine& m)
 {
     const double theta = atan2(st.s, st.c);
-    const double sn = sin(theta), cs = cos(theta);
+    double sn, cs;
+    sincos(theta, &sn, &cs);
     const double F[3][3] = {{cs, 0.0 - sn, 0.0}, {sn, cs, 0.0}, {0.0, 0.0, (1.0 - cs) + cs}};
     const double ft[3] = {st.tx, st.ty, 0.0};
     Affine r;
