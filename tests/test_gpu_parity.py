@@ -28,10 +28,12 @@ def F():
     return f
 
 
-def _perturbed(rng, base, P, sxy=0.03, sth=0.01):
+def _perturbed(rng, base, P, sxy=0.03, sth=0.01, drifted=0):
+    """P poses around `base`; the last `drifted` of them with four times the noise (the particles whose brushfire chains are long)"""
     out = np.zeros((P, 4))
     for i in range(P):
-        out[i] = O.se2_mul(base, O.se2(rng.normal(0, sxy), rng.normal(0, sxy), rng.normal(0, sth)))
+        k = 4.0 if i >= P - drifted else 1.0
+        out[i] = O.se2_mul(base, O.se2(rng.normal(0, k * sxy), rng.normal(0, k * sxy), rng.normal(0, k * sth)))
     return out
 
 
@@ -59,7 +61,37 @@ def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
         assert c["brushfire_routed"] == 0, c
 
 
-def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode):
+def test_drifted_poses_long_chains_default_routing(F):
+    """72 particles mapped WITHOUT scan matching, six of them from poses off by up to ~25 cm / 9 degrees: those re-draw walls and
+    remove others in every update (long raise waves, queues that outgrow the first brushfire stage), and the default routing (>= 64
+    particles) sends them -- the particles with the most obstacle events -- to the big-queue stage: maps bit-exact, and the counters
+    show that the path ran."""
+    P, steps = 72, 6
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    rng = np.random.default_rng(11)
+    pf = O.PF(O.default_options(particles=P, seed=7))
+    pose0 = O.se2(*odom[0])
+    pf.set_prior(pose0)
+    assert pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    ctx.init(pts[0], pose0)
+    for k in range(1, steps + 1):
+        poses = _perturbed(rng, O.se2(*truth[k]), P, 0.02, 0.006, drifted=6)
+        pf.set_poses(poses)
+        pf.stage_set_scan(pts[k])
+        pf.stage_update_maps()
+        ctx.set_poses(poses)
+        ctx.update_maps(pts[k])
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    c = ctx.counters()
+    ctx.close()
+    print("counters", c)
+    assert c["brushfire_routed"] > 0 and c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
+
+
+def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
     opts = O.default_options(particles=P, seed=7)
@@ -77,7 +109,7 @@ def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode):
     flips = 0
     for k in range(1, steps + 1):
         base = O.se2(*truth[k])
-        start = _perturbed(rng, base, P)
+        start = _perturbed(rng, base, P, sxy, sth, drifted)
         # ---- stage (i): scan match on identical maps + identical start poses
         pf.set_poses(start)
         pf.set_weights(w=np.zeros(P), ws=np.zeros(P))
