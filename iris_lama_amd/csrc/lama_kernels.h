@@ -388,8 +388,10 @@ __device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, co
 // ------------------------------------------------------------------------------------------------
 // k_scan_match: PFSlam2D::scanMatch (src/pf_slam2d.cpp:416-437) for every particle of the shard.
 // ------------------------------------------------------------------------------------------------
+// (128 VGPRs: four waves per SIMD.  Left alone the allocator takes 136 since the single-lane step calls sincos -- three waves per SIMD,
+// +50 % at 3000 particles -- for 2 us at 30.)
 template <bool BIGSQ>
-__global__ __launch_bounds__(SM_BLOCK) void k_scan_match(DevParams prm, const double* __restrict__ pts, int n, Affine mtf,
+__global__ __launch_bounds__(SM_BLOCK) __attribute__((amdgpu_num_vgpr(128))) void k_scan_match(DevParams prm, const double* __restrict__ pts, int n, Affine mtf,
                                                           double* __restrict__ loglik_out, int32_t* __restrict__ iters_out)
 {
     __shared__ SMShared sh;
