@@ -291,6 +291,8 @@ typedef struct lama_hip_counters {
                                            brushfire is one serial chain, so a map update lasts as long as its longest chain --
                                            bf_longest_chain_sum / map updates against bf_cells / (particles x map updates) is the spread   */
     uint64_t bf_longest_chain_last;     /* the largest per-particle count of the last map update                                           */
+    uint64_t brushfire_early;           /* ... of which: particles the PREVIOUS update had routed and that therefore ran their ray-cast and their
+                                           brushfire in the early lane, ahead of everybody else's ray-cast (counted in brushfire_routed too)   */
     uint64_t brushfire_routed;          /* particle updates whose brushfire ran in the big-queue stage from the start, beside the first stage:
                                            their obstacle-event count (known before the brushfire starts) marked them as the long chains   */
 } lama_hip_counters;

@@ -80,9 +80,15 @@ struct DevParams {
     uint64_t* q_raise;     // [P][qcap]
     uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
     uint32_t* slow;        // [P] 1 = a stage handed this particle to the next (bigger / slower) stage
-    uint32_t* slow_list;   // [3][P] ([2]: the routed particles) particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
-    uint32_t* slow_n;      // [3]    ... and how many; [2]: particles routed to the big-queue stage before the brushfire started (k_bf_route)
+    uint32_t* slow_list;   // [4][P] ([2]: the routed particles, [3]: replay hand-overs of the early lane) particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
+    uint32_t* slow_n;      // [5]    ... and how many; [2]: particles routed to the big-queue stage before the brushfire started (k_bf_route); [3]: early lane's replay hand-overs; [4]: early-lane particles
     uint8_t* heavy;        // [P]    1 = routed: the first brushfire stage skips the particle (nullptr: routing is off)
+    // early lane (k_early_list): the particles that were routed in the PREVIOUS update are usually the long chains again; their
+    // modifying ray-cast kernels and their brushfire run on a stream of their own, ahead of everybody else's
+    const uint32_t* elist;   // [cap] this launch belongs to the early lane: its particles ... (nullptr: main lane)
+    const uint32_t* elist_n; //       ... and how many
+    const uint8_t* early;    // [P]   main lane: 1 = the particle is in the early lane, skip it (nullptr: there is none)
+    uint32_t lane;           //       0 main / 1 early: which hand-over segment the ordered replay uses
     uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
     uint32_t* act_count;   // [P]
     uint64_t* occ_hit;     // [P][occ_cap][16] one bit per occupancy cell: hit in the current scan (all zero between scans)
@@ -97,6 +103,16 @@ struct DevParams {
     uint32_t strategy;     // 0 = GaussNewton, 1 = LevenbergMarquard (cfg.solver_strategy; Slam2D / Loc2D "lm")
     double lo_miss, lo_hit, lo_min, lo_max;   // ProbabilisticOccupancyMap parameters (float-rounded, as the reference stores them)
 };
+
+// the particle of workgroup `bx` of a per-particle launch: early-lane launches walk their list, main-lane launches skip the early
+// lane's particles; -1: nothing to do
+__device__ inline int lane_particle(const DevParams& prm, int first_particle, int bx)
+{
+    if (prm.elist) return bx < (int)*prm.elist_n ? (int)prm.elist[bx] : -1;
+    const int p = first_particle + bx;
+    return (prm.early && prm.early[p]) ? -1 : p;
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // SE2 (unit complex + translation): include/lama/sophus/so2.hpp:168-176,205-214,322-324;

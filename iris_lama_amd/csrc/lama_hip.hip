@@ -85,6 +85,12 @@ struct lama_hip_ctx {
     uint32_t* d_slow_list = nullptr; uint32_t* d_slow_n = nullptr;      // hand-over list of the brushfire's first stage
     // routing of the long brushfire chains (k_bf_route): second stream + events for the big-queue stage that runs beside the first one
     uint8_t* d_heavy = nullptr;
+    // early lane: the particles routed in the previous update (d_heavy still holds them; valid while the particle set is unchanged)
+    uint8_t* d_early = nullptr; uint32_t* d_elist = nullptr;
+    hipStream_t stream3 = nullptr; hipEvent_t ev_alloc = nullptr, ev_go = nullptr, ev_early = nullptr;
+    bool early_ok = false;            // the last map update routed over the whole pool and nothing has permuted the particles since
+    uint32_t early_candidates = 0;    // routed + early-lane particles of the last map update (none: the early lane is not even launched)
+    uint32_t early_on = 1;            // LAMA_HIP_BF_ROUTE's fifth number (0: no early lane)
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
@@ -192,7 +198,7 @@ DevParams make_params(const lama_hip_ctx* c, int which)
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
-    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.heavy = nullptr;
+    p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.heavy = nullptr; p.elist = nullptr; p.elist_n = nullptr; p.early = nullptr; p.lane = 0;
     p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
@@ -251,9 +257,9 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
         HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-    if (maps) { c->h_slow_n.resize(3); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
+    if (maps) { c->h_slow_n.resize(5); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1]; c->ctr.brushfire_routed += c->h_slow_n[2]; }
+    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1] + c->h_slow_n[3]; c->ctr.brushfire_routed += c->h_slow_n[2] + c->h_slow_n[4]; c->ctr.brushfire_early += c->h_slow_n[4]; c->early_candidates = c->h_slow_n[2] + c->h_slow_n[4]; }
     if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
     if (e != 0) {
@@ -566,11 +572,12 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
     HIPCHK(c, hipMemcpyAsync(c->d_tfs, tfs.data(), sizeof(double) * tfs.size(), hipMemcpyHostToDevice, c->stream));
     DevParams prm = make_params(c, c->cur);
+    bool early_lane = false;
     {
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
         (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        (void)hipMemsetAsync(c->d_slow_n, 0, 3 * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->d_slow_n, 0, 5 * sizeof(uint32_t), c->stream);
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
@@ -614,8 +621,38 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL(k_raycast, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first);
         } else {
             // patch-centric visits: a workgroup owns one occupancy patch of one particle, no global atomics on the counters
+            // Early lane: the particles the previous update routed (the long brushfire chains; usually long again) get their modifying
+            // ray-cast kernels and their brushfire on a stream of their own right after the allocation phase -- their chain, which is
+            // what the update waits for, no longer starts behind everybody else's ray-cast.
+            const bool two_waves_e = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
+            early_lane = c->early_ok && c->early_candidates > 0 && c->early_on && two_waves_e && c->cfg.brushfire_mode == 0 && first == 0 && count == c->P &&
+                         count >= c->route_min_count && c->route_cap > 0;
+            if (early_lane)
+                hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, (const uint8_t*)c->d_heavy, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, c->route_cap);
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
+            if (early_lane) {
+                // The early lane's own ray-cast kernels run HERE, on an otherwise idle chip (~0.1 ms for a few particles); its
+                // brushfire goes to a stream of its own.  The main lane's 96 k-workgroup launches must not reach the dispatcher before
+                // the early lane's big-queue workgroups (84 KB of LDS each) are placed -- a saturated chip refills every freed slot
+                // with the saturating kernel's next workgroup and starves them until it has drained -- so the main lane waits for an
+                // event that the early stream records directly in front of its brushfire kernel.
+                DevParams pe = prm;
+                pe.elist = c->d_elist; pe.elist_n = c->d_slow_n + 4; pe.lane = 1;
+                const unsigned eg = c->route_cap;
+                hipLaunchKernelGGL(k_ray_patches, dim3(eg, 128u), dim3(256), 0, c->stream, pe, (const lama_dev::RayRec*)c->d_rrec,
+                                   (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, 0);
+                hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
+                hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
+                HIPCHK(c, hipEventRecord(c->ev_alloc, c->stream));
+                HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_alloc, 0));
+                hipLaunchKernelGGL(k_mark_early, dim3(1), dim3(64), 0, c->stream3, pe);
+                HIPCHK(c, hipEventRecord(c->ev_go, c->stream3));
+                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(eg), dim3(2 * UM_BLOCK), 0, c->stream3, pe, 0, 2);
+                HIPCHK(c, hipEventRecord(c->ev_early, c->stream3));
+                HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_go, 0));
+                prm.early = c->d_early;                          // everybody else: the main lane skips them
+            }
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
                                (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, (int)first);
             const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
@@ -665,7 +702,9 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, false>), dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 0);
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 0);
         }
+        if (early_lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_early, 0));
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
+        c->early_ok = route && first == 0 && count == c->P;      // d_heavy now holds this update's routed particles (early lane included)
         t.stop();
     }
     HIPCHK(c, hipGetLastError());
@@ -732,8 +771,8 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->ctr.window_patches = c->W;
     if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
-        unsigned a = 0, b = 0, pc = 0, d = 0;
-        if (std::sscanf(rr, "%u,%u,%u,%u", &a, &b, &pc, &d) == 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); }
+        unsigned a = 0, b = 0, pc = 0, d = 0, e = 1;
+        if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; }
     }
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
@@ -771,11 +810,16 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
-    CHK(hipMalloc(&c->d_slow_list, 3 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 3 * P * 4));
+    CHK(hipMalloc(&c->d_slow_list, 4 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 4 * P * 4));
     CHK(hipMalloc(&c->d_heavy, P));                  CHK(hipMemset(c->d_heavy, 0, P));
+    CHK(hipMalloc(&c->d_early, P));                  CHK(hipMemset(c->d_early, 0, P));
+    CHK(hipMalloc(&c->d_elist, 256 * 4));            CHK(hipMemset(c->d_elist, 0, 256 * 4));
     CHK(hipStreamCreate(&c->stream2));
+    CHK(hipStreamCreate(&c->stream3));
+    CHK(hipEventCreateWithFlags(&c->ev_alloc, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
+    CHK(hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&c->ev_route, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
-    CHK(hipMalloc(&c->d_slow_n, 16));                CHK(hipMemset(c->d_slow_n, 0, 16));
+    CHK(hipMalloc(&c->d_slow_n, 32));                CHK(hipMemset(c->d_slow_n, 0, 32));
     CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
     CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
@@ -802,7 +846,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -811,6 +855,10 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->stream2) (void)hipStreamDestroy(c->stream2);
+    if (c->stream3) (void)hipStreamDestroy(c->stream3);
+    if (c->ev_alloc) (void)hipEventDestroy(c->ev_alloc);
+    if (c->ev_early) (void)hipEventDestroy(c->ev_early);
+    if (c->ev_go) (void)hipEventDestroy(c->ev_go);
     if (c->ev_route) (void)hipEventDestroy(c->ev_route);
     if (c->ev_heavy) (void)hipEventDestroy(c->ev_heavy);
     delete c;
@@ -912,6 +960,7 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
         if (sample_idx[i] < 0 || (uint32_t)sample_idx[i] >= c->P) return fail(c, LAMA_HIP_E_INVALID, "sample_idx out of range");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int dst = 1 - c->cur;
+    c->early_ok = false;                                            // particle indices change meaning
     HIPCHK(c, hipMemcpyAsync(c->d_idx, sample_idx, sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, c->set[dst].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
     {
@@ -1568,6 +1617,7 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     if (n == 0) return LAMA_HIP_OK;
     for (uint32_t k = 0; k < n; ++k) if (particles[k] >= c->P || !bufs[k] || bytes[k] < (uint64_t)BLOB_HEAD) return LAMA_HIP_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    c->early_ok = false;                                            // other particles sit in these slots now
     // 1. what is coming: the blobs' heads in one copy
     c->h_ship_desc.resize(n);
     for (uint32_t k = 0; k < n; ++k) c->h_ship_desc[k] = ShipDesc{(uint8_t*)const_cast<void*>(bufs[k]), particles[k], 0, 0, 0};

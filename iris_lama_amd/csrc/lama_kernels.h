@@ -1234,7 +1234,8 @@ template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_any, BfLds<LQ_LDS, RQ_LDS>& sh)
 {
     const int p = __builtin_amdgcn_readfirstlane(p_any);      // wave-uniform (the resume stage reads it from the hand-over list): scalar base addresses
-    if (!RESUME && prm.heavy != nullptr && prm.heavy[p] != 0) return;   // routed to the big-queue stage, which runs beside this one (k_bf_route)
+    // routed to the big-queue stage, which runs beside this one (k_bf_route), or a particle of the early lane
+    if (!RESUME && prm.heavy != nullptr && (prm.heavy[p] != 0 || (prm.early != nullptr && prm.early[p] != 0))) return;
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
@@ -2047,17 +2048,21 @@ __global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_parti
     __shared__ uint32_t part[256];
     const int tid = threadIdx.x;
     if (map_update_aborted(prm)) { for (int i = tid; i < count; i += 256) prm.heavy[first_particle + i] = 0; return; }
-    uint32_t sum = 0;
-    for (int i = tid; i < count; i += 256) { const int p = first_particle + i; sum += prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]; }
-    part[tid] = sum;
+    __shared__ uint32_t cnts[256];
+    uint32_t sum = 0, cn = 0;                                  // (the early lane's particles are not in this pool: the first stage skips them too)
+    for (int i = tid; i < count; i += 256) { const int p = first_particle + i; if (prm.early && prm.early[p]) continue; sum += prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]; ++cn; }
+    part[tid] = sum; cnts[tid] = cn;
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) { if (tid < off) part[tid] += part[tid + off]; __syncthreads(); }
-    const uint32_t mean = part[0] / (uint32_t)count;
+    for (int off = 128; off > 0; off >>= 1) { if (tid < off) { part[tid] += part[tid + off]; cnts[tid] += cnts[tid + off]; } __syncthreads(); }
+    const uint32_t mean = part[0] / (cnts[0] ? cnts[0] : 1u);
     const uint32_t scaled = (uint32_t)(((uint64_t)mean * percent) / 100u);
     const uint32_t thr = scaled > min_events ? scaled : min_events;
     for (int i = tid; i < count; i += 256) {
         const int p = first_particle + i;
         const uint32_t q = prm.qsizes[2 * p] + prm.qsizes[2 * p + 1];
+        // an early-lane particle is on its way already (its queue sizes are from before the lane emptied them -- or zero, when the lane
+        // was faster): it keeps its place in the early lane of the NEXT update only while it is still over the threshold
+        if (prm.early && prm.early[p]) { prm.heavy[p] = q > thr ? 1 : 0; continue; }
         uint8_t h = 0;
         if (q > thr) {
             const uint32_t k = atomicAdd(prm.slow_n + 2, 1u);
@@ -2069,7 +2074,28 @@ __global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_parti
     if (tid == 0 && prm.slow_n[2] > cap) prm.slow_n[2] = cap;         // (more candidates than places: the others stay in the first stage)
 }
 
-// `routed` (resume stages only): walk the list of the routed particles (k_bf_route) instead of the first stage's hand-over list
+// early lane: the particles the previous update routed (d_heavy still holds its flags) -> list + skip flags of this update
+__global__ __launch_bounds__(256) void k_early_list(const uint8_t* __restrict__ heavy_prev, uint8_t* __restrict__ early, uint32_t* __restrict__ elist,
+                                                     uint32_t* __restrict__ elist_n, int P, uint32_t cap)
+{
+    for (int p = threadIdx.x; p < P; p += 256) {
+        uint8_t e = 0;
+        if (heavy_prev[p]) { const uint32_t k = atomicAdd(elist_n, 1u); if (k < cap) { e = 1; elist[k] = (uint32_t)p; } }
+        early[p] = e;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && *elist_n > cap) *elist_n = cap;
+}
+// the early lane's particles go to the big-queue brushfire stage directly: flag them as handed over
+__global__ __launch_bounds__(64) void k_mark_early(DevParams prm)
+{
+    if (map_update_aborted(prm)) return;                      // nothing was queued for them: the host grows the arenas and repeats the update
+    const uint32_t n = *prm.elist_n;
+    for (uint32_t i = threadIdx.x; i < n; i += 64) prm.slow[prm.elist[i]] = 1;
+}
+
+// `routed` (resume stages only): 1 = walk the list of the routed particles (k_bf_route) instead of the first stage's hand-over list,
+// 2 = the early lane's list
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle, int routed = 0)
 {
@@ -2090,8 +2116,9 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
 #endif
         return;
     }
-    const uint32_t n = routed ? prm.slow_n[2] : prm.slow_n[0];
-    const uint32_t* list = prm.slow_list + (routed ? 2 * (size_t)prm.P : 0);
+    if (routed == 2 && map_update_aborted(prm)) return;      // (the other lists are empty after an aborted allocation phase; this one is not)
+    const uint32_t n = routed == 2 ? *prm.elist_n : (routed ? prm.slow_n[2] : prm.slow_n[0]);
+    const uint32_t* list = routed == 2 ? prm.elist : prm.slow_list + (routed ? 2 * (size_t)prm.P : 0);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)list[i], sh);
         __syncthreads();                                 // every wave is done with this particle's LDS before the next one is loaded

@@ -334,7 +334,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
     if (n > (uint32_t)SORT_CAP) {                             // hand over to the next (bigger) stage: flag + list entry
         if (threadIdx.x == 0) {
             if (RESUME) atomicOr(prm.err, ERR_QUEUE);
-            else { prm.slow[p] = 1; prm.slow_list[prm.P + atomicAdd(prm.slow_n + 1, 1u)] = (uint32_t)p; }
+            else { const uint32_t seg = prm.lane ? 3u : 1u; prm.slow[p] = 1; prm.slow_list[(size_t)seg * prm.P + atomicAdd(prm.slow_n + seg, 1u)] = (uint32_t)p; }
         }
         return;
     }
@@ -457,10 +457,15 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
 {
     __shared__ ReplayLds<SORT_CAP, EV_CAP> sh;
     if (map_update_aborted(prm)) return;                      // the allocation phase failed: the maps stay untouched (ERR_CLEAN_ABORT)
-    if (!RESUME) { ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, first_particle + (int)blockIdx.x, sh); return; }
-    const uint32_t n = prm.slow_n[1];
+    if (!RESUME) {
+        const int p = lane_particle(prm, first_particle, (int)blockIdx.x);
+        if (p >= 0) ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, p, sh);
+        return;
+    }
+    const uint32_t seg = prm.lane ? 3u : 1u;                  // the lane's own hand-over segment
+    const uint32_t n = prm.slow_n[seg];
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, (int)prm.slow_list[prm.P + i], sh);
+        ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, (int)prm.slow_list[(size_t)seg * prm.P + i], sh);
         __syncthreads();
     }
 }

@@ -282,10 +282,11 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     __shared__ uint16_t lbeam[RPT_CHUNK];        // ... and beam index
     __shared__ uint32_t actw[32], newm[32], wrapm[32];
     __shared__ uint32_t list_n[2];               // by round parity: the idle one is cleared while the other one is in use
-    const int p = first_particle + blockIdx.x;
+    const int p = lane_particle(prm, first_particle, (int)blockIdx.x);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // first map-modifying kernel of the update: nothing is touched when the allocation phase failed (the host grows and retries)
     if (map_update_aborted(prm)) { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicOr(prm.err, ERR_CLEAN_ABORT); return; }
+    if (p < 0) return;                                             // (another lane's particle)
     const int count = prm.counts[2 * p + 1];
     const size_t WW = (size_t)prm.W * prm.W;
     uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;

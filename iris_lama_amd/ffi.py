@@ -45,7 +45,7 @@ class HipCounters(C.Structure):
                 ("sequential_raycast_scans", C.c_uint64), ("parallel_raycast_scans", C.c_uint64),
                 ("brushfire_handovers", C.c_uint32), ("replay_handovers", C.c_uint32),
                 ("window_patches", C.c_uint32), ("window_growths", C.c_uint32),
-                ("bf_longest_chain_sum", C.c_uint64), ("bf_longest_chain_last", C.c_uint64), ("brushfire_routed", C.c_uint64)]
+                ("bf_longest_chain_sum", C.c_uint64), ("bf_longest_chain_last", C.c_uint64), ("brushfire_early", C.c_uint64), ("brushfire_routed", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -61,7 +61,8 @@ def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
         assert c["brushfire_routed"] == 0, c
 
 
-def test_drifted_poses_long_chains_default_routing(F):
+@pytest.mark.parametrize("cap", [0, 24])
+def test_drifted_poses_long_chains_default_routing(F, cap):
     """72 particles mapped WITHOUT scan matching, six of them from poses off by up to ~25 cm / 9 degrees: those re-draw walls and
     remove others in every update (long raise waves, queues that outgrow the first brushfire stage), and the default routing (>= 64
     particles) sends them -- the particles with the most obstacle events -- to the big-queue stage: maps bit-exact, and the counters
@@ -73,7 +74,9 @@ def test_drifted_poses_long_chains_default_routing(F):
     pose0 = O.se2(*odom[0])
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    # cap = 24: arenas that the run outgrows several times (updates that are aborted in their allocation phase and repeated after
+    # growth) while particles sit in the routed / early lanes
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, dm_patch_capacity=cap, occ_patch_capacity=cap))
     ctx.init(pts[0], pose0)
     for k in range(1, steps + 1):
         poses = _perturbed(rng, O.se2(*truth[k]), P, 0.02, 0.006, drifted=6)
@@ -89,6 +92,8 @@ def test_drifted_poses_long_chains_default_routing(F):
     ctx.close()
     print("counters", c)
     assert c["brushfire_routed"] > 0 and c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
+    assert c["brushfire_early"] > 0, c          # routed in one update, early lane in the next (no resample in between)
+    assert (c["arena_growths"] > 0) == (cap != 0), c
 
 
 def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0):

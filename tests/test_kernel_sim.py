@@ -98,6 +98,9 @@ def test_long_chains_are_routed_to_the_big_queue_stage(Fsim, monkeypatch):
     monkeypatch.setenv("LAMA_HIP_BF_ROUTE", "1,0,90,1")
     c = _run(Fsim, 2, 2)
     assert c["brushfire_routed"] >= 2 and c["brushfire_waves"] == 2, c
+    # ... and a particle routed in one update runs the next one in the EARLY lane (its modifying ray-cast kernels and its brushfire on
+    # a stream of their own, the main lane skips it) as long as no resample has moved the particles in between
+    assert c["brushfire_early"] >= 1, c
 
 
 @pytest.mark.parametrize("seq_ray", [0, 1])
