@@ -91,6 +91,7 @@ struct lama_hip_ctx {
     bool early_ok = false;            // the last map update routed over the whole pool and nothing has permuted the particles since
     uint32_t early_candidates = 0;    // routed + early-lane particles of the last map update (none: the early lane is not even launched)
     uint32_t early_on = 1;            // LAMA_HIP_BF_ROUTE's fifth number (0: no early lane)
+    uint32_t early_min_count = 1024;  // below ~4 workgroups per CU everybody else's ray-cast is too short to be worth overtaking (an override sets 0)
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
@@ -626,7 +627,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             // what the update waits for, no longer starts behind everybody else's ray-cast.
             const bool two_waves_e = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
             early_lane = c->early_ok && c->early_candidates > 0 && c->early_on && two_waves_e && c->cfg.brushfire_mode == 0 && first == 0 && count == c->P &&
-                         count >= c->route_min_count && c->route_cap > 0;
+                         count >= std::max<uint32_t>(c->route_min_count, c->early_min_count) && c->route_cap > 0;
             if (early_lane)
                 hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, (const uint8_t*)c->d_heavy, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, c->route_cap);
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
@@ -772,7 +773,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     c->ctr.window_patches = c->W;
     if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
         unsigned a = 0, b = 0, pc = 0, d = 0, e = 1;
-        if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; }
+        if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; c->early_min_count = 0; }
     }
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58

@@ -62,7 +62,7 @@ def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
 
 
 @pytest.mark.parametrize("cap", [0, 24])
-def test_drifted_poses_long_chains_default_routing(F, cap):
+def test_drifted_poses_long_chains_default_routing(F, cap, monkeypatch):
     """72 particles mapped WITHOUT scan matching, six of them from poses off by up to ~25 cm / 9 degrees: those re-draw walls and
     remove others in every update (long raise waves, queues that outgrow the first brushfire stage), and the default routing (>= 64
     particles) sends them -- the particles with the most obstacle events -- to the big-queue stage: maps bit-exact, and the counters
@@ -74,6 +74,7 @@ def test_drifted_poses_long_chains_default_routing(F, cap):
     pose0 = O.se2(*odom[0])
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
+    monkeypatch.setenv("LAMA_HIP_BF_ROUTE", "64,48,150,64,1")      # the defaults, but the early lane from 64 particles on (default: 1024)
     # cap = 24: arenas that the run outgrows several times (updates that are aborted in their allocation phase and repeated after
     # growth) while particles sit in the routed / early lanes
     ctx = F.HipContext(F.default_cfg(particles=P, profile=1, dm_patch_capacity=cap, occ_patch_capacity=cap))
