@@ -94,6 +94,7 @@ struct lama_hip_ctx {
     uint32_t early_min_count = 1024;  // below ~4 workgroups per CU everybody else's ray-cast is too short to be worth overtaking (an override sets 0)
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
+    bool route_forced = false; uint32_t num_cus = 256;
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
@@ -560,6 +561,15 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
     return LAMA_HIP_OK;
 }
 
+// how many particles may go to the big-queue stage beside the first one: an 84 KB workgroup takes the LDS of seven first-stage
+// workgroups, and a first stage that no longer fits the chip in one round (12 per CU) costs far more than the routing saves
+static uint32_t route_places(const lama_hip_ctx* c, uint32_t count)
+{
+    const uint32_t slots = c->num_cus * 12u;
+    if (c->route_forced || count >= slots) return c->route_cap;                 // (several rounds anyway)
+    return std::min<uint32_t>(c->route_cap, std::max<uint32_t>(8u, (slots - count) / 7u));
+}
+
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count)
 {
     {
@@ -629,7 +639,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             early_lane = c->early_ok && c->early_candidates > 0 && c->early_on && two_waves_e && c->cfg.brushfire_mode == 0 && first == 0 && count == c->P &&
                          count >= std::max<uint32_t>(c->route_min_count, c->early_min_count) && c->route_cap > 0;
             if (early_lane)
-                hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, (const uint8_t*)c->d_heavy, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, c->route_cap);
+                hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, (const uint8_t*)c->d_heavy, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, route_places(c, count));
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
             if (early_lane) {
@@ -640,7 +650,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 // event that the early stream records directly in front of its brushfire kernel.
                 DevParams pe = prm;
                 pe.elist = c->d_elist; pe.elist_n = c->d_slow_n + 4; pe.lane = 1;
-                const unsigned eg = c->route_cap;
+                const unsigned eg = route_places(c, count);
                 hipLaunchKernelGGL(k_ray_patches, dim3(eg, 128u), dim3(256), 0, c->stream, pe, (const lama_dev::RayRec*)c->d_rrec,
                                    (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, 0);
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
@@ -688,9 +698,9 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 // for a third of it to finish: their kernel follows k_bf_route directly in this stream, the first stage goes to the
                 // second stream behind an event -- the cross-queue signal is what makes it the later dispatch.
                 prm.heavy = c->d_heavy;
-                hipLaunchKernelGGL(k_bf_route, dim3(1), dim3(256), 0, c->stream, prm, (int)first, (int)count, c->route_min_events, c->route_percent, c->route_cap);
+                hipLaunchKernelGGL(k_bf_route, dim3(1), dim3(256), 0, c->stream, prm, (int)first, (int)count, c->route_min_events, c->route_percent, route_places(c, count));
                 HIPCHK(c, hipEventRecord(c->ev_route, c->stream));
-                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(std::min<unsigned>(c->route_cap, 256u)), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 1);
+                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(route_places(c, count)), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 1);
                 HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_route, 0));
                 hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(count), dim3(2 * UM_BLOCK), 0, c->stream2, prm, (int)first, 0);
                 HIPCHK(c, hipEventRecord(c->ev_heavy, c->stream2));
@@ -773,7 +783,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     c->ctr.window_patches = c->W;
     if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
         unsigned a = 0, b = 0, pc = 0, d = 0, e = 1;
-        if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; c->early_min_count = 0; }
+        if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; c->early_min_count = 0; c->route_forced = true; }
     }
     c->scale = 1.0 / cfg.resolution;
     c->off = double(2642244ull >> 1) * 32.0;                      // src/sdm/map.cpp:55-58
@@ -784,6 +794,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
 
 #define CHK(call) do { if ((call) != hipSuccess) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; } } while (0)
     CHK(hipSetDevice(cfg.device));
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, cfg.device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = (uint32_t)prop.multiProcessorCount; }
     CHK(hipStreamCreate(&c->stream));
     CHK(hipEventCreate(&c->ev0));
     CHK(hipEventCreate(&c->ev1));

@@ -2056,7 +2056,18 @@ __global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_parti
     for (int off = 128; off > 0; off >>= 1) { if (tid < off) { part[tid] += part[tid + off]; cnts[tid] += cnts[tid + off]; } __syncthreads(); }
     const uint32_t mean = part[0] / (cnts[0] ? cnts[0] : 1u);
     const uint32_t scaled = (uint32_t)(((uint64_t)mean * percent) / 100u);
-    const uint32_t thr = scaled > min_events ? scaled : min_events;
+    uint32_t thr = scaled > min_events ? scaled : min_events;
+    // more candidates than places: the places go to the LONGEST chains -- raise the threshold until they fit
+    for (int round = 0; round < 24; ++round) {
+        uint32_t over = 0;
+        for (int i = tid; i < count; i += 256) { const int p = first_particle + i; if (prm.early && prm.early[p]) continue; over += (prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]) > thr ? 1u : 0u; }
+        __syncthreads();
+        cnts[tid] = over;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) { if (tid < off) cnts[tid] += cnts[tid + off]; __syncthreads(); }
+        if (cnts[0] <= cap) break;                                // (the same decision in every thread)
+        thr += thr / 4u + 1u;
+    }
     for (int i = tid; i < count; i += 256) {
         const int p = first_particle + i;
         const uint32_t q = prm.qsizes[2 * p] + prm.qsizes[2 * p + 1];

@@ -98,6 +98,8 @@ inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new wsim_event{0}; return
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
 constexpr unsigned hipEventDisableTiming = 2;
+struct hipDeviceProp_t { int multiProcessorCount = 256; };
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t{}; return hipSuccess; }
 inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }   // launches run to completion in program order here
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.0f; return hipSuccess; }

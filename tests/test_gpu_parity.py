@@ -48,11 +48,12 @@ def test_stagewise_parity_corridor(F, P, steps, seq_ray, bf_waves, bf_mode):
     _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode)
 
 
-@pytest.mark.parametrize("route", ["1,0,110,8", "1,0,0,256", "1000000,0,150,64"])
+@pytest.mark.parametrize("route", ["1,0,110,8", "1,0,0,256", "1,0,0,4", "1000000,0,150,64"])
 def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
     """k_bf_route: particles with many more obstacle events than the pool's mean are the long brushfire chains; they run in the
     big-queue stage on a second stream beside the first stage, which skips them.  Forced on 40 particles: (a) threshold 110 % of the
-    mean, 8 places; (b) everybody over the threshold, more candidates than places; (c) routing off -- bit-exact maps in all three."""
+    mean, 8 places; (b) everybody over the threshold; (c) the same with 4 places: they go to the longest chains; (d) routing off --
+    bit-exact maps in all four."""
     monkeypatch.setenv("LAMA_HIP_BF_ROUTE", route)
     c = _stagewise(F, 40, 6, 0, 2, 0)
     if route.startswith("1,"):
