@@ -90,6 +90,8 @@ struct lama_hip_ctx {
     hipStream_t stream3 = nullptr; hipEvent_t ev_alloc = nullptr, ev_go = nullptr, ev_early = nullptr;
     bool early_ok = false;            // the last map update routed over the whole pool and nothing has permuted the particles since
     uint32_t early_candidates = 0;    // routed + early-lane particles of the last map update (none: the early lane is not even launched)
+    std::vector<double> h_ll; bool ll_valid = false;   // log-likelihoods of the last scan match, in the current particle order
+    PinVec<uint32_t> h_hlist; uint32_t* d_hlist = nullptr;   // the worst-fitting particles of that scan match (early lane)
     uint32_t early_on = 1;            // LAMA_HIP_BF_ROUTE's fifth number (0: no early lane)
     uint32_t early_min_count = 1024;  // below ~4 workgroups per CU everybody else's ray-cast is too short to be worth overtaking (an override sets 0)
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
@@ -290,7 +292,17 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             uint64_t mx = 0, sum = 0; uint32_t arg = 0;
             for (uint32_t p = 0; p < c->P; ++p) { sum += st[4 * p + 3]; if (st[4 * p + 3] > mx) { mx = st[4 * p + 3]; arg = p; } }
             c->ctr.bf_longest_chain_sum += mx; c->ctr.bf_longest_chain_last = mx;
-            if (std::getenv("LAMA_HIP_DEBUG_TAIL")) std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire);
+            if (std::getenv("LAMA_HIP_DEBUG_TAIL")) {
+                // (how well would the scan match's log-likelihood have predicted the longest chain? its rank among the pool, 0 = lowest)
+                uint32_t rank = 0; double ll = 0, mean_ll = 0;
+                if (c->h_results.size() >= c->results_bytes && c->P > 1) {
+                    const double* L = reinterpret_cast<const double*>(c->h_results.data() + sizeof(double) * 4 * c->P);
+                    ll = L[arg];
+                    for (uint32_t p = 0; p < c->P; ++p) { rank += L[p] < ll ? 1u : 0u; mean_ll += L[p]; }
+                    mean_ll /= c->P;
+                }
+                std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms; log-lik of that particle %.1f (pool mean %.1f), rank %u of %u\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire, ll, mean_ll, rank, c->P);
+            }
         }
         if (maps) return grow_arenas(c);
     }
@@ -636,10 +648,27 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             // ray-cast kernels and their brushfire on a stream of their own right after the allocation phase -- their chain, which is
             // what the update waits for, no longer starts behind everybody else's ray-cast.
             const bool two_waves_e = c->cfg.brushfire_waves == 2 || (c->cfg.brushfire_waves == 0 && count <= BF_TW_MAX_PARTICLES);
-            early_lane = c->early_ok && c->early_candidates > 0 && c->early_on && two_waves_e && c->cfg.brushfire_mode == 0 && first == 0 && count == c->P &&
+            early_lane = c->early_on && two_waves_e && c->cfg.brushfire_mode == 0 && first == 0 && count == c->P &&
                          count >= std::max<uint32_t>(c->route_min_count, c->early_min_count) && c->route_cap > 0;
+            uint32_t host_n = 0;
+            if (early_lane && c->ll_valid) {
+                // the particles whose scan match of this step fitted far worse than the pool's (log-likelihood below 2.5 times the
+                // mean, both negative): theirs are the long chains of this update -- known before anything is queued
+                const uint32_t places = route_places(c, count);
+                double mean = 0; for (uint32_t p = 0; p < c->P; ++p) mean += c->h_ll[p]; mean /= c->P;
+                const double lim = 2.5 * std::min(mean, 0.0) - 5.0;
+                std::vector<std::pair<double, uint32_t>> cand;
+                for (uint32_t p = 0; p < c->P; ++p) if (c->h_ll[p] < lim) cand.emplace_back(c->h_ll[p], p);
+                if (cand.size() > places) { std::partial_sort(cand.begin(), cand.begin() + places, cand.end()); cand.resize(places); }
+                c->h_hlist.resize(256);
+                for (auto& e : cand) c->h_hlist[host_n++] = e.second;
+                if (host_n) HIPCHK(c, hipMemcpyAsync(c->d_hlist, c->h_hlist.data(), sizeof(uint32_t) * host_n, hipMemcpyHostToDevice, c->stream));
+            }
+            const bool prev_ok = c->early_ok && c->early_candidates > 0;
+            early_lane = early_lane && (host_n > 0 || prev_ok);
             if (early_lane)
-                hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, (const uint8_t*)c->d_heavy, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, route_places(c, count));
+                hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, prev_ok ? (const uint8_t*)c->d_heavy : (const uint8_t*)nullptr,
+                                   (const uint32_t*)c->d_hlist, host_n, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, route_places(c, count));
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
             const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
             if (early_lane) {
@@ -826,6 +855,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_heavy, P));                  CHK(hipMemset(c->d_heavy, 0, P));
     CHK(hipMalloc(&c->d_early, P));                  CHK(hipMemset(c->d_early, 0, P));
     CHK(hipMalloc(&c->d_elist, 256 * 4));            CHK(hipMemset(c->d_elist, 0, 256 * 4));
+    CHK(hipMalloc(&c->d_hlist, 256 * 4));            CHK(hipMemset(c->d_hlist, 0, 256 * 4));
     CHK(hipStreamCreate(&c->stream2));
     CHK(hipStreamCreate(&c->stream3));
     CHK(hipEventCreateWithFlags(&c->ev_alloc, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
@@ -858,7 +888,7 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
         (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
         (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
@@ -960,6 +990,7 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     if (poses_out) std::memcpy(poses_out, r, sizeof(double) * 4 * c->P);
     if (loglik_out) std::memcpy(loglik_out, r + sizeof(double) * 4 * c->P, sizeof(double) * c->P);
     if (iters_out) std::memcpy(iters_out, r + sizeof(double) * 5 * c->P, sizeof(int32_t) * c->P);
+    c->h_ll.resize(c->P); std::memcpy(c->h_ll.data(), r + sizeof(double) * 4 * c->P, sizeof(double) * c->P); c->ll_valid = true;
     return LAMA_HIP_OK;
 }
 
@@ -973,6 +1004,7 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const int dst = 1 - c->cur;
     c->early_ok = false;                                            // particle indices change meaning
+    if (c->ll_valid) { std::vector<double> nl(c->P); for (uint32_t i = 0; i < c->P; ++i) nl[i] = c->h_ll[sample_idx[i]]; c->h_ll.swap(nl); }
     HIPCHK(c, hipMemcpyAsync(c->d_idx, sample_idx, sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, c->set[dst].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
     {
@@ -1629,7 +1661,7 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     if (n == 0) return LAMA_HIP_OK;
     for (uint32_t k = 0; k < n; ++k) if (particles[k] >= c->P || !bufs[k] || bytes[k] < (uint64_t)BLOB_HEAD) return LAMA_HIP_E_INVALID;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    c->early_ok = false;                                            // other particles sit in these slots now
+    c->early_ok = false; c->ll_valid = false;                       // other particles sit in these slots now
     // 1. what is coming: the blobs' heads in one copy
     c->h_ship_desc.resize(n);
     for (uint32_t k = 0; k < n; ++k) c->h_ship_desc[k] = ShipDesc{(uint8_t*)const_cast<void*>(bufs[k]), particles[k], 0, 0, 0};

@@ -2057,17 +2057,25 @@ __global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_parti
     const uint32_t mean = part[0] / (cnts[0] ? cnts[0] : 1u);
     const uint32_t scaled = (uint32_t)(((uint64_t)mean * percent) / 100u);
     uint32_t thr = scaled > min_events ? scaled : min_events;
-    // more candidates than places: the places go to the LONGEST chains -- raise the threshold until they fit
-    for (int round = 0; round < 24; ++round) {
+    // more candidates than places: the places go to the LONGEST chains -- raise the threshold while more than `cap` stay above it
+    // (never so far that nobody does: then the first `cap` that come get the places)
+    auto count_over = [&](uint32_t t) {
         uint32_t over = 0;
-        for (int i = tid; i < count; i += 256) { const int p = first_particle + i; if (prm.early && prm.early[p]) continue; over += (prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]) > thr ? 1u : 0u; }
+        for (int i = tid; i < count; i += 256) { const int p = first_particle + i; if (prm.early && prm.early[p]) continue; over += (prm.qsizes[2 * p] + prm.qsizes[2 * p + 1]) > t ? 1u : 0u; }
         __syncthreads();
         cnts[tid] = over;
         __syncthreads();
         for (int off = 128; off > 0; off >>= 1) { if (tid < off) cnts[tid] += cnts[tid + off]; __syncthreads(); }
-        if (cnts[0] <= cap) break;                                // (the same decision in every thread)
-        thr += thr / 4u + 1u;
-    }
+        return cnts[0];                                           // (the same value in every thread)
+    };
+    if (count_over(thr) > cap)
+        for (int round = 0; round < 48; ++round) {
+            const uint32_t next = thr + thr / 8u + 1u;
+            const uint32_t over = count_over(next);
+            if (over == 0u) break;
+            thr = next;
+            if (over <= cap) break;
+        }
     for (int i = tid; i < count; i += 256) {
         const int p = first_particle + i;
         const uint32_t q = prm.qsizes[2 * p] + prm.qsizes[2 * p + 1];
@@ -2085,17 +2093,27 @@ __global__ __launch_bounds__(256) void k_bf_route(DevParams prm, int first_parti
     if (tid == 0 && prm.slow_n[2] > cap) prm.slow_n[2] = cap;         // (more candidates than places: the others stay in the first stage)
 }
 
-// early lane: the particles the previous update routed (d_heavy still holds its flags) -> list + skip flags of this update
-__global__ __launch_bounds__(256) void k_early_list(const uint8_t* __restrict__ heavy_prev, uint8_t* __restrict__ early, uint32_t* __restrict__ elist,
-                                                     uint32_t* __restrict__ elist_n, int P, uint32_t cap)
+// early lane: list + skip flags of this update from (i) the host's list -- the particles whose scan match of THIS step fitted worst:
+// the longest chain of an update is the particle with the lowest log-likelihood of the pool (its scan disagrees with its map, so it
+// re-draws it), rank 0 or 1 of 3000 in every update with a long chain -- and (ii) the particles the previous update routed
+// (`heavy_prev`, nullptr: not valid any more)
+__global__ __launch_bounds__(256) void k_early_list(const uint8_t* __restrict__ heavy_prev, const uint32_t* __restrict__ host_list, uint32_t host_n,
+                                                     uint8_t* __restrict__ early, uint32_t* __restrict__ elist, uint32_t* __restrict__ elist_n, int P, uint32_t cap)
 {
-    for (int p = threadIdx.x; p < P; p += 256) {
-        uint8_t e = 0;
-        if (heavy_prev[p]) { const uint32_t k = atomicAdd(elist_n, 1u); if (k < cap) { e = 1; elist[k] = (uint32_t)p; } }
-        early[p] = e;
+    for (int p = threadIdx.x; p < P; p += 256) early[p] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < host_n && n < cap; ++i) { const uint32_t p = host_list[i]; if (p < (uint32_t)P && !early[p]) { early[p] = 1; elist[n++] = p; } }
+        *elist_n = n;
     }
     __syncthreads();
-    if (threadIdx.x == 0 && *elist_n > cap) *elist_n = cap;
+    if (heavy_prev) {
+        for (int p = threadIdx.x; p < P; p += 256)
+            if (heavy_prev[p] && !early[p]) { const uint32_t k = atomicAdd(elist_n, 1u); if (k < cap) { early[p] = 1; elist[k] = (uint32_t)p; } }
+        __syncthreads();
+        if (threadIdx.x == 0 && *elist_n > cap) *elist_n = cap;
+    }
 }
 // the early lane's particles go to the big-queue brushfire stage directly: flag them as handed over
 __global__ __launch_bounds__(64) void k_mark_early(DevParams prm)
