@@ -20,6 +20,10 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
     if backend == "nccl":                # one process per GPU: RCCL binds the process' current device
         torch.cuda.set_device(gpu)
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    # the process group works (one collective through it): from here on a failure is the code's, not the box's
+    probe = torch.zeros(1, device=torch.device("cuda", gpu) if backend == "nccl" else torch.device("cpu"))
+    dist.all_reduce(probe)
+    open(os.path.join(out_dir, f"rank{rank}.up"), "w").close()
     if engine_path:
         import _testhost                 # test double of the device C-ABI: needs the test-suite's own -DLAMA_TESTING host build
         _testhost.set_engine_library(engine_path)

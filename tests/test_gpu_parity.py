@@ -521,7 +521,12 @@ def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.00
         p.start()
     for p in procs:
         p.join(900)
-        assert p.exitcode == 0
+    if any(p.exitcode != 0 for p in procs) and not all(os.path.exists(os.path.join(out, f"rank{r}.up")) for r in range(world)):
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        pytest.skip(f"the {backend} process group of {world} ranks could not be brought up on this box (exit codes {[p.exitcode for p in procs]})")
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     res = [pickle.load(open(os.path.join(out, f"rank{r}.pkl"), "rb")) for r in range(world)]
     assert [(r["lo"], r["hi"]) for r in res] == [(k * P // world, (k + 1) * P // world) for k in range(world)]
     assert [r["device"] for r in res] == list(devices) and all(r["backend"] == backend for r in res)
