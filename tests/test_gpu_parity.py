@@ -62,6 +62,33 @@ def test_long_chains_are_routed_to_the_big_queue_stage(F, monkeypatch, route):
         assert c["brushfire_routed"] == 0, c
 
 
+def test_routing_and_early_lane_change_nothing_at_3000_particles(F, monkeypatch):
+    """BASELINE config 2's pool free-running for 25 scans -- long enough for a few particles to drift and grow brushfire chains
+    three to seven times the pool's mean -- with the default routing / early lane and with both switched off: poses, weights and the
+    device-side checksums of every particle's maps are identical, and the counters show that the lanes were used."""
+    P, steps = 3000, 25
+    pts, odom, _ = F.corridor_log(steps, 1080)
+    out = []
+    for route in (None, "64,48,150,0,0"):
+        if route is None:
+            monkeypatch.delenv("LAMA_HIP_BF_ROUTE", raising=False)
+        else:
+            monkeypatch.setenv("LAMA_HIP_BF_ROUTE", route)
+        pf = F.PFSlam2D(F.pf_options(particles=P, seed=42))
+        pf.set_prior(*odom[0])
+        for k in range(steps + 1):
+            pf.update(pts[k], odom[k], float(k))
+        c = pf.hip_context()
+        out.append(dict(poses=pf.poses().copy(), w=pf.weights()[0].copy(), dm=c.map_checksums(F.MAP_DISTANCE), occ=c.map_checksums(F.MAP_OCCUPANCY),
+                        ctr=c.counters()))
+        pf.close()
+    a, b = out
+    assert a["ctr"]["brushfire_routed"] > 0 and a["ctr"]["brushfire_early"] > 0, a["ctr"]
+    assert b["ctr"]["brushfire_routed"] == 0 and b["ctr"]["brushfire_early"] == 0, b["ctr"]
+    for k in ("poses", "w", "dm", "occ"):
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("cap", [0, 24])
 def test_drifted_poses_long_chains_default_routing(F, cap, monkeypatch):
     """72 particles mapped WITHOUT scan matching, six of them from poses off by up to ~25 cm / 9 degrees: those re-draw walls and
