@@ -13,7 +13,8 @@ host memory, clones shipped GPU to GPU with peer copies), run by rank 0 while th
 one-process-per-GPU driver (iris_lama_amd/distributed.py over torch.distributed: an RCCL all-gather of the log-likelihoods plus
 particle shipping over xGMI), timed with the barrier / max-over-ranks bracket, is reported beside it ("torch_distributed_ranks"),
 and so are: the same pool unsharded on one GPU ("single_gpu_same_pool", the base of the curve), one GPU's share alone on one GPU
-("strong_scaling_ceiling": what no sharding can beat -- a particle's exact brushfire is a serial chain), the WEAK-scaling run (the
+("strong_scaling_ceiling": what no sharding can beat -- a particle's exact brushfire is a serial chain; "longest_chain_bound": the
+longest chain of the pool, which bounds the step at ANY number of GPUs), the WEAK-scaling run (the
 3000-particle pool on every GPU, "weak_scaling"), and a variant whose measurement gain makes the filter resample
 (meas_sigma_gain = 1e-4, SURVEY 8(d): it must resample and ship particles -- asserted -- and reports the exchange times).
 The N = 1 line carries the single-GPU rate at 3000 particles ("other_particle_counts").
@@ -495,6 +496,15 @@ def main():
                                             "ceiling_speedup": single["ms_per_step"] / share["ms_per_step"],
                                             "note": "step time of the unsharded pool / step time of ONE GPU's share alone on one GPU: no exchange, "
                                                     "no imbalance -- the curve cannot rise above it, because a particle's exact brushfire is a serial chain"}
+        # what bounds the fixed pool at ANY number of GPUs: a map update lasts as long as the longest brushfire chain of the pool, on
+        # whichever GPU holds that particle (counted on the unsharded single-GPU run of the same pool and steps)
+        cs = single["counters"]
+        longest = cs["bf_longest_chain_sum"] / max(single["updates"], 1)
+        result["longest_chain_bound"] = {"mean_pops_per_particle": round(cs["bf_cells"] / (P_total * max(single["updates"], 1)), 1),
+                                         "mean_longest_chain_pops": round(longest, 1),
+                                         "ms_at_0.7_us_per_pop": round(longest * 0.7e-3, 3),
+                                         "note": "a particle's exact brushfire is one serial chain (~0.7 us per pop for a chain that has a CU to itself): "
+                                                 "no sharding makes the step shorter than scan match + ray-cast of one share + this"}
         result["weak_scaling"] = {"particles_per_gpu": weak["particles_per_gpu"], "particles": weak["particles_per_gpu"] * world,
                                   "value": weak["value"], "ms_per_step": weak["ms_per_step"], "exchange_ms": weak["exchange_ms"],
                                   "single_gpu_base": {"particles": P_total, "value": single["value"], "ms_per_step": single["ms_per_step"]} if weak["particles_per_gpu"] == P_total else None,
