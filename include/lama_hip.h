@@ -295,8 +295,22 @@ typedef struct lama_hip_counters {
                                            brushfire in the early lane, ahead of everybody else's ray-cast (counted in brushfire_routed too)   */
     uint64_t brushfire_routed;          /* particle updates whose brushfire ran in the big-queue stage from the start, beside the first stage:
                                            their obstacle-event count (known before the brushfire starts) marked them as the long chains   */
+    /* round 5: memory that follows the maps (one particle set, in-place resampling, per-particle regions in pooled planes) */
+    uint64_t pool_growths;              /* times a patch pool was re-allocated larger (geometric)                                          */
+    uint64_t resample_clones;           /* particles a resample / the first scan really COPIED: a particle that survives keeps its home and
+                                           regions, only the second and further copies of a multiply drawn particle are written           */
+    uint64_t resample_bytes;            /* bytes those copies read (= wrote): directories + used slots of every plane                       */
+    uint64_t hbm_bytes_allocated;       /* device memory the context holds for the maps now: patch pools + directories                     */
+    uint64_t hbm_bytes_used;            /* ... of which used: the allocated patches of all particles (all planes) + directories            */
+    uint64_t hbm_bytes_total;           /* everything the context has allocated on the device (maps, queues, scratch)                      */
+    uint32_t peer_access;               /* lama_hip_blob_copy between two devices: 1 = the last such copy went GPU to GPU directly (peer access
+                                           enabled both ways), 0 = it was staged by the runtime (peer access refused) or none was made      */
+    uint32_t struct_bytes;              /* sizeof(lama_hip_counters) of the library that filled the struct (see lama_hip_get_counters_sized) */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
+/* The same for a caller compiled against another version of this header: at most `bytes` bytes are written (the struct
+ * grows at its END only, a consumer built against an older header passes its own sizeof and is never written past). */
+int32_t lama_hip_get_counters_sized(lama_hip_ctx* ctx, void* out, uint32_t bytes);
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);
 
 #ifdef __cplusplus

@@ -62,7 +62,7 @@ __device__ inline int cn_slot(CanonLds& sh, uint32_t key)
 struct CnMap {
     const DevParams& prm;
     int p;
-    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
+    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask; int cap;
     // side-effect free cell index (slot*1024 + ci) or -1 when the patch does not exist / outside the window
     __device__ inline int peek(int x, int y) const
     {
@@ -81,7 +81,7 @@ struct CnMap {
     {
         if ((uint32_t)x >= prm.WC || (uint32_t)y >= prm.WC) { atomicOr(prm.err, ERR_WINDOW); return -1; }
         const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
-        const int slot = dir_get_or_alloc(dir, pidx, prm.counts + 2 * p, (int)prm.dm_cap, ERR_DM_CAP, prm.err);
+        const int slot = dir_get_or_alloc(dir, pidx, prm.counts + 2 * p, cap, ERR_DM_CAP, prm.err);
         if (slot < 0) return -1;
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
         atomicOr((unsigned long long*)(mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
@@ -95,9 +95,8 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
     const int p = first_particle + blockIdx.x;
     const int tid = threadIdx.x;
     if (map_update_aborted(prm)) return;
-    const size_t WW = (size_t)prm.W * prm.W;
-    const CnMap M{prm, p, prm.dm_dir + (size_t)p * WW, prm.dm_sv + (size_t)p * prm.dm_cap * 1024,
-                  prm.dm_obs + (size_t)p * prm.dm_cap * 1024, prm.dm_mask + (size_t)p * prm.dm_cap * 16};
+    const PV pv = pview(prm, p);
+    const CnMap M{prm, p, pv.dm_dir, pv.dm_sv, pv.dm_obs, pv.dm_mask, (int)pv.dm_cap};
     uint64_t* list = prm.q_lower + (size_t)p * prm.qcap;          // pending lower entries, appended in place
     uint64_t* fa = prm.q_raise + (size_t)p * prm.qcap;
     const uint32_t FCAP = prm.qcap / 2;

@@ -1,23 +1,31 @@
 // lama_dev.h -- device-side data model and scalar math of the MI355X scan-matching path.
 //
-// HBM layout (one "particle set"; the context keeps two and resample() copies set A -> set B,
-// mirroring particles_[2] of the reference, src/pf_slam2d.cpp:558-574):
+// HBM layout (ONE particle set; resample() is done in place, see below):
 //
-//   per particle p (all arrays indexed [p][...], strides in DevParams):
-//     dm_dir  int16 [W*W]         window directory: patch (wy*W+wx) -> slot in the DM arena, -1 = absent
-//     occ_dir int16 [W*W]         same for the occupancy arena
-//     dm_sv   uint16[cap][1024]   DM plane A: bit15 valid_obstacle | bit14 is_queued | bits13..0 sqdist
-//     dm_obs  uint32[cap][1024]   DM plane B: int16 obstacle.x | int16 obstacle.y << 16
-//     dm_mask uint64[cap][16]     Container::mask of the DM patch
-//     occ     uint32[cap][1024]   frequency cell: uint16 occupied | uint16 visited << 16
-//     occ_mask uint64[cap][16]
+//   per HOME h (a directory slot; P of them):
+//     dm_dir  int16 [W*W]         window directory: patch (wy*W+wx) -> slot in the particle's DM region, -1 = absent
+//     occ_dir int16 [W*W]         same for the occupancy region
+//   pooled planes, shared by all particles; a particle owns one contiguous REGION of `cap` patches in each pool
+//   (PartRec: home, dm_base, dm_cap, occ_base, occ_cap -- bases and capacities in patches, per particle):
+//     dm_sv   uint16[pool][1024]  DM plane A: bit15 valid_obstacle | bit14 is_queued | bits13..0 sqdist
+//     dm_obs  uint32[pool][1024]  DM plane B: int16 obstacle.x | int16 obstacle.y << 16
+//     dm_mask uint64[pool][16]    Container::mask of the DM patch
+//     occ     uint32[pool][1024]  frequency cell: uint16 occupied | uint16 visited << 16
+//     occ_mask uint64[pool][16]
+//   per particle p (logical index, the reference's particles_[current][p]):
 //     counts  int32 [2]           allocated DM / occupancy slots
+//
+// The reference keeps two particle sets and copies patch POINTERS on resample (src/pf_slam2d.cpp:558-574,
+// include/lama/cow_ptr.h:86-118).  Here a resample is a permutation of the PartRec table: a particle that survives keeps its
+// home and its regions (nothing moves), only the second and further copies of a multiply drawn particle are copied -- into the
+// homes and regions of particles that died.  Regions have per-particle capacities and grow one particle at a time (a host-side
+// region allocator over the pools), so HBM follows what the maps use instead of P x the largest particle.
 //
 // The reference's records are distance_t (10 B AoS) and frequency (4 B); the split DM planes keep the
 // 2 bytes the match kernel gathers (sqdist+valid) apart from the 4 bytes only the brushfire needs.
 // A cell is addressed by window-relative cell coordinates (rx, ry) = map coordinate - window origin;
 // the map coordinate itself is the reference's (offset by 42,275,904 cells) and is only
-// ever formed in fp64 / uint32, never fp32.  Unused arena slots are always all-zero (calloc semantics
+// ever formed in fp64 / uint32, never fp32.  Unused region slots and free pool space are always all-zero (calloc semantics
 // of Container::alloc, src/sdm/container.cpp:76-95).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -55,17 +63,26 @@ struct Affine {            // rows 0..2 of [R | t]
     double t[3];
 };
 
+// where logical particle p keeps its maps: the home of its two directories and its region in each pool (patches)
+struct PartRec {
+    uint32_t home;
+    uint32_t dm_base, dm_cap;
+    uint32_t occ_base, occ_cap;
+    uint32_t r0, r1, r2;
+};
+
 struct DevParams {
     uint32_t P;            // particles in this context
     uint32_t W;            // window side in patches
     uint32_t WC;           // window side in cells (W*32)
     uint32_t wx0, wy0;     // window origin in map cells
-    uint32_t dm_cap, occ_cap, qcap;
+    uint32_t qcap;
+    const PartRec* part;   // [P] logical particle -> home / regions
     uint32_t max_sqdist;
     uint32_t max_iter;
     double scale, off, resolution, maxdist, meas_sigma;
     double trunc_ray, trunc_range;
-    // particle set
+    // directories [home][W*W], pooled planes [pool patch][...]
     int16_t* dm_dir;
     int16_t* occ_dir;
     uint16_t* dm_sv;
@@ -73,7 +90,7 @@ struct DevParams {
     uint64_t* dm_mask;
     uint32_t* occ;
     uint64_t* occ_mask;
-    int32_t* counts;       // [P][2]
+    int32_t* counts;       // [P][2] (logical particle)
     // shared
     double* poses;         // [P][4]
     uint64_t* q_lower;     // [P][qcap]
@@ -91,18 +108,55 @@ struct DevParams {
     uint32_t lane;           //       0 main / 1 early: which hand-over segment the ordered replay uses
     uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
     uint32_t* act_count;   // [P]
-    uint64_t* occ_hit;     // [P][occ_cap][16] one bit per occupancy cell: hit in the current scan (all zero between scans)
+    uint64_t* occ_hit;     // [occupancy pool patch][16] one bit per occupancy cell: hit in the current scan (all zero between scans)
     uint32_t act_cap;
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
     uint64_t* dbg;         // [P][8] cycle counters of the profiling build (LAMA_PROFILE_BF), else unused
-    uint32_t* guard;       // [P][2] upper bound of the distance-map patches the update may still allocate; block ticket (k_occ_reverse_dir)
+    uint32_t* guard;       // [P] upper bound of the distance-map patches the update may still allocate (k_occ_reverse_dir); read by the host
     uint32_t guard_r;      // patches around an occupancy patch the brushfire can reach: ceil((sqrt(max_sqdist) + 1) / 32)
     // occupancy cell policy / ray rule (cfg.occupancy_policy, cfg.ray_rule)
     uint32_t occ_policy, ray_rule;
     uint32_t strategy;     // 0 = GaussNewton, 1 = LevenbergMarquard (cfg.solver_strategy; Slam2D / Loc2D "lm")
     double lo_miss, lo_hit, lo_min, lo_max;   // ProbabilisticOccupancyMap parameters (float-rounded, as the reference stores them)
 };
+
+// Particle p's view of the maps: its directories, its regions of the pooled planes (slot-relative addressing inside), capacities.
+struct PV {
+    int16_t* dm_dir; int16_t* occ_dir;
+    uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
+    uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit;
+    int32_t* counts;
+    uint32_t dm_cap, occ_cap, occ_base;
+};
+// The table is written by the host between launches and never by a kernel: read through the constant address space, so that a
+// wave-uniform particle index gives scalar loads (s_load_dwordx8) and the regions' base addresses / capacities stay in SGPRs --
+// a global load of a uniform address lands in VGPRs whenever the kernel also stores to global memory (the buffer resources of the
+// brushfire's straight-line pop are built from these values).
+#ifdef LAMA_WAVE_SIM
+typedef const PartRec* PartTablePtr;
+#else
+typedef const __attribute__((address_space(4))) PartRec* PartTablePtr;
+#endif
+__device__ inline PV pview(const DevParams& prm, int p)
+{
+    PartTablePtr t = (PartTablePtr)prm.part + p;
+    PartRec r;
+    r.home = t->home; r.dm_base = t->dm_base; r.dm_cap = t->dm_cap; r.occ_base = t->occ_base; r.occ_cap = t->occ_cap;
+    const size_t WW = (size_t)prm.W * prm.W;
+    PV v;
+    v.dm_dir = prm.dm_dir + (size_t)r.home * WW;
+    v.occ_dir = prm.occ_dir + (size_t)r.home * WW;
+    v.dm_sv = prm.dm_sv + (size_t)r.dm_base * 1024;
+    v.dm_obs = prm.dm_obs + (size_t)r.dm_base * 1024;
+    v.dm_mask = prm.dm_mask + (size_t)r.dm_base * 16;
+    v.occ = prm.occ + (size_t)r.occ_base * 1024;
+    v.occ_mask = prm.occ_mask + (size_t)r.occ_base * 16;
+    v.occ_hit = prm.occ_hit + (size_t)r.occ_base * 16;
+    v.counts = prm.counts + 2 * (size_t)p;
+    v.dm_cap = r.dm_cap; v.occ_cap = r.occ_cap; v.occ_base = r.occ_base;
+    return v;
+}
 
 // the particle of workgroup `bx` of a per-particle launch: early-lane launches walk their list, main-lane launches skip the early
 // lane's particles; -1: nothing to do

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -19,11 +20,53 @@ using namespace lama_dev;
 
 namespace {
 
-struct ParticleSet {
-    int16_t* dm_dir = nullptr; int16_t* occ_dir = nullptr;
-    uint16_t* dm_sv = nullptr; uint32_t* dm_obs = nullptr; uint64_t* dm_mask = nullptr;
-    uint32_t* occ = nullptr; uint64_t* occ_mask = nullptr;
-    int32_t* counts = nullptr;
+// The maps of all particles of a context: two directories per HOME (P homes), pooled planes in which every particle owns one
+// contiguous region per map kind (lama_dev.h).  The reference's patches are heap objects shared through cow_ptr
+// (include/lama/cow_ptr.h:86-118); here memory follows use through per-particle region capacities, and a resample moves nothing
+// that survives.
+struct MapStore {
+    int16_t* dm_dir = nullptr; int16_t* occ_dir = nullptr;          // [P homes][W*W]
+    uint16_t* dm_sv = nullptr; uint32_t* dm_obs = nullptr; uint64_t* dm_mask = nullptr;     // [dm_pool patches][...]
+    uint32_t* occ = nullptr; uint64_t* occ_mask = nullptr; uint64_t* occ_hit = nullptr;     // [occ_pool patches][...]
+    int32_t* rev = nullptr;                                         // [occ_pool patches] region slot -> directory position (per scan)
+    int32_t* counts = nullptr;                                      // [P][2] logical particle
+    uint32_t dm_pool = 0, occ_pool = 0;                             // pool capacities in patches
+};
+
+// First-fit allocator of contiguous regions (in patches) over a pool; neighbouring free blocks coalesce.  Host side only: the device
+// sees the result as PartRec::dm_base / occ_base.  Free space is always all-zero on the device (k_zero_regions).
+struct RegionAlloc {
+    std::map<uint32_t, uint32_t> free_;        // offset -> length
+    uint32_t cap = 0, used = 0;
+    void reset(uint32_t c) { free_.clear(); cap = c; used = 0; if (c) free_[0] = c; }
+    bool alloc(uint32_t n, uint32_t& off)
+    {
+        if (n == 0) { off = 0; return true; }
+        for (auto it = free_.begin(); it != free_.end(); ++it) {
+            if (it->second < n) continue;
+            off = it->first;
+            const uint32_t rest = it->second - n;
+            free_.erase(it);
+            if (rest) free_[off + n] = rest;
+            used += n;
+            return true;
+        }
+        return false;
+    }
+    void release(uint32_t off, uint32_t n)
+    {
+        if (n == 0) return;
+        used -= n;
+        auto nx = free_.lower_bound(off);
+        if (nx != free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { off = pv->first; n += pv->second; free_.erase(pv); }
+        }
+        if (nx != free_.end() && off + n == nx->first) { n += nx->second; free_.erase(nx); }
+        free_[off] = n;
+    }
+    void extend(uint32_t newcap) { if (newcap > cap) { const uint32_t o = cap, n = newcap - cap; cap = newcap; used += n; release(o, n); } }
+    uint32_t largest_free() const { uint32_t m = 0; for (auto& kv : free_) m = std::max(m, kv.second); return m; }
 };
 
 } // namespace
@@ -74,8 +117,17 @@ struct lama_hip_ctx {
     uint32_t max_sqdist = 0;
     double scale = 0, off = 0;
 
-    ParticleSet set[2];
-    int cur = 0;
+    MapStore ms;
+    RegionAlloc ra_dm, ra_occ;
+    std::vector<PartRec> h_part;     // logical particle -> home / regions (host truth) ...
+    PartRec* d_part = nullptr;        // ... and its device copy
+    PinVec<PartRec> h_part_stage;     // (page-locked staging of the upload)
+    PinVec<CloneJob> h_jobs; CloneJob* d_jobs = nullptr; uint32_t jobs_cap = 0;
+    PinVec<ZeroJob> h_zjobs; ZeroJob* d_zjobs = nullptr; uint32_t zjobs_cap = 0;
+    uint32_t floor_dm = 256, floor_occ = 256;      // smallest region a particle gets (cfg.dm_patch_capacity / occ_patch_capacity)
+    uint32_t guard_head = 0;          // distance-map head room the allocation guard asked for lately (max over particles, decays)
+    PinVec<uint32_t> h_guard;         // the guard's per-particle bound of the last map update
+    uint64_t clone_bytes = 0;         // bytes the particle copies of the last resample moved (counters)
     double* d_poses = nullptr;
     uint64_t* d_qlower = nullptr; uint64_t* d_qraise = nullptr;
     uint64_t* d_stats = nullptr;
@@ -97,10 +149,9 @@ struct lama_hip_ctx {
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     bool route_forced = false; uint32_t num_cus = 256;
-    uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr; uint64_t* d_occ_hit = nullptr;
+    uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
-    int32_t* d_rev = nullptr; size_t rev_cap = 0;
     int32_t* d_err = nullptr;
     double* d_pts = nullptr; uint32_t pts_cap = 0; uint32_t last_n = 0;
     PinVec<uint64_t> h_stats;
@@ -114,7 +165,7 @@ struct lama_hip_ctx {
     uint8_t* d_results = nullptr;
     size_t results_bytes = 0;
     PinVec<uint8_t> h_results;
-    int32_t* d_idx = nullptr; int32_t* d_oldcounts = nullptr;
+    int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
 
     double scan_reach = 0.0;          // largest point distance of the resident scan (sensor frame, metres)
@@ -187,34 +238,29 @@ void host_scan_tf(const double* pose4, const Affine& m, double* out12)
     }
 }
 
-DevParams make_params(const lama_hip_ctx* c, int which)
+DevParams make_params(const lama_hip_ctx* c)
 {
     DevParams p;
     p.P = c->P; p.W = c->W; p.WC = c->WC; p.wx0 = c->wx0; p.wy0 = c->wy0;
-    p.dm_cap = c->cfg.dm_patch_capacity; p.occ_cap = c->cfg.occ_patch_capacity; p.qcap = c->cfg.queue_capacity;
+    p.qcap = c->cfg.queue_capacity; p.part = c->d_part;
     p.max_sqdist = c->max_sqdist; p.max_iter = c->cfg.max_iter;
     p.scale = c->scale; p.off = c->off; p.resolution = c->cfg.resolution;
     p.maxdist = std::sqrt((double)c->max_sqdist) * c->cfg.resolution;
     p.meas_sigma = c->cfg.meas_sigma;
     p.trunc_ray = c->cfg.truncated_ray; p.trunc_range = c->cfg.truncated_range;
-    const ParticleSet& s = c->set[which];
+    const MapStore& s = c->ms;
     p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
     p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.heavy = nullptr; p.elist = nullptr; p.elist_n = nullptr; p.early = nullptr; p.lane = 0;
-    p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->d_occ_hit; p.act_cap = c->cfg.active_capacity;
+    p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->ms.occ_hit; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
     // float argument, stored in double members
     auto logods = [](float prob) { return (double)(float)std::log(prob / (1.0 - prob)); };
     p.lo_miss = logods(0.4f); p.lo_hit = logods(0.7f); p.lo_min = logods(0.12f); p.lo_max = logods(0.97f);
     return p;
-}
-
-SetPtrs set_ptrs(const ParticleSet& s)
-{
-    return SetPtrs{s.dm_dir, s.occ_dir, s.dm_sv, s.dm_obs, s.dm_mask, s.occ, s.occ_mask, s.counts};
 }
 
 int32_t upload_scan(lama_hip_ctx* c, const double* pts, uint32_t n)
@@ -245,9 +291,10 @@ void resolve_timers(lama_hip_ctx* c);
 
 // End of an API call: one stream synchronisation that brings back the device error word and, when asked, the
 // per-particle patch counts and statistics (a single host round trip per call).
-int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm = 0, uint32_t need_occ = 0);
+int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ);
 int32_t recover_update(lama_hip_ctx* c, int32_t e);
 int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t first, uint32_t count);
+int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx);
 
 int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = false, bool err_in_results = false)
 {
@@ -257,7 +304,8 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
     const bool stats = maps || match;
     if (stats) {
         c->h_stats.resize((size_t)c->P * 4);
-        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+        if (maps) { c->h_guard.resize(c->P); HIPCHK(c, hipMemcpyAsync(c->h_guard.data(), c->d_guard, sizeof(uint32_t) * c->P, hipMemcpyDeviceToHost, c->stream)); }
         HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
     }
     if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
@@ -274,8 +322,8 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             if (rr != LAMA_HIP_E_CAPACITY) return rr;      // done (or another error); E_CAPACITY: the arenas are at their limit
         }
         if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (the mapped area is wider than 1016 patches)");
-        if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "distance-map patch arena full (raise cfg.dm_patch_capacity)");
-        if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "occupancy patch arena full (raise cfg.occ_patch_capacity)");
+        if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's distance map exceeds 32767 patches (or the device is out of memory)");
+        if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's occupancy map exceeds 32767 patches (or the device is out of memory)");
         if (e & ERR_QUEUE) return fail(c, LAMA_HIP_E_CAPACITY, "brushfire queue full (raise cfg.queue_capacity)");
         return fail(c, LAMA_HIP_E_NUMERIC, "unit complex number is (near) zero (SophusException in the reference)");
     }
@@ -304,100 +352,247 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
                 std::fprintf(stderr, "brushfire pops: mean %.0f max %llu (particle %u) handovers %u brushfire %.3f ms; log-lik of that particle %.1f (pool mean %.1f), rank %u of %u\n", (double)sum / c->P, (unsigned long long)mx, arg, c->h_slow_n[0], c->ctr.ms_brushfire, ll, mean_ll, rank, c->P);
             }
         }
-        if (maps) return grow_arenas(c);
+        if (maps) return grow_arenas(c, 0, 0);
     }
     return LAMA_HIP_OK;
 }
 
-// The reference's maps allocate patches on demand without bound (src/sdm/map.cpp:400-411).  The device arenas are doubled
-// whenever a particle has filled more than half of one (checked after every map update, when the counts are on the host and
-// the stream is idle): a new allocation, one strided device-to-device copy per plane, the other particle set restarts empty
-// (resample() rewrites it completely).  `cfg` then carries the new capacities.
-int32_t resize_arenas(lama_hip_ctx* c, uint32_t ndc, uint32_t noc);
+// ------------------------------------------------------------------------------------------------
+// Memory that follows the maps.  The reference's maps allocate patches on demand without bound (src/sdm/map.cpp:400-411) and share
+// them between particles copy-on-write (include/lama/cow_ptr.h:86-118).  Here every particle owns one contiguous region of each
+// pool; a region has the capacity ITS particle needs (counts are on the host after every map update) and is moved to a larger one
+// -- that particle alone -- when it runs short; the pools themselves grow geometrically when the allocator finds no room.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t MAX_PATCHES = 32767u;      // directory entries are int16
 
-int32_t grow_arenas(lama_hip_ctx* c, uint32_t need_dm, uint32_t need_occ)      // need_*: patches an incoming particle brings
+static uint32_t round_up32(uint32_t v) { return (v + 31u) / 32u * 32u; }
+
+// the region capacity a particle with `count` used slots should have so that the next update normally fits (`extra`: head room
+// asked for explicitly, e.g. the allocation guard's bound)
+static uint32_t want_capacity(uint32_t floor_cap, uint32_t count, uint32_t extra)
 {
-    uint32_t mdm = (need_dm + 1) / 2, mocc = (need_occ + 1) / 2;
-    for (uint32_t p = 0; p < c->P; ++p) { mdm = std::max<uint32_t>(mdm, (uint32_t)c->h_counts[2 * p]); mocc = std::max<uint32_t>(mocc, (uint32_t)c->h_counts[2 * p + 1]); }
-    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
-    uint32_t ndc = dc, noc = oc;
-    while (2 * mdm > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
-    while (2 * mocc > noc && noc < 32767u) noc = std::min<uint32_t>(2 * noc, 32767u);
-    return resize_arenas(c, ndc, noc);
+    const uint32_t head = std::max<uint32_t>(std::max<uint32_t>(32u, count / 4u), extra);
+    return std::min<uint32_t>(MAX_PATCHES, std::max<uint32_t>(floor_cap, round_up32(count + head)));
 }
 
-// new capacities (>= the current ones) for both particle sets; the current set's contents are kept
-int32_t resize_arenas(lama_hip_ctx* c, uint32_t ndc, uint32_t noc)
+int32_t upload_part(lama_hip_ctx* c)
 {
-    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
-    if (ndc == dc && noc == oc) return LAMA_HIP_OK;
-    const size_t P = c->P;
-    auto regrow = [&](auto*& arr, size_t old_stride_b, size_t new_stride_b, bool keep) -> hipError_t {
+    c->h_part_stage.resize(c->P);
+    std::memcpy(c->h_part_stage.data(), c->h_part.data(), sizeof(PartRec) * c->P);
+    HIPCHK(c, hipMemcpyAsync(c->d_part, c->h_part_stage.data(), sizeof(PartRec) * c->P, hipMemcpyHostToDevice, c->stream));
+    return LAMA_HIP_OK;
+}
+
+// a pool that holds at least `min_patches`: new planes, the old contents copied, the tail zeroed (free pool space is all-zero)
+int32_t grow_pool(lama_hip_ctx* c, bool dm, uint32_t min_patches)
+{
+    MapStore& m = c->ms;
+    const uint32_t old = dm ? m.dm_pool : m.occ_pool;
+    if (min_patches <= old) return LAMA_HIP_OK;
+    uint64_t want = std::max<uint64_t>(min_patches, (uint64_t)old + old / 2u);
+    want = (want + 1023u) / 1024u * 1024u;
+    const uint64_t per_patch = dm ? (2048 + 4096 + 128) : (4096 + 128 + 128 + 4);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        // old and new planes coexist during the copy; leave 1 GB for everything else
+        const uint64_t room = free_b > (1ull << 30) ? free_b - (1ull << 30) : 0;
+        if (want * per_patch > room) want = std::max<uint64_t>(min_patches, room / per_patch);
+        if (want < min_patches || want * per_patch > room)
+            return fail(c, LAMA_HIP_E_CAPACITY, std::string(dm ? "distance-map" : "occupancy") + " pool: not enough device memory for " + std::to_string(min_patches) + " patches");
+    }
+    if (want > 0xFFFFFFFFull) return fail(c, LAMA_HIP_E_CAPACITY, "patch pool beyond 2^32 patches");
+    const uint32_t nw = (uint32_t)want;
+    auto regrow = [&](auto*& arr, size_t bytes_per_patch, bool keep) -> hipError_t {
         void* fresh = nullptr;
-        hipError_t e = hipMalloc(&fresh, P * new_stride_b);
+        hipError_t e = hipMalloc(&fresh, (size_t)nw * bytes_per_patch);
         if (e != hipSuccess) return e;
-        e = hipMemsetAsync(fresh, 0, P * new_stride_b, c->stream);
-        if (e == hipSuccess && keep) e = hipMemcpy2DAsync(fresh, new_stride_b, arr, old_stride_b, old_stride_b, P, hipMemcpyDeviceToDevice, c->stream);
+        if (keep && old) e = hipMemcpyAsync(fresh, arr, (size_t)old * bytes_per_patch, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemsetAsync((char*)fresh + (keep ? (size_t)old * bytes_per_patch : 0), 0, (size_t)(nw - (keep ? old : 0)) * bytes_per_patch, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) { (void)hipFree(fresh); return e; }
-        (void)hipFree(arr);
+        if (arr) (void)hipFree(arr);
         arr = reinterpret_cast<std::remove_reference_t<decltype(arr)>>(fresh);
         return hipSuccess;
     };
-    for (int s = 0; s < 2; ++s) {
-        ParticleSet& ps = c->set[s];
-        const bool keep = s == c->cur;
-        if (ndc != dc) {
-            HIPCHK(c, regrow(ps.dm_sv, (size_t)dc * 2048, (size_t)ndc * 2048, keep));
-            HIPCHK(c, regrow(ps.dm_obs, (size_t)dc * 4096, (size_t)ndc * 4096, keep));
-            HIPCHK(c, regrow(ps.dm_mask, (size_t)dc * 128, (size_t)ndc * 128, keep));
-        }
-        if (noc != oc) {
-            HIPCHK(c, regrow(ps.occ, (size_t)oc * 4096, (size_t)noc * 4096, keep));
-            HIPCHK(c, regrow(ps.occ_mask, (size_t)oc * 128, (size_t)noc * 128, keep));
-        }
-        if (!keep) HIPCHK(c, hipMemsetAsync(ps.counts, 0, P * 2 * 4, c->stream));      // its (zeroed) arenas hold nothing
+    if (dm) {
+        HIPCHK(c, regrow(m.dm_sv, 2048, true)); HIPCHK(c, regrow(m.dm_obs, 4096, true)); HIPCHK(c, regrow(m.dm_mask, 128, true));
+        m.dm_pool = nw; c->ra_dm.extend(nw);
+    } else {
+        HIPCHK(c, regrow(m.occ, 4096, true)); HIPCHK(c, regrow(m.occ_mask, 128, true));
+        HIPCHK(c, regrow(m.occ_hit, 128, true));                    // (all zero between scans; kept: an update may be in its allocation phase)
+        HIPCHK(c, regrow(m.rev, 4, false));
+        m.occ_pool = nw; c->ra_occ.extend(nw);
     }
-    if (noc != oc) HIPCHK(c, regrow(c->d_occ_hit, (size_t)oc * 128, (size_t)noc * 128, false));   // all zero between scans
+    c->ctr.pool_growths += 1;
+    return LAMA_HIP_OK;
+}
+
+int32_t region_alloc(lama_hip_ctx* c, bool dm, uint32_t n, uint32_t& off)
+{
+    RegionAlloc& ra = dm ? c->ra_dm : c->ra_occ;
+    if (ra.alloc(n, off)) return LAMA_HIP_OK;
+    const int32_t rc = grow_pool(c, dm, ra.cap + n);
+    if (rc) return rc;
+    if (!ra.alloc(n, off)) return fail(c, LAMA_HIP_E_CAPACITY, "patch pool exhausted");
+    return LAMA_HIP_OK;
+}
+
+static int32_t ensure_job_buffers(lama_hip_ctx* c, uint32_t nj, uint32_t nz)
+{
+    if (nj > c->jobs_cap) {
+        (void)hipFree(c->d_jobs); c->d_jobs = nullptr; c->jobs_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(nj, 256u);
+        HIPCHK(c, hipMalloc(&c->d_jobs, sizeof(CloneJob) * cap));
+        c->jobs_cap = cap;
+    }
+    if (nz > c->zjobs_cap) {
+        (void)hipFree(c->d_zjobs); c->d_zjobs = nullptr; c->zjobs_cap = 0;
+        const uint32_t cap = std::max<uint32_t>(nz, 256u);
+        HIPCHK(c, hipMalloc(&c->d_zjobs, sizeof(ZeroJob) * cap));
+        c->zjobs_cap = cap;
+    }
+    return LAMA_HIP_OK;
+}
+
+// run the jobs in c->h_jobs / c->h_zjobs: `zero_first` = the zero jobs free regions no job reads (resample); else they free the jobs'
+// own sources (growth) and run behind the copies
+static int32_t run_jobs(lama_hip_ctx* c, bool zero_first)
+{
+    const uint32_t nj = (uint32_t)c->h_jobs.size(), nz = (uint32_t)c->h_zjobs.size();
+    if (nj == 0 && nz == 0) return LAMA_HIP_OK;
+    const int32_t rb = ensure_job_buffers(c, nj, nz);
+    if (rb) return rb;
+    const DevParams prm = make_params(c);
+    if (nj) HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), sizeof(CloneJob) * nj, hipMemcpyHostToDevice, c->stream));
+    if (nz) HIPCHK(c, hipMemcpyAsync(c->d_zjobs, c->h_zjobs.data(), sizeof(ZeroJob) * nz, hipMemcpyHostToDevice, c->stream));
+    if (nz && zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const ZeroJob*)c->d_zjobs);
+    if (nj) hipLaunchKernelGGL(k_clone_particles, dim3(nj, 7, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const CloneJob*)c->d_jobs);
+    if (nz && !zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const ZeroJob*)c->d_zjobs);
+    HIPCHK(c, hipGetLastError());
+    return LAMA_HIP_OK;
+}
+
+// Give the listed particles regions of (at least) the capacities asked for; a particle whose region is large enough keeps it.  The
+// used slots move with one launch for all of them, the old regions go back to the allocator zeroed.  Synchronises the stream.
+struct CapRequest { uint32_t p, dm_cap, occ_cap; };
+int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
+{
+    struct Old { uint32_t dm_base, dm_cap, occ_base, occ_cap; };
+    std::vector<Old> released;
+    c->h_jobs.resize(0); c->h_zjobs.resize(0);
+    for (const CapRequest& r : reqs) {
+        PartRec& pr = c->h_part[r.p];
+        const bool gd = r.dm_cap > pr.dm_cap, go = r.occ_cap > pr.occ_cap;
+        if (!gd && !go) continue;
+        if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
+        CloneJob j{};
+        j.src_home = j.dst_home = pr.home;
+        j.src_dm = j.dst_dm = pr.dm_base; j.src_occ = j.dst_occ = pr.occ_base;
+        j.sdm = c->h_counts[2 * r.p]; j.socc = c->h_counts[2 * r.p + 1];
+        Old o{pr.dm_base, 0, pr.occ_base, 0};
+        if (gd) {
+            uint32_t off = 0;
+            const int32_t rc = region_alloc(c, true, r.dm_cap, off);
+            if (rc) return rc;
+            o.dm_cap = pr.dm_cap; j.dst_dm = off; pr.dm_base = off; pr.dm_cap = r.dm_cap;
+        }
+        if (go) {
+            uint32_t off = 0;
+            const int32_t rc = region_alloc(c, false, r.occ_cap, off);
+            if (rc) return rc;
+            o.occ_cap = pr.occ_cap; j.dst_occ = off; pr.occ_base = off; pr.occ_cap = r.occ_cap;
+        }
+        c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = j;
+        ZeroJob z{o.dm_base, o.occ_base, gd ? j.sdm : 0, go ? j.socc : 0};
+        c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z;
+        released.push_back(o);
+    }
+    if (released.empty()) return LAMA_HIP_OK;
+    int32_t rc = run_jobs(c, false);
+    if (rc) return rc;
+    rc = upload_part(c);
+    if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->cfg.dm_patch_capacity = ndc; c->cfg.occ_patch_capacity = noc;
+    for (const Old& o : released) { c->ra_dm.release(o.dm_base, o.dm_cap); c->ra_occ.release(o.occ_base, o.occ_cap); }     // (only now: no job of the batch may land in a region another one still reads)
     c->ctr.arena_growths += 1;
     return LAMA_HIP_OK;
 }
 
-// A map update whose allocation phase failed (ERR_CLEAN_ABORT: no cell was modified): clear what the phase left behind, double the
-// arena that ran out and run the same update again.  The reference's maps simply allocate (src/sdm/map.cpp:400-411).
+// after a map update (counts on the host, stream idle): every particle keeps head room for the next one
+int32_t grow_arenas(lama_hip_ctx* c, uint32_t /*need_dm*/, uint32_t /*need_occ*/)
+{
+    std::vector<CapRequest> reqs;
+    // the guard's bound of the last update says what the next one will ask for (open space: many occupancy patches without a
+    // distance-map patch nearby); decays so that one wide view does not pin the head room for ever
+    uint32_t gmax = 0;
+    for (uint32_t p = 0; p < c->P && p < c->h_guard.size(); ++p) gmax = std::max(gmax, c->h_guard[p]);
+    c->guard_head = std::max(gmax, c->guard_head - c->guard_head / 8u);
+    for (uint32_t p = 0; p < c->P; ++p) {
+        const PartRec& pr = c->h_part[p];
+        const uint32_t dmc = (uint32_t)c->h_counts[2 * p], occ = (uint32_t)c->h_counts[2 * p + 1];
+        const uint32_t gh = p < c->h_guard.size() ? c->h_guard[p] : 0u;
+        uint32_t nd = pr.dm_cap, no = pr.occ_cap;
+        if (dmc + std::max<uint32_t>(std::max<uint32_t>(16u, dmc / 16u), gh) > pr.dm_cap) nd = want_capacity(c->floor_dm, dmc, gh + gh / 4u);
+        if (occ + std::max<uint32_t>(16u, occ / 16u) > pr.occ_cap) no = want_capacity(c->floor_occ, occ, 0u);
+        if (nd > pr.dm_cap || no > pr.occ_cap) reqs.push_back(CapRequest{p, std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
+    }
+    if (reqs.empty()) return LAMA_HIP_OK;
+    return set_capacities(c, reqs);
+}
+
+// A map update whose allocation phase failed (ERR_CLEAN_ABORT: no cell was modified): clear what the phase left behind, give the
+// particles that ran short what they asked for and run the same update again.  The reference's maps simply allocate
+// (src/sdm/map.cpp:400-411).  What a particle asked for: the occupancy allocations count on past the capacity (dir_alloc_one), the
+// distance-map bound is the guard's (k_occ_reverse_dir -> guard[2p]).
 int32_t recover_update(lama_hip_ctx* c, int32_t e)
 {
-    const uint32_t dc = c->cfg.dm_patch_capacity, oc = c->cfg.occ_patch_capacity;
-    const uint32_t ndc = (e & ERR_DM_CAP) ? std::min<uint32_t>(2 * dc, 32767u) : dc, noc = (e & ERR_OCC_CAP) ? std::min<uint32_t>(2 * oc, 32767u) : oc;
-    // at the hard limit the distance-map guard (an upper bound) must not be what fails the update: repeat it unguarded -- once
-    const bool at_limit = ndc == dc && noc == oc;
-    if (at_limit && (c->unguarded_retry || !(e & ERR_DM_CAP) || (e & ERR_OCC_CAP))) return LAMA_HIP_E_CAPACITY;
     ++c->recover_depth;
-    c->unguarded_retry = at_limit;
     // the aborted pass changed nothing on the device; undo what it did on the host (wrap-guard bound, scan / launch counters)
     c->visit_bound = c->saved_visit_bound;
     {
         const lama_hip_counters now = c->ctr;
         c->ctr = c->saved_ctr;
-        c->ctr.arena_growths = now.arena_growths; c->ctr.dm_patches = now.dm_patches; c->ctr.occ_patches = now.occ_patches;
+        c->ctr.arena_growths = now.arena_growths; c->ctr.pool_growths = now.pool_growths; c->ctr.dm_patches = now.dm_patches; c->ctr.occ_patches = now.occ_patches;
     }
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     const size_t WW = (size_t)c->W * c->W;
     hipLaunchKernelGGL(k_update_cleanup, dim3(c->P, (unsigned)((WW + 255) / 256)), dim3(256), 0, c->stream, prm);
-    HIPCHK(c, hipMemsetAsync(c->d_occ_hit, 0, (size_t)c->P * oc * 128, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->ms.occ_hit, 0, (size_t)c->ms.occ_pool * 128, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_act_count, 0, (size_t)c->P * 4, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_guard, 0, (size_t)c->P * 8, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
-    // the failed allocations may have raised the patch counts: the host mirror must hold them before the arenas are re-laid out
-    HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->set[c->cur].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+    // the counts hold what every particle WANTED (allocations count on past the capacity); the guard its distance-map bound
+    c->h_guard.resize(c->P);
+    HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_guard.data(), c->d_guard, sizeof(uint32_t) * c->P, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    int32_t rc = resize_arenas(c, ndc, noc);
+    std::vector<CapRequest> reqs;
+    bool at_limit = false, fixed_counts = false;
+    for (uint32_t p = 0; p < c->P; ++p) {
+        PartRec& pr = c->h_part[p];
+        uint32_t wdm = (uint32_t)c->h_counts[2 * p], wocc = (uint32_t)c->h_counts[2 * p + 1];
+        uint32_t nd = pr.dm_cap, no = pr.occ_cap;
+        if (wocc > pr.occ_cap) { no = want_capacity(c->floor_occ, wocc, 0u); c->h_counts[2 * p + 1] = (int32_t)pr.occ_cap; fixed_counts = true; }
+        if (wdm > pr.dm_cap) { c->h_counts[2 * p] = (int32_t)pr.dm_cap; wdm = pr.dm_cap; fixed_counts = true; nd = want_capacity(c->floor_dm, wdm, 64u); }
+        const uint32_t gh = c->h_guard[p];
+        if ((e & ERR_DM_CAP) && !c->unguarded_retry && (uint64_t)wdm + gh > pr.dm_cap) {
+            if ((uint64_t)wdm + gh > MAX_PATCHES) at_limit = true;      // the guard's bound does not fit the hard limit: run this update unguarded
+            nd = std::max(nd, std::min<uint32_t>(MAX_PATCHES, round_up32(wdm + gh + gh / 8u + 16u)));
+        }
+        if (nd > pr.dm_cap || no > pr.occ_cap) {
+            if (no > MAX_PATCHES || (wocc > MAX_PATCHES)) { --c->recover_depth; return LAMA_HIP_E_CAPACITY; }
+            reqs.push_back(CapRequest{p, std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
+        }
+    }
+    if (fixed_counts) HIPCHK(c, hipMemcpyAsync(c->ms.counts, c->h_counts.data(), sizeof(int32_t) * 2 * c->P, hipMemcpyHostToDevice, c->stream));
+    if (reqs.empty() && !at_limit) { --c->recover_depth; return LAMA_HIP_E_CAPACITY; }     // nothing to grow: a real limit
+    if (at_limit && c->unguarded_retry) { --c->recover_depth; return LAMA_HIP_E_CAPACITY; }
+    int32_t rc = set_capacities(c, reqs);
+    const bool saved_unguarded = c->unguarded_retry;
+    c->unguarded_retry = at_limit;
     if (rc == LAMA_HIP_OK) rc = run_update_maps(c, c->last_n, c->last_mtf, c->last_first, c->last_count);
     if (rc == LAMA_HIP_OK) rc = check_device_errors(c, true, false);
     --c->recover_depth;
-    c->unguarded_retry = false;
+    c->unguarded_retry = saved_unguarded;
     return rc;
 }
 
@@ -467,31 +662,31 @@ int32_t regrid_window(lama_hip_ctx* c, uint32_t newW, int64_t nox, int64_t noy)
     const int dx = (int)(nox - ox), dy = (int)(noy - oy);
     const size_t WW = (size_t)c->W * c->W, nWW = (size_t)newW * newW, P = c->P;
     if (!c->initialised && newW == c->W) { c->wx0 = (uint32_t)(nox * 32); c->wy0 = (uint32_t)(noy * 32); return LAMA_HIP_OK; }   // nothing mapped yet
-    ParticleSet& a = c->set[c->cur];
-    ParticleSet& b = c->set[1 - c->cur];
-    if (newW == c->W) {
-        const dim3 grid((unsigned)P, (unsigned)((WW + 255) / 256));
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, b.dm_dir, c->W, c->W, dx, dy, WW, WW, c->d_err);
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, b.occ_dir, c->W, c->W, dx, dy, WW, WW, c->d_err);
-        HIPCHK(c, hipGetLastError());
-        std::swap(a.dm_dir, b.dm_dir);
-        std::swap(a.occ_dir, b.occ_dir);
-    } else {
-        int16_t* nd[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
-        for (int k = 0; k < 2; ++k)
-            for (int m = 0; m < 2; ++m) {
-                HIPCHK(c, hipMalloc(&nd[k][m], P * nWW * 2));
-                HIPCHK(c, hipMemsetAsync(nd[k][m], 0xFF, P * nWW * 2, c->stream));
-            }
-        const dim3 grid((unsigned)P, (unsigned)((std::max(WW, nWW) + 255) / 256));
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.dm_dir, nd[c->cur][0], c->W, newW, dx, dy, WW, nWW, c->d_err);
-        hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, a.occ_dir, nd[c->cur][1], c->W, newW, dx, dy, WW, nWW, c->d_err);
-        HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (int k = 0; k < 2; ++k) {
-            (void)hipFree(c->set[k].dm_dir); (void)hipFree(c->set[k].occ_dir);
-            c->set[k].dm_dir = nd[k][0]; c->set[k].occ_dir = nd[k][1];
-        }
+    // both directories of every home are re-tiled into fresh arrays (same side: a permutation; larger side: the window grew), then the
+    // old arrays are released.  A failed allocation leaves the window as it was (nothing leaks).
+    MapStore& m = c->ms;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && 2 * P * nWW * 2 + (1ull << 28) > free_b)
+            return fail(c, LAMA_HIP_E_WINDOW, "not enough device memory to re-tile the window directories (" + std::to_string(2 * P * nWW * 2 >> 20) + " MB for a " + std::to_string(newW) + "-patch window)");
+    }
+    int16_t* nd[2] = {nullptr, nullptr};
+    for (int k = 0; k < 2; ++k) {
+        hipError_t e = hipMalloc(&nd[k], P * nWW * 2);
+        if (e == hipSuccess && newW != c->W) e = hipMemsetAsync(nd[k], 0xFF, P * nWW * 2, c->stream);
+        if (e != hipSuccess) { (void)hipFree(nd[0]); (void)hipFree(nd[1]); c->error = std::string("window directories: ") + hipGetErrorString(e); return LAMA_HIP_E_HIP; }
+    }
+    const dim3 grid((unsigned)P, (unsigned)((std::max(WW, nWW) + 255) / 256));
+    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, m.dm_dir, nd[0], c->W, newW, dx, dy, WW, nWW, c->d_err);
+    hipLaunchKernelGGL(k_shift_window, grid, dim3(256), 0, c->stream, m.occ_dir, nd[1], c->W, newW, dx, dy, WW, nWW, c->d_err);
+    {
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { (void)hipFree(nd[0]); (void)hipFree(nd[1]); c->error = std::string("k_shift_window: ") + hipGetErrorString(e); return LAMA_HIP_E_HIP; }
+    }
+    (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir);
+    m.dm_dir = nd[0]; m.occ_dir = nd[1];
+    if (newW != c->W) {
         c->W = newW; c->WC = newW * 32; c->cfg.window_patches = newW;
         c->ctr.window_growths += 1;
     }
@@ -548,18 +743,13 @@ int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t 
 // still to come): afterwards either every patch the update needs exists or an error bit is set and no map cell has been modified
 int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t n, uint32_t first, uint32_t count, int alloc_only)
 {
-    const size_t need = (size_t)c->P * n, need_rev = (size_t)c->P * c->cfg.occ_patch_capacity;
+    const size_t need = (size_t)c->P * n;
     if (need > c->rrec_cap) {
         (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); c->d_rrec = nullptr; c->d_rbbox = nullptr; c->d_rchunk = nullptr; c->rrec_cap = 0;
         HIPCHK(c, hipMalloc(&c->d_rrec, need * sizeof(lama_dev::RayRec)));
         HIPCHK(c, hipMalloc(&c->d_rbbox, need * sizeof(uint64_t)));
         HIPCHK(c, hipMalloc(&c->d_rchunk, (size_t)c->P * ((n + 63) / 64) * sizeof(lama_dev::RayChunk)));     // per 64 beams of a particle
         c->rrec_cap = need;
-    }
-    if (need_rev > c->rev_cap) {
-        (void)hipFree(c->d_rev); c->d_rev = nullptr; c->rev_cap = 0;
-        HIPCHK(c, hipMalloc(&c->d_rev, need_rev * sizeof(int32_t)));
-        c->rev_cap = need_rev;
     }
     hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
                        c->d_rrec, c->d_rbbox, alloc_only, c->d_rchunk);
@@ -568,7 +758,7 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
     double far = c->scan_reach;                                   // no cell further than truncated_range from the sensor is touched
     if (c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
     const int reach_cells = (int)std::ceil(far * c->scale) + 2;
-    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->d_rev, (int)first, (const double*)c->d_tfs, reach_cells,
+    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->ms.rev, (int)first, (const double*)c->d_tfs, reach_cells,
                        c->unguarded_retry ? 1 : 0);
     return LAMA_HIP_OK;
 }
@@ -594,7 +784,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     tfs.resize((size_t)c->P * 12);
     for (uint32_t p = 0; p < c->P; ++p) host_scan_tf(&c->h_poses[4 * p], mtf, &tfs[12 * (size_t)p]);
     HIPCHK(c, hipMemcpyAsync(c->d_tfs, tfs.data(), sizeof(double) * tfs.size(), hipMemcpyHostToDevice, c->stream));
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     bool early_lane = false;
     {
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
@@ -628,15 +818,16 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             const double side = 32.0 * c->cfg.resolution;
             const double rp = c->scan_reach / side + 2.5;
             const uint32_t bound = (uint32_t)std::min(32767.0, std::ceil(3.1416 * rp * rp));
-            uint32_t mdm = 0, mocc = 0;
-            for (uint32_t p = 0; p < c->P; ++p) { mdm = std::max<uint32_t>(mdm, (uint32_t)c->h_counts[2 * p]); mocc = std::max<uint32_t>(mocc, (uint32_t)c->h_counts[2 * p + 1]); }
-            uint32_t ndc = c->cfg.dm_patch_capacity, noc = c->cfg.occ_patch_capacity;
-            while (mdm + bound > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
-            while (mocc + bound > noc && noc < 32767u) noc = std::min<uint32_t>(2 * noc, 32767u);
-            if (ndc != c->cfg.dm_patch_capacity || noc != c->cfg.occ_patch_capacity) {
-                const int32_t rg = resize_arenas(c, ndc, noc);
+            std::vector<CapRequest> reqs;
+            for (uint32_t p = first; p < first + count; ++p) {
+                const PartRec& pr = c->h_part[p];
+                const uint32_t nd = std::min<uint32_t>(MAX_PATCHES, round_up32((uint32_t)c->h_counts[2 * p] + bound)), no = std::min<uint32_t>(MAX_PATCHES, round_up32((uint32_t)c->h_counts[2 * p + 1] + bound));
+                if (nd > pr.dm_cap || no > pr.occ_cap) reqs.push_back(CapRequest{p, std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
+            }
+            if (!reqs.empty()) {
+                const int32_t rg = set_capacities(c, reqs);
                 if (rg) return rg;
-                prm = make_params(c, c->cur);
+                prm = make_params(c);
             }
         }
         if (sequential) {
@@ -681,7 +872,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 pe.elist = c->d_elist; pe.elist_n = c->d_slow_n + 4; pe.lane = 1;
                 const unsigned eg = route_places(c, count);
                 hipLaunchKernelGGL(k_ray_patches, dim3(eg, 128u), dim3(256), 0, c->stream, pe, (const lama_dev::RayRec*)c->d_rrec,
-                                   (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, 0);
+                                   (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->ms.rev, (int)n, 0);
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
                 hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
                 HIPCHK(c, hipEventRecord(c->ev_alloc, c->stream));
@@ -694,7 +885,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 prm.early = c->d_early;                          // everybody else: the main lane skips them
             }
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
-                               (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->d_rev, (int)n, (int)first);
+                               (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->ms.rev, (int)n, (int)first);
             const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
             if (count <= 512) {
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
@@ -751,6 +942,85 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     return LAMA_HIP_OK;
 }
 
+
+// new particle i := old particle idx[i] (pose + both maps), IN PLACE (resample(), src/pf_slam2d.cpp:558-574; the first scan's
+// copies, :204-216).  The first new particle that draws an old one takes over its home and regions -- nothing moves --, every further
+// copy of it goes to the home of a particle nobody drew; its regions are reused when they have the source's capacities, else they
+// go back to the allocator (zeroed where used) and fresh ones are taken.  What the device copies is exactly the clones.
+int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
+{
+    const uint32_t P = c->P;
+    std::vector<uint8_t> taken(P, 0);
+    std::vector<PartRec> np(P);
+    std::vector<int32_t> nc(2 * (size_t)P);
+    std::vector<double> npose(4 * (size_t)P);
+    std::vector<uint32_t> clones;                                   // new particles that need a copy
+    for (uint32_t i = 0; i < P; ++i) {
+        const uint32_t j = (uint32_t)idx[i];
+        std::memcpy(&npose[4 * i], &c->h_poses[4 * j], sizeof(double) * 4);
+        nc[2 * i] = c->h_counts[2 * j]; nc[2 * i + 1] = c->h_counts[2 * j + 1];
+        if (!taken[j]) { taken[j] = 1; np[i] = c->h_part[j]; } else clones.push_back(i);
+    }
+    std::vector<uint32_t> dead;                                     // old particles nobody drew: their homes / regions are free
+    for (uint32_t j = 0; j < P; ++j) if (!taken[j]) dead.push_back(j);
+    c->h_jobs.resize(0); c->h_zjobs.resize(0);
+    c->clone_bytes = 0;
+    const size_t WW = (size_t)c->W * c->W;
+    // first pass: dead particles whose regions cannot be reused as they are go back to the allocator (so that the clones can have them)
+    // -- a dead particle is matched with the clone of the same rank; capacities are mostly equal (particles of one filter map the
+    // same world), so the common case is a plain overwrite
+    struct Slot { uint32_t home; bool keep_dm, keep_occ; PartRec rec; int32_t odm, oocc; };
+    std::vector<Slot> slots(dead.size());
+    for (size_t k = 0; k < dead.size(); ++k) {
+        const uint32_t d = dead[k], i = clones[k], j = (uint32_t)idx[i];
+        const PartRec& dr = c->h_part[d];
+        const PartRec& sr = c->h_part[j];
+        Slot sl{dr.home, dr.dm_cap == sr.dm_cap, dr.occ_cap == sr.occ_cap, dr, c->h_counts[2 * d], c->h_counts[2 * d + 1]};
+        ZeroJob z{dr.dm_base, dr.occ_base, 0, 0};
+        if (!sl.keep_dm) { z.ndm = sl.odm; c->ra_dm.release(dr.dm_base, dr.dm_cap); }
+        if (!sl.keep_occ) { z.nocc = sl.oocc; c->ra_occ.release(dr.occ_base, dr.occ_cap); }
+        if (z.ndm || z.nocc) { c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z; }
+        slots[k] = sl;
+    }
+    for (size_t k = 0; k < dead.size(); ++k) {
+        const uint32_t i = clones[k], j = (uint32_t)idx[i];
+        const PartRec sr = c->h_part[j];
+        Slot& sl = slots[k];
+        PartRec r{};
+        r.home = sl.home;
+        r.dm_cap = sr.dm_cap; r.occ_cap = sr.occ_cap;
+        CloneJob job{};
+        job.src_home = sr.home; job.dst_home = sl.home;
+        job.src_dm = sr.dm_base; job.src_occ = sr.occ_base;
+        job.sdm = c->h_counts[2 * j]; job.socc = c->h_counts[2 * j + 1];
+        if (sl.keep_dm) { r.dm_base = sl.rec.dm_base; job.odm = sl.odm; }
+        else { const int32_t rc = region_alloc(c, true, sr.dm_cap, r.dm_base); if (rc) return rc; job.odm = 0; }
+        if (sl.keep_occ) { r.occ_base = sl.rec.occ_base; job.oocc = sl.oocc; }
+        else { const int32_t rc = region_alloc(c, false, sr.occ_cap, r.occ_base); if (rc) return rc; job.oocc = 0; }
+        job.dst_dm = r.dm_base; job.dst_occ = r.occ_base;
+        np[i] = r;
+        c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = job;
+        c->clone_bytes += 2 * (uint64_t)WW * 2 + (uint64_t)job.sdm * (2048 + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
+    }
+    c->h_part = np;
+    std::memcpy(c->h_poses.data(), npose.data(), npose.size() * sizeof(double));
+    std::memcpy(c->h_counts.data(), nc.data(), nc.size() * sizeof(int32_t));
+    int32_t rc = upload_part(c);                                    // (the jobs carry absolute bases; the table is for everybody after them)
+    if (rc) return rc;
+    {
+        Timer t(c, &c->ctr.ms_resample, &c->ctr.launches_resample);
+        rc = run_jobs(c, true);
+        t.stop();
+    }
+    if (rc) return rc;
+    HIPCHK(c, hipMemcpyAsync(c->ms.counts, c->h_counts.data(), sizeof(int32_t) * 2 * P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * P, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    resolve_timers(c);
+    c->ctr.resample_clones += clones.size();
+    c->ctr.resample_bytes += c->clone_bytes;
+    return LAMA_HIP_OK;
+}
 
 } // namespace
 
@@ -828,16 +1098,33 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipEventCreate(&c->ev0));
     CHK(hipEventCreate(&c->ev1));
     const size_t P = c->P, WW = (size_t)c->W * c->W, dc = cfg.dm_patch_capacity, oc = cfg.occ_patch_capacity;
-    for (int s = 0; s < 2; ++s) {
-        ParticleSet& ps = c->set[s];
-        CHK(hipMalloc(&ps.dm_dir, P * WW * 2));      CHK(hipMemset(ps.dm_dir, 0xFF, P * WW * 2));
-        CHK(hipMalloc(&ps.occ_dir, P * WW * 2));     CHK(hipMemset(ps.occ_dir, 0xFF, P * WW * 2));
-        CHK(hipMalloc(&ps.dm_sv, P * dc * 2048));    CHK(hipMemset(ps.dm_sv, 0, P * dc * 2048));
-        CHK(hipMalloc(&ps.dm_obs, P * dc * 4096));   CHK(hipMemset(ps.dm_obs, 0, P * dc * 4096));
-        CHK(hipMalloc(&ps.dm_mask, P * dc * 128));   CHK(hipMemset(ps.dm_mask, 0, P * dc * 128));
-        CHK(hipMalloc(&ps.occ, P * oc * 4096));      CHK(hipMemset(ps.occ, 0, P * oc * 4096));
-        CHK(hipMalloc(&ps.occ_mask, P * oc * 128));  CHK(hipMemset(ps.occ_mask, 0, P * oc * 128));
-        CHK(hipMalloc(&ps.counts, P * 2 * 4));       CHK(hipMemset(ps.counts, 0, P * 2 * 4));
+    {
+        // one particle set: directories per home, pooled planes with one region per particle and map kind (lama_dev.h).  The pools
+        // start at P x the configured capacities and grow with the maps.
+        MapStore& m = c->ms;
+        c->floor_dm = (uint32_t)dc; c->floor_occ = (uint32_t)oc;
+        if (P * dc > 0xFFFFFFFFull || P * oc > 0xFFFFFFFFull) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_INVALID; }
+        m.dm_pool = (uint32_t)(P * dc); m.occ_pool = (uint32_t)(P * oc);
+        CHK(hipMalloc(&m.dm_dir, P * WW * 2));                 CHK(hipMemset(m.dm_dir, 0xFF, P * WW * 2));
+        CHK(hipMalloc(&m.occ_dir, P * WW * 2));                CHK(hipMemset(m.occ_dir, 0xFF, P * WW * 2));
+        CHK(hipMalloc(&m.dm_sv, (size_t)m.dm_pool * 2048));    CHK(hipMemset(m.dm_sv, 0, (size_t)m.dm_pool * 2048));
+        CHK(hipMalloc(&m.dm_obs, (size_t)m.dm_pool * 4096));   CHK(hipMemset(m.dm_obs, 0, (size_t)m.dm_pool * 4096));
+        CHK(hipMalloc(&m.dm_mask, (size_t)m.dm_pool * 128));   CHK(hipMemset(m.dm_mask, 0, (size_t)m.dm_pool * 128));
+        CHK(hipMalloc(&m.occ, (size_t)m.occ_pool * 4096));     CHK(hipMemset(m.occ, 0, (size_t)m.occ_pool * 4096));
+        CHK(hipMalloc(&m.occ_mask, (size_t)m.occ_pool * 128)); CHK(hipMemset(m.occ_mask, 0, (size_t)m.occ_pool * 128));
+        CHK(hipMalloc(&m.occ_hit, (size_t)m.occ_pool * 128));  CHK(hipMemset(m.occ_hit, 0, (size_t)m.occ_pool * 128));
+        CHK(hipMalloc(&m.rev, (size_t)m.occ_pool * 4));
+        CHK(hipMalloc(&m.counts, P * 2 * 4));                  CHK(hipMemset(m.counts, 0, P * 2 * 4));
+        c->ra_dm.reset(m.dm_pool); c->ra_occ.reset(m.occ_pool);
+        c->h_part.resize(P);
+        for (size_t p = 0; p < P; ++p) {
+            PartRec r{};
+            r.home = (uint32_t)p; r.dm_cap = (uint32_t)dc; r.occ_cap = (uint32_t)oc;
+            (void)c->ra_dm.alloc((uint32_t)dc, r.dm_base); (void)c->ra_occ.alloc((uint32_t)oc, r.occ_base);
+            c->h_part[p] = r;
+        }
+        CHK(hipMalloc(&c->d_part, P * sizeof(PartRec)));
+        CHK(hipMemcpy(c->d_part, c->h_part.data(), P * sizeof(PartRec), hipMemcpyHostToDevice));
     }
     c->results_bytes = P * 4 * 8 + P * 8 + P * 4 + 8;
     CHK(hipMalloc(&c->d_results, c->results_bytes));   CHK(hipMemset(c->d_results, 0, c->results_bytes));
@@ -866,9 +1153,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
-    CHK(hipMalloc(&c->d_occ_hit, P * oc * 128));     CHK(hipMemset(c->d_occ_hit, 0, P * oc * 128));
     CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
-    CHK(hipMalloc(&c->d_idx, P * 4));
     CHK(hipMalloc(&c->d_oldcounts, P * 2 * 4));
     CHK(hipDeviceSynchronize());
 #undef CHK
@@ -883,14 +1168,15 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (int s = 0; s < 2; ++s) {
-        ParticleSet& ps = c->set[s];
-        (void)hipFree(ps.dm_dir); (void)hipFree(ps.occ_dir); (void)hipFree(ps.dm_sv); (void)hipFree(ps.dm_obs);
-        (void)hipFree(ps.dm_mask); (void)hipFree(ps.occ); (void)hipFree(ps.occ_mask); (void)hipFree(ps.counts);
+    {
+        MapStore& m = c->ms;
+        (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir); (void)hipFree(m.dm_sv); (void)hipFree(m.dm_obs); (void)hipFree(m.dm_mask);
+        (void)hipFree(m.occ); (void)hipFree(m.occ_mask); (void)hipFree(m.occ_hit); (void)hipFree(m.rev); (void)hipFree(m.counts);
+        (void)hipFree(c->d_part); (void)hipFree(c->d_jobs); (void)hipFree(c->d_zjobs);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_occ_hit); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk); (void)hipFree(c->d_rev);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
-    (void)hipFree(c->d_idx); (void)hipFree(c->d_oldcounts);
+    (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -948,13 +1234,8 @@ int32_t lama_hip_pf_init(lama_hip_ctx* c, const double* pts, uint32_t n, const d
     if (rc) return rc;
     if (c->P > 1) {                                                 // copy-construct the others (:206-216)
         std::vector<int32_t> idx(c->P, 0);
-        HIPCHK(c, hipMemcpyAsync(c->d_idx, idx.data(), sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemsetAsync(c->d_oldcounts, 0, sizeof(int32_t) * 2 * c->P, c->stream));
-        Timer t(c, &c->ctr.ms_resample, &c->ctr.launches_resample);
-        hipLaunchKernelGGL(k_copy_particles, dim3(c->P, 7), dim3(256), 0, c->stream, set_ptrs(c->set[c->cur]), set_ptrs(c->set[c->cur]),
-                           c->d_idx, c->d_oldcounts, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, 1);
-        t.stop();
-        HIPCHK(c, hipGetLastError());
+        rc = permute_particles(c, idx.data());
+        if (rc) return rc;
     }
     rc = check_device_errors(c, true, false);
     if (rc) return rc;
@@ -972,7 +1253,7 @@ int32_t lama_hip_pf_scan_match(lama_hip_ctx* c, const double* pts, uint32_t n, c
     int32_t rc = upload_scan(c, pts, n);
     if (rc) return rc;
     const Affine mtf = moving_tf(origin3, quat);
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     {
         Timer t(c, &c->ctr.ms_scan_match, &c->ctr.launches_scan_match);
         if (c->max_sqdist > (uint32_t)SM_LUT) hipLaunchKernelGGL(k_scan_match<true>, dim3(c->P), dim3(SM_BLOCK), 0, c->stream, prm, c->d_pts, (int)n, mtf, c->d_loglik, c->d_iters);
@@ -1002,30 +1283,9 @@ int32_t lama_hip_pf_resample(lama_hip_ctx* c, const int32_t* sample_idx)
     for (uint32_t i = 0; i < c->P; ++i)
         if (sample_idx[i] < 0 || (uint32_t)sample_idx[i] >= c->P) return fail(c, LAMA_HIP_E_INVALID, "sample_idx out of range");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const int dst = 1 - c->cur;
     c->early_ok = false;                                            // particle indices change meaning
     if (c->ll_valid) { std::vector<double> nl(c->P); for (uint32_t i = 0; i < c->P; ++i) nl[i] = c->h_ll[sample_idx[i]]; c->h_ll.swap(nl); }
-    HIPCHK(c, hipMemcpyAsync(c->d_idx, sample_idx, sizeof(int32_t) * c->P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, c->set[dst].counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
-    {
-        Timer t(c, &c->ctr.ms_resample, &c->ctr.launches_resample);
-        hipLaunchKernelGGL(k_copy_particles, dim3(c->P, 7), dim3(256), 0, c->stream, set_ptrs(c->set[dst]), set_ptrs(c->set[c->cur]),
-                           c->d_idx, c->d_oldcounts, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, 0);
-        t.stop();
-    }
-    HIPCHK(c, hipGetLastError());
-    std::vector<double> np(c->h_poses.size());
-    std::vector<int32_t> nc(c->h_counts.size());
-    for (uint32_t i = 0; i < c->P; ++i) {
-        std::memcpy(&np[4 * i], &c->h_poses[4 * sample_idx[i]], sizeof(double) * 4);
-        nc[2 * i] = c->h_counts[2 * sample_idx[i]]; nc[2 * i + 1] = c->h_counts[2 * sample_idx[i] + 1];
-    }
-    std::memcpy(c->h_poses.data(), np.data(), np.size() * sizeof(double));
-    std::memcpy(c->h_counts.data(), nc.data(), nc.size() * sizeof(int32_t));
-    HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->cur = dst;
-    return LAMA_HIP_OK;
+    return permute_particles(c, sample_idx);
 }
 
 int32_t lama_hip_pf_update_maps_begin(lama_hip_ctx* c, const double* pts, uint32_t n, const double* origin3, const double* quat)
@@ -1072,11 +1332,11 @@ int32_t lama_hip_pf_patch_ids(lama_hip_ctx* c, uint32_t particle, int32_t kind, 
     if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
     ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const ParticleSet& s = c->set[c->cur];
+    const MapStore& s = c->ms;
     const size_t WW = (size_t)c->W * c->W;
     const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
     std::vector<int16_t> dir(WW);
-    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + particle * WW, WW * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + c->h_part[particle].home * WW, WW * 2, hipMemcpyDeviceToHost));
     std::vector<uint64_t> ids;
     for (uint32_t wy = 0; wy < c->W; ++wy)
         for (uint32_t wx = 0; wx < c->W; ++wx)
@@ -1095,7 +1355,7 @@ int32_t lama_hip_pf_map_checksums(lama_hip_ctx* c, int32_t kind, uint64_t* out)
     HIPCHK(c, hipSetDevice(c->cfg.device));
     uint64_t* d_out = nullptr;
     HIPCHK(c, hipMalloc(&d_out, sizeof(uint64_t) * c->P));
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     hipLaunchKernelGGL(k_map_checksum, dim3(c->P), dim3(256), 0, c->stream, prm, kind == LAMA_HIP_MAP_DISTANCE ? 0 : 1, d_out);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(uint64_t) * c->P, hipMemcpyDeviceToHost, c->stream);
@@ -1116,12 +1376,13 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
     if (n == 0) return LAMA_HIP_OK;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    ParticleSet& s = c->set[c->cur];
+    MapStore& s = c->ms;
     const size_t WW = (size_t)c->W * c->W;
+    const PartRec pr = c->h_part[particle];
     for (int kind = 0; kind < 2; ++kind) {
         const bool dm = kind == 0;
-        const size_t cap = dm ? c->cfg.dm_patch_capacity : c->cfg.occ_patch_capacity;
-        int16_t* d_dir = (dm ? s.dm_dir : s.occ_dir) + particle * WW;
+        const size_t base = dm ? pr.dm_base : pr.occ_base;          // the particle's region in the pool (patches)
+        int16_t* d_dir = (dm ? s.dm_dir : s.occ_dir) + pr.home * WW;
         std::vector<int16_t> dir(WW);
         HIPCHK(c, hipMemcpy(dir.data(), d_dir, WW * 2, hipMemcpyDeviceToHost));
         int count = c->h_counts[2 * particle + (dm ? 0 : 1)];
@@ -1134,8 +1395,8 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
             const int slot = dir[pidx];
             if (slot < 0) continue;
             const int last = count - 1;
-            auto plane_move = [&](void* base, size_t bytes_per_slot) -> hipError_t {
-                char* b = (char*)base + (size_t)particle * cap * bytes_per_slot;
+            auto plane_move = [&](void* plane, size_t bytes_per_slot) -> hipError_t {
+                char* b = (char*)plane + base * bytes_per_slot;
                 if (slot != last) {
                     hipError_t e = hipMemcpyAsync(b + (size_t)slot * bytes_per_slot, b + (size_t)last * bytes_per_slot, bytes_per_slot, hipMemcpyDeviceToDevice, c->stream);
                     if (e != hipSuccess) return e;
@@ -1146,7 +1407,7 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
                 HIPCHK(c, plane_move(s.dm_sv, 2048)); HIPCHK(c, plane_move(s.dm_obs, 4096)); HIPCHK(c, plane_move(s.dm_mask, 128));
             } else {
                 HIPCHK(c, plane_move(s.occ, 4096)); HIPCHK(c, plane_move(s.occ_mask, 128));
-                if (c->d_occ_hit) HIPCHK(c, plane_move(c->d_occ_hit, 128));
+                HIPCHK(c, plane_move(s.occ_hit, 128));
             }
             if (slot != last)
                 for (size_t q = 0; q < WW; ++q) if (dir[q] == last) { dir[q] = (int16_t)slot; break; }
@@ -1171,14 +1432,15 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY)) return LAMA_HIP_E_INVALID;
     ENTER(c);
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    const ParticleSet& s = c->set[c->cur];
+    const MapStore& s = c->ms;
     const size_t WW = (size_t)c->W * c->W;
     const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
+    const PartRec pr = c->h_part[particle];
     const uint32_t count = (uint32_t)c->h_counts[2 * particle + (dm ? 0 : 1)];
     if (num_patches) *num_patches = count;
     if (count == 0 || cap == 0) return LAMA_HIP_OK;
     std::vector<int16_t> dir(WW);
-    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + particle * WW, WW * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + pr.home * WW, WW * 2, hipMemcpyDeviceToHost));
     // (reference patch id, slot), ascending id
     std::vector<std::pair<uint64_t, int>> order;
     for (uint32_t wy = 0; wy < c->W; ++wy)
@@ -1191,16 +1453,16 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     std::sort(order.begin(), order.end());
     if (order.size() != count) return fail(c, LAMA_HIP_E_STATE, "directory / count mismatch");
     std::vector<uint64_t> hmask((size_t)count * 16);
-    HIPCHK(c, hipMemcpy(hmask.data(), (dm ? s.dm_mask : s.occ_mask) + (size_t)particle * (dm ? c->cfg.dm_patch_capacity : c->cfg.occ_patch_capacity) * 16,
+    HIPCHK(c, hipMemcpy(hmask.data(), (dm ? s.dm_mask : s.occ_mask) + (size_t)(dm ? pr.dm_base : pr.occ_base) * 16,
                         hmask.size() * 8, hipMemcpyDeviceToHost));
     std::vector<uint16_t> hsv; std::vector<uint32_t> hobs, hocc;
     if (dm) {
         hsv.resize((size_t)count * 1024); hobs.resize((size_t)count * 1024);
-        HIPCHK(c, hipMemcpy(hsv.data(), s.dm_sv + (size_t)particle * c->cfg.dm_patch_capacity * 1024, hsv.size() * 2, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(hobs.data(), s.dm_obs + (size_t)particle * c->cfg.dm_patch_capacity * 1024, hobs.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hsv.data(), s.dm_sv + (size_t)pr.dm_base * 1024, hsv.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hobs.data(), s.dm_obs + (size_t)pr.dm_base * 1024, hobs.size() * 4, hipMemcpyDeviceToHost));
     } else {
         hocc.resize((size_t)count * 1024);
-        HIPCHK(c, hipMemcpy(hocc.data(), s.occ + (size_t)particle * c->cfg.occ_patch_capacity * 1024, hocc.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hocc.data(), s.occ + (size_t)pr.occ_base * 1024, hocc.size() * 4, hipMemcpyDeviceToHost));
     }
     const uint32_t nout = std::min<uint32_t>(cap, count);
     for (uint32_t k = 0; k < nout; ++k) {
@@ -1250,7 +1512,7 @@ int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* p
     }
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, poses, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     if (c->max_sqdist > (uint32_t)SM_LUT) hipLaunchKernelGGL(k_loglik_batch<true>, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
     else hipLaunchKernelGGL(k_loglik_batch<false>, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes, c->d_bout);
     HIPCHK(c, hipGetLastError());
@@ -1277,7 +1539,7 @@ int32_t lama_hip_eval_batch(lama_hip_ctx* c, uint32_t particle, const double* pt
     }
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, poses, sizeof(double) * 4 * B, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     {
         Timer t(c, &c->ctr.ms_eval_batch, &c->ctr.launches_eval_batch);
         hipLaunchKernelGGL(k_eval_batch, dim3(B), dim3(SM_BLOCK), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, c->d_bposes,
@@ -1321,7 +1583,7 @@ int32_t lama_hip_map_sample_likelihood(lama_hip_ctx* c, uint32_t particle, const
         for (int j = 0; j < 3; ++j) base.R[i][j] = (fixed.R[i][0] * mtf.R[0][j] + fixed.R[i][1] * mtf.R[1][j]) + fixed.R[i][2] * mtf.R[2][j];
         base.t[i] = (fixed.R[i][0] * mtf.t[0] + fixed.R[i][1] * mtf.t[1]) + fixed.R[i][2] * mtf.t[2];
     }
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     hipLaunchKernelGGL(k_sample_likelihood, dim3(K), dim3(64), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, (int)point_step, base,
                        c->d_bposes, c->d_bout);
     HIPCHK(c, hipGetLastError());
@@ -1466,10 +1728,8 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
         std::sort(dil.begin(), dil.end());
         dil.erase(std::unique(dil.begin(), dil.end()), dil.end());
         const uint64_t want = (uint64_t)c->h_counts[2 * particle] + dil.size();
-        uint32_t ndc = c->cfg.dm_patch_capacity;
-        while (want > ndc && ndc < 32767u) ndc = std::min<uint32_t>(2 * ndc, 32767u);
-        if (ndc != c->cfg.dm_patch_capacity) {
-            const int32_t rg = resize_arenas(c, ndc, c->cfg.occ_patch_capacity);
+        if (want > c->h_part[particle].dm_cap) {
+            const int32_t rg = set_capacities(c, {CapRequest{particle, (uint32_t)std::min<uint64_t>(MAX_PATCHES, (want + 31u) / 32u * 32u), c->h_part[particle].occ_cap}});
             if (rg) return rg;
         }
         c->last_guarded = false;
@@ -1477,12 +1737,12 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     uint32_t* d_cells = nullptr;
     HIPCHK(c, hipMalloc(&d_cells, sizeof(uint32_t) * 2 * (size_t)n));
     HIPCHK(c, hipMemcpyAsync(d_cells, cells_xy, sizeof(uint32_t) * 2 * (size_t)n, hipMemcpyHostToDevice, c->stream));
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     // queue capacity bounds one batch of additions; larger lists go in slices (each followed by dm->update(): adding
     // obstacles then updating in slices yields the same distance map only if no slice boundary matters -- so a list
     // longer than the queue is rejected instead)
     if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
-    HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, sizeof(uint32_t), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, 5 * sizeof(uint32_t), c->stream));    // all five: check_device_errors(maps) adds every word to the counters
     hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
     hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
     hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
@@ -1536,7 +1796,7 @@ static int32_t match_eval_impl(lama_hip_ctx* c, uint32_t particle, const double*
     if (e == hipSuccess) e = hipMemcpyAsync(d_pose, pose, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
         const Affine mtf = moving_tf(origin3, quat);
-        DevParams prm = make_params(c, c->cur);
+        DevParams prm = make_params(c);
         hipLaunchKernelGGL(k_match_eval, dim3((n + 255) / 256), dim3(256), 0, c->stream, prm, (int)particle, c->d_pts, (int)n, mtf, d_pose, d_out,
                            jacobian ? d_out + n : nullptr, cell_mode);
         e = hipGetLastError();
@@ -1567,7 +1827,7 @@ static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double
     }
     HIPCHK(c, hipMemcpyAsync(c->d_bposes, pose_inout, sizeof(double) * 4, hipMemcpyHostToDevice, c->stream));
     const Affine mtf = moving_tf(origin3, quat);
-    DevParams prm = make_params(c, c->cur);
+    DevParams prm = make_params(c);
     if (strategy >= 0) prm.strategy = strategy;
     if (max_iterations) prm.max_iter = max_iterations;
     if (c->max_sqdist > (uint32_t)SM_LUT)
@@ -1638,8 +1898,8 @@ int32_t lama_hip_pf_export_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
     for (uint32_t k = 0; k < n; ++k) c->h_ship_desc[k] = ShipDesc{(uint8_t*)bufs[k], particles[k], 0, 0, 0};
     const int32_t rc = upload_ship_desc(c, n);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_export_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(c->set[c->cur]), (const ShipDesc*)c->d_ship_desc,
-                       (const double*)c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5),
+    hipLaunchKernelGGL(k_export_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, make_params(c), (const ShipDesc*)c->d_ship_desc,
+                       (const double*)c->d_poses, (int32_t)(c->wx0 >> 5), (int32_t)(c->wy0 >> 5),
                        (int32_t)c->visit_bound, mapped_box_rel(c, 0), mapped_box_rel(c, 1));
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1691,18 +1951,24 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
         c->h_ship_desc[k].wdx = (int32_t)((int64_t)(c->wx0 >> 5) - (int64_t)hdr[2]);
         c->h_ship_desc[k].wdy = (int32_t)((int64_t)(c->wy0 >> 5) - (int64_t)hdr[3]);
     }
-    if (max_dm > c->cfg.dm_patch_capacity || max_occ > c->cfg.occ_patch_capacity) {      // the sender's arenas may have grown before ours
-        rc = grow_arenas(c, max_dm, max_occ);
-        if (rc) return rc;
-        if (max_dm > c->cfg.dm_patch_capacity || max_occ > c->cfg.occ_patch_capacity) return fail(c, LAMA_HIP_E_CAPACITY, "incoming particle exceeds the patch limit");
+    {   // every destination region must hold what its incoming particle brings (the sender's maps may have grown before ours)
+        std::vector<CapRequest> reqs;
+        for (uint32_t k = 0; k < n; ++k) {
+            int32_t hdr[8];
+            std::memcpy(hdr, c->h_ship_heads.data() + (size_t)BLOB_HEAD * k + 32, 32);
+            const PartRec& pr = c->h_part[particles[k]];
+            const uint32_t nd = want_capacity(c->floor_dm, (uint32_t)hdr[0], 0u), no = want_capacity(c->floor_occ, (uint32_t)hdr[1], 0u);
+            if ((uint32_t)hdr[0] > pr.dm_cap || (uint32_t)hdr[1] > pr.occ_cap) reqs.push_back(CapRequest{particles[k], std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
+        }
+        (void)max_dm; (void)max_occ;
+        if (!reqs.empty()) { rc = set_capacities(c, reqs); if (rc) return rc; }
     }
     // 2. the copies
     rc = upload_ship_desc(c, n);
     if (rc) return rc;
-    ParticleSet& s = c->set[c->cur];
-    HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, s.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
-    hipLaunchKernelGGL(k_import_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, set_ptrs(s), (const ShipDesc*)c->d_ship_desc, (const int32_t*)c->d_oldcounts,
-                       c->d_poses, c->W, c->cfg.dm_patch_capacity, c->cfg.occ_patch_capacity, c->d_err);
+    HIPCHK(c, hipMemcpyAsync(c->d_oldcounts, c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToDevice, c->stream));
+    hipLaunchKernelGGL(k_import_particles, dim3(n, 7, SHIP_SPLIT), dim3(256), 0, c->stream, make_params(c), (const ShipDesc*)c->d_ship_desc, (const int32_t*)c->d_oldcounts,
+                       c->d_poses, c->d_err);
     HIPCHK(c, hipGetLastError());
     // the import itself reports what it could not place (a patch of the sender's window outside this one: ERR_WINDOW) -- not the
     // next, unrelated call on the context
@@ -1783,11 +2049,38 @@ int32_t lama_hip_debug_log(lama_hip_ctx* c, uint64_t* out /* 131072 words */)
     return LAMA_HIP_OK;
 }
 
+// device memory the context holds: the maps (pools + directories), of which used, and everything
+static void memory_figures(const lama_hip_ctx* c, lama_hip_counters* o)
+{
+    const MapStore& m = c->ms;
+    const uint64_t P = c->P, WW = (uint64_t)c->W * c->W;
+    const uint64_t dirs = 2 * P * WW * 2;
+    uint64_t dm_used = 0, occ_used = 0;
+    for (uint32_t p = 0; p < c->P; ++p) { dm_used += (uint64_t)c->h_counts[2 * p]; occ_used += (uint64_t)c->h_counts[2 * p + 1]; }
+    o->hbm_bytes_allocated = dirs + (uint64_t)m.dm_pool * (2048 + 4096 + 128) + (uint64_t)m.occ_pool * (4096 + 128 + 128 + 4);
+    o->hbm_bytes_used = dirs + dm_used * (2048 + 4096 + 128) + occ_used * (4096 + 128 + 128 + 4);
+    const uint64_t other = 2 * P * (uint64_t)c->cfg.queue_capacity * 8 + P * (uint64_t)c->cfg.active_capacity * 8 + (uint64_t)c->rrec_cap * (sizeof(lama_dev::RayRec) + 8) +
+                           P * (16 * 8 + 12 * 8 + 4 * 8 + 64) + (1u << 20) + (uint64_t)c->pts_cap * 24;
+    o->hbm_bytes_total = o->hbm_bytes_allocated + other;
+}
+
 int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
 {
     if (!c || !out) return LAMA_HIP_E_INVALID;
     ENTER(c);
     *out = c->ctr;
+    memory_figures(c, out);
+    out->struct_bytes = (uint32_t)sizeof(lama_hip_counters);
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_get_counters_sized(lama_hip_ctx* c, void* out, uint32_t bytes)
+{
+    if (!c || !out) return LAMA_HIP_E_INVALID;
+    lama_hip_counters full;
+    const int32_t rc = lama_hip_get_counters(c, &full);
+    if (rc) return rc;
+    std::memcpy(out, &full, std::min<size_t>(bytes, sizeof(full)));
     return LAMA_HIP_OK;
 }
 
@@ -1799,7 +2092,7 @@ int32_t lama_hip_reset_counters(lama_hip_ctx* c)
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->ctr.dm_patches = old.dm_patches; c->ctr.occ_patches = old.occ_patches;
     c->ctr.brushfire_mode = old.brushfire_mode; c->ctr.brushfire_waves = old.brushfire_waves;
-    c->ctr.window_patches = c->W;
+    c->ctr.window_patches = c->W; c->ctr.peer_access = old.peer_access;
     return LAMA_HIP_OK;
 }
 

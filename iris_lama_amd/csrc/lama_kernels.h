@@ -396,8 +396,9 @@ __global__ __launch_bounds__(SM_BLOCK) __attribute__((amdgpu_num_vgpr(128))) voi
 {
     __shared__ SMShared sh;
     const int p = blockIdx.x;
-    const int16_t* dir = prm.dm_dir + (size_t)p * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, p);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = prm.poses + 4 * p;
         sh.state = SE2{q[0], q[1], q[2], q[3]};
@@ -445,8 +446,9 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
                                                            int do_solve)
 {
     __shared__ SMShared sh;
-    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, particle);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         sh.state = SE2{pose_io[0], pose_io[1], pose_io[2], pose_io[3]};
         sh.tf = scan_tf(sh.state, mtf);
@@ -487,8 +489,9 @@ __global__ __launch_bounds__(256) void k_match_eval(DevParams prm, int particle,
                                                      int cell_mode /* 1: DynamicDistanceMap::distance(w2m(hit)), no interpolation (MatchSurface2D::error) */)
 {
     __shared__ Affine tfs;
-    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, particle);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) tfs = scan_tf(SE2{pose[0], pose[1], pose[2], pose[3]}, mtf);
     __syncthreads();
     const Affine tf = tfs;
@@ -513,8 +516,9 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
     __shared__ double lut[SM_LUT];
     __shared__ Affine tfs;
     const int b = blockIdx.x;
-    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, particle);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
         tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
@@ -539,8 +543,9 @@ __global__ __launch_bounds__(SM_BLOCK) void k_eval_batch(DevParams prm, int part
     __shared__ double tot[2];
     __shared__ Affine tfs;
     const int b = blockIdx.x;
-    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, particle);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
         tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
@@ -573,8 +578,9 @@ __global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int par
 {
     __shared__ double terms[SL_MAX_TERMS];
     const int k = blockIdx.x;
-    const int16_t* dir = prm.dm_dir + (size_t)particle * prm.W * prm.W;
-    const uint16_t* sv = prm.dm_sv + (size_t)particle * prm.dm_cap * 1024;
+    const PV pv_ = pview(prm, particle);
+    const int16_t* dir = pv_.dm_dir;
+    const uint16_t* sv = pv_.dm_sv;
     const double tx = base.t[0] + xy[2 * k], ty = base.t[1] + xy[2 * k + 1];
     const int nterms = (n + step - 1) / step;
     for (int j = threadIdx.x; j < nterms; j += 64) {
@@ -672,13 +678,14 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
     const int p = first_particle + blockIdx.x;
     const int lane = threadIdx.x;
     const size_t WW = (size_t)prm.W * prm.W;
-    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
-    int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
-    uint16_t* dm_sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
-    uint32_t* dm_obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
-    uint64_t* dm_mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
-    uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
-    uint64_t* occ_mask = prm.occ_mask + (size_t)p * prm.occ_cap * 16;
+    const PV pv = pview(prm, p);
+    int16_t* dm_dir = pv.dm_dir;
+    int16_t* occ_dir = pv.occ_dir;
+    uint16_t* dm_sv = pv.dm_sv;
+    uint32_t* dm_obs = pv.dm_obs;
+    uint64_t* dm_mask = pv.dm_mask;
+    uint32_t* occ = pv.occ;
+    uint64_t* occ_mask = pv.occ_mask;
     uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
     uint64_t* q_raise = prm.q_raise + (size_t)p * prm.qcap;
     int dm_count = prm.counts[2 * p], occ_count = prm.counts[2 * p + 1];
@@ -762,7 +769,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
             const bool want = act && inwin;
             const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5);
             const uint32_t ci = (rx & 31u) | ((ry & 31u) << 5);
-            const int slot = coop_slot(occ_dc, occ_dir, occ_count, (int)prm.occ_cap, want, pidx, ERR_OCC_CAP, prm.err);
+            const int slot = coop_slot(occ_dc, occ_dir, occ_count, (int)pv.occ_cap, want, pidx, ERR_OCC_CAP, prm.err);
             bool changed = false;
             if (want && slot >= 0) {
                 uint32_t* cell = occ + (size_t)slot * 1024 + ci;
@@ -799,7 +806,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
                 if (vis == 0) atomicOr((unsigned long long*)(occ_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
                 }
             }
-            const int dslot = coop_slot(dm_dc, dm_dir, dm_count, (int)prm.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
+            const int dslot = coop_slot(dm_dc, dm_dir, dm_count, (int)pv.dm_cap, changed, pidx, ERR_DM_CAP, prm.err);
             bool push = false;
             if (changed && dslot >= 0) {
                 const uint64_t bit = 1ull << (ci & 63);
@@ -1240,10 +1247,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
     const size_t WW = (size_t)prm.W * prm.W;
-    int16_t* dir = prm.dm_dir + (size_t)p * WW;
-    uint16_t* sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
-    uint32_t* obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
-    uint64_t* mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
+    const PV pv = pview(prm, p);                               // (p is wave-uniform: scalar loads)
+    int16_t* dir = pv.dm_dir;
+    uint16_t* sv = pv.dm_sv;
+    uint32_t* obs = pv.dm_obs;
+    uint64_t* mask = pv.dm_mask;
+    const uint32_t dm_cap = pv.dm_cap;
     uint64_t* g_lower = prm.q_lower + (size_t)p * prm.qcap;
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
     int count = prm.counts[2 * p];
@@ -1413,7 +1422,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     // patch to allocate, a neighbour whose obstacle cell is another neighbour (raise() handles them in order) -- take the general code.
     if (TW) {
         uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
-        const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
+        const BufRsrc rsv = buf_make(sv, dm_cap * 2048u), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
         const bool is_oc = lane == 5;
         const uint32_t rolem = lane < 6 ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
 
@@ -1425,7 +1434,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             if (is_nb && !inwin) atomicOr(prm.err, ERR_WINDOW);
             const bool nb = is_nb && inwin;
             const bool fresh = nb && slot < 0;
-            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
             const bool nbok = nb && slot >= 0;
             if (nbok) {
                 const uint64_t bit = 1ull << (ci & 63);
@@ -1583,7 +1592,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         if (is_nb && !inwin) atomicOr(prm.err, ERR_WINDOW);
         const bool nb = is_nb && inwin;
         const bool fresh = nb && slot < 0;
-        if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+        if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
         const bool nbok = nb && slot >= 0;
         if (nbok) {
             const uint64_t bit = 1ull << (ci & 63);
@@ -1637,7 +1646,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     if (TW) {
         BFT(7);                                                    // (profiling build: everything before the lower wave)
         uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
-        const BufRsrc rsv = buf_make(sv, prm.dm_cap * 2048u), robs = buf_make(obs, prm.dm_cap * 4096u), rmask = buf_make(mask, prm.dm_cap * 128u);
+        const BufRsrc rsv = buf_make(sv, dm_cap * 2048u), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
         const bool is_oc = lane == 5, role = lane < 6;
         const uint32_t rolem = role ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
 
@@ -1676,7 +1685,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             if (away && !inwin) atomicOr(prm.err, ERR_WINDOW);
             const bool nb = away && inwin;
             const bool fresh = nb && slot < 0;
-            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
             const bool nbok = nb && slot >= 0;
             if (nbok) {
                 const uint64_t bit = 1ull << (ci & 63);
@@ -1925,7 +1934,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             if (away && !inwin) atomicOr(prm.err, ERR_WINDOW);
             const bool nb = away && inwin;
             const bool fresh = nb && slot < 0;
-            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)prm.dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
+            if (__ballot(fresh)) { const int ns_ = coop_slot(dc, dir, count, (int)dm_cap, fresh, pidx, ERR_DM_CAP, prm.err); if (fresh) slot = ns_; }
             const bool nbok = nb && slot >= 0;
             if (nbok) {
                 const uint64_t bit = 1ull << (ci & 63);
@@ -2175,7 +2184,8 @@ __global__ __launch_bounds__(256) void k_map_checksum(DevParams prm, int kind /*
     __shared__ uint64_t part[4];
     const int p = blockIdx.x;
     const size_t WW = (size_t)prm.W * prm.W;
-    const int16_t* dir = (kind == 0 ? prm.dm_dir : prm.occ_dir) + (size_t)p * WW;
+    const PV pv = pview(prm, p);
+    const int16_t* dir = kind == 0 ? pv.dm_dir : pv.occ_dir;
     uint64_t acc = 0;
     for (uint32_t w = 0; w < (uint32_t)WW; ++w) {
         const int slot = dir[w];
@@ -2186,12 +2196,12 @@ __global__ __launch_bounds__(256) void k_map_checksum(DevParams prm, int kind /*
         for (uint32_t c = threadIdx.x; c < 1024u; c += 256u) {
             uint64_t f;
             if (kind == 0) {
-                const uint64_t m = (prm.dm_mask[((size_t)p * prm.dm_cap + slot) * 16 + (c >> 6)] >> (c & 63)) & 1ull;
-                f = (uint64_t)prm.dm_sv[((size_t)p * prm.dm_cap + slot) * 1024 + c] | ((uint64_t)prm.dm_obs[((size_t)p * prm.dm_cap + slot) * 1024 + c] << 16) | (m << 48);
+                const uint64_t m = (pv.dm_mask[(size_t)slot * 16 + (c >> 6)] >> (c & 63)) & 1ull;
+                f = (uint64_t)pv.dm_sv[(size_t)slot * 1024 + c] | ((uint64_t)pv.dm_obs[(size_t)slot * 1024 + c] << 16) | (m << 48);
             } else {
                 // Container mask of a frequency cell = "visited != 0", plus the plane bits kept for uint16 wraps (as in the download)
-                const uint32_t ov = prm.occ[((size_t)p * prm.occ_cap + slot) * 1024 + c];
-                const uint64_t m = ((prm.occ_mask[((size_t)p * prm.occ_cap + slot) * 16 + (c >> 6)] >> (c & 63)) & 1ull) | ((ov >> 16) ? 1ull : 0ull);
+                const uint32_t ov = pv.occ[(size_t)slot * 1024 + c];
+                const uint64_t m = ((pv.occ_mask[(size_t)slot * 16 + (c >> 6)] >> (c & 63)) & 1ull) | ((ov >> 16) ? 1ull : 0ull);
                 f = (uint64_t)ov | (m << 48);
             }
             acc += cks_cell(id, c, f);
@@ -2220,7 +2230,7 @@ struct GlobalStore {
 struct BfCtx {
     const DevParams& prm;
     int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
-    int count;
+    int count; int cap;
     GlobalStore lower, raise;
     uint32_t nl, nr;
     uint64_t processed;
@@ -2233,7 +2243,7 @@ __device__ inline int bf_get(BfCtx& c, int rx, int ry)
     const uint32_t pidx = ((uint32_t)ry >> 5) * c.prm.W + ((uint32_t)rx >> 5);
     int slot = c.dir[pidx];
     if (slot < 0) {
-        if (c.count >= (int)c.prm.dm_cap) { atomicOr(c.prm.err, ERR_DM_CAP); return -1; }
+        if (c.count >= c.cap) { atomicOr(c.prm.err, ERR_DM_CAP); return -1; }
         slot = c.count++;
         c.dir[pidx] = (int16_t)slot;
     }
@@ -2317,8 +2327,8 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
     const int p = first_particle + blockIdx.x;
     if (prm.slow[p] == 0 || threadIdx.x != 0) return;
     const size_t WW = (size_t)prm.W * prm.W;
-    BfCtx c{prm, prm.dm_dir + (size_t)p * WW, prm.dm_sv + (size_t)p * prm.dm_cap * 1024, prm.dm_obs + (size_t)p * prm.dm_cap * 1024,
-            prm.dm_mask + (size_t)p * prm.dm_cap * 16, prm.counts[2 * p],
+    const PV pv = pview(prm, p);
+    BfCtx c{prm, pv.dm_dir, pv.dm_sv, pv.dm_obs, pv.dm_mask, prm.counts[2 * p], (int)pv.dm_cap,
             GlobalStore{prm.q_lower + (size_t)p * prm.qcap}, GlobalStore{prm.q_raise + (size_t)p * prm.qcap},
             prm.qsizes[2 * p], prm.qsizes[2 * p + 1], 0};
     while (c.nr > 0) {                                                              // :162-173
@@ -2364,10 +2374,11 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
     __shared__ uint32_t lds_dc[DC_SIZE];
     const int lane = threadIdx.x;
     const size_t WW = (size_t)prm.W * prm.W;
-    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
-    uint16_t* dm_sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
-    uint32_t* dm_obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
-    uint64_t* dm_mask = prm.dm_mask + (size_t)p * prm.dm_cap * 16;
+    const PV pv = pview(prm, p);
+    int16_t* dm_dir = pv.dm_dir;
+    uint16_t* dm_sv = pv.dm_sv;
+    uint32_t* dm_obs = pv.dm_obs;
+    uint64_t* dm_mask = pv.dm_mask;
     uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
     int dm_count = prm.counts[2 * p];
     for (int k = lane; k < DC_SIZE; k += UM_BLOCK) lds_dc[k] = DC_EMPTY;
@@ -2382,7 +2393,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
         if (act && !inwin) atomicOr(prm.err, ERR_WINDOW);
         const bool want = act && inwin;
         const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
-        const int slot = coop_slot(dc, dm_dir, dm_count, (int)prm.dm_cap, want, pidx, ERR_DM_CAP, prm.err);
+        const int slot = coop_slot(dc, dm_dir, dm_count, (int)pv.dm_cap, want, pidx, ERR_DM_CAP, prm.err);
         // duplicates inside one 64-cell step: the first occurrence wins (a later addObstacle of the same cell returns early)
         bool first = true;
         for (int l = 0; l < 63; ++l) {       // executed by all lanes (uniform control flow around the shuffles)
@@ -2459,7 +2470,7 @@ __global__ __launch_bounds__(256) void k_occ_max_visited(DevParams prm, uint32_t
 {
     const int p = blockIdx.x;
     const uint32_t n = (uint32_t)prm.counts[2 * p + 1] * 1024u;
-    const uint32_t* cells = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    const uint32_t* cells = pview(prm, p).occ;
     uint32_t m = 0;
     for (uint32_t k = threadIdx.x; k < n; k += 256u) { const uint32_t v = cells[k] >> 16; m = v > m ? v : m; }
     for (int off = 32; off > 0; off >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)m, off, 64); m = o > m ? o : m; }
@@ -2467,44 +2478,70 @@ __global__ __launch_bounds__(256) void k_occ_max_visited(DevParams prm, uint32_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_copy_particles -- dst particle i := src particle idx[i] (directories, counts, used slots of every
-// plane); slots of dst beyond the source's count that the old dst owner had used are re-zeroed so the
-// "unused slot == calloc'd" invariant holds.  grid = (P, 7 planes), 256 threads, 16-byte vectors.
+// k_clone_particles -- the particle copies of resample() / of the first scan (src/pf_slam2d.cpp:204-216, 558-574), done IN PLACE:
+// the host has turned the sampled indices into a permutation of the PartRec table -- a particle that survives keeps its home and
+// its regions, so nothing of it moves -- and lists here only the second and further copies of a multiply drawn particle, each
+// with the home / regions of a particle that died as its destination.  The same job form moves ONE particle's used slots to a
+// larger region when its maps outgrow their capacity (src_home == dst_home: the directories stay where they are).
+// Slots of the destination beyond the source's count that the old owner had used are re-zeroed ("unused slot == calloc'd").
+// grid = (jobs, 7 planes, CLONE_SPLIT), 256 threads, 16-byte vectors.  All counts are the host's mirror: no device-side reads.
 // ------------------------------------------------------------------------------------------------
-struct SetPtrs {
-    int16_t* dm_dir; int16_t* occ_dir; uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask; uint32_t* occ; uint64_t* occ_mask; int32_t* counts;
+struct CloneJob {
+    uint32_t src_home, dst_home;
+    uint32_t src_dm, dst_dm;       // region bases (patches) in the distance-map pool
+    uint32_t src_occ, dst_occ;     // ... in the occupancy pool
+    int32_t sdm, socc;             // used slots of the source
+    int32_t odm, oocc;             // slots the destination region's previous owner had used (0: a region fresh from the allocator)
+    uint32_t pad0, pad1;
 };
+constexpr int CLONE_SPLIT = 2;
 
-__global__ __launch_bounds__(256) void k_copy_particles(SetPtrs dst, SetPtrs src, const int32_t* __restrict__ idx,
-                                                         const int32_t* __restrict__ old_dst_counts, uint32_t W,
-                                                         uint32_t dm_cap, uint32_t occ_cap, int same_set)
+__global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const CloneJob* __restrict__ jobs)
 {
-    const int i = blockIdx.x;
-    const int j = idx[i];
-    if (same_set && i == j) return;
+    const CloneJob j = jobs[blockIdx.x];
     const int plane = blockIdx.y;
-    const int sdm = src.counts[2 * j], socc = src.counts[2 * j + 1];
-    const int odm = old_dst_counts[2 * i], oocc = old_dst_counts[2 * i + 1];
-    const size_t WW = (size_t)W * W;
-    const uint4* s; uint4* d; size_t ncopy, nzero;   // in 16-byte units
+    const size_t WW = (size_t)prm.W * prm.W;
+    const uint4* s; uint4* d; size_t ncopy, nzero = 0;   // in 16-byte units
+    const size_t zdm = j.odm > j.sdm ? (size_t)(j.odm - j.sdm) : 0, zocc = j.oocc > j.socc ? (size_t)(j.oocc - j.socc) : 0;
     switch (plane) {
-    case 0: s = (const uint4*)(src.dm_dir + j * WW); d = (uint4*)(dst.dm_dir + i * WW); ncopy = WW * 2 / 16; nzero = 0; break;
-    case 1: s = (const uint4*)(src.occ_dir + j * WW); d = (uint4*)(dst.occ_dir + i * WW); ncopy = WW * 2 / 16; nzero = 0; break;
-    case 2: s = (const uint4*)(src.dm_sv + (size_t)j * dm_cap * 1024); d = (uint4*)(dst.dm_sv + (size_t)i * dm_cap * 1024);
-            ncopy = (size_t)sdm * 2048 / 16; nzero = odm > sdm ? (size_t)(odm - sdm) * 2048 / 16 : 0; break;
-    case 3: s = (const uint4*)(src.dm_obs + (size_t)j * dm_cap * 1024); d = (uint4*)(dst.dm_obs + (size_t)i * dm_cap * 1024);
-            ncopy = (size_t)sdm * 4096 / 16; nzero = odm > sdm ? (size_t)(odm - sdm) * 4096 / 16 : 0; break;
-    case 4: s = (const uint4*)(src.dm_mask + (size_t)j * dm_cap * 16); d = (uint4*)(dst.dm_mask + (size_t)i * dm_cap * 16);
-            ncopy = (size_t)sdm * 128 / 16; nzero = odm > sdm ? (size_t)(odm - sdm) * 128 / 16 : 0; break;
-    case 5: s = (const uint4*)(src.occ + (size_t)j * occ_cap * 1024); d = (uint4*)(dst.occ + (size_t)i * occ_cap * 1024);
-            ncopy = (size_t)socc * 4096 / 16; nzero = oocc > socc ? (size_t)(oocc - socc) * 4096 / 16 : 0; break;
-    default: s = (const uint4*)(src.occ_mask + (size_t)j * occ_cap * 16); d = (uint4*)(dst.occ_mask + (size_t)i * occ_cap * 16);
-            ncopy = (size_t)socc * 128 / 16; nzero = oocc > socc ? (size_t)(oocc - socc) * 128 / 16 : 0; break;
+    case 0: if (j.src_home == j.dst_home) return;
+            s = (const uint4*)(prm.dm_dir + j.src_home * WW); d = (uint4*)(prm.dm_dir + j.dst_home * WW); ncopy = WW * 2 / 16; break;
+    case 1: if (j.src_home == j.dst_home) return;
+            s = (const uint4*)(prm.occ_dir + j.src_home * WW); d = (uint4*)(prm.occ_dir + j.dst_home * WW); ncopy = WW * 2 / 16; break;
+    case 2: s = (const uint4*)(prm.dm_sv + (size_t)j.src_dm * 1024); d = (uint4*)(prm.dm_sv + (size_t)j.dst_dm * 1024);
+            ncopy = (size_t)j.sdm * 2048 / 16; nzero = zdm * 2048 / 16; break;
+    case 3: s = (const uint4*)(prm.dm_obs + (size_t)j.src_dm * 1024); d = (uint4*)(prm.dm_obs + (size_t)j.dst_dm * 1024);
+            ncopy = (size_t)j.sdm * 4096 / 16; nzero = zdm * 4096 / 16; break;
+    case 4: s = (const uint4*)(prm.dm_mask + (size_t)j.src_dm * 16); d = (uint4*)(prm.dm_mask + (size_t)j.dst_dm * 16);
+            ncopy = (size_t)j.sdm * 128 / 16; nzero = zdm * 128 / 16; break;
+    case 5: s = (const uint4*)(prm.occ + (size_t)j.src_occ * 1024); d = (uint4*)(prm.occ + (size_t)j.dst_occ * 1024);
+            ncopy = (size_t)j.socc * 4096 / 16; nzero = zocc * 4096 / 16; break;
+    default: s = (const uint4*)(prm.occ_mask + (size_t)j.src_occ * 16); d = (uint4*)(prm.occ_mask + (size_t)j.dst_occ * 16);
+            ncopy = (size_t)j.socc * 128 / 16; nzero = zocc * 128 / 16; break;
     }
-    for (size_t k = threadIdx.x; k < ncopy; k += 256) d[k] = s[k];
+    if (s == d) return;                                             // (a job that only re-zeroes nothing: same region, same place)
+    const size_t t0 = (size_t)blockIdx.z * 256 + threadIdx.x, step = 256 * (size_t)gridDim.z;
+    for (size_t k = t0; k < ncopy; k += step) d[k] = s[k];
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (size_t k = threadIdx.x; k < nzero; k += 256) d[ncopy + k] = z;
-    if (plane == 0 && threadIdx.x == 0) { dst.counts[2 * i] = sdm; dst.counts[2 * i + 1] = socc; }
+    for (size_t k = t0; k < nzero; k += step) d[ncopy + k] = z;
+}
+
+// A region that goes back to the allocator is zeroed where it was used: free pool space is all-zero, so a region handed out later
+// needs no preparation.  grid = (regions, 5 planes, CLONE_SPLIT); the occupancy hit bits are zero between scans anyway.
+struct ZeroJob { uint32_t dm_base, occ_base; int32_t ndm, nocc; };
+__global__ __launch_bounds__(256) void k_zero_regions(DevParams prm, const ZeroJob* __restrict__ jobs)
+{
+    const ZeroJob j = jobs[blockIdx.x];
+    uint4* d; size_t n;
+    switch (blockIdx.y) {
+    case 0: d = (uint4*)(prm.dm_sv + (size_t)j.dm_base * 1024); n = (size_t)j.ndm * 2048 / 16; break;
+    case 1: d = (uint4*)(prm.dm_obs + (size_t)j.dm_base * 1024); n = (size_t)j.ndm * 4096 / 16; break;
+    case 2: d = (uint4*)(prm.dm_mask + (size_t)j.dm_base * 16); n = (size_t)j.ndm * 128 / 16; break;
+    case 3: d = (uint4*)(prm.occ + (size_t)j.occ_base * 1024); n = (size_t)j.nocc * 4096 / 16; break;
+    default: d = (uint4*)(prm.occ_mask + (size_t)j.occ_base * 16); n = (size_t)j.nocc * 128 / 16; break;
+    }
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n; k += 256 * (size_t)gridDim.z) d[k] = z;
 }
 
 
@@ -2532,25 +2569,27 @@ __device__ inline const uint4* blob_plane(const uint8_t* blob, int plane, size_t
 
 // grid (n, 7 planes, SHIP_SPLIT): every plane of every outgoing particle in parallel
 constexpr int SHIP_SPLIT = 4;
-__global__ __launch_bounds__(256) void k_export_particles(SetPtrs src, const ShipDesc* __restrict__ desc, const double* __restrict__ poses, uint32_t W,
-                                                           uint32_t dm_cap, uint32_t occ_cap, int32_t wx_patch, int32_t wy_patch, int32_t visit_bound,
+__global__ __launch_bounds__(256) void k_export_particles(DevParams prm, const ShipDesc* __restrict__ desc, const double* __restrict__ poses,
+                                                           int32_t wx_patch, int32_t wy_patch, int32_t visit_bound,
                                                            int32_t bbox_x, int32_t bbox_y)
 {
     const ShipDesc d = desc[blockIdx.x];
     const int j = (int)d.particle, plane = blockIdx.y;
-    const int dmc = src.counts[2 * j], occ = src.counts[2 * j + 1];
+    const uint32_t W = prm.W;
+    const PV src = pview(prm, j);
+    const int dmc = src.counts[0], occ = src.counts[1];
     const size_t WW = (size_t)W * W;
     size_t n16;
     uint4* out = const_cast<uint4*>(blob_plane(d.blob, plane, WW, dmc, occ, n16));
     const uint4* in;
     switch (plane) {
-    case 0: in = (const uint4*)(src.dm_dir + j * WW); break;
-    case 1: in = (const uint4*)(src.occ_dir + j * WW); break;
-    case 2: in = (const uint4*)(src.dm_sv + (size_t)j * dm_cap * 1024); break;
-    case 3: in = (const uint4*)(src.dm_obs + (size_t)j * dm_cap * 1024); break;
-    case 4: in = (const uint4*)(src.dm_mask + (size_t)j * dm_cap * 16); break;
-    case 5: in = (const uint4*)(src.occ + (size_t)j * occ_cap * 1024); break;
-    default: in = (const uint4*)(src.occ_mask + (size_t)j * occ_cap * 16); break;
+    case 0: in = (const uint4*)src.dm_dir; break;
+    case 1: in = (const uint4*)src.occ_dir; break;
+    case 2: in = (const uint4*)src.dm_sv; break;
+    case 3: in = (const uint4*)src.dm_obs; break;
+    case 4: in = (const uint4*)src.dm_mask; break;
+    case 5: in = (const uint4*)src.occ; break;
+    default: in = (const uint4*)src.occ_mask; break;
     }
     for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
     if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
@@ -2573,11 +2612,13 @@ __global__ __launch_bounds__(64) void k_gather_blob_heads(const ShipDesc* __rest
 // grid (n, 7 planes, SHIP_SPLIT).  The directories are translated when the sender's window sits elsewhere (see k_shift_window); slots the
 // destination used before and the incoming particle does not are zeroed ("unused slot == zero"); old_counts = the destination's counts
 // before the import.
-__global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const ShipDesc* __restrict__ desc, const int32_t* __restrict__ old_counts, double* __restrict__ poses,
-                                                           uint32_t W, uint32_t dm_cap, uint32_t occ_cap, int32_t* err)
+__global__ __launch_bounds__(256) void k_import_particles(DevParams prm, const ShipDesc* __restrict__ desc, const int32_t* __restrict__ old_counts, double* __restrict__ poses,
+                                                           int32_t* err)
 {
     const ShipDesc d = desc[blockIdx.x];
     const int i = (int)d.particle, plane = blockIdx.y;
+    const uint32_t W = prm.W;
+    const PV dst = pview(prm, i);                                // (the host has made the regions large enough for what is coming)
     const int32_t* hh = reinterpret_cast<const int32_t*>(d.blob + 32);
     const int dmc = hh[0], occ = hh[1];
     const int odm = old_counts[2 * i], oocc = old_counts[2 * i + 1];
@@ -2587,13 +2628,13 @@ __global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const Shi
     const uint4* in = blob_plane(d.blob, plane, WWs, dmc, occ, n16);
     uint4* out; size_t nzero = 0;
     switch (plane) {
-    case 0: out = (uint4*)(dst.dm_dir + i * WW); break;
-    case 1: out = (uint4*)(dst.occ_dir + i * WW); break;
-    case 2: out = (uint4*)(dst.dm_sv + (size_t)i * dm_cap * 1024); nzero = odm > dmc ? (size_t)(odm - dmc) * 2048 / 16 : 0; break;
-    case 3: out = (uint4*)(dst.dm_obs + (size_t)i * dm_cap * 1024); nzero = odm > dmc ? (size_t)(odm - dmc) * 4096 / 16 : 0; break;
-    case 4: out = (uint4*)(dst.dm_mask + (size_t)i * dm_cap * 16); nzero = odm > dmc ? (size_t)(odm - dmc) * 128 / 16 : 0; break;
-    case 5: out = (uint4*)(dst.occ + (size_t)i * occ_cap * 1024); nzero = oocc > occ ? (size_t)(oocc - occ) * 4096 / 16 : 0; break;
-    default: out = (uint4*)(dst.occ_mask + (size_t)i * occ_cap * 16); nzero = oocc > occ ? (size_t)(oocc - occ) * 128 / 16 : 0; break;
+    case 0: out = (uint4*)dst.dm_dir; break;
+    case 1: out = (uint4*)dst.occ_dir; break;
+    case 2: out = (uint4*)dst.dm_sv; nzero = odm > dmc ? (size_t)(odm - dmc) * 2048 / 16 : 0; break;
+    case 3: out = (uint4*)dst.dm_obs; nzero = odm > dmc ? (size_t)(odm - dmc) * 4096 / 16 : 0; break;
+    case 4: out = (uint4*)dst.dm_mask; nzero = odm > dmc ? (size_t)(odm - dmc) * 128 / 16 : 0; break;
+    case 5: out = (uint4*)dst.occ; nzero = oocc > occ ? (size_t)(oocc - occ) * 4096 / 16 : 0; break;
+    default: out = (uint4*)dst.occ_mask; nzero = oocc > occ ? (size_t)(oocc - occ) * 128 / 16 : 0; break;
     }
     if (plane < 2 && (d.wdx != 0 || d.wdy != 0 || Ws != W)) {
         const int16_t* sdir = reinterpret_cast<const int16_t*>(in);
@@ -2616,7 +2657,7 @@ __global__ __launch_bounds__(256) void k_import_particles(SetPtrs dst, const Shi
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < nzero; k += 256 * SHIP_SPLIT) out[n16 + k] = z;
     if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
-        dst.counts[2 * i] = dmc; dst.counts[2 * i + 1] = occ;
+        dst.counts[0] = dmc; dst.counts[1] = occ;
         const double* hp = reinterpret_cast<const double*>(d.blob);
         for (int k = 0; k < 4; ++k) poses[4 * i + k] = hp[k];
     }

@@ -60,7 +60,9 @@ __device__ inline int dir_alloc_one(int16_t* dir, uint32_t pidx, int32_t* count,
             const uint32_t locked = (v & ~(0xFFFFu << sh)) | (0xFFFEu << sh);
             if (atomicCAS(w, v, locked) == v) {
                 int ns = atomicAdd(count, 1);
-                if (ns >= cap) { atomicSub(count, 1); atomicOr(err, errbit); ns = -3; }
+                // (a failed allocation leaves the counter incremented: after a cleanly aborted allocation phase it tells the host how
+                // many patches the particle WANTED, and its region is grown by exactly that -- recover_update resets the count)
+                if (ns >= cap) { atomicOr(err, errbit); ns = -3; }
                 for (;;) {      // publish our half (the other half may change concurrently)
                     const uint32_t cur = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const uint32_t nv = (cur & ~(0xFFFFu << sh)) | (((uint32_t)(uint16_t)(int16_t)ns) << sh);
@@ -209,9 +211,10 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     if (hit && (rx >= prm.WC || ry >= prm.WC)) { atomicOr(prm.err, ERR_WINDOW); hit = false; }
     const uint32_t pidx = (ry >> 5) * prm.W + (rx >> 5), ci = (rx & 31u) | ((ry & 31u) << 5);
     int slot = -1;
-    if (hit) slot = dir_get_or_alloc(prm.occ_dir + (size_t)p * WW, pidx, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+    const PV pv = pview(prm, p);
+    if (hit) slot = dir_get_or_alloc(pv.occ_dir, pidx, prm.counts + 2 * p + 1, (int)pv.occ_cap, ERR_OCC_CAP, prm.err);
     hit = hit && slot >= 0 && !alloc_only;
-    if (hit) atomicOr((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), 1ull << (ci & 63));
+    if (hit) atomicOr((unsigned long long*)(pv.occ_hit + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
     // the hits are order-sensitive visits (t = 0): appended with one counter update per wave (their order in the list is free,
     // k_ray_replay sorts)
     const unsigned long long hm = __ballot(hit);
@@ -339,11 +342,12 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         return;
     }
     const size_t WW = (size_t)prm.W * prm.W;
-    int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
-    int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
-    uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
-    uint16_t* dm_sv = prm.dm_sv + (size_t)p * prm.dm_cap * 1024;
-    uint32_t* dm_obs = prm.dm_obs + (size_t)p * prm.dm_cap * 1024;
+    const PV pv = pview(prm, p);
+    int16_t* occ_dir = pv.occ_dir;
+    int16_t* dm_dir = pv.dm_dir;
+    uint32_t* occ = pv.occ;
+    uint16_t* dm_sv = pv.dm_sv;
+    uint32_t* dm_obs = pv.dm_obs;
     uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
     uint64_t* q_raise = prm.q_raise + (size_t)p * prm.qcap;
 
@@ -387,13 +391,13 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
                 vis = (vis + 1) & 0xFFFFu;
                 changed = !was_free && (vis != 0 && 4u * o < vis);
             }
-            if (vis == 0) atomicOr((unsigned long long*)(prm.occ_mask + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), (unsigned long long)bit);
+            if (vis == 0) atomicOr((unsigned long long*)(pv.occ_mask + (size_t)slot * 16 + (ci >> 6)), (unsigned long long)bit);
             if (!changed) continue;
             if (!dm_loaded) {                                               // add/removeObstacle: get() = allocate + mask bit
-                dslot = dir_get_or_alloc(dm_dir, pidx, prm.counts + 2 * p, (int)prm.dm_cap, ERR_DM_CAP, prm.err);
+                dslot = dir_get_or_alloc(dm_dir, pidx, prm.counts + 2 * p, (int)pv.dm_cap, ERR_DM_CAP, prm.err);
                 dm_loaded = true;
                 if (dslot >= 0) {
-                    atomicOr((unsigned long long*)(prm.dm_mask + ((size_t)p * prm.dm_cap + dslot) * 16 + (ci >> 6)), (unsigned long long)bit);
+                    atomicOr((unsigned long long*)(pv.dm_mask + (size_t)dslot * 16 + (ci >> 6)), (unsigned long long)bit);
                     s = dm_sv[dslot * 1024 + (int)ci];
                 }
             }
@@ -411,7 +415,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         }
         *cell = o | (vis << 16);
         if (dirty) { dm_sv[dslot * 1024 + (int)ci] = s; dm_obs[dslot * 1024 + (int)ci] = 0; }
-        if (had_hit) atomicAnd((unsigned long long*)(prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16 + (ci >> 6)), ~(unsigned long long)bit);
+        if (had_hit) atomicAnd((unsigned long long*)(pv.occ_hit + (size_t)slot * 16 + (ci >> 6)), ~(unsigned long long)bit);
     }
     __syncthreads();
 

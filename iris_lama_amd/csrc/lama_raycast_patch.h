@@ -157,7 +157,8 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
     const uint32_t steps = (r.nnf & 0xFFFFu) - 1u;
     const uint32_t t0 = 1u + (uint32_t)(((uint64_t)steps * (uint32_t)seg) / RW_SEG), t1 = (uint32_t)(((uint64_t)steps * (uint32_t)(seg + 1)) / RW_SEG);
     const size_t WW = (size_t)prm.W * prm.W;
-    int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
+    const PV pv = pview(prm, p);
+    int16_t* occ_dir = pv.occ_dir;
     if (t0 > t1) return;
     const uint32_t a0 = r.a01 & 0xFFFFu, a1 = r.a01 >> 16, nn = r.nnf & 0xFFFFu;
     const uint32_t k0 = (uint32_t)(((uint64_t)(2u * t0 * a0 + nn) * r.magic) >> 42), k1 = (uint32_t)(((uint64_t)(2u * t0 * a1 + nn) * r.magic) >> 42);
@@ -170,13 +171,13 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
     uint32_t kx = neg0 ? k0 + (rx & 31u) + 1u : k0 + 32u - (rx & 31u), ky = neg1 ? k1 + (ry & 31u) + 1u : k1 + 32u - (ry & 31u);
     auto step_of = [nn](uint32_t k, uint32_t a) { return k > a ? 0xFFFFFFFFu : (2u * nn * k - nn + 2u * a - 1u) / (2u * a); };
     uint32_t tx = step_of(kx, a0), ty = step_of(ky, a1);
-    (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+    (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)pv.occ_cap, ERR_OCC_CAP, prm.err);
     for (;;) {
         const uint32_t t = tx < ty ? tx : ty;
         if (t > t1) break;
         if (tx == t) { X = neg0 ? X - 1u : X + 1u; kx += 32u; tx = step_of(kx, a0); }
         if (ty == t) { Y = neg1 ? Y - 1u : Y + 1u; ky += 32u; ty = step_of(ky, a1); }
-        (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)prm.occ_cap, ERR_OCC_CAP, prm.err);
+        (void)dir_get_or_alloc(occ_dir, Y * prm.W + X, prm.counts + 2 * p + 1, (int)pv.occ_cap, ERR_OCC_CAP, prm.err);
     }
 }
 
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
     const int p = first_particle + blockIdx.x;
     const uint32_t W = prm.W, WW = W * W;
     const int tid = threadIdx.x, r = (int)prm.guard_r;
-    const int16_t* occ_dir = prm.occ_dir + (size_t)p * WW;
-    const int16_t* dm_dir = prm.dm_dir + (size_t)p * WW;
+    const PV pv = pview(prm, p);
+    const int16_t* occ_dir = pv.occ_dir;
+    const int16_t* dm_dir = pv.dm_dir;
     // the patches the scan can touch: sensor origin (tf.translation(), src/pf_slam2d.cpp:452) +- reach, window-relative patch units
     const int scx = (int)(w2m(prm, tfs[12 * (size_t)p + 9]) - prm.wx0), scy = (int)(w2m(prm, tfs[12 * (size_t)p + 10]) - prm.wy0);
     const int bx0 = imax((scx - reach_cells) >> 5, 0), bx1 = imin((scx + reach_cells) >> 5, (int)W - 1);
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
         for (int k = 0; k < 8; ++k) {
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
             if (slot < 0) continue;
-            rev[(size_t)p * prm.occ_cap + slot] = (int32_t)(w0 + (uint32_t)k);
+            rev[(size_t)pv.occ_base + slot] = (int32_t)(w0 + (uint32_t)k);
             if (!bounded || x0 + k < bx0 || x0 + k > bx1 || wy < by0 || wy > by1) continue;       // out of the scan's reach: nothing changes there
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
@@ -251,7 +253,9 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
     }
     if (need) atomicAdd(&need_s, need);
     __syncthreads();
-    if (tid == 0 && bounded && !guard_off && (uint64_t)prm.counts[2 * p] + need_s > prm.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
+    // (the bound itself is left for the host: a particle whose region is too small is grown by what it asks for -- guard[p])
+    if (tid == 0) prm.guard[p] = bounded ? need_s : 0u;
+    if (tid == 0 && bounded && !guard_off && (uint64_t)prm.counts[2 * p] + need_s > pv.dm_cap) atomicOr(prm.err, ERR_DM_CAP);
 }
 
 // developer build (-DLAMA_PROFILE_RAY, tools/prof_ray.py): event counts and per-phase cycles of k_ray_patches, summed over the launch
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     if (p < 0) return;                                             // (another lane's particle)
     const int count = prm.counts[2 * p + 1];
     const size_t WW = (size_t)prm.W * prm.W;
-    uint32_t* occ = prm.occ + (size_t)p * prm.occ_cap * 1024;
+    const PV pv = pview(prm, p);
+    uint32_t* occ = pv.occ;
     const RayRec* prec = recs + (size_t)p * n;
     const uint64_t* pbb = bbox + (size_t)p * n;
     const int nck = (n + 63) / 64;                                 // <= 64: lane c of a wave holds chunk c (scans of up to 4096 points)
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     if (lane < nck) ck = chunks[(size_t)p * nck + lane];
     if (tid < 2) list_n[tid] = 0;
     int slot = blockIdx.y;
-    uint32_t pidx_next = slot < count ? (uint32_t)rev[(size_t)p * prm.occ_cap + slot] : 0u;
+    uint32_t pidx_next = slot < count ? (uint32_t)rev[(size_t)pv.occ_base + slot] : 0u;
     uint32_t par = 0;                                              // parity of the round
 #ifdef LAMA_PROFILE_RAY
     uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -310,7 +315,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     __syncthreads();
     for (; slot < count; slot += gridDim.y) {
         const uint32_t pidx = pidx_next;
-        if (slot + (int)gridDim.y < count) pidx_next = (uint32_t)rev[(size_t)p * prm.occ_cap + slot + gridDim.y];
+        if (slot + (int)gridDim.y < count) pidx_next = (uint32_t)rev[(size_t)pv.occ_base + slot + gridDim.y];
         const int px = (int)((pidx % prm.W) * 32u), py = (int)((pidx / prm.W) * 32u);       // window-relative origin of the patch
 #ifdef LAMA_PROFILE_RAY
         tprev = __builtin_readcyclecounter();
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
         // ---- 1. the patch: its cells and hit bits are requested now, classified below (after the candidates' loads are out too)
         uint32_t v[4];
         uint64_t hw[4];
-        const uint64_t* hitw = prm.occ_hit + ((size_t)p * prm.occ_cap + slot) * 16;
+        const uint64_t* hitw = pv.occ_hit + (size_t)slot * 16;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { v[j] = occ[(size_t)slot * 1024 + tid + 256 * j]; hw[j] = hitw[wave + 4 * j]; }
         bool has_act = false;
@@ -448,10 +453,10 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
             const uint64_t nm = (uint64_t)newm[2 * tid] | ((uint64_t)newm[2 * tid + 1] << 32);
             const uint64_t wm = (uint64_t)wrapm[2 * tid] | ((uint64_t)wrapm[2 * tid + 1] << 32);
             if (nm) {   // removeObstacle on a cell that cannot be an obstacle = get(): patch allocation + mask bit (:228-234)
-                const int ds = dir_get_or_alloc(prm.dm_dir + (size_t)p * WW, pidx, prm.counts + 2 * p, (int)prm.dm_cap, ERR_DM_CAP, prm.err);
-                if (ds >= 0) atomicOr((unsigned long long*)(prm.dm_mask + ((size_t)p * prm.dm_cap + ds) * 16 + tid), (unsigned long long)nm);
+                const int ds = dir_get_or_alloc(pv.dm_dir, pidx, prm.counts + 2 * p, (int)pv.dm_cap, ERR_DM_CAP, prm.err);
+                if (ds >= 0) atomicOr((unsigned long long*)(pv.dm_mask + (size_t)ds * 16 + tid), (unsigned long long)nm);
             }
-            if (wm) atomicOr((unsigned long long*)(prm.occ_mask + ((size_t)p * prm.occ_cap + slot) * 16 + tid), (unsigned long long)wm);
+            if (wm) atomicOr((unsigned long long*)(pv.occ_mask + (size_t)slot * 16 + tid), (unsigned long long)wm);
         }
         __syncthreads();
         RPT_T(12);

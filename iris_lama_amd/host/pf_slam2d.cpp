@@ -696,10 +696,11 @@ std::shared_ptr<const DynamicDistanceMap> PFSlam2D::getParticleDistanceMap(size_
     const uint32_t r = (uint32_t)std::ceil(options_.l2_max * (1.0 / options_.resolution));    // DynamicDistanceMap::setMaxDistance :149-153
     m.max_sqdist = r * r;
     if (!downloadParticleDistanceMap(i, m.ids, m.cells, m.masks)) return nullptr;
-    auto dm = std::make_shared<DynamicDistanceMap>(std::move(m));
-    const PFSlam2D* o = ownerOf((uint32_t)i);
-    dm->bindDevice(o->eng_, o->ctx_, (uint32_t)i - o->lo_);
-    return dm;
+    // A snapshot the CALLER owns is never bound to the device: the slot (ctx, i - lo_) holds another particle's map after the next
+    // update() / resample, and the context dies with this object -- a lama::MatchSurface2D built on the snapshot would then
+    // evaluate against the wrong map or a freed context.  Such a problem is refused by MatchSurface2D ("the
+    // distance map does not live on the device"); getDistanceMap()'s view, which update() drops, is the one that is bound.
+    return std::make_shared<DynamicDistanceMap>(std::move(m));
 }
 
 // src/pf_slam2d.cpp:49-104 (same buckets; plain loops instead of Eigen::Map)

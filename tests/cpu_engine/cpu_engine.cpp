@@ -311,6 +311,15 @@ int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
     out->dm_patches = d; out->occ_patches = o;
     return LAMA_HIP_OK;
 }
+int32_t lama_hip_get_counters_sized(lama_hip_ctx* c, void* out, uint32_t bytes)
+{
+    lama_hip_counters full;
+    const int32_t rc = lama_hip_get_counters(c, &full);
+    if (rc) return rc;
+    full.struct_bytes = (uint32_t)sizeof(full);
+    std::memcpy(out, &full, std::min<size_t>(bytes, sizeof(full)));
+    return LAMA_HIP_OK;
+}
 int32_t lama_hip_reset_counters(lama_hip_ctx* c) { std::memset(&c->ctr, 0, sizeof(c->ctr)); return LAMA_HIP_OK; }
 
 

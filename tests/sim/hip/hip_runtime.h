@@ -91,6 +91,10 @@ inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t
     for (size_t r = 0; r < height; ++r) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
     return hipSuccess;
 }
+inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) { *free_b = (size_t)64 << 30; *total_b = (size_t)64 << 30; return hipSuccess; }
+inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+constexpr hipError_t hipErrorPeerAccessAlreadyEnabled = 704;
 inline hipError_t hipStreamCreate(hipStream_t* s) { *s = new wsim_stream{0}; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

@@ -112,6 +112,47 @@ def test_update_that_runs_out_of_patches_is_repeated_after_growth(Fsim, seq_ray)
     assert c["arena_growths"] >= 3, c
 
 
+def test_in_place_resampling_with_regions_of_different_sizes(Fsim):
+    """Round 5: ONE particle set.  A resample is a permutation of the particle table: survivors keep their home and regions, only
+    the further copies of a multiply drawn particle are copied into the homes of the particles that died.  Regions of 8 patches to
+    start with, so the particles' regions are moved, grown and recycled through the allocator all the time; three resamples
+    (a dead particle in front of / behind its source, one source drawn three times, the identity) -- maps bit-exact against the
+    oracle after every update, and only the clones were copied."""
+    F, P, steps = Fsim, 4, 3
+    pts, odom, truth = F.corridor_log(steps, 360)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, device=0, dm_patch_capacity=8, occ_patch_capacity=8))
+    ctx.init(pts[0], pose0)
+    c0 = ctx.counters()
+    assert c0["resample_clones"] == P - 1 and c0["hbm_bytes_used"] <= c0["hbm_bytes_allocated"], c0
+    rng = np.random.default_rng(5)
+    plans = {1: [1, 1, 3, 3], 2: [0, 2, 2, 2], 3: [0, 1, 2, 3]}
+    clones = P - 1
+    for k in range(1, steps + 1):
+        # particles spread over the corridor: their maps (and region sizes) differ
+        start = np.stack([O.se2_mul(O.se2(*truth[k]), O.se2(*rng.normal(0, [0.4, 0.1, 0.05]))) for _ in range(P)])
+        idx = np.array(plans[k], dtype=np.int32)
+        pf.set_poses(start)
+        pf.stage_resample_with(idx)
+        ctx.set_poses(start)
+        ctx.resample(idx)
+        clones += P - len(set(plans[k]))
+        assert np.array_equal(ctx.get_poses(), pf.poses())
+        pf.stage_set_scan(pts[k])
+        pf.stage_update_maps()
+        ctx.update_maps(pts[k])
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    c = ctx.counters()
+    assert c["resample_clones"] == clones, (c["resample_clones"], clones)
+    assert c["arena_growths"] >= 2 and c["hbm_bytes_used"] <= c["hbm_bytes_allocated"], c
+    ctx.close()
+
+
 def test_batched_export_and_import_between_two_contexts(Fsim):
     """The resample of a sharded pool: all outgoing particles of one context leave in ONE export launch, arrive in another context
     in ONE import launch (two slots take the same blob), and the receiving context carries on -- maps bit-exact against the oracle
