@@ -130,6 +130,17 @@ def cpu_baseline(pts, odom, P, updates, warm, bytes_only=False):
     return cores, res
 
 
+def memory_block(cc):
+    """Device memory of a context after a run: what the maps hold against what they use -- one particle set,
+    per-particle regions in pooled planes -- and what the resamples of the run really copied."""
+    n = max(cc["launches_resample"], 1)
+    return {"hbm_bytes_allocated": int(cc["hbm_bytes_allocated"]), "hbm_bytes_used": int(cc["hbm_bytes_used"]),
+            "allocated_over_used": round(cc["hbm_bytes_allocated"] / max(cc["hbm_bytes_used"], 1), 3),
+            "hbm_bytes_total": int(cc["hbm_bytes_total"]), "pool_growths": int(cc["pool_growths"]), "region_growths": int(cc["arena_growths"]),
+            "resample_launches": int(cc["launches_resample"]), "clones_copied": int(cc["resample_clones"]),
+            "clone_bytes": int(cc["resample_bytes"]), "resample_kernel_ms": cc["ms_resample"] / n if cc["launches_resample"] else 0.0}
+
+
 def chain_spread(cc, particles):
     """A particle's exact brushfire is ONE serial chain of pops, so a map update lasts as long as the longest chain of the pool:
     mean chain, mean over the updates of the longest one, and the pace of that longest chain (brushfire time / its pops)."""
@@ -189,6 +200,87 @@ def next_rows(F, with_cpu=True):
         out.update(single_pose_rows(F, with_cpu))
     except Exception as e:
         out["error_single_pose"] = str(e)
+    try:
+        out["loc2d_map_load"] = loc2d_map_load(F, with_cpu)
+    except Exception as e:
+        out["error_loc2d_map_load"] = str(e)
+    return out
+
+
+def floor_plan_cells(width_m, height_m, room_m=4.0, wall_cells=2, res=0.05):
+    """Occupied cells (map coordinates, the order Loc2D::Init walks an occupancy map in: x outer, y inner is NOT guaranteed by the
+    reference -- it visits patch by patch; here row-major) of a generated office floor: rooms of room_m x room_m metres, walls
+    `wall_cells` thick, a 1 m door in every wall segment."""
+    import numpy as np
+    W, H = int(round(width_m / res)), int(round(height_m / res))
+    occ = np.zeros((H, W), dtype=bool)
+    step, door = int(round(room_m / res)), int(round(1.0 / res))
+    for x in range(0, W, step):
+        occ[:, x:x + wall_cells] = True
+    for y in range(0, H, step):
+        occ[y:y + wall_cells, :] = True
+    occ[:, W - wall_cells:] = True
+    occ[H - wall_cells:, :] = True
+    for x in range(0, W - step, step):                # doors in the vertical walls (not in the outer shell)
+        for y in range(0, H - step, step):
+            if x > 0: occ[y + step // 2 - door // 2:y + step // 2 + door // 2, x:x + wall_cells] = False
+            if y > 0: occ[y:y + wall_cells, x + step // 2 - door // 2:x + step // 2 + door // 2] = False
+    ys, xs = np.nonzero(occ)
+    off = (2642244 >> 1) * 32                        # Map's origin offset (src/sdm/map.cpp:55-58)
+    return np.stack([xs + off, ys + off], axis=1).astype(np.uint32)
+
+
+def loc2d_map_load(F, with_cpu, budget_s=45.0):
+    """Loc2D::Init's distance-map build (src/loc2d.cpp:61-108: addObstacle for every occupied cell, then dm->update()) for a generated
+    floor plan, on the device (lama_hip_map_add_obstacles: k_dm_add_obstacles + ONE exact brushfire = one serial chain of pops) with
+    the CPU beside it.  A quarter-size plan first; the 100 m x 60 m plan only when the measured pace says it fits `budget_s`."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    out = {}
+    for label, (w, h) in (("plan_50x30m", (50.0, 30.0)), ("plan_100x60m", (100.0, 60.0))):
+        cells = floor_plan_cells(w, h)
+        row = {"occupied_cells": int(len(cells)), "l2_max_m": 1.0, "resolution_m": 0.05}
+        if label != "plan_50x30m":
+            prev = out["plan_50x30m"]
+            predicted = prev["gpu_seconds"] * len(cells) / max(prev["occupied_cells"], 1)
+            row["predicted_gpu_seconds"] = predicted
+            if predicted > budget_s:
+                row["skipped"] = "predicted device time beyond the bench's budget"
+                out[label] = row
+                continue
+        cfg = F.default_cfg(particles=1, l2_max=1.0, queue_capacity=1 << 20, window_patches=128, profile=1)
+        ctx = F.HipContext(cfg)
+        t0 = time.perf_counter()
+        ctx.add_obstacles(0, cells)
+        row["gpu_seconds"] = time.perf_counter() - t0
+        c = ctx.counters()
+        row["pops"] = int(c["bf_cells"]); row["dm_patches"] = int(c["dm_patches"])
+        row["gpu_us_per_pop"] = 1e6 * row["gpu_seconds"] / max(row["pops"], 1)
+        row["hbm_bytes_allocated"] = int(c["hbm_bytes_allocated"]); row["hbm_bytes_used"] = int(c["hbm_bytes_used"])
+        ctx.close()
+        if with_cpu:
+            import _oracle as O
+            dm = O.DM.new(l2_max=1.0)
+            t0 = time.perf_counter()
+            for x, y in cells: dm.add(int(x), int(y))
+            t1 = time.perf_counter()
+            n = dm.update()
+            t2 = time.perf_counter()
+            row["cpu_oracle_port"] = {"add_seconds_incl_ctypes": t1 - t0, "update_seconds": t2 - t1, "pops": int(n), "us_per_pop": 1e6 * (t2 - t1) / max(int(n), 1)}
+            assert int(n) == row["pops"], (n, row["pops"])      # the same chain, pop for pop
+            del dm
+            try:
+                import _reference as R
+                if R.available():
+                    dm = R.DM.new(l2_max=1.0)
+                    for x, y in cells: dm.add(int(x), int(y))
+                    t1 = time.perf_counter()
+                    n = dm.update()
+                    row["cpu_reference_build"] = {"update_seconds": time.perf_counter() - t1, "pops": int(n)}
+                    del dm
+            except Exception:
+                pass
+        out[label] = row
     return out
 
 
@@ -408,6 +500,14 @@ def main():
                                 "import_per_resample": 1e3 * float(np.mean([x["import_s"] for x in ships])) if ships else 0.0,
                                 "local_copies_per_resample": 1e3 * float(np.mean([x["local_copies_s"] for x in ships])) if ships else 0.0},
                    devices=min(gpus, torch.cuda.device_count()))
+        try:      # peer access and the achieved GPU-to-GPU rate of lama_hip_blob_copy, from the shards' counters
+            cs = [pf.shard_context(r).counters() for r in range(gpus)]
+            b, ms = sum(x["peer_copy_bytes"] for x in cs), sum(x["peer_copy_ms"] for x in cs)
+            out["peer"] = {"peer_access": bool(all(x["peer_access"] for x in cs)) if b else None, "bytes": int(b), "ms": ms,
+                           "GBps": (b / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                           "note": "peer_access None: no copy crossed a device boundary (all shards on one device)" if not b else "hipEvents on the destination's stream"}
+        except Exception as e:
+            out["peer"] = {"error": str(e)}
         pf.close()
         return out
 
@@ -478,6 +578,10 @@ def main():
                                "resample": c["ms_resample"] / max(c["launches_resample"], 1) if c["launches_resample"] else 0.0,
                                "measured_in": "second pass of the same steps with hipEvent brackets on (ms_per_step there: %.4f)" % prof_run["ms_per_step"]},
         "brushfire_chains": chain_spread(c, P_total // world),
+        "memory": memory_block(c),
+        "devices_visible": torch.cuda.device_count(), "process_group": {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                                                                        "ranks": world},
+        "value_source": "one process, one context (lama::PFSlam2D on one GPU)",
     }
     if world == 1:
         result["summary_buckets_ms_per_update"] = run(P_total, K, W, summary=True)["buckets_ms"]
@@ -491,7 +595,11 @@ def main():
                                              "exchange_ms_per_step": main_run["exchange_ms_per_step"],
                                              "note": "one process per GPU, all-gather of the log-likelihoods over the process group, barrier + max over ranks"}
         result["value"], result["ms_per_step"] = cpp_multi["value"], cpp_multi["ms_per_step"]
-        result["value_source"] = f"lama::PFSlam2D, Options::gpus = {world} (one process, {cpp_multi['devices']} device(s)), run by rank 0"
+        # (since round 4 the N > 1 `value` is the C++ object's, not the torch.distributed ranks' -- ADVICE r04: said here, at the top level)
+        result["value_source"] = f"lama::PFSlam2D, Options::gpus = {world} (one process, {cpp_multi['devices']} device(s)), run by rank 0; rounds 1-3 reported torch_distributed_ranks here"
+        if torch.cuda.device_count() < world:
+            result["devices_short"] = f"{torch.cuda.device_count()} device(s) for {world} shards: the shards SHARE devices, this is not a scaling measurement"
+        result["peer_access"] = cpp_multi.get("peer")
         result["strong_scaling_ceiling"] = {"particles_per_gpu": max(P_total // world, 1), "ms_per_step_of_one_share_alone": share["ms_per_step"],
                                             "ceiling_speedup": single["ms_per_step"] / share["ms_per_step"],
                                             "note": "step time of the unsharded pool / step time of ONE GPU's share alone on one GPU: no exchange, "
@@ -520,7 +628,8 @@ def main():
                                              "resamples": resample_run["resamples"], "shipped_particles": resample_run["shipped_particles"],
                                              "shipped_bytes": resample_run["shipped_bytes"],
                                              "exchange_ms_per_step": resample_run["exchange_ms_per_step"] if world > 1 else None,
-                                             "resample_kernel_ms": resample_run["counters"]["ms_resample"] / max(resample_run["counters"]["launches_resample"], 1)}
+                                             "resample_kernel_ms": resample_run["counters"]["ms_resample"] / max(resample_run["counters"]["launches_resample"], 1),
+                                             "memory": memory_block(resample_run["counters"])}
     cores, base = (None, None)
     if not args.no_cpu and world > 1:
         # the CPU baseline is reported by the N = 1 line only; the sharded line still needs the algorithmic bytes per
@@ -593,12 +702,16 @@ def main():
                              "brushfire_ms": cc["ms_brushfire"] / max(cc["launches_brushfire"], 1),
                              "scan_match_ms": cc["ms_scan_match"] / max(cc["launches_scan_match"], 1),
                              "brushfire_chains": chain_spread(cc, P), "brushfire_handovers": cc["brushfire_handovers"],
-                             "brushfire_routed": cc["brushfire_routed"]}
+                             "brushfire_routed": cc["brushfire_routed"], "memory": memory_block(cc)}
             if base and "bytes" in base:       # same log, same per-particle footprint: the P = 30 byte counts apply
                 bf_s = cc["ms_brushfire"] / max(cc["launches_brushfire"], 1) * 1e-3
                 extra[str(P)]["roofline_frac_brushfire"] = base["bytes"]["brushfire"] * P / bf_s / 1e9 / HBM_PEAK_GBS
                 extra[str(P)]["roofline_frac_step"] = base["bytes"]["total"] * P / (r["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBS
         result["other_particle_counts"] = extra
+        # what a resample costs now that it is done in place: the 3000-particle pool with the gain that makes it
+        # resample (1e-4), per-kernel brackets on
+        rr = run(3000, K, W, profile=True, gain=1e-4)
+        result["resample_3000"] = {"meas_sigma_gain": 1e-4, "resamples": rr["resamples"], "ms_per_step": rr["ms_per_step"], "memory": memory_block(rr["counters"])}
         # opt-in level-synchronous brushfire (cfg.brushfire_mode = 1; NOT bit-identical to the reference in the obstacle
         # offsets of tie cells) -- reported for information, never as `value`
         canon = {}

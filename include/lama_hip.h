@@ -232,7 +232,10 @@ int32_t lama_hip_pf_export_particles(lama_hip_ctx* ctx, uint32_t n, const uint32
                                      uint64_t* bytes_out);
 int32_t lama_hip_pf_import_particles(lama_hip_ctx* ctx, uint32_t n, const uint32_t* particles, const void* const* device_bufs, const uint64_t* bytes);
 
-/* Device staging buffers for particle shipping when ONE process drives several contexts (lama::PFSlam2D with Options::gpus > 1: a
+/* (Peer access: the first lama_hip_blob_copy between two devices queries hipDeviceCanAccessPeer and enables access in both
+ * directions, once per pair and process; when the platform refuses it the copy still works -- the runtime stages it through host
+ * memory -- and lama_hip_counters::peer_access says 0.)
+ * Device staging buffers for particle shipping when ONE process drives several contexts (lama::PFSlam2D with Options::gpus > 1: a
  * host thread per GPU, src/pf_slam2d.cpp:254-302's two parallel regions become G device streams): allocate / free a buffer on the
  * context's device, and copy between buffers of two contexts -- hipMemcpyPeerAsync when they live on different GPUs (xGMI), a
  * plain device copy otherwise.  The copy is complete when the call returns. */
@@ -306,11 +309,14 @@ typedef struct lama_hip_counters {
     uint32_t peer_access;               /* lama_hip_blob_copy between two devices: 1 = the last such copy went GPU to GPU directly (peer access
                                            enabled both ways), 0 = it was staged by the runtime (peer access refused) or none was made      */
     uint32_t struct_bytes;              /* sizeof(lama_hip_counters) of the library that filled the struct (see lama_hip_get_counters_sized) */
+    double peer_copy_ms;                /* device time (hipEvents on the destination's stream) of the cross-device lama_hip_blob_copy calls ... */
+    uint64_t peer_copy_bytes;           /* ... and the bytes they moved INTO this context: bytes / ms = the achieved xGMI rate               */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 /* The same for a caller compiled against another version of this header: at most `bytes` bytes are written (the struct
  * grows at its END only, a consumer built against an older header passes its own sizeof and is never written past). */
 int32_t lama_hip_get_counters_sized(lama_hip_ctx* ctx, void* out, uint32_t bytes);
+uint32_t lama_hip_counters_bytes(void);     /* sizeof(lama_hip_counters) in the library (a binding checks its own mirror against it) */
 int32_t lama_hip_reset_counters(lama_hip_ctx* ctx);
 
 #ifdef __cplusplus

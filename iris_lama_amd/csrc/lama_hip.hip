@@ -2011,14 +2011,52 @@ int32_t lama_hip_blob_free(lama_hip_ctx* c, void* buf)
     return LAMA_HIP_OK;
 }
 
+// Peer access between two devices, enabled once per ordered pair and process: without it hipMemcpyPeerAsync is
+// staged through host memory by the runtime instead of going GPU to GPU over xGMI.  Returns 1 when BOTH directions are enabled.
+static int peer_access_between(int a, int b)
+{
+    static std::map<std::pair<int, int>, int> state;              // calls on the contexts involved are serialised by the caller (one exchange at a time)
+    auto one_way = [&](int from, int to) -> int {
+        const auto key = std::make_pair(from, to);
+        auto it = state.find(key);
+        if (it != state.end()) return it->second;
+        int can = 0, ok = 0;
+        if (hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can) {
+            if (hipSetDevice(from) == hipSuccess) {
+                const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+                ok = (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) ? 1 : 0;
+                if (!ok) (void)hipGetLastError();
+            }
+        } else (void)hipGetLastError();
+        state[key] = ok;
+        return ok;
+    };
+    const int ab = one_way(a, b), ba = one_way(b, a);
+    return ab && ba;
+}
+
 int32_t lama_hip_blob_copy(lama_hip_ctx* dc, void* dst, lama_hip_ctx* sc, const void* src, uint64_t bytes)
 {
     if (!dc || !sc || !dst || !src) return LAMA_HIP_E_INVALID;
     if (bytes == 0) return LAMA_HIP_OK;
+    if (dc->cfg.device == sc->cfg.device) {
+        HIPCHK(dc, hipSetDevice(dc->cfg.device));
+        HIPCHK(dc, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dc->stream));
+        HIPCHK(dc, hipStreamSynchronize(dc->stream));
+        return LAMA_HIP_OK;
+    }
+    // two devices: peer access first (queried and enabled once per pair), then the copy on the destination's stream; without peer
+    // access the same call still works -- the runtime stages it -- and the counters say so (peer_access = 0)
+    const int peer = peer_access_between(dc->cfg.device, sc->cfg.device);
+    dc->ctr.peer_access = sc->ctr.peer_access = (uint32_t)peer;
     HIPCHK(dc, hipSetDevice(dc->cfg.device));
-    if (dc->cfg.device == sc->cfg.device) HIPCHK(dc, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, dc->stream));
-    else HIPCHK(dc, hipMemcpyPeerAsync(dst, dc->cfg.device, src, sc->cfg.device, bytes, dc->stream));      // GPU to GPU over xGMI
+    hipEvent_t e0 = dc->ev0, e1 = dc->ev1;
+    HIPCHK(dc, hipEventRecord(e0, dc->stream));
+    HIPCHK(dc, hipMemcpyPeerAsync(dst, dc->cfg.device, src, sc->cfg.device, bytes, dc->stream));      // GPU to GPU over xGMI
+    HIPCHK(dc, hipEventRecord(e1, dc->stream));
     HIPCHK(dc, hipStreamSynchronize(dc->stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { dc->ctr.peer_copy_ms += ms; dc->ctr.peer_copy_bytes += bytes; }
     return LAMA_HIP_OK;
 }
 
@@ -2073,6 +2111,8 @@ int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
     out->struct_bytes = (uint32_t)sizeof(lama_hip_counters);
     return LAMA_HIP_OK;
 }
+
+uint32_t lama_hip_counters_bytes(void) { return (uint32_t)sizeof(lama_hip_counters); }
 
 int32_t lama_hip_get_counters_sized(lama_hip_ctx* c, void* out, uint32_t bytes)
 {

@@ -48,7 +48,7 @@ class HipCounters(C.Structure):
                 ("bf_longest_chain_sum", C.c_uint64), ("bf_longest_chain_last", C.c_uint64), ("brushfire_early", C.c_uint64), ("brushfire_routed", C.c_uint64),
                 ("pool_growths", C.c_uint64), ("resample_clones", C.c_uint64), ("resample_bytes", C.c_uint64),
                 ("hbm_bytes_allocated", C.c_uint64), ("hbm_bytes_used", C.c_uint64), ("hbm_bytes_total", C.c_uint64),
-                ("peer_access", C.c_uint32), ("struct_bytes", C.c_uint32)]
+                ("peer_access", C.c_uint32), ("struct_bytes", C.c_uint32), ("peer_copy_ms", C.c_double), ("peer_copy_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -59,7 +59,7 @@ HIP_SYMBOLS = [
     "lama_hip_last_error", "lama_hip_pf_init", "lama_hip_pf_set_poses", "lama_hip_pf_get_poses",
     "lama_hip_pf_scan_match", "lama_hip_pf_resample", "lama_hip_pf_update_maps", "lama_hip_pf_map_patches",
     "lama_hip_pf_download_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
-    "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_get_counters_sized", "lama_hip_reset_counters",
+    "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_get_counters_sized", "lama_hip_counters_bytes", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
     "lama_hip_pf_patch_ids", "lama_hip_pf_delete_patches", "lama_hip_pf_update_maps_begin", "lama_hip_sync", "lama_hip_ctx_device",
@@ -132,6 +132,8 @@ def _bind_hip(L):
         L.lama_hip_pf_import_particles.argtypes = [vp, u32, vp, vp, vp]
         L.lama_hip_get_counters.argtypes = [vp, vp]
         L.lama_hip_get_counters_sized.argtypes = [vp, vp, u32]
+        L.lama_hip_counters_bytes.argtypes = []
+        L.lama_hip_counters_bytes.restype = C.c_uint32
         L.lama_hip_reset_counters.argtypes = [vp]
         L.lama_hip_map_add_obstacles.argtypes = [vp, u32, vp, u32]
         L.lama_hip_match_solve.argtypes = [vp, u32, vp, u32, vp, vp, vp, vp, vp, i32]

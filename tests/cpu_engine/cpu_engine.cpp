@@ -311,6 +311,7 @@ int32_t lama_hip_get_counters(lama_hip_ctx* c, lama_hip_counters* out)
     out->dm_patches = d; out->occ_patches = o;
     return LAMA_HIP_OK;
 }
+uint32_t lama_hip_counters_bytes(void) { return (uint32_t)sizeof(lama_hip_counters); }
 int32_t lama_hip_get_counters_sized(lama_hip_ctx* c, void* out, uint32_t bytes)
 {
     lama_hip_counters full;

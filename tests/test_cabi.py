@@ -28,6 +28,17 @@ def test_hip_library_exports_header_symbols():
         assert hasattr(L, n), n
 
 
+def test_counters_struct_matches_the_ctypes_mirror():
+    """lama_hip_counters grows at its end; the Python mirror must be the library's struct, byte for byte in size, and a
+    caller built against an older (shorter) header is served by lama_hip_get_counters_sized without being written past."""
+    if not os.path.exists(F.HIP_LIB):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "iris_lama_amd"), "hip"], check=True)
+    L = C.CDLL(F.HIP_LIB)
+    L.lama_hip_counters_bytes.restype = C.c_uint32
+    assert L.lama_hip_counters_bytes() == C.sizeof(F.HipCounters)
+    assert F.HipCounters._fields_[-3][0] == "struct_bytes"
+
+
 def test_host_library_exports_header_symbols():
     names = _declared("lama_host.h", "lama_")
     assert set(names) == set(F.HOST_SYMBOLS), set(names) ^ set(F.HOST_SYMBOLS)
