@@ -260,6 +260,7 @@ public:
     struct Writer {
         std::function<uint32_t(std::vector<uint32_t>& /*x,y pairs*/, double /*max distance*/)> apply;   // addObstacle list + update()
         std::function<bool(sdm::HostMap&)> download;
+        std::function<void(const sdm::HostMap&)> upload;           // Map::read for a device map: replace it by these patches
     };
     void bindWriter(Writer w) { writer_ = std::move(w); }
     void setMaxDistance(double distance)                                                                    // :149-153
@@ -267,6 +268,26 @@ public:
         const uint32_t r = (uint32_t)std::ceil(distance * scale);
         host_.max_sqdist = r * r;
         max_distance_ = distance;
+    }
+    // Map::read (src/sdm/map.cpp:533-575) for the live device map: the patches of `m` / of the `.sdm` file REPLACE the map on the
+    // device (lama_hip_pf_upload_map) -- a distance map built once (by the reference, by an earlier run through write()) is loaded
+    // instead of rebuilt obstacle by obstacle.  Resolution, patch size and the squared radius must be this map's.
+    void load(const sdm::HostMap& m)
+    {
+        if (!writer_.upload) throw std::logic_error("lama::DynamicDistanceMap::load: this map is a host snapshot of a device map");
+        if (m.kind != sdm::kDistanceMap || m.patch_length != patch_length || std::abs(m.resolution - resolution) > 1e-6 * resolution  /* the file stores a float */)
+            throw std::invalid_argument("lama::DynamicDistanceMap::load: not a distance map of this resolution / patch size");
+        if (m.max_sqdist != host_.max_sqdist) throw std::invalid_argument("lama::DynamicDistanceMap::load: the map was built with another l2_max");
+        pending_.clear();
+        writer_.upload(m);
+        stale_.store(true, std::memory_order_release);
+    }
+    bool read(const std::string& filename)
+    {
+        sdm::HostMap m;
+        if (!sdm::read(m, filename)) return false;
+        load(m);
+        return true;
     }
     void addObstacle(const Vector3ui& c) { pending_.push_back(c(0)); pending_.push_back(c(1)); }             // :212-226 (runs in update())
     void addObstacle(const Vector3d& p) { addObstacle(w2m(p)); }

@@ -145,6 +145,16 @@ int32_t lama_hip_pf_map_patches(lama_hip_ctx* ctx, uint32_t particle, int32_t ki
 int32_t lama_hip_pf_download_map(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t cap,
                                  uint64_t* patch_ids, uint8_t* cells, uint64_t* masks, uint32_t* num_patches);
 
+/* The inverse of lama_hip_pf_download_map -- Map::read (src/sdm/map.cpp:533-575) for a map that lives on the device: particle
+ * `particle`'s map of `kind` is REPLACED by the given patches (the reference's record formats, as download returns them and as a
+ * `.sdm` file stores them: lama::sdm::read).  A distance map built elsewhere -- by the reference, by an earlier run, by another
+ * context -- is put in place without replaying addObstacle() + update(): Loc2D's static map of a building is one serial brushfire
+ * chain of millions of pops when it is built on the device (bench.py: next_rows.loc2d_map_load), a file read when it is loaded.
+ * patch_ids need not be sorted; a patch outside the largest window is LAMA_HIP_E_WINDOW.  On a context that has not seen
+ * lama_hip_pf_init it also places the map window (like lama_hip_map_add_obstacles). */
+int32_t lama_hip_pf_upload_map(lama_hip_ctx* ctx, uint32_t particle, int32_t kind, uint32_t num_patches,
+                               const uint64_t* patch_ids, const uint8_t* cells, const uint64_t* masks);
+
 /* The same map update split in two, so that the host work of the NEXT scan (odometry prediction, motion sampling) overlaps
  * with the kernels: _begin queues the work on the context's stream and returns; its status (window / capacity errors) and
  * counters are collected by lama_hip_sync, or implicitly at the start of the next call on the context, whichever comes

@@ -154,6 +154,11 @@ const char* lama_loc_last_error(const lama_loc* l);
 const char* lama_loc_engine_origin(const lama_loc* l);
 /* distance_map->addObstacle(w2m(x, y)) for every world point, then distance_map->update() */
 int lama_loc_set_obstacles_world(lama_loc* l, const double* xy, uint32_t n);
+/* distance_map->write(file) / distance_map->read(file): the reference's .sdm format (Map::write / Map::read, src/sdm/map.cpp:489-575).
+ * read REPLACES the device map by the file's patches (lama_hip_pf_upload_map): a static map is loaded instead of rebuilt. */
+int lama_loc_write_distance_map(lama_loc* l, const char* filename);
+int lama_loc_read_distance_map(lama_loc* l, const char* filename);
+void* lama_loc_device_context(const lama_loc* l);      /* the lama_hip_ctx behind the object (NULL before the first map / update) */
 void lama_loc_set_pose(lama_loc* l, double x, double y, double yaw);
 int lama_loc_get_pose(const lama_loc* l, double* pose4);
 int lama_loc_update(lama_loc* l, const double* pts_xyz, uint32_t n, const double* origin3, const double* quat_wxyz,

@@ -5,13 +5,14 @@
 //   per HOME h (a directory slot; P of them):
 //     dm_dir  int16 [W*W]         window directory: patch (wy*W+wx) -> slot in the particle's DM region, -1 = absent
 //     occ_dir int16 [W*W]         same for the occupancy region
-//   pooled planes, shared by all particles; a particle owns one contiguous REGION of `cap` patches in each pool
-//   (PartRec: home, dm_base, dm_cap, occ_base, occ_cap -- bases and capacities in patches, per particle):
-//     dm_sv   uint16[pool][1024]  DM plane A: bit15 valid_obstacle | bit14 is_queued | bits13..0 sqdist
-//     dm_obs  uint32[pool][1024]  DM plane B: int16 obstacle.x | int16 obstacle.y << 16
-//     dm_mask uint64[pool][16]    Container::mask of the DM patch
-//     occ     uint32[pool][1024]  frequency cell: uint16 occupied | uint16 visited << 16
-//     occ_mask uint64[pool][16]
+//   pooled planes, shared by all particles (a pool is a list of CHUNKS -- it grows by another chunk, nothing is ever copied to
+//   grow it); a particle owns one contiguous REGION of `cap` patches of each map kind inside one chunk
+//   (PartRec: home, capacities, and the region's address in every plane -- per particle):
+//     dm_sv   uint16[cap][1024]   DM plane A: bit15 valid_obstacle | bit14 is_queued | bits13..0 sqdist
+//     dm_obs  uint32[cap][1024]   DM plane B: int16 obstacle.x | int16 obstacle.y << 16
+//     dm_mask uint64[cap][16]     Container::mask of the DM patch
+//     occ     uint32[cap][1024]   frequency cell: uint16 occupied | uint16 visited << 16
+//     occ_mask uint64[cap][16]
 //   per particle p (logical index, the reference's particles_[current][p]):
 //     counts  int32 [2]           allocated DM / occupancy slots
 //
@@ -63,12 +64,14 @@ struct Affine {            // rows 0..2 of [R | t]
     double t[3];
 };
 
-// where logical particle p keeps its maps: the home of its two directories and its region in each pool (patches)
+// where logical particle p keeps its maps: the home of its two directories, the capacities of its two regions (patches) and
+// where each plane of them starts (the host's region allocator places a region inside one chunk of the pool)
 struct PartRec {
-    uint32_t home;
-    uint32_t dm_base, dm_cap;
-    uint32_t occ_base, occ_cap;
-    uint32_t r0, r1, r2;
+    uint32_t home, dm_cap, occ_cap, r0;
+    uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
+    uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit;
+    int32_t* rev;          // [occ_cap] region slot -> directory position, rebuilt per scan (k_occ_reverse_dir)
+    uint64_t r1;
 };
 
 struct DevParams {
@@ -82,14 +85,9 @@ struct DevParams {
     uint32_t max_iter;
     double scale, off, resolution, maxdist, meas_sigma;
     double trunc_ray, trunc_range;
-    // directories [home][W*W], pooled planes [pool patch][...]
+    // directories [home][W*W] (the planes are reached through PartRec)
     int16_t* dm_dir;
     int16_t* occ_dir;
-    uint16_t* dm_sv;
-    uint32_t* dm_obs;
-    uint64_t* dm_mask;
-    uint32_t* occ;
-    uint64_t* occ_mask;
     int32_t* counts;       // [P][2] (logical particle)
     // shared
     double* poses;         // [P][4]
@@ -108,7 +106,6 @@ struct DevParams {
     uint32_t lane;           //       0 main / 1 early: which hand-over segment the ordered replay uses
     uint64_t* act;         // [P][act_cap] active visits of the parallel ray-cast (lama_raycast_par.h)
     uint32_t* act_count;   // [P]
-    uint64_t* occ_hit;     // [occupancy pool patch][16] one bit per occupancy cell: hit in the current scan (all zero between scans)
     uint32_t act_cap;
     uint64_t* stats;       // [P][4] iterations, evals, ray_cells, bf_cells of the last call
     int32_t* err;
@@ -126,8 +123,8 @@ struct PV {
     int16_t* dm_dir; int16_t* occ_dir;
     uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
     uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit;
-    int32_t* counts;
-    uint32_t dm_cap, occ_cap, occ_base;
+    int32_t* counts; int32_t* rev;
+    uint32_t dm_cap, occ_cap;
 };
 // The table is written by the host between launches and never by a kernel: read through the constant address space, so that a
 // wave-uniform particle index gives scalar loads (s_load_dwordx8) and the regions' base addresses / capacities stay in SGPRs --
@@ -141,20 +138,15 @@ typedef const __attribute__((address_space(4))) PartRec* PartTablePtr;
 __device__ inline PV pview(const DevParams& prm, int p)
 {
     PartTablePtr t = (PartTablePtr)prm.part + p;
-    PartRec r;
-    r.home = t->home; r.dm_base = t->dm_base; r.dm_cap = t->dm_cap; r.occ_base = t->occ_base; r.occ_cap = t->occ_cap;
     const size_t WW = (size_t)prm.W * prm.W;
+    const uint32_t home = t->home;
     PV v;
-    v.dm_dir = prm.dm_dir + (size_t)r.home * WW;
-    v.occ_dir = prm.occ_dir + (size_t)r.home * WW;
-    v.dm_sv = prm.dm_sv + (size_t)r.dm_base * 1024;
-    v.dm_obs = prm.dm_obs + (size_t)r.dm_base * 1024;
-    v.dm_mask = prm.dm_mask + (size_t)r.dm_base * 16;
-    v.occ = prm.occ + (size_t)r.occ_base * 1024;
-    v.occ_mask = prm.occ_mask + (size_t)r.occ_base * 16;
-    v.occ_hit = prm.occ_hit + (size_t)r.occ_base * 16;
+    v.dm_dir = prm.dm_dir + (size_t)home * WW;
+    v.occ_dir = prm.occ_dir + (size_t)home * WW;
+    v.dm_sv = t->dm_sv; v.dm_obs = t->dm_obs; v.dm_mask = t->dm_mask;
+    v.occ = t->occ; v.occ_mask = t->occ_mask; v.occ_hit = t->occ_hit; v.rev = t->rev;
     v.counts = prm.counts + 2 * (size_t)p;
-    v.dm_cap = r.dm_cap; v.occ_cap = r.occ_cap; v.occ_base = r.occ_base;
+    v.dm_cap = t->dm_cap; v.occ_cap = t->occ_cap;
     return v;
 }
 

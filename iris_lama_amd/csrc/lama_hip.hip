@@ -21,20 +21,26 @@ using namespace lama_dev;
 namespace {
 
 // The maps of all particles of a context: two directories per HOME (P homes), pooled planes in which every particle owns one
-// contiguous region per map kind (lama_dev.h).  The reference's patches are heap objects shared through cow_ptr
-// (include/lama/cow_ptr.h:86-118); here memory follows use through per-particle region capacities, and a resample moves nothing
-// that survives.
+// contiguous region per map kind (lama_dev.h).  A pool is a list of CHUNKS: it grows by another chunk (never by copying), a region
+// lies inside one chunk.  The reference's patches are heap objects shared through cow_ptr (include/lama/cow_ptr.h:86-118); here
+// memory follows use through per-particle region capacities, and a resample moves nothing that survives.
+struct RegionAlloc;
+struct PoolChunk {
+    uint8_t* plane[4] = {nullptr, nullptr, nullptr, nullptr};      // dm: sv, obs, mask, - ; occ: occ, occ_mask, occ_hit, rev
+    uint32_t patches = 0;
+};
 struct MapStore {
     int16_t* dm_dir = nullptr; int16_t* occ_dir = nullptr;          // [P homes][W*W]
-    uint16_t* dm_sv = nullptr; uint32_t* dm_obs = nullptr; uint64_t* dm_mask = nullptr;     // [dm_pool patches][...]
-    uint32_t* occ = nullptr; uint64_t* occ_mask = nullptr; uint64_t* occ_hit = nullptr;     // [occ_pool patches][...]
-    int32_t* rev = nullptr;                                         // [occ_pool patches] region slot -> directory position (per scan)
     int32_t* counts = nullptr;                                      // [P][2] logical particle
-    uint32_t dm_pool = 0, occ_pool = 0;                             // pool capacities in patches
+    std::vector<PoolChunk> dm_chunks, occ_chunks;
 };
+constexpr size_t DM_PLANE_B[3] = {2048, 4096, 128};                 // dm_sv, dm_obs, dm_mask bytes per patch
+constexpr size_t OCC_PLANE_B[4] = {4096, 128, 128, 4};              // occ, occ_mask, occ_hit, rev
+// the host's record of a particle: home + region (chunk, offset, capacity) per map kind; the device gets PartRec (addresses)
+struct HostPart { uint32_t home, dm_chunk, dm_off, dm_cap, occ_chunk, occ_off, occ_cap; };
 
 // First-fit allocator of contiguous regions (in patches) over a pool; neighbouring free blocks coalesce.  Host side only: the device
-// sees the result as PartRec::dm_base / occ_base.  Free space is always all-zero on the device (k_zero_regions).
+// sees the result as the plane addresses in PartRec.  Free space is always all-zero on the device (k_zero_regions).
 struct RegionAlloc {
     std::map<uint32_t, uint32_t> free_;        // offset -> length
     uint32_t cap = 0, used = 0;
@@ -118,8 +124,8 @@ struct lama_hip_ctx {
     double scale = 0, off = 0;
 
     MapStore ms;
-    RegionAlloc ra_dm, ra_occ;
-    std::vector<PartRec> h_part;     // logical particle -> home / regions (host truth) ...
+    std::vector<RegionAlloc> ra_dm, ra_occ;     // one allocator per chunk
+    std::vector<HostPart> h_part;     // logical particle -> home / regions (host truth) ...
     PartRec* d_part = nullptr;        // ... and its device copy
     PinVec<PartRec> h_part_stage;     // (page-locked staging of the upload)
     PinVec<CloneJob> h_jobs; CloneJob* d_jobs = nullptr; uint32_t jobs_cap = 0;
@@ -249,12 +255,11 @@ DevParams make_params(const lama_hip_ctx* c)
     p.meas_sigma = c->cfg.meas_sigma;
     p.trunc_ray = c->cfg.truncated_ray; p.trunc_range = c->cfg.truncated_range;
     const MapStore& s = c->ms;
-    p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.dm_sv = s.dm_sv; p.dm_obs = s.dm_obs; p.dm_mask = s.dm_mask;
-    p.occ = s.occ; p.occ_mask = s.occ_mask; p.counts = s.counts;
+    p.dm_dir = s.dm_dir; p.occ_dir = s.occ_dir; p.counts = s.counts;
     p.guard = c->d_guard;
     p.guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
     p.poses = c->d_poses; p.q_lower = c->d_qlower; p.q_raise = c->d_qraise; p.stats = c->d_stats; p.qsizes = c->d_qsizes; p.err = c->d_err; p.dbg = c->d_dbg; p.slow = c->d_slow; p.slow_list = c->d_slow_list; p.slow_n = c->d_slow_n; p.heavy = nullptr; p.elist = nullptr; p.elist_n = nullptr; p.early = nullptr; p.lane = 0;
-    p.act = c->d_act; p.act_count = c->d_act_count; p.occ_hit = c->ms.occ_hit; p.act_cap = c->cfg.active_capacity;
+    p.act = c->d_act; p.act_count = c->d_act_count; p.act_cap = c->cfg.active_capacity;
     p.occ_policy = c->cfg.occupancy_policy; p.ray_rule = c->cfg.ray_rule; p.strategy = c->cfg.solver_strategy;
     // ProbabilisticOccupancyMap's parameters (probabilistic_occupancy_map.cpp:43-59): logods(p) = float(log(p / (1 - p))) of a
     // float argument, stored in double members
@@ -375,66 +380,86 @@ static uint32_t want_capacity(uint32_t floor_cap, uint32_t count, uint32_t extra
     return std::min<uint32_t>(MAX_PATCHES, std::max<uint32_t>(floor_cap, round_up32(count + head)));
 }
 
+static PartRec dev_part(const lama_hip_ctx* c, const HostPart& h)
+{
+    PartRec r{};
+    r.home = h.home; r.dm_cap = h.dm_cap; r.occ_cap = h.occ_cap;
+    const PoolChunk& d = c->ms.dm_chunks[h.dm_chunk];
+    const PoolChunk& o = c->ms.occ_chunks[h.occ_chunk];
+    r.dm_sv = (uint16_t*)(d.plane[0] + (size_t)h.dm_off * DM_PLANE_B[0]);
+    r.dm_obs = (uint32_t*)(d.plane[1] + (size_t)h.dm_off * DM_PLANE_B[1]);
+    r.dm_mask = (uint64_t*)(d.plane[2] + (size_t)h.dm_off * DM_PLANE_B[2]);
+    r.occ = (uint32_t*)(o.plane[0] + (size_t)h.occ_off * OCC_PLANE_B[0]);
+    r.occ_mask = (uint64_t*)(o.plane[1] + (size_t)h.occ_off * OCC_PLANE_B[1]);
+    r.occ_hit = (uint64_t*)(o.plane[2] + (size_t)h.occ_off * OCC_PLANE_B[2]);
+    r.rev = (int32_t*)(o.plane[3] + (size_t)h.occ_off * OCC_PLANE_B[3]);
+    return r;
+}
+
 int32_t upload_part(lama_hip_ctx* c)
 {
     c->h_part_stage.resize(c->P);
-    std::memcpy(c->h_part_stage.data(), c->h_part.data(), sizeof(PartRec) * c->P);
+    for (uint32_t p = 0; p < c->P; ++p) c->h_part_stage[p] = dev_part(c, c->h_part[p]);
     HIPCHK(c, hipMemcpyAsync(c->d_part, c->h_part_stage.data(), sizeof(PartRec) * c->P, hipMemcpyHostToDevice, c->stream));
     return LAMA_HIP_OK;
 }
 
-// a pool that holds at least `min_patches`: new planes, the old contents copied, the tail zeroed (free pool space is all-zero)
-int32_t grow_pool(lama_hip_ctx* c, bool dm, uint32_t min_patches)
+// one more chunk for a pool, of at least `min_patches` (free pool space is all-zero: the chunk is zeroed here).  Nothing that
+// exists is copied or moved: a pool grows to whatever the device holds without a second copy of itself.
+int32_t add_chunk(lama_hip_ctx* c, bool dm, uint32_t min_patches)
 {
-    MapStore& m = c->ms;
-    const uint32_t old = dm ? m.dm_pool : m.occ_pool;
-    if (min_patches <= old) return LAMA_HIP_OK;
-    uint64_t want = std::max<uint64_t>(min_patches, (uint64_t)old + old / 2u);
+    std::vector<PoolChunk>& chunks = dm ? c->ms.dm_chunks : c->ms.occ_chunks;
+    uint64_t total = 0;
+    for (const PoolChunk& k : chunks) total += k.patches;
+    uint64_t want = std::max<uint64_t>(std::max<uint64_t>(min_patches, total / 2u), 1024u);      // geometric: the number of chunks stays small
     want = (want + 1023u) / 1024u * 1024u;
     const uint64_t per_patch = dm ? (2048 + 4096 + 128) : (4096 + 128 + 128 + 4);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-        // old and new planes coexist during the copy; leave 1 GB for everything else
-        const uint64_t room = free_b > (1ull << 30) ? free_b - (1ull << 30) : 0;
-        if (want * per_patch > room) want = std::max<uint64_t>(min_patches, room / per_patch);
-        if (want < min_patches || want * per_patch > room)
-            return fail(c, LAMA_HIP_E_CAPACITY, std::string(dm ? "distance-map" : "occupancy") + " pool: not enough device memory for " + std::to_string(min_patches) + " patches");
+        const uint64_t room = free_b > (1ull << 30) ? free_b - (1ull << 30) : 0;       // leave 1 GB for everything else
+        if (want * per_patch > room) want = room / per_patch / 32u * 32u;
+        if (want < min_patches)
+            return fail(c, LAMA_HIP_E_CAPACITY, std::string(dm ? "distance-map" : "occupancy") + " pool: the device has no room for " + std::to_string(min_patches) + " more patches");
     }
-    if (want > 0xFFFFFFFFull) return fail(c, LAMA_HIP_E_CAPACITY, "patch pool beyond 2^32 patches");
-    const uint32_t nw = (uint32_t)want;
-    auto regrow = [&](auto*& arr, size_t bytes_per_patch, bool keep) -> hipError_t {
-        void* fresh = nullptr;
-        hipError_t e = hipMalloc(&fresh, (size_t)nw * bytes_per_patch);
-        if (e != hipSuccess) return e;
-        if (keep && old) e = hipMemcpyAsync(fresh, arr, (size_t)old * bytes_per_patch, hipMemcpyDeviceToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemsetAsync((char*)fresh + (keep ? (size_t)old * bytes_per_patch : 0), 0, (size_t)(nw - (keep ? old : 0)) * bytes_per_patch, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) { (void)hipFree(fresh); return e; }
-        if (arr) (void)hipFree(arr);
-        arr = reinterpret_cast<std::remove_reference_t<decltype(arr)>>(fresh);
-        return hipSuccess;
-    };
-    if (dm) {
-        HIPCHK(c, regrow(m.dm_sv, 2048, true)); HIPCHK(c, regrow(m.dm_obs, 4096, true)); HIPCHK(c, regrow(m.dm_mask, 128, true));
-        m.dm_pool = nw; c->ra_dm.extend(nw);
-    } else {
-        HIPCHK(c, regrow(m.occ, 4096, true)); HIPCHK(c, regrow(m.occ_mask, 128, true));
-        HIPCHK(c, regrow(m.occ_hit, 128, true));                    // (all zero between scans; kept: an update may be in its allocation phase)
-        HIPCHK(c, regrow(m.rev, 4, false));
-        m.occ_pool = nw; c->ra_occ.extend(nw);
+    if (want > 0xFFFFFFF0ull) want = 0xFFFFFFF0ull;
+    PoolChunk k;
+    k.patches = (uint32_t)want;
+    const int nplanes = dm ? 3 : 4;
+    for (int i = 0; i < nplanes; ++i) {
+        const size_t bytes = (size_t)k.patches * (dm ? DM_PLANE_B[i] : OCC_PLANE_B[i]);
+        hipError_t e = hipMalloc(&k.plane[i], bytes);
+        if (e == hipSuccess && !(!dm && i == 3)) e = hipMemsetAsync(k.plane[i], 0, bytes, c->stream);     // (rev is rebuilt per scan)
+        if (e != hipSuccess) {
+            for (int j = 0; j <= i; ++j) (void)hipFree(k.plane[j]);
+            (void)hipGetLastError();
+            return fail(c, LAMA_HIP_E_CAPACITY, std::string(dm ? "distance-map" : "occupancy") + " pool: " + hipGetErrorString(e));
+        }
     }
+    chunks.push_back(k);
+    (dm ? c->ra_dm : c->ra_occ).emplace_back();
+    (dm ? c->ra_dm : c->ra_occ).back().reset(k.patches);
     c->ctr.pool_growths += 1;
     return LAMA_HIP_OK;
 }
 
-int32_t region_alloc(lama_hip_ctx* c, bool dm, uint32_t n, uint32_t& off)
+int32_t region_alloc(lama_hip_ctx* c, bool dm, uint32_t n, uint32_t& chunk, uint32_t& off)
 {
-    RegionAlloc& ra = dm ? c->ra_dm : c->ra_occ;
-    if (ra.alloc(n, off)) return LAMA_HIP_OK;
-    const int32_t rc = grow_pool(c, dm, ra.cap + n);
+    std::vector<RegionAlloc>& ras = dm ? c->ra_dm : c->ra_occ;
+    for (uint32_t k = 0; k < ras.size(); ++k)
+        if (ras[k].alloc(n, off)) { chunk = k; return LAMA_HIP_OK; }
+    const int32_t rc = add_chunk(c, dm, n);
     if (rc) return rc;
-    if (!ra.alloc(n, off)) return fail(c, LAMA_HIP_E_CAPACITY, "patch pool exhausted");
+    chunk = (uint32_t)ras.size() - 1;
+    if (!ras[chunk].alloc(n, off)) return fail(c, LAMA_HIP_E_CAPACITY, "patch pool exhausted");
     return LAMA_HIP_OK;
+}
+static void region_release(lama_hip_ctx* c, bool dm, uint32_t chunk, uint32_t off, uint32_t n) { (dm ? c->ra_dm : c->ra_occ)[chunk].release(off, n); }
+
+// addresses of a region's planes (dm: sv, obs, mask -> [0..2]; occ: occ, occ_mask -> [3..4]) for the clone / zero jobs
+static void region_ptrs(const lama_hip_ctx* c, const HostPart& h, void* out[5])
+{
+    const PartRec r = dev_part(c, h);
+    out[0] = r.dm_sv; out[1] = r.dm_obs; out[2] = r.dm_mask; out[3] = r.occ; out[4] = r.occ_mask;
 }
 
 static int32_t ensure_job_buffers(lama_hip_ctx* c, uint32_t nj, uint32_t nz)
@@ -465,9 +490,9 @@ static int32_t run_jobs(lama_hip_ctx* c, bool zero_first)
     const DevParams prm = make_params(c);
     if (nj) HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), sizeof(CloneJob) * nj, hipMemcpyHostToDevice, c->stream));
     if (nz) HIPCHK(c, hipMemcpyAsync(c->d_zjobs, c->h_zjobs.data(), sizeof(ZeroJob) * nz, hipMemcpyHostToDevice, c->stream));
-    if (nz && zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const ZeroJob*)c->d_zjobs);
+    if (nz && zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, (const ZeroJob*)c->d_zjobs);
     if (nj) hipLaunchKernelGGL(k_clone_particles, dim3(nj, 7, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const CloneJob*)c->d_jobs);
-    if (nz && !zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const ZeroJob*)c->d_zjobs);
+    if (nz && !zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, (const ZeroJob*)c->d_zjobs);
     HIPCHK(c, hipGetLastError());
     return LAMA_HIP_OK;
 }
@@ -477,35 +502,39 @@ static int32_t run_jobs(lama_hip_ctx* c, bool zero_first)
 struct CapRequest { uint32_t p, dm_cap, occ_cap; };
 int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
 {
-    struct Old { uint32_t dm_base, dm_cap, occ_base, occ_cap; };
+    struct Old { bool dm; uint32_t chunk, off, cap; };
     std::vector<Old> released;
     c->h_jobs.resize(0); c->h_zjobs.resize(0);
     for (const CapRequest& r : reqs) {
-        PartRec& pr = c->h_part[r.p];
-        const bool gd = r.dm_cap > pr.dm_cap, go = r.occ_cap > pr.occ_cap;
+        HostPart& hp = c->h_part[r.p];
+        const bool gd = r.dm_cap > hp.dm_cap, go = r.occ_cap > hp.occ_cap;
         if (!gd && !go) continue;
         if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
-        CloneJob j{};
-        j.src_home = j.dst_home = pr.home;
-        j.src_dm = j.dst_dm = pr.dm_base; j.src_occ = j.dst_occ = pr.occ_base;
-        j.sdm = c->h_counts[2 * r.p]; j.socc = c->h_counts[2 * r.p + 1];
-        Old o{pr.dm_base, 0, pr.occ_base, 0};
+        const HostPart before = hp;
         if (gd) {
-            uint32_t off = 0;
-            const int32_t rc = region_alloc(c, true, r.dm_cap, off);
+            uint32_t ch = 0, off = 0;
+            const int32_t rc = region_alloc(c, true, r.dm_cap, ch, off);
             if (rc) return rc;
-            o.dm_cap = pr.dm_cap; j.dst_dm = off; pr.dm_base = off; pr.dm_cap = r.dm_cap;
+            released.push_back(Old{true, hp.dm_chunk, hp.dm_off, hp.dm_cap});
+            hp.dm_chunk = ch; hp.dm_off = off; hp.dm_cap = r.dm_cap;
         }
         if (go) {
-            uint32_t off = 0;
-            const int32_t rc = region_alloc(c, false, r.occ_cap, off);
+            uint32_t ch = 0, off = 0;
+            const int32_t rc = region_alloc(c, false, r.occ_cap, ch, off);
             if (rc) return rc;
-            o.occ_cap = pr.occ_cap; j.dst_occ = off; pr.occ_base = off; pr.occ_cap = r.occ_cap;
+            released.push_back(Old{false, hp.occ_chunk, hp.occ_off, hp.occ_cap});
+            hp.occ_chunk = ch; hp.occ_off = off; hp.occ_cap = r.occ_cap;
         }
+        CloneJob j{};
+        j.src_home = j.dst_home = hp.home;
+        j.sdm = c->h_counts[2 * r.p]; j.socc = c->h_counts[2 * r.p + 1];
+        void* sp[5]; void* dp[5];
+        region_ptrs(c, before, sp); region_ptrs(c, hp, dp);
+        ZeroJob z{};
+        for (int k = 0; k < 5; ++k) { j.s[k] = sp[k]; j.d[k] = dp[k]; z.d[k] = (sp[k] != dp[k]) ? sp[k] : nullptr; }
+        z.ndm = j.sdm; z.nocc = j.socc;
         c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = j;
-        ZeroJob z{o.dm_base, o.occ_base, gd ? j.sdm : 0, go ? j.socc : 0};
         c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z;
-        released.push_back(o);
     }
     if (released.empty()) return LAMA_HIP_OK;
     int32_t rc = run_jobs(c, false);
@@ -513,7 +542,7 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
     rc = upload_part(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (const Old& o : released) { c->ra_dm.release(o.dm_base, o.dm_cap); c->ra_occ.release(o.occ_base, o.occ_cap); }     // (only now: no job of the batch may land in a region another one still reads)
+    for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of the batch may land in a region another one still reads)
     c->ctr.arena_growths += 1;
     return LAMA_HIP_OK;
 }
@@ -528,7 +557,7 @@ int32_t grow_arenas(lama_hip_ctx* c, uint32_t /*need_dm*/, uint32_t /*need_occ*/
     for (uint32_t p = 0; p < c->P && p < c->h_guard.size(); ++p) gmax = std::max(gmax, c->h_guard[p]);
     c->guard_head = std::max(gmax, c->guard_head - c->guard_head / 8u);
     for (uint32_t p = 0; p < c->P; ++p) {
-        const PartRec& pr = c->h_part[p];
+        const HostPart& pr = c->h_part[p];
         const uint32_t dmc = (uint32_t)c->h_counts[2 * p], occ = (uint32_t)c->h_counts[2 * p + 1];
         const uint32_t gh = p < c->h_guard.size() ? c->h_guard[p] : 0u;
         uint32_t nd = pr.dm_cap, no = pr.occ_cap;
@@ -557,7 +586,7 @@ int32_t recover_update(lama_hip_ctx* c, int32_t e)
     DevParams prm = make_params(c);
     const size_t WW = (size_t)c->W * c->W;
     hipLaunchKernelGGL(k_update_cleanup, dim3(c->P, (unsigned)((WW + 255) / 256)), dim3(256), 0, c->stream, prm);
-    HIPCHK(c, hipMemsetAsync(c->ms.occ_hit, 0, (size_t)c->ms.occ_pool * 128, c->stream));
+    for (const PoolChunk& k : c->ms.occ_chunks) HIPCHK(c, hipMemsetAsync(k.plane[2], 0, (size_t)k.patches * 128, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_act_count, 0, (size_t)c->P * 4, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_err, 0, sizeof(int32_t), c->stream));
     // the counts hold what every particle WANTED (allocations count on past the capacity); the guard its distance-map bound
@@ -568,7 +597,7 @@ int32_t recover_update(lama_hip_ctx* c, int32_t e)
     std::vector<CapRequest> reqs;
     bool at_limit = false, fixed_counts = false;
     for (uint32_t p = 0; p < c->P; ++p) {
-        PartRec& pr = c->h_part[p];
+        HostPart& pr = c->h_part[p];
         uint32_t wdm = (uint32_t)c->h_counts[2 * p], wocc = (uint32_t)c->h_counts[2 * p + 1];
         uint32_t nd = pr.dm_cap, no = pr.occ_cap;
         if (wocc > pr.occ_cap) { no = want_capacity(c->floor_occ, wocc, 0u); c->h_counts[2 * p + 1] = (int32_t)pr.occ_cap; fixed_counts = true; }
@@ -758,7 +787,7 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
     double far = c->scan_reach;                                   // no cell further than truncated_range from the sensor is touched
     if (c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
     const int reach_cells = (int)std::ceil(far * c->scale) + 2;
-    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, c->ms.rev, (int)first, (const double*)c->d_tfs, reach_cells,
+    hipLaunchKernelGGL(k_occ_reverse_dir, dim3(count), dim3(256), 0, c->stream, prm, (int)first, (const double*)c->d_tfs, reach_cells,
                        c->unguarded_retry ? 1 : 0);
     return LAMA_HIP_OK;
 }
@@ -820,7 +849,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             const uint32_t bound = (uint32_t)std::min(32767.0, std::ceil(3.1416 * rp * rp));
             std::vector<CapRequest> reqs;
             for (uint32_t p = first; p < first + count; ++p) {
-                const PartRec& pr = c->h_part[p];
+                const HostPart& pr = c->h_part[p];
                 const uint32_t nd = std::min<uint32_t>(MAX_PATCHES, round_up32((uint32_t)c->h_counts[2 * p] + bound)), no = std::min<uint32_t>(MAX_PATCHES, round_up32((uint32_t)c->h_counts[2 * p + 1] + bound));
                 if (nd > pr.dm_cap || no > pr.occ_cap) reqs.push_back(CapRequest{p, std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
             }
@@ -872,7 +901,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 pe.elist = c->d_elist; pe.elist_n = c->d_slow_n + 4; pe.lane = 1;
                 const unsigned eg = route_places(c, count);
                 hipLaunchKernelGGL(k_ray_patches, dim3(eg, 128u), dim3(256), 0, c->stream, pe, (const lama_dev::RayRec*)c->d_rrec,
-                                   (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->ms.rev, (int)n, 0);
+                                   (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (int)n, 0);
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
                 hipLaunchKernelGGL((k_ray_replay<8192, 8192, true, RP_BLOCK_LARGE>), dim3(eg), dim3(RP_BLOCK_LARGE), 0, c->stream, pe, 0);
                 HIPCHK(c, hipEventRecord(c->ev_alloc, c->stream));
@@ -885,7 +914,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 prm.early = c->d_early;                          // everybody else: the main lane skips them
             }
             hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
-                               (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (const int32_t*)c->ms.rev, (int)n, (int)first);
+                               (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (int)n, (int)first);
             const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
             if (count <= 512) {
                 hipLaunchKernelGGL((k_ray_replay<RP_SORT_SMALL, RP_SORT_SMALL, false, RP_BLOCK_LARGE>), dim3(count), dim3(RP_BLOCK_LARGE), 0, c->stream, prm, (int)first);
@@ -951,7 +980,7 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
 {
     const uint32_t P = c->P;
     std::vector<uint8_t> taken(P, 0);
-    std::vector<PartRec> np(P);
+    std::vector<HostPart> np(P);
     std::vector<int32_t> nc(2 * (size_t)P);
     std::vector<double> npose(4 * (size_t)P);
     std::vector<uint32_t> clones;                                   // new particles that need a copy
@@ -969,35 +998,37 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
     // first pass: dead particles whose regions cannot be reused as they are go back to the allocator (so that the clones can have them)
     // -- a dead particle is matched with the clone of the same rank; capacities are mostly equal (particles of one filter map the
     // same world), so the common case is a plain overwrite
-    struct Slot { uint32_t home; bool keep_dm, keep_occ; PartRec rec; int32_t odm, oocc; };
+    struct Slot { bool keep_dm, keep_occ; HostPart rec; int32_t odm, oocc; };
     std::vector<Slot> slots(dead.size());
     for (size_t k = 0; k < dead.size(); ++k) {
         const uint32_t d = dead[k], i = clones[k], j = (uint32_t)idx[i];
-        const PartRec& dr = c->h_part[d];
-        const PartRec& sr = c->h_part[j];
-        Slot sl{dr.home, dr.dm_cap == sr.dm_cap, dr.occ_cap == sr.occ_cap, dr, c->h_counts[2 * d], c->h_counts[2 * d + 1]};
-        ZeroJob z{dr.dm_base, dr.occ_base, 0, 0};
-        if (!sl.keep_dm) { z.ndm = sl.odm; c->ra_dm.release(dr.dm_base, dr.dm_cap); }
-        if (!sl.keep_occ) { z.nocc = sl.oocc; c->ra_occ.release(dr.occ_base, dr.occ_cap); }
+        const HostPart& dr = c->h_part[d];
+        const HostPart& sr = c->h_part[j];
+        Slot sl{dr.dm_cap == sr.dm_cap, dr.occ_cap == sr.occ_cap, dr, c->h_counts[2 * d], c->h_counts[2 * d + 1]};
+        void* dp[5];
+        region_ptrs(c, dr, dp);
+        ZeroJob z{};
+        if (!sl.keep_dm) { z.ndm = sl.odm; z.d[0] = dp[0]; z.d[1] = dp[1]; z.d[2] = dp[2]; region_release(c, true, dr.dm_chunk, dr.dm_off, dr.dm_cap); }
+        if (!sl.keep_occ) { z.nocc = sl.oocc; z.d[3] = dp[3]; z.d[4] = dp[4]; region_release(c, false, dr.occ_chunk, dr.occ_off, dr.occ_cap); }
         if (z.ndm || z.nocc) { c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z; }
         slots[k] = sl;
     }
     for (size_t k = 0; k < dead.size(); ++k) {
         const uint32_t i = clones[k], j = (uint32_t)idx[i];
-        const PartRec sr = c->h_part[j];
+        const HostPart sr = c->h_part[j];
         Slot& sl = slots[k];
-        PartRec r{};
-        r.home = sl.home;
+        HostPart r = sl.rec;                                        // the dead particle's home; its regions where they are kept
         r.dm_cap = sr.dm_cap; r.occ_cap = sr.occ_cap;
         CloneJob job{};
-        job.src_home = sr.home; job.dst_home = sl.home;
-        job.src_dm = sr.dm_base; job.src_occ = sr.occ_base;
+        job.src_home = sr.home; job.dst_home = r.home;
         job.sdm = c->h_counts[2 * j]; job.socc = c->h_counts[2 * j + 1];
-        if (sl.keep_dm) { r.dm_base = sl.rec.dm_base; job.odm = sl.odm; }
-        else { const int32_t rc = region_alloc(c, true, sr.dm_cap, r.dm_base); if (rc) return rc; job.odm = 0; }
-        if (sl.keep_occ) { r.occ_base = sl.rec.occ_base; job.oocc = sl.oocc; }
-        else { const int32_t rc = region_alloc(c, false, sr.occ_cap, r.occ_base); if (rc) return rc; job.oocc = 0; }
-        job.dst_dm = r.dm_base; job.dst_occ = r.occ_base;
+        if (sl.keep_dm) job.odm = sl.odm;
+        else { const int32_t rc = region_alloc(c, true, sr.dm_cap, r.dm_chunk, r.dm_off); if (rc) return rc; job.odm = 0; }
+        if (sl.keep_occ) job.oocc = sl.oocc;
+        else { const int32_t rc = region_alloc(c, false, sr.occ_cap, r.occ_chunk, r.occ_off); if (rc) return rc; job.oocc = 0; }
+        void* sp[5]; void* dp[5];
+        region_ptrs(c, sr, sp); region_ptrs(c, r, dp);
+        for (int q = 0; q < 5; ++q) { job.s[q] = sp[q]; job.d[q] = dp[q]; }
         np[i] = r;
         c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = job;
         c->clone_bytes += 2 * (uint64_t)WW * 2 + (uint64_t)job.sdm * (2048 + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
@@ -1103,28 +1134,23 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
         // start at P x the configured capacities and grow with the maps.
         MapStore& m = c->ms;
         c->floor_dm = (uint32_t)dc; c->floor_occ = (uint32_t)oc;
-        if (P * dc > 0xFFFFFFFFull || P * oc > 0xFFFFFFFFull) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_INVALID; }
-        m.dm_pool = (uint32_t)(P * dc); m.occ_pool = (uint32_t)(P * oc);
+        if (P * dc > 0xFFFFFFF0ull || P * oc > 0xFFFFFFF0ull) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_INVALID; }
         CHK(hipMalloc(&m.dm_dir, P * WW * 2));                 CHK(hipMemset(m.dm_dir, 0xFF, P * WW * 2));
         CHK(hipMalloc(&m.occ_dir, P * WW * 2));                CHK(hipMemset(m.occ_dir, 0xFF, P * WW * 2));
-        CHK(hipMalloc(&m.dm_sv, (size_t)m.dm_pool * 2048));    CHK(hipMemset(m.dm_sv, 0, (size_t)m.dm_pool * 2048));
-        CHK(hipMalloc(&m.dm_obs, (size_t)m.dm_pool * 4096));   CHK(hipMemset(m.dm_obs, 0, (size_t)m.dm_pool * 4096));
-        CHK(hipMalloc(&m.dm_mask, (size_t)m.dm_pool * 128));   CHK(hipMemset(m.dm_mask, 0, (size_t)m.dm_pool * 128));
-        CHK(hipMalloc(&m.occ, (size_t)m.occ_pool * 4096));     CHK(hipMemset(m.occ, 0, (size_t)m.occ_pool * 4096));
-        CHK(hipMalloc(&m.occ_mask, (size_t)m.occ_pool * 128)); CHK(hipMemset(m.occ_mask, 0, (size_t)m.occ_pool * 128));
-        CHK(hipMalloc(&m.occ_hit, (size_t)m.occ_pool * 128));  CHK(hipMemset(m.occ_hit, 0, (size_t)m.occ_pool * 128));
-        CHK(hipMalloc(&m.rev, (size_t)m.occ_pool * 4));
         CHK(hipMalloc(&m.counts, P * 2 * 4));                  CHK(hipMemset(m.counts, 0, P * 2 * 4));
-        c->ra_dm.reset(m.dm_pool); c->ra_occ.reset(m.occ_pool);
+        // first chunk of each pool: P regions of the configured capacity
+        if (add_chunk(c, true, (uint32_t)(P * dc)) != LAMA_HIP_OK || add_chunk(c, false, (uint32_t)(P * oc)) != LAMA_HIP_OK) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; }
+        c->ctr.pool_growths = 0;
         c->h_part.resize(P);
         for (size_t p = 0; p < P; ++p) {
-            PartRec r{};
+            HostPart r{};
             r.home = (uint32_t)p; r.dm_cap = (uint32_t)dc; r.occ_cap = (uint32_t)oc;
-            (void)c->ra_dm.alloc((uint32_t)dc, r.dm_base); (void)c->ra_occ.alloc((uint32_t)oc, r.occ_base);
+            if (region_alloc(c, true, (uint32_t)dc, r.dm_chunk, r.dm_off) != LAMA_HIP_OK || region_alloc(c, false, (uint32_t)oc, r.occ_chunk, r.occ_off) != LAMA_HIP_OK) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; }
             c->h_part[p] = r;
         }
         CHK(hipMalloc(&c->d_part, P * sizeof(PartRec)));
-        CHK(hipMemcpy(c->d_part, c->h_part.data(), P * sizeof(PartRec), hipMemcpyHostToDevice));
+        if (upload_part(c) != LAMA_HIP_OK) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; }
+        CHK(hipStreamSynchronize(c->stream));
     }
     c->results_bytes = P * 4 * 8 + P * 8 + P * 4 + 8;
     CHK(hipMalloc(&c->d_results, c->results_bytes));   CHK(hipMemset(c->d_results, 0, c->results_bytes));
@@ -1170,8 +1196,9 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     {
         MapStore& m = c->ms;
-        (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir); (void)hipFree(m.dm_sv); (void)hipFree(m.dm_obs); (void)hipFree(m.dm_mask);
-        (void)hipFree(m.occ); (void)hipFree(m.occ_mask); (void)hipFree(m.occ_hit); (void)hipFree(m.rev); (void)hipFree(m.counts);
+        (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir); (void)hipFree(m.counts);
+        for (PoolChunk& k : m.dm_chunks) for (int i = 0; i < 4; ++i) (void)hipFree(k.plane[i]);
+        for (PoolChunk& k : m.occ_chunks) for (int i = 0; i < 4; ++i) (void)hipFree(k.plane[i]);
         (void)hipFree(c->d_part); (void)hipFree(c->d_jobs); (void)hipFree(c->d_zjobs);
     }
     (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk);
@@ -1378,11 +1405,11 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
     HIPCHK(c, hipStreamSynchronize(c->stream));
     MapStore& s = c->ms;
     const size_t WW = (size_t)c->W * c->W;
-    const PartRec pr = c->h_part[particle];
+    const HostPart hp = c->h_part[particle];
+    const PartRec pr = dev_part(c, hp);                             // the particle's regions (plane addresses)
     for (int kind = 0; kind < 2; ++kind) {
         const bool dm = kind == 0;
-        const size_t base = dm ? pr.dm_base : pr.occ_base;          // the particle's region in the pool (patches)
-        int16_t* d_dir = (dm ? s.dm_dir : s.occ_dir) + pr.home * WW;
+        int16_t* d_dir = (dm ? s.dm_dir : s.occ_dir) + hp.home * WW;
         std::vector<int16_t> dir(WW);
         HIPCHK(c, hipMemcpy(dir.data(), d_dir, WW * 2, hipMemcpyDeviceToHost));
         int count = c->h_counts[2 * particle + (dm ? 0 : 1)];
@@ -1396,7 +1423,7 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
             if (slot < 0) continue;
             const int last = count - 1;
             auto plane_move = [&](void* plane, size_t bytes_per_slot) -> hipError_t {
-                char* b = (char*)plane + base * bytes_per_slot;
+                char* b = (char*)plane;
                 if (slot != last) {
                     hipError_t e = hipMemcpyAsync(b + (size_t)slot * bytes_per_slot, b + (size_t)last * bytes_per_slot, bytes_per_slot, hipMemcpyDeviceToDevice, c->stream);
                     if (e != hipSuccess) return e;
@@ -1404,10 +1431,10 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
                 return hipMemsetAsync(b + (size_t)last * bytes_per_slot, 0, bytes_per_slot, c->stream);
             };
             if (dm) {
-                HIPCHK(c, plane_move(s.dm_sv, 2048)); HIPCHK(c, plane_move(s.dm_obs, 4096)); HIPCHK(c, plane_move(s.dm_mask, 128));
+                HIPCHK(c, plane_move(pr.dm_sv, 2048)); HIPCHK(c, plane_move(pr.dm_obs, 4096)); HIPCHK(c, plane_move(pr.dm_mask, 128));
             } else {
-                HIPCHK(c, plane_move(s.occ, 4096)); HIPCHK(c, plane_move(s.occ_mask, 128));
-                HIPCHK(c, plane_move(s.occ_hit, 128));
+                HIPCHK(c, plane_move(pr.occ, 4096)); HIPCHK(c, plane_move(pr.occ_mask, 128));
+                HIPCHK(c, plane_move(pr.occ_hit, 128));
             }
             if (slot != last)
                 for (size_t q = 0; q < WW; ++q) if (dir[q] == last) { dir[q] = (int16_t)slot; break; }
@@ -1435,12 +1462,13 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     const MapStore& s = c->ms;
     const size_t WW = (size_t)c->W * c->W;
     const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
-    const PartRec pr = c->h_part[particle];
+    const HostPart hp = c->h_part[particle];
+    const PartRec pr = dev_part(c, hp);
     const uint32_t count = (uint32_t)c->h_counts[2 * particle + (dm ? 0 : 1)];
     if (num_patches) *num_patches = count;
     if (count == 0 || cap == 0) return LAMA_HIP_OK;
     std::vector<int16_t> dir(WW);
-    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + pr.home * WW, WW * 2, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(dir.data(), (dm ? s.dm_dir : s.occ_dir) + hp.home * WW, WW * 2, hipMemcpyDeviceToHost));
     // (reference patch id, slot), ascending id
     std::vector<std::pair<uint64_t, int>> order;
     for (uint32_t wy = 0; wy < c->W; ++wy)
@@ -1453,16 +1481,16 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     std::sort(order.begin(), order.end());
     if (order.size() != count) return fail(c, LAMA_HIP_E_STATE, "directory / count mismatch");
     std::vector<uint64_t> hmask((size_t)count * 16);
-    HIPCHK(c, hipMemcpy(hmask.data(), (dm ? s.dm_mask : s.occ_mask) + (size_t)(dm ? pr.dm_base : pr.occ_base) * 16,
+    HIPCHK(c, hipMemcpy(hmask.data(), dm ? pr.dm_mask : pr.occ_mask,
                         hmask.size() * 8, hipMemcpyDeviceToHost));
     std::vector<uint16_t> hsv; std::vector<uint32_t> hobs, hocc;
     if (dm) {
         hsv.resize((size_t)count * 1024); hobs.resize((size_t)count * 1024);
-        HIPCHK(c, hipMemcpy(hsv.data(), s.dm_sv + (size_t)pr.dm_base * 1024, hsv.size() * 2, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(hobs.data(), s.dm_obs + (size_t)pr.dm_base * 1024, hobs.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hsv.data(), pr.dm_sv, hsv.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hobs.data(), pr.dm_obs, hobs.size() * 4, hipMemcpyDeviceToHost));
     } else {
         hocc.resize((size_t)count * 1024);
-        HIPCHK(c, hipMemcpy(hocc.data(), s.occ + (size_t)pr.occ_base * 1024, hocc.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hocc.data(), pr.occ, hocc.size() * 4, hipMemcpyDeviceToHost));
     }
     const uint32_t nout = std::min<uint32_t>(cap, count);
     for (uint32_t k = 0; k < nout; ++k) {
@@ -1491,6 +1519,93 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
             }
         }
     }
+    return LAMA_HIP_OK;
+}
+
+int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t n, const uint64_t* patch_ids, const uint8_t* cells,
+                               const uint64_t* masks)
+{
+    if (!c || particle >= c->P || (kind != LAMA_HIP_MAP_DISTANCE && kind != LAMA_HIP_MAP_OCCUPANCY) || (n && (!patch_ids || !cells || !masks))) return LAMA_HIP_E_INVALID;
+    ENTER(c);
+    if (n > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
+    if (n) {   // the window must hold the patches (it is centred / moved / grown for them)
+        int64_t x0 = INT64_MAX, x1 = INT64_MIN, y0 = INT64_MAX, y1 = INT64_MIN;
+        for (uint32_t k = 0; k < n; ++k) {
+            const int64_t px = (int64_t)(patch_ids[k] / 2642244ull), py = (int64_t)(patch_ids[k] % 2642244ull);
+            x0 = std::min(x0, px); x1 = std::max(x1, px); y0 = std::min(y0, py); y1 = std::max(y1, py);
+        }
+        if (x1 - x0 + 1 > LAMA_HIP_MAX_WINDOW || y1 - y0 + 1 > LAMA_HIP_MAX_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "the map is wider than the largest device window (1016 patches)");
+        const int32_t rw = ensure_window(c, x0, x1, y0, y1);
+        if (rw) return rw;
+    }
+    if (!c->initialised) {
+        for (uint32_t p = 0; p < c->P; ++p) { c->h_poses[4 * p] = 1.0; c->h_poses[4 * p + 1] = 0.0; c->h_poses[4 * p + 2] = 0.0; c->h_poses[4 * p + 3] = 0.0; }
+        HIPCHK(c, hipMemcpyAsync(c->d_poses, c->h_poses.data(), sizeof(double) * 4 * c->P, hipMemcpyHostToDevice, c->stream));
+        c->initialised = true;
+    }
+    {   // room for the patches (the particle's region moves if it must; what it held is replaced below)
+        const HostPart& hp = c->h_part[particle];
+        const uint32_t cap = dm ? hp.dm_cap : hp.occ_cap;
+        if (n > cap) {
+            const uint32_t want = want_capacity(dm ? c->floor_dm : c->floor_occ, n, 0u);
+            const int32_t rg = set_capacities(c, {CapRequest{particle, dm ? want : hp.dm_cap, dm ? hp.occ_cap : want}});
+            if (rg) return rg;
+        }
+    }
+    const HostPart hp = c->h_part[particle];
+    const PartRec pr = dev_part(c, hp);
+    const size_t WW = (size_t)c->W * c->W;
+    const int32_t old = c->h_counts[2 * particle + (dm ? 0 : 1)];
+    // directory: slot k = the k-th given patch; a patch given twice is an error
+    std::vector<int16_t> dir(WW, (int16_t)-1);
+    for (uint32_t k = 0; k < n; ++k) {
+        const int64_t wx = (int64_t)(patch_ids[k] / 2642244ull) - (int64_t)(c->wx0 >> 5), wy = (int64_t)(patch_ids[k] % 2642244ull) - (int64_t)(c->wy0 >> 5);
+        if (wx < 0 || wy < 0 || wx >= (int64_t)c->W || wy >= (int64_t)c->W) return fail(c, LAMA_HIP_E_WINDOW, "a patch of the uploaded map fell outside the device window");
+        int16_t& e = dir[(size_t)wy * c->W + (size_t)wx];
+        if (e >= 0) return fail(c, LAMA_HIP_E_INVALID, "a patch index appears twice in the uploaded map");
+        e = (int16_t)k;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    // what the particle held before: zero the slots the new map does not overwrite ("unused slot == calloc'd")
+    if (old > (int32_t)n) {
+        const size_t keep = n, gone = (size_t)old - n;
+        if (dm) {
+            HIPCHK(c, hipMemsetAsync((char*)pr.dm_sv + keep * 2048, 0, gone * 2048, c->stream));
+            HIPCHK(c, hipMemsetAsync((char*)pr.dm_obs + keep * 4096, 0, gone * 4096, c->stream));
+            HIPCHK(c, hipMemsetAsync((char*)pr.dm_mask + keep * 128, 0, gone * 128, c->stream));
+        } else {
+            HIPCHK(c, hipMemsetAsync((char*)pr.occ + keep * 4096, 0, gone * 4096, c->stream));
+            HIPCHK(c, hipMemsetAsync((char*)pr.occ_mask + keep * 128, 0, gone * 128, c->stream));
+        }
+    }
+    if (n) {
+        if (dm) {      // distance_t (10 B: int16 obstacle[3], uint16 sqdist, bool valid_obstacle, bool is_queued) -> the two planes
+            std::vector<uint16_t> hsv((size_t)n * 1024); std::vector<uint32_t> hobs((size_t)n * 1024);
+            for (size_t k = 0; k < n; ++k)
+                for (int ci = 0; ci < 1024; ++ci) {
+                    const uint8_t* o = cells + k * 10240 + 10 * (size_t)ci;
+                    int16_t ox, oy; uint16_t sq;
+                    std::memcpy(&ox, o, 2); std::memcpy(&oy, o + 2, 2); std::memcpy(&sq, o + 6, 2);
+                    if (sq > SV_SQMASK) return fail(c, LAMA_HIP_E_INVALID, "the uploaded distance map holds a squared distance beyond 16383 cells^2 (l2_max above 127 cells)");
+                    hsv[k * 1024 + ci] = (uint16_t)(sq | (o[8] ? SV_VALID : 0) | (o[9] ? SV_QUEUED : 0));
+                    hobs[k * 1024 + ci] = ((uint32_t)(uint16_t)ox) | (((uint32_t)(uint16_t)oy) << 16);      // (pack_obs)
+                }
+            HIPCHK(c, hipMemcpy(pr.dm_sv, hsv.data(), hsv.size() * 2, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pr.dm_obs, hobs.data(), hobs.size() * 4, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pr.dm_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
+        } else {       // frequency {u16 occupied, u16 visited} / float log-odds: 4 B cells as they are
+            HIPCHK(c, hipMemcpy(pr.occ, cells, (size_t)n * 4096, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pr.occ_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
+        }
+    }
+    HIPCHK(c, hipMemcpy((dm ? c->ms.dm_dir : c->ms.occ_dir) + hp.home * WW, dir.data(), WW * 2, hipMemcpyHostToDevice));
+    c->h_counts[2 * particle + (dm ? 0 : 1)] = (int32_t)n;
+    HIPCHK(c, hipMemcpy(c->ms.counts + 2 * particle + (dm ? 0 : 1), &c->h_counts[2 * particle + (dm ? 0 : 1)], sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!dm) c->visit_bound = 65535u;                             // unknown counters: let the wrap guard look before the next parallel ray-cast
+    c->early_ok = false;
     return LAMA_HIP_OK;
 }
 
@@ -1956,7 +2071,7 @@ int32_t lama_hip_pf_import_particles(lama_hip_ctx* c, uint32_t n, const uint32_t
         for (uint32_t k = 0; k < n; ++k) {
             int32_t hdr[8];
             std::memcpy(hdr, c->h_ship_heads.data() + (size_t)BLOB_HEAD * k + 32, 32);
-            const PartRec& pr = c->h_part[particles[k]];
+            const HostPart& pr = c->h_part[particles[k]];
             const uint32_t nd = want_capacity(c->floor_dm, (uint32_t)hdr[0], 0u), no = want_capacity(c->floor_occ, (uint32_t)hdr[1], 0u);
             if ((uint32_t)hdr[0] > pr.dm_cap || (uint32_t)hdr[1] > pr.occ_cap) reqs.push_back(CapRequest{particles[k], std::max(nd, pr.dm_cap), std::max(no, pr.occ_cap)});
         }
@@ -2095,7 +2210,10 @@ static void memory_figures(const lama_hip_ctx* c, lama_hip_counters* o)
     const uint64_t dirs = 2 * P * WW * 2;
     uint64_t dm_used = 0, occ_used = 0;
     for (uint32_t p = 0; p < c->P; ++p) { dm_used += (uint64_t)c->h_counts[2 * p]; occ_used += (uint64_t)c->h_counts[2 * p + 1]; }
-    o->hbm_bytes_allocated = dirs + (uint64_t)m.dm_pool * (2048 + 4096 + 128) + (uint64_t)m.occ_pool * (4096 + 128 + 128 + 4);
+    uint64_t dm_pool = 0, occ_pool = 0;
+    for (const PoolChunk& k : m.dm_chunks) dm_pool += k.patches;
+    for (const PoolChunk& k : m.occ_chunks) occ_pool += k.patches;
+    o->hbm_bytes_allocated = dirs + dm_pool * (2048 + 4096 + 128) + occ_pool * (4096 + 128 + 128 + 4);
     o->hbm_bytes_used = dirs + dm_used * (2048 + 4096 + 128) + occ_used * (4096 + 128 + 128 + 4);
     const uint64_t other = 2 * P * (uint64_t)c->cfg.queue_capacity * 8 + P * (uint64_t)c->cfg.active_capacity * 8 + (uint64_t)c->rrec_cap * (sizeof(lama_dev::RayRec) + 8) +
                            P * (16 * 8 + 12 * 8 + 4 * 8 + 64) + (1u << 20) + (uint64_t)c->pts_cap * 24;

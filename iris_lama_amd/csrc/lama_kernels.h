@@ -2488,11 +2488,10 @@ __global__ __launch_bounds__(256) void k_occ_max_visited(DevParams prm, uint32_t
 // ------------------------------------------------------------------------------------------------
 struct CloneJob {
     uint32_t src_home, dst_home;
-    uint32_t src_dm, dst_dm;       // region bases (patches) in the distance-map pool
-    uint32_t src_occ, dst_occ;     // ... in the occupancy pool
     int32_t sdm, socc;             // used slots of the source
     int32_t odm, oocc;             // slots the destination region's previous owner had used (0: a region fresh from the allocator)
-    uint32_t pad0, pad1;
+    const void* s[5];              // source region: dm_sv, dm_obs, dm_mask, occ, occ_mask
+    void* d[5];                    // destination region, same order
 };
 constexpr int CLONE_SPLIT = 2;
 
@@ -2503,23 +2502,18 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
     const size_t WW = (size_t)prm.W * prm.W;
     const uint4* s; uint4* d; size_t ncopy, nzero = 0;   // in 16-byte units
     const size_t zdm = j.odm > j.sdm ? (size_t)(j.odm - j.sdm) : 0, zocc = j.oocc > j.socc ? (size_t)(j.oocc - j.socc) : 0;
-    switch (plane) {
-    case 0: if (j.src_home == j.dst_home) return;
-            s = (const uint4*)(prm.dm_dir + j.src_home * WW); d = (uint4*)(prm.dm_dir + j.dst_home * WW); ncopy = WW * 2 / 16; break;
-    case 1: if (j.src_home == j.dst_home) return;
-            s = (const uint4*)(prm.occ_dir + j.src_home * WW); d = (uint4*)(prm.occ_dir + j.dst_home * WW); ncopy = WW * 2 / 16; break;
-    case 2: s = (const uint4*)(prm.dm_sv + (size_t)j.src_dm * 1024); d = (uint4*)(prm.dm_sv + (size_t)j.dst_dm * 1024);
-            ncopy = (size_t)j.sdm * 2048 / 16; nzero = zdm * 2048 / 16; break;
-    case 3: s = (const uint4*)(prm.dm_obs + (size_t)j.src_dm * 1024); d = (uint4*)(prm.dm_obs + (size_t)j.dst_dm * 1024);
-            ncopy = (size_t)j.sdm * 4096 / 16; nzero = zdm * 4096 / 16; break;
-    case 4: s = (const uint4*)(prm.dm_mask + (size_t)j.src_dm * 16); d = (uint4*)(prm.dm_mask + (size_t)j.dst_dm * 16);
-            ncopy = (size_t)j.sdm * 128 / 16; nzero = zdm * 128 / 16; break;
-    case 5: s = (const uint4*)(prm.occ + (size_t)j.src_occ * 1024); d = (uint4*)(prm.occ + (size_t)j.dst_occ * 1024);
-            ncopy = (size_t)j.socc * 4096 / 16; nzero = zocc * 4096 / 16; break;
-    default: s = (const uint4*)(prm.occ_mask + (size_t)j.src_occ * 16); d = (uint4*)(prm.occ_mask + (size_t)j.dst_occ * 16);
-            ncopy = (size_t)j.socc * 128 / 16; nzero = zocc * 128 / 16; break;
+    const size_t bytes[5] = {2048, 4096, 128, 4096, 128};
+    if (plane < 2) {
+        if (j.src_home == j.dst_home) return;
+        const int16_t* dir = plane == 0 ? prm.dm_dir : prm.occ_dir;
+        s = (const uint4*)(dir + j.src_home * WW); d = (uint4*)(const_cast<int16_t*>(dir) + j.dst_home * WW); ncopy = WW * 2 / 16;
+    } else {
+        const int k = plane - 2;
+        s = (const uint4*)j.s[k]; d = (uint4*)j.d[k];
+        const bool dm = k < 3;
+        ncopy = (size_t)(dm ? j.sdm : j.socc) * bytes[k] / 16; nzero = (dm ? zdm : zocc) * bytes[k] / 16;
     }
-    if (s == d) return;                                             // (a job that only re-zeroes nothing: same region, same place)
+    if (s == d) return;                                             // (this plane of the particle stays where it is)
     const size_t t0 = (size_t)blockIdx.z * 256 + threadIdx.x, step = 256 * (size_t)gridDim.z;
     for (size_t k = t0; k < ncopy; k += step) d[k] = s[k];
     const uint4 z = make_uint4(0, 0, 0, 0);
@@ -2528,20 +2522,17 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
 
 // A region that goes back to the allocator is zeroed where it was used: free pool space is all-zero, so a region handed out later
 // needs no preparation.  grid = (regions, 5 planes, CLONE_SPLIT); the occupancy hit bits are zero between scans anyway.
-struct ZeroJob { uint32_t dm_base, occ_base; int32_t ndm, nocc; };
-__global__ __launch_bounds__(256) void k_zero_regions(DevParams prm, const ZeroJob* __restrict__ jobs)
+struct ZeroJob { void* d[5]; int32_t ndm, nocc; };
+__global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob* __restrict__ jobs)
 {
     const ZeroJob j = jobs[blockIdx.x];
-    uint4* d; size_t n;
-    switch (blockIdx.y) {
-    case 0: d = (uint4*)(prm.dm_sv + (size_t)j.dm_base * 1024); n = (size_t)j.ndm * 2048 / 16; break;
-    case 1: d = (uint4*)(prm.dm_obs + (size_t)j.dm_base * 1024); n = (size_t)j.ndm * 4096 / 16; break;
-    case 2: d = (uint4*)(prm.dm_mask + (size_t)j.dm_base * 16); n = (size_t)j.ndm * 128 / 16; break;
-    case 3: d = (uint4*)(prm.occ + (size_t)j.occ_base * 1024); n = (size_t)j.nocc * 4096 / 16; break;
-    default: d = (uint4*)(prm.occ_mask + (size_t)j.occ_base * 16); n = (size_t)j.nocc * 128 / 16; break;
-    }
+    const size_t bytes[5] = {2048, 4096, 128, 4096, 128};
+    const int k = blockIdx.y;
+    uint4* d = (uint4*)j.d[k];
+    const size_t n = (size_t)(k < 3 ? j.ndm : j.nocc) * bytes[k] / 16;
+    if (!d) return;
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n; k += 256 * (size_t)gridDim.z) d[k] = z;
+    for (size_t i = (size_t)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * (size_t)gridDim.z) d[i] = z;
 }
 
 

@@ -199,7 +199,7 @@ __device__ inline int imax(int a, int b) { return a > b ? a : b; }
 constexpr int RD_MARK_SIDE = 256;                            // the marked region (scan box grown by guard_r) is at most this many patches wide
 constexpr int RD_MARK_WORDS = RD_MARK_SIDE * RD_MARK_SIDE / 32;
 
-__global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t* __restrict__ rev, int first_particle,
+__global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int first_particle,
                                                           const double* __restrict__ tfs /*[P][12]*/, int reach_cells, int guard_off)
 {
     __shared__ uint32_t mark[RD_MARK_WORDS];                  // positions of the region within guard_r patches of an occupancy patch in reach
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int32_t*
         for (int k = 0; k < 8; ++k) {
             const int slot = (int)(int16_t)((ww[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
             if (slot < 0) continue;
-            rev[(size_t)pv.occ_base + slot] = (int32_t)(w0 + (uint32_t)k);
+            pv.rev[slot] = (int32_t)(w0 + (uint32_t)k);
             if (!bounded || x0 + k < bx0 || x0 + k > bx1 || wy < by0 || wy > by1) continue;       // out of the scan's reach: nothing changes there
             for (int dy = -r; dy <= r; ++dy)
                 for (int dx = -r; dx <= r; ++dx) {
@@ -277,7 +277,7 @@ constexpr int RPT_CHUNK = 256;        // candidate beams tested per round: the r
 constexpr int RPT_WALK = 4;           // lanes that share the cells of one (beam, patch) crossing
 
 __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec* __restrict__ recs, const uint64_t* __restrict__ bbox,
-                                                      const RayChunk* __restrict__ chunks, const int32_t* __restrict__ rev, int n, int first_particle)
+                                                      const RayChunk* __restrict__ chunks, int n, int first_particle)
 {
     static_assert(RPT_CHUNK == 256, "one candidate beam per thread and round");
     __shared__ uint32_t cnt[1024];
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     if (lane < nck) ck = chunks[(size_t)p * nck + lane];
     if (tid < 2) list_n[tid] = 0;
     int slot = blockIdx.y;
-    uint32_t pidx_next = slot < count ? (uint32_t)rev[(size_t)pv.occ_base + slot] : 0u;
+    uint32_t pidx_next = slot < count ? (uint32_t)pv.rev[slot] : 0u;
     uint32_t par = 0;                                              // parity of the round
 #ifdef LAMA_PROFILE_RAY
     uint64_t tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     __syncthreads();
     for (; slot < count; slot += gridDim.y) {
         const uint32_t pidx = pidx_next;
-        if (slot + (int)gridDim.y < count) pidx_next = (uint32_t)rev[(size_t)pv.occ_base + slot + gridDim.y];
+        if (slot + (int)gridDim.y < count) pidx_next = (uint32_t)pv.rev[slot + gridDim.y];
         const int px = (int)((pidx % prm.W) * 32u), py = (int)((pidx / prm.W) * 32u);       // window-relative origin of the patch
 #ifdef LAMA_PROFILE_RAY
         tprev = __builtin_readcyclecounter();

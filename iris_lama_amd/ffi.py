@@ -58,7 +58,7 @@ HIP_SYMBOLS = [
     "lama_hip_default_cfg", "lama_hip_device_count", "lama_hip_ctx_create", "lama_hip_ctx_destroy",
     "lama_hip_last_error", "lama_hip_pf_init", "lama_hip_pf_set_poses", "lama_hip_pf_get_poses",
     "lama_hip_pf_scan_match", "lama_hip_pf_resample", "lama_hip_pf_update_maps", "lama_hip_pf_map_patches",
-    "lama_hip_pf_download_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
+    "lama_hip_pf_download_map", "lama_hip_pf_upload_map", "lama_hip_match_batch", "lama_hip_pf_export_particle",
     "lama_hip_pf_import_particle", "lama_hip_get_counters", "lama_hip_get_counters_sized", "lama_hip_counters_bytes", "lama_hip_reset_counters",
     "lama_hip_map_add_obstacles", "lama_hip_match_solve", "lama_hip_eval_batch", "lama_hip_map_sample_likelihood",
     "lama_hip_pgo_create", "lama_hip_pgo_destroy", "lama_hip_pgo_last_error", "lama_hip_pgo_linearize",
@@ -125,6 +125,7 @@ def _bind_hip(L):
         L.lama_hip_ctx_device.restype = C.c_int32
         L.lama_hip_pf_map_patches.argtypes = [vp, u32, i32, vp]
         L.lama_hip_pf_download_map.argtypes = [vp, u32, i32, u32, vp, vp, vp, vp]
+        L.lama_hip_pf_upload_map.argtypes = [vp, u32, i32, u32, vp, vp, vp]
         L.lama_hip_match_batch.argtypes = [vp, u32, vp, u32, vp, vp, vp, u32, vp]
         L.lama_hip_pf_export_particle.argtypes = [vp, u32, vp, u64, vp]
         L.lama_hip_pf_import_particle.argtypes = [vp, u32, vp, u64]
@@ -264,6 +265,16 @@ class HipContext:
         self._chk(self.L.lama_hip_pf_download_map(self.h, particle, kind, n, _p(ids), _p(cells), _p(masks), C.byref(got)))
         assert got.value == n
         return {int(ids[k]): (cells[k], masks[k]) for k in range(n)}
+
+    def upload_map(self, particle, kind, patches):
+        """The inverse of download_map: replace the particle's map of `kind` by {patch id: (cells[1024], mask[16])}."""
+        ids = np.array(sorted(patches), dtype=np.uint64)
+        dt = DIST_T if kind == MAP_DISTANCE else FREQ_T
+        cells = np.zeros((len(ids), 1024), dtype=dt)
+        masks = np.zeros((len(ids), 16), dtype=np.uint64)
+        for k, i in enumerate(ids):
+            cells[k], masks[k] = patches[int(i)]
+        self._chk(self.L.lama_hip_pf_upload_map(self.h, particle, kind, len(ids), _p(ids), _p(cells), _p(masks)))
 
     def match_batch(self, particle, pts, poses, origin=None, quat=None):
         pts, origin, quat = self._scan(pts, origin, quat)
@@ -433,6 +444,7 @@ HOST_SYMBOLS = [
     "lama_slam_view_bounds", "lama_slam_view_cells", "lama_slam_view_occupancy", "lama_slam_view_distance_cells", "lama_slam_view_distance_points",
     "lama_slam_match_eval", "lama_slam_match_solve",
     "lama_loc_create", "lama_loc_destroy", "lama_loc_last_error", "lama_loc_engine_origin", "lama_loc_set_obstacles_world",
+    "lama_loc_write_distance_map", "lama_loc_read_distance_map", "lama_loc_device_context",
     "lama_loc_set_pose", "lama_loc_get_pose", "lama_loc_update", "lama_loc_covar", "lama_loc_rmse", "lama_loc_iterations",
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
     "lama_loc_global_localization_active", "lama_loc_gloc_candidates", "lama_loc_sampling_likelihoods",
@@ -475,7 +487,7 @@ def _bind_host(L):
         "lama_slam_match_solve": (i32, [vp, vp, u32, vp, vp, vp, C.c_char_p, C.c_char_p, d, u32, vp, vp]),
         "lama_loc_create": (vp, [d, d, d, d, u32, i32, vp, i32]), "lama_loc_destroy": (None, [vp]),
         "lama_loc_last_error": (C.c_char_p, [vp]), "lama_loc_engine_origin": (C.c_char_p, [vp]),
-        "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_set_pose": (None, [vp, d, d, d]),
+        "lama_loc_set_obstacles_world": (i32, [vp, vp, u32]), "lama_loc_write_distance_map": (i32, [vp, C.c_char_p]), "lama_loc_read_distance_map": (i32, [vp, C.c_char_p]), "lama_loc_device_context": (vp, [vp]), "lama_loc_set_pose": (None, [vp, d, d, d]),
         "lama_loc_get_pose": (i32, [vp, vp]), "lama_loc_update": (i32, [vp, vp, u32, vp, vp, vp, d, i32]),
         "lama_loc_covar": (i32, [vp, vp]), "lama_loc_rmse": (d, [vp]), "lama_loc_iterations": (u32, [vp]),
         "lama_loc_create2": (vp, [d, d, d, d, u32, u32, u32, d, d, i32, vp, i32]),
@@ -866,6 +878,25 @@ class Loc2D:
     def set_obstacles_world(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1, 2)
         self._chk(self.L.lama_loc_set_obstacles_world(self.h, _p(xy), len(xy)))
+
+    def write_distance_map(self, filename):
+        self._chk(self.L.lama_loc_write_distance_map(self.h, str(filename).encode()))
+
+    def hip_context(self):
+        """Borrowed HipContext view of the device context (map downloads in tests)."""
+        ctx = HipContext.__new__(HipContext)
+        ctx.L = hip_lib() if self.engine_origin().endswith("liblama_hip.so") else C.CDLL(self.engine_origin())
+        if ctx.L is not hip_lib_or_none():
+            _bind_hip(ctx.L)
+        ctx.cfg = None
+        ctx.P = 1
+        ctx.h = C.c_void_p(self.L.lama_loc_device_context(self.h))
+        ctx._is_borrowed = True
+        return ctx
+
+    def read_distance_map(self, filename):
+        """distance_map->read(file): the file's patches replace the device map (no addObstacle / update() replay)."""
+        self._chk(self.L.lama_loc_read_distance_map(self.h, str(filename).encode()))
 
     def set_pose(self, x, y, yaw):
         self.L.lama_loc_set_pose(self.h, float(x), float(y), float(yaw))

@@ -58,6 +58,7 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
     BIND(sync, lama_hip_sync)
     BIND(pf_map_patches, lama_hip_pf_map_patches)
     BIND(pf_download_map, lama_hip_pf_download_map)
+    BIND(pf_upload_map, lama_hip_pf_upload_map)
     BIND(match_batch, lama_hip_match_batch)
     BIND(pf_export_particle, lama_hip_pf_export_particle)
     BIND(pf_import_particle, lama_hip_pf_import_particle)

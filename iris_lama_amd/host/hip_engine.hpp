@@ -33,6 +33,7 @@ struct HipEngine {
     decltype(&lama_hip_pf_export_particle) pf_export_particle = nullptr;
     decltype(&lama_hip_pf_import_particle) pf_import_particle = nullptr;
     decltype(&lama_hip_get_counters) get_counters = nullptr;
+    decltype(&lama_hip_pf_upload_map) pf_upload_map = nullptr;
     decltype(&lama_hip_reset_counters) reset_counters = nullptr;
     decltype(&lama_hip_map_add_obstacles) map_add_obstacles = nullptr;
     decltype(&lama_hip_match_solve) match_solve = nullptr;

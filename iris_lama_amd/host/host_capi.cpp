@@ -498,6 +498,18 @@ int lama_loc_set_obstacles_world(lama_loc* h, const double* xy, uint32_t n)
         return 0;
     } catch (const std::exception& e) { h->error = e.what(); return -1; }
 }
+void* lama_loc_device_context(const lama_loc* h) { return h ? (void*)h->l.deviceContext() : nullptr; }
+int lama_loc_write_distance_map(lama_loc* h, const char* filename)
+{
+    try { return h->l.distance_map->write(filename) ? 0 : -1; } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
+int lama_loc_read_distance_map(lama_loc* h, const char* filename)
+{
+    try {
+        if (!h->l.distance_map->read(filename)) { h->error = std::string("cannot read ") + filename; return -1; }
+        return 0;
+    } catch (const std::exception& e) { h->error = e.what(); return -1; }
+}
 void lama_loc_set_pose(lama_loc* h, double x, double y, double yaw) { h->l.setPose(Pose2D(x, y, yaw)); }
 int lama_loc_get_pose(const lama_loc* h, double* pose4) { h->l.getPose().state.toArray(pose4); return 0; }
 int lama_loc_update(lama_loc* h, const double* pts, uint32_t n, const double* origin3, const double* quat, const double* odom_xyr, double ts, int force)

@@ -48,6 +48,11 @@ void Loc2D::Init(const Options& o)
         m.ids.assign(n, 0); m.cells.assign((size_t)n * 10 * 1024, 0); m.masks.assign((size_t)n * 16, 0);
         return eng_->pf_download_map(ctx_, 0, 0, n, m.ids.data(), m.cells.data(), m.masks.data(), &got) == 0 && got == n;
     };
+    w.upload = [this](const sdm::HostMap& m) {
+        ensureContext();
+        const int32_t rc = eng_->pf_upload_map(ctx_, 0, 0 /* distance map */, (uint32_t)m.ids.size(), m.ids.data(), m.cells.data(), m.masks.data());
+        if (rc) fail(rc, "lama_hip_pf_upload_map");
+    };
     distance_map->bindWriter(std::move(w));
     rmse_ = 0.0;
     cov_ = Matrix3d::Identity();

@@ -95,3 +95,42 @@ def segment_world_scan(segs, x, y, yaw, beams=1080, fov=np.deg2rad(270.0), max_r
         r = r + noise
     keep = np.isfinite(r) & (r <= max_range)
     return np.stack([r[keep] * np.cos(phi[keep]), r[keep] * np.sin(phi[keep]), np.zeros(keep.sum())], axis=1)
+
+
+def hall_segments(side=104.0, rooms=4, gap=6.0):
+    """Wall segments (S, 4) of a square hall of `side` metres divided into rooms x rooms bays by interior walls with a `gap`-metre
+    opening in the middle of every bay side (so that a robot can drive through all of them), plus a 1 m pillar in every bay."""
+    segs = [(0.0, 0.0, side, 0.0), (side, 0.0, side, side), (side, side, 0.0, side), (0.0, side, 0.0, 0.0)]
+    bay = side / rooms
+    for i in range(1, rooms):
+        c = i * bay
+        for j in range(rooms):
+            a, b = j * bay, (j + 1) * bay
+            m = 0.5 * (a + b)
+            segs += [(c, a, c, m - gap / 2), (c, m + gap / 2, c, b)]       # wall x = c, opening around y = m
+            segs += [(a, c, m - gap / 2, c), (m + gap / 2, c, b, c)]       # wall y = c, opening around x = m
+    for i in range(rooms):
+        for j in range(rooms):
+            cx, cy = (i + 0.3) * bay, (j + 0.7) * bay
+            segs += [(cx - .5, cy - .5, cx + .5, cy - .5), (cx + .5, cy - .5, cx + .5, cy + .5), (cx + .5, cy + .5, cx - .5, cy + .5), (cx - .5, cy + .5, cx - .5, cy - .5)]
+    return np.array(segs)
+
+
+def hall_tour(side=104.0, rooms=4, step=6.5):
+    """Poses (x, y, yaw) of a serpentine tour through the centres of all bays of hall_segments, every `step` metres, heading along
+    the path."""
+    bay = side / rooms
+    centres = []
+    for j in range(rooms):
+        cols = range(rooms) if j % 2 == 0 else range(rooms - 1, -1, -1)
+        centres += [((i + 0.5) * bay, (j + 0.5) * bay) for i in cols]
+    out = []
+    for (x0, y0), (x1, y1) in zip(centres[:-1], centres[1:]):
+        d = np.hypot(x1 - x0, y1 - y0)
+        n = max(int(np.ceil(d / step)), 1)
+        yaw = np.arctan2(y1 - y0, x1 - x0)
+        for k in range(n):
+            t = k / n
+            out.append((x0 + t * (x1 - x0), y0 + t * (y1 - y0), yaw))
+    out.append((centres[-1][0], centres[-1][1], out[-1][2]))
+    return np.array(out)

@@ -218,6 +218,28 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     return LAMA_HIP_OK;
 }
 
+int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t n, const uint64_t* ids, const uint8_t* cells, const uint64_t* masks)
+{
+    if (!c->init) {
+        for (uint32_t i = 0; i < c->cfg.particles; ++i) {
+            c->dm[i] = std::make_shared<DynamicDistanceMap>(c->cfg.resolution, c->cfg.patch_size);
+            c->dm[i]->setMaxDistance(c->cfg.l2_max);
+            c->occ[i] = std::make_shared<FrequencyOccupancyMap>(c->cfg.resolution, c->cfg.patch_size);
+        }
+        c->init = true;
+    }
+    Map& m = kind == LAMA_HIP_MAP_DISTANCE ? (Map&)*c->dm[particle] : (c->cfg.occupancy_policy == 1 ? (Map&)*c->pocc[particle] : (Map&)*c->occ[particle]);
+    const size_t cb = (kind == LAMA_HIP_MAP_DISTANCE ? 10 : 4) * 1024;
+    m.patches.clear();
+    for (uint32_t k = 0; k < n; ++k) {
+        auto ct = std::make_shared<Container>(5u, (uint32_t)(cb / 1024));
+        ct->data.assign(cells + k * cb, cells + (k + 1) * cb);
+        ct->mask.assign(masks + (size_t)k * 16, masks + (size_t)(k + 1) * 16);
+        m.patches[ids[k]] = ct;
+    }
+    return LAMA_HIP_OK;
+}
+
 int32_t lama_hip_match_batch(lama_hip_ctx* c, uint32_t particle, const double* pts, uint32_t n, const double* origin, const double* quat,
                              const double* poses, uint32_t B, double* out)
 {

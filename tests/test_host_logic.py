@@ -204,6 +204,43 @@ def test_loc2d_host_matches_oracle():
     assert h.rmse() < 0.05
 
 
+def test_loc2d_reads_a_prebuilt_distance_map(tmp_path):
+    """distance_map->write(file) / ->read(file) (Map::write / Map::read, src/sdm/map.cpp:489-575) through the host class: a Loc2D
+    whose map was READ localises exactly like the one that built it, and a file written by the oracle reads the same way (host
+    plumbing on the engine double; the device side of lama_hip_pf_upload_map is a -m gpu test)."""
+    from _worlds import corridor_obstacles
+    obst = corridor_obstacles()
+    pts, odom, truth = F.corridor_log(3, 360)
+    odm = O.DM.new(l2_max=1.0)
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        odm.add(int(c[0]), int(c[1]))
+    odm.update()
+    f_host, f_orc = str(tmp_path / "host.sdm"), str(tmp_path / "oracle.sdm")
+    a = F.Loc2D()
+    a.set_obstacles_world(obst)
+    a.write_distance_map(f_host)
+    odm.write(f_orc)
+    # (the two files hold the same patches; their order in the file differs: the reference walks an unordered map)
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    res = []
+    for src in (None, f_host, f_orc):
+        h = a if src is None else F.Loc2D()
+        if src is not None:
+            h.read_distance_map(src)
+        h.set_pose(*start)
+        out = []
+        for k in range(4):
+            h.update(pts[k], odom[k], float(k), force=(k == 0))
+            out.append((h.pose().copy(), h.iterations(), h.rmse()))
+        res.append(out)
+    for other in res[1:]:
+        for x, y in zip(res[0], other):
+            assert np.array_equal(x[0], y[0]) and x[1] == y[1] and x[2] == y[2]
+    with pytest.raises(F.LamaError):
+        F.Loc2D(l2_max=0.5).read_distance_map(f_host)            # built with another l2_max: refused
+
+
 def test_loc2d_rank_deficient_covariance_host_matches_oracle():
     """Solver::calculateCovariance's rank-deficient branch (src/nlls/solver.cpp:143-149): in a corridor whose ends are
     out of sight the x column of the Jacobian is exactly zero; the reference then returns V diag(1/sv^2 | 3.0) V^T.

@@ -153,6 +153,37 @@ def test_in_place_resampling_with_regions_of_different_sizes(Fsim):
     ctx.close()
 
 
+def test_uploaded_map_replaces_a_particles_map(Fsim):
+    """lama_hip_pf_upload_map (Map::read for a device map): particle 1's maps are replaced by particle 0's downloaded ones -- a
+    smaller map over a larger one, so slots are re-zeroed --, the uploaded maps equal the oracle's and stay live."""
+    F, P = Fsim, 2
+    pts, odom, truth = F.corridor_log(2, 360)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, device=0, dm_patch_capacity=8, occ_patch_capacity=8))
+    ctx.init(pts[0], pose0)
+    # particle 1 maps further down the corridor: more patches than particle 0
+    poses = np.stack([O.se2(*truth[0]), O.se2(truth[1][0] + 4.0, truth[1][1], 0.0)])
+    pf.set_poses(poses); pf.stage_set_scan(pts[1]); pf.stage_update_maps()
+    ctx.set_poses(poses); ctx.update_maps(pts[1])
+    d0, o0 = ctx.download_map(0, F.MAP_DISTANCE), ctx.download_map(0, F.MAP_OCCUPANCY)
+    assert len(ctx.download_map(1, F.MAP_OCCUPANCY)) > len(o0)
+    ctx.upload_map(1, F.MAP_DISTANCE, d0); ctx.upload_map(1, F.MAP_OCCUPANCY, o0)
+    pf.stage_resample_with(np.array([0, 0], dtype=np.int32))
+    for i in range(P):
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+    nxt = np.stack([O.se2(*truth[2]), O.se2(truth[2][0] + 0.3, truth[2][1] - 0.1, 0.02)])
+    pf.set_poses(nxt); pf.stage_set_scan(pts[2]); pf.stage_update_maps()
+    ctx.set_poses(nxt); ctx.update_maps(pts[2])
+    for i in range(P):
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"after the update: occ p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"after the update: dm p{i}")
+    ctx.close()
+
+
 def test_batched_export_and_import_between_two_contexts(Fsim):
     """The resample of a sharded pool: all outgoing particles of one context leave in ONE export launch, arrive in another context
     in ONE import launch (two slots take the same blob), and the receiving context carries on -- maps bit-exact against the oracle
