@@ -125,6 +125,55 @@ def test_drifted_poses_long_chains_default_routing(F, cap, monkeypatch):
     assert (c["arena_growths"] > 0) == (cap != 0), c
 
 
+def test_early_lane_and_routing_at_1536_particles_against_the_oracle(F, monkeypatch):
+    """a DIRECT oracle comparison of the routed / early-lane path at its default thresholds (pools of 1,024 particles
+    and more; no environment override).  1,536 particles, teacher forced, ten scans with scan matching (its log-likelihoods feed
+    the early lane) and a resample in the middle; eight particles start every scan far off (the long chains).  After every scan
+    the device's checksum of EVERY particle's two maps equals the oracle's, a sample is compared cell by cell, and the counters
+    show that the big-queue stage and the early lane ran."""
+    monkeypatch.delenv("LAMA_HIP_BF_ROUTE", raising=False)
+    P, steps, drifted = 1536, 10, 8
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    rng = np.random.default_rng(17)
+    pf = O.PF(O.default_options(particles=P, seed=7, threads=min(64, os.cpu_count() or 1)))
+    pose0 = O.se2(*odom[0])
+    pf.set_prior(pose0)
+    assert pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1))
+    ctx.init(pts[0], pose0)
+    for k in range(1, steps + 1):
+        start = _perturbed(rng, O.se2(*truth[k]), P, 0.03, 0.01, drifted)
+        pf.set_poses(start)
+        pf.set_weights(w=np.zeros(P), ws=np.zeros(P))
+        pf.stage_set_scan(pts[k])
+        pf.stage_scan_match()
+        ctx.set_poses(start)
+        g_poses, g_ll, g_it = ctx.scan_match(pts[k])
+        o_poses = pf.poses()
+        same = g_it == np.array([pf.counters(i)["iterations"] for i in range(P)])
+        assert same.mean() > 0.999 and np.abs(g_poses[same] - o_poses[same]).max() <= POSE_TOL
+        if k == 5:
+            idx = np.sort(rng.integers(0, P, size=P)).astype(np.int32)
+            pf.stage_resample_with(idx)
+            ctx.resample(idx)
+            o_poses = pf.poses()
+        # the drifted particles map from where they started (far off: the scan disagrees with their map, they re-draw it)
+        o_poses[P - drifted:] = start[P - drifted:] if k != 5 else o_poses[P - drifted:]
+        pf.set_poses(o_poses)
+        ctx.set_poses(o_poses)
+        pf.stage_update_maps()
+        ctx.update_maps(pts[k])
+        assert np.array_equal(ctx.map_checksums(F.MAP_DISTANCE), pf.map_checksums(0)), k
+        assert np.array_equal(ctx.map_checksums(F.MAP_OCCUPANCY), pf.map_checksums(1)), k
+    for i in (0, 1, 700, P - drifted - 1, P - drifted, P - 2, P - 1):
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+    c = ctx.counters()
+    ctx.close()
+    assert c["brushfire_routed"] > 0 and c["brushfire_early"] > 0, c
+    assert c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
+
+
 def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
