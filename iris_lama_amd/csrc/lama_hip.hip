@@ -411,7 +411,7 @@ int32_t add_chunk(lama_hip_ctx* c, bool dm, uint32_t min_patches)
     std::vector<PoolChunk>& chunks = dm ? c->ms.dm_chunks : c->ms.occ_chunks;
     uint64_t total = 0;
     for (const PoolChunk& k : chunks) total += k.patches;
-    uint64_t want = std::max<uint64_t>(std::max<uint64_t>(min_patches, total / 2u), 1024u);      // geometric: the number of chunks stays small
+    uint64_t want = std::max<uint64_t>(std::max<uint64_t>(min_patches, total / 4u), 1024u);      // geometric: the number of chunks stays small, the last one mostly used
     want = (want + 1023u) / 1024u * 1024u;
     const uint64_t per_patch = dm ? (2048 + 4096 + 128) : (4096 + 128 + 128 + 4);
     size_t free_b = 0, total_b = 0;
@@ -502,47 +502,60 @@ static int32_t run_jobs(lama_hip_ctx* c, bool zero_first)
 struct CapRequest { uint32_t p, dm_cap, occ_cap; };
 int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
 {
+    // The particles of one filter map the same world and outgrow their regions together.  Moved all at once, every new region would
+    // have to exist beside every old one (a second copy of the maps, and a pool that never gets its first half back: the freed
+    // regions are all smaller than the next request).  So the movers go in groups: a group's old regions are zeroed and released
+    // before the next group allocates -- first fit from the lowest address then places the next new regions into the space the
+    // previous groups left (neighbouring free regions coalesce), and the pool stays at live data + head room + one group.
+    constexpr size_t GROUP = 64;
     struct Old { bool dm; uint32_t chunk, off, cap; };
-    std::vector<Old> released;
-    c->h_jobs.resize(0); c->h_zjobs.resize(0);
-    for (const CapRequest& r : reqs) {
-        HostPart& hp = c->h_part[r.p];
-        const bool gd = r.dm_cap > hp.dm_cap, go = r.occ_cap > hp.occ_cap;
-        if (!gd && !go) continue;
-        if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
-        const HostPart before = hp;
-        if (gd) {
-            uint32_t ch = 0, off = 0;
-            const int32_t rc = region_alloc(c, true, r.dm_cap, ch, off);
-            if (rc) return rc;
-            released.push_back(Old{true, hp.dm_chunk, hp.dm_off, hp.dm_cap});
-            hp.dm_chunk = ch; hp.dm_off = off; hp.dm_cap = r.dm_cap;
+    bool any = false;
+    for (size_t g0 = 0; g0 < reqs.size(); g0 += GROUP) {
+        std::vector<Old> released;
+        c->h_jobs.resize(0); c->h_zjobs.resize(0);
+        for (size_t q = g0; q < std::min(reqs.size(), g0 + GROUP); ++q) {
+            const CapRequest& r = reqs[q];
+            HostPart& hp = c->h_part[r.p];
+            const bool gd = r.dm_cap > hp.dm_cap, go = r.occ_cap > hp.occ_cap;
+            if (!gd && !go) continue;
+            if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
+            const HostPart before = hp;
+            if (gd) {
+                uint32_t ch = 0, off = 0;
+                const int32_t rc = region_alloc(c, true, r.dm_cap, ch, off);
+                if (rc) return rc;
+                released.push_back(Old{true, hp.dm_chunk, hp.dm_off, hp.dm_cap});
+                hp.dm_chunk = ch; hp.dm_off = off; hp.dm_cap = r.dm_cap;
+            }
+            if (go) {
+                uint32_t ch = 0, off = 0;
+                const int32_t rc = region_alloc(c, false, r.occ_cap, ch, off);
+                if (rc) return rc;
+                released.push_back(Old{false, hp.occ_chunk, hp.occ_off, hp.occ_cap});
+                hp.occ_chunk = ch; hp.occ_off = off; hp.occ_cap = r.occ_cap;
+            }
+            CloneJob j{};
+            j.src_home = j.dst_home = hp.home;
+            j.sdm = c->h_counts[2 * r.p]; j.socc = c->h_counts[2 * r.p + 1];
+            void* sp[5]; void* dp[5];
+            region_ptrs(c, before, sp); region_ptrs(c, hp, dp);
+            ZeroJob z{};
+            for (int k = 0; k < 5; ++k) { j.s[k] = sp[k]; j.d[k] = dp[k]; z.d[k] = (sp[k] != dp[k]) ? sp[k] : nullptr; }
+            z.ndm = j.sdm; z.nocc = j.socc;
+            c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = j;
+            c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z;
         }
-        if (go) {
-            uint32_t ch = 0, off = 0;
-            const int32_t rc = region_alloc(c, false, r.occ_cap, ch, off);
-            if (rc) return rc;
-            released.push_back(Old{false, hp.occ_chunk, hp.occ_off, hp.occ_cap});
-            hp.occ_chunk = ch; hp.occ_off = off; hp.occ_cap = r.occ_cap;
-        }
-        CloneJob j{};
-        j.src_home = j.dst_home = hp.home;
-        j.sdm = c->h_counts[2 * r.p]; j.socc = c->h_counts[2 * r.p + 1];
-        void* sp[5]; void* dp[5];
-        region_ptrs(c, before, sp); region_ptrs(c, hp, dp);
-        ZeroJob z{};
-        for (int k = 0; k < 5; ++k) { j.s[k] = sp[k]; j.d[k] = dp[k]; z.d[k] = (sp[k] != dp[k]) ? sp[k] : nullptr; }
-        z.ndm = j.sdm; z.nocc = j.socc;
-        c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = j;
-        c->h_zjobs.resize(c->h_zjobs.size() + 1); c->h_zjobs[c->h_zjobs.size() - 1] = z;
+        if (released.empty()) continue;
+        any = true;
+        const int32_t rc = run_jobs(c, false);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of the group may land in a region another one still reads)
     }
-    if (released.empty()) return LAMA_HIP_OK;
-    int32_t rc = run_jobs(c, false);
-    if (rc) return rc;
-    rc = upload_part(c);
+    if (!any) return LAMA_HIP_OK;
+    const int32_t rc = upload_part(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of the batch may land in a region another one still reads)
     c->ctr.arena_growths += 1;
     return LAMA_HIP_OK;
 }
