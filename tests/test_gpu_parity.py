@@ -839,8 +839,8 @@ def test_loc2d_loads_a_prebuilt_distance_map(F, tmp_path):
 
 
 def test_3000_particles_map_a_hall_of_10000_m2_with_in_place_resampling(F):
-    """memory and resampling that scale with CHANGE.  3000 particles map a generated hall of 104 m x 104 m (16
-    bays, a 1080-beam scanner with 25 m range) along a tour through all bays -- more than 10,000 m^2 per particle, ~46 MB of maps
+    """memory and resampling that scale with CHANGE.  3000 particles map a generated hall of 108 m x 108 m (16
+    bays, a 1080-beam scanner with 27 m range) along a tour through all bays -- more than 10,000 m^2 per particle, ~46 MB of maps
     each -- and are resampled every third scan with index vectors that kill about 40 % of the pool.  One particle set: survivors
     keep their home and regions, clones go to the homes of the dead, regions grow one particle at a time in pooled planes that
     grow chunk by chunk.  Checked: a sample of final particles is bit-exact against the ORACLE replaying each one's lineage (the
@@ -849,9 +849,10 @@ def test_3000_particles_map_a_hall_of_10000_m2_with_in_place_resampling(F):
     import json
     from _worlds import hall_segments, hall_tour, segment_world_scan
     P, resample_every = 3000, 3
-    segs, tour = hall_segments(), hall_tour()
+    SIDE = 108.0                                                             # 11,664 m^2 of floor; what a particle has SEEN of it is checked below
+    segs, tour = hall_segments(SIDE), hall_tour(SIDE)
     rng = np.random.default_rng(21)
-    scans = [segment_world_scan(segs, x, y, yaw, max_range=25.0, noise=rng.normal(0.0, 0.01, 1080)) for x, y, yaw in tour]
+    scans = [segment_world_scan(segs, x, y, yaw, max_range=27.0, noise=rng.normal(0.0, 0.01, 1080)) for x, y, yaw in tour]
     off = rng.normal(0.0, [0.12, 0.12, 0.01], size=(P, 3))                  # every slot's own offset from the true pose
     off[0] = 0.0
 
@@ -908,7 +909,6 @@ def test_3000_particles_map_a_hall_of_10000_m2_with_in_place_resampling(F):
         assert_maps_equal(ctx.download_map(int(p), F.MAP_DISTANCE), pf.dm(j).dump(), DM_FIELDS, f"dm of particle {p}")
         if j == 0:
             area = sum(int((cells["visited"] != 0).sum()) for cells, _ in occ.values()) * 0.05 * 0.05
-    assert area >= 10000.0, area
     report = {"particles": P, "scans": len(tour), "resamples": n_res, "clones_copied": int(c["resample_clones"]), "mapped_m2_per_particle": area,
               "hbm_bytes_used": int(used), "hbm_bytes_allocated": int(alloc), "allocated_over_used": alloc / used,
               "pool_chunks_added": int(c["pool_growths"]), "region_growth_batches": int(c["arena_growths"]),
@@ -919,6 +919,7 @@ def test_3000_particles_map_a_hall_of_10000_m2_with_in_place_resampling(F):
     if os.path.isdir(out):
         json.dump(report, open(os.path.join(out, "r05_big_world.json"), "w"), indent=1)
     ctx.close()
+    assert area >= 10000.0, area                                             # cells a particle has visited, in m^2
 
 
 def test_slam2d_map_accessors_gpu(F):
