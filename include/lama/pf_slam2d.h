@@ -86,9 +86,10 @@ public:
         bool profile = false;              // bracket kernels with hipEvents (see lama_hip_get_counters)
         uint32_t brushfire_mode = 0;       // 0 exact (default, bit-identical to the reference), 1 level-synchronous canonical tie rule (opt-in, NOT bit-identical; lama_hip.h)
         // Device map storage (0 = the device library's defaults).  The reference's maps are unbounded (src/sdm/map.cpp:400-411);
-        // here the patch arenas GROW on demand (doubled whenever a particle uses more than half of them) and the map window
-        // (window_patches x 1.6 m at 0.05 m: default 128 = 204.8 m, at most 248) FOLLOWS the robot; only a mapped area larger
-        // than the window side is an error.
+        // here every particle's patch regions GROW with its own maps (one particle at a time, inside pooled planes that grow chunk by
+        // chunk; the two capacities below are the smallest region a particle gets) and the map window (window_patches x 1.6 m at
+        // 0.05 m: starts at 128 = 204.8 m) FOLLOWS the robot and GROWS with the mapped area up to 1016 patches = 1.6 km; only a map
+        // wider than that -- or one whose window directories no longer fit the device memory -- is an error.
         uint32_t window_patches = 0;       // side of the square map window in patches (multiple of 8)
         uint32_t dm_patch_capacity = 0;    // initial distance-map patches per particle
         uint32_t occ_patch_capacity = 0;   // initial occupancy patches per particle
