@@ -711,7 +711,14 @@ def main():
         # what a resample costs now that it is done in place: the 3000-particle pool with the gain that makes it
         # resample (1e-4), per-kernel brackets on
         rr = run(3000, K, W, profile=True, gain=1e-4)
-        result["resample_3000"] = {"meas_sigma_gain": 1e-4, "resamples": rr["resamples"], "ms_per_step": rr["ms_per_step"], "memory": memory_block(rr["counters"])}
+        mb = memory_block(rr["counters"])
+        rs = rr["counters"]["ms_resample"] * 1e-3
+        result["resample_3000"] = {"meas_sigma_gain": 1e-4, "resamples": rr["resamples"], "ms_per_step": rr["ms_per_step"], "memory": mb,
+                                   # the copy kernel of the in-place resample against the HBM roof: every clone byte is read once and
+                                   # written once (hipEvents around the job upload + k_zero_regions + k_clone_particles)
+                                   "roofline_clone_copy": {"bound": "hbm", "achieved": 2 * mb["clone_bytes"] / rs / 1e9 if rs > 0 else None, "peak": HBM_PEAK_GBS,
+                                                           "unit": "GB/s", "frac": (2 * mb["clone_bytes"] / rs / 1e9 / HBM_PEAK_GBS) if rs > 0 else None,
+                                                           "clones_per_resample": mb["clones_copied"] / max(mb["resample_launches"], 1)}}
         # opt-in level-synchronous brushfire (cfg.brushfire_mode = 1; NOT bit-identical to the reference in the obstacle
         # offsets of tie cells) -- reported for information, never as `value`
         canon = {}

@@ -2495,29 +2495,43 @@ struct CloneJob {
 };
 constexpr int CLONE_SPLIT = 2;
 
+// (the region addresses come out of the job list: tell the compiler that they are GLOBAL addresses -- a pointer loaded from memory
+// is a generic one to it, and generic loads / stores go the slower flat path)
+#ifdef LAMA_WAVE_SIM
+typedef uint4 vec16;
+typedef uint4 g_uint4;
+__device__ inline vec16 vec16_zero() { return make_uint4(0, 0, 0, 0); }
+#else
+typedef unsigned int vec16 __attribute__((ext_vector_type(4)));      // (a plain vector type: HIP's uint4 class has no address-space-qualified members)
+typedef __attribute__((address_space(1))) vec16 g_uint4;
+__device__ inline vec16 vec16_zero() { return vec16{0u, 0u, 0u, 0u}; }
+#endif
 __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const CloneJob* __restrict__ jobs)
 {
-    const CloneJob j = jobs[blockIdx.x];
+    const CloneJob* __restrict__ J = jobs + blockIdx.x;            // (fields are read where they are needed: no by-value copy, no scratch)
     const int plane = blockIdx.y;
     const size_t WW = (size_t)prm.W * prm.W;
-    const uint4* s; uint4* d; size_t ncopy, nzero = 0;   // in 16-byte units
-    const size_t zdm = j.odm > j.sdm ? (size_t)(j.odm - j.sdm) : 0, zocc = j.oocc > j.socc ? (size_t)(j.oocc - j.socc) : 0;
-    const size_t bytes[5] = {2048, 4096, 128, 4096, 128};
+    const g_uint4* s; g_uint4* d; size_t ncopy, nzero = 0;         // in 16-byte units
     if (plane < 2) {
-        if (j.src_home == j.dst_home) return;
-        const int16_t* dir = plane == 0 ? prm.dm_dir : prm.occ_dir;
-        s = (const uint4*)(dir + j.src_home * WW); d = (uint4*)(const_cast<int16_t*>(dir) + j.dst_home * WW); ncopy = WW * 2 / 16;
+        const uint32_t sh = J->src_home, dh = J->dst_home;
+        if (sh == dh) return;
+        int16_t* dir = plane == 0 ? prm.dm_dir : prm.occ_dir;
+        s = (const g_uint4*)(uintptr_t)(dir + sh * WW); d = (g_uint4*)(uintptr_t)(dir + dh * WW); ncopy = WW * 2 / 16;
     } else {
         const int k = plane - 2;
-        s = (const uint4*)j.s[k]; d = (uint4*)j.d[k];
         const bool dm = k < 3;
-        ncopy = (size_t)(dm ? j.sdm : j.socc) * bytes[k] / 16; nzero = (dm ? zdm : zocc) * bytes[k] / 16;
+        const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
+        const int32_t used = dm ? J->sdm : J->socc, old = dm ? J->odm : J->oocc;
+        s = (const g_uint4*)(uintptr_t)J->s[k]; d = (g_uint4*)(uintptr_t)J->d[k];
+        ncopy = (size_t)used * bytes / 16; nzero = old > used ? (size_t)(old - used) * bytes / 16 : 0;
     }
     if (s == d) return;                                             // (this plane of the particle stays where it is)
     const size_t t0 = (size_t)blockIdx.z * 256 + threadIdx.x, step = 256 * (size_t)gridDim.z;
-    for (size_t k = t0; k < ncopy; k += step) d[k] = s[k];
-    const uint4 z = make_uint4(0, 0, 0, 0);
-    for (size_t k = t0; k < nzero; k += step) d[ncopy + k] = z;
+    size_t k = t0;
+    for (; k + step < ncopy; k += 2 * step) { const vec16 a = s[k], b2 = s[k + step]; d[k] = a; d[k + step] = b2; }     // two loads in flight per thread
+    for (; k < ncopy; k += step) { const vec16 a = s[k]; d[k] = a; }
+    const vec16 z = vec16_zero();
+    for (size_t q = t0; q < nzero; q += step) d[ncopy + q] = z;
 }
 
 // A region that goes back to the allocator is zeroed where it was used: free pool space is all-zero, so a region handed out later
@@ -2525,13 +2539,13 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
 struct ZeroJob { void* d[5]; int32_t ndm, nocc; };
 __global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob* __restrict__ jobs)
 {
-    const ZeroJob j = jobs[blockIdx.x];
-    const size_t bytes[5] = {2048, 4096, 128, 4096, 128};
+    const ZeroJob* __restrict__ J = jobs + blockIdx.x;
     const int k = blockIdx.y;
-    uint4* d = (uint4*)j.d[k];
-    const size_t n = (size_t)(k < 3 ? j.ndm : j.nocc) * bytes[k] / 16;
+    const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
+    g_uint4* d = (g_uint4*)(uintptr_t)J->d[k];
+    const size_t n = (size_t)(k < 3 ? J->ndm : J->nocc) * bytes / 16;
     if (!d) return;
-    const uint4 z = make_uint4(0, 0, 0, 0);
+    const vec16 z = vec16_zero();
     for (size_t i = (size_t)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * (size_t)gridDim.z) d[i] = z;
 }
 
