@@ -1056,6 +1056,13 @@ __device__ __forceinline__ uint32_t opq(uint32_t x) { return x; }
 #else
 __device__ __forceinline__ uint32_t opq(uint32_t x) { asm("" : "+v"(x)); return x; }
 #endif
+// The same, but the value is also kept WHERE it is computed: the optimiser sinks a computation into the only (conditional) block that
+// uses it, i.e. behind the loads' `s_waitcnt`; a volatile empty asm is neither sunk nor hoisted.
+#ifdef LAMA_WAVE_SIM
+__device__ __forceinline__ uint32_t pin(uint32_t x) { return x; }
+#else
+__device__ __forceinline__ uint32_t pin(uint32_t x) { asm volatile("" : "+v"(x)); return x; }
+#endif
 // 0 / ~0 words of the unsigned comparisons a < b and a <= b, for operands below 2^31
 __device__ __forceinline__ uint32_t m_lt(uint32_t a, uint32_t b) { return opq((uint32_t)((int32_t)(opq(a) - b) >> 31)); }
 __device__ __forceinline__ uint32_t m_le(uint32_t a, uint32_t b) { return ~m_lt(b, a); }
@@ -1754,6 +1761,22 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t s = buf_load_u16(rsv, m_sel(have, coff * 2u, BUF_OOB));
                 const uint32_t ob = buf_load_u32(robs, m_sel(have, coff * 4u, BUF_OOB));
                 const unsigned long long unk = __ballot(unknown != 0u);
+                // Round 5: what lower() computes from the popped cell's obstacle offset alone -- the "away" test, every neighbour's new
+                // squared distance, the offset it would store and the entry it would push (:296-305, :319-326) -- needs no loaded
+                // value on this path: the entry carries the offset the cell had when it was queued, and an entry whose cell says
+                // otherwise (`stale`) goes to the general code.  Written HERE, between the loads and their first use, these ~30
+                // instructions run in the shadow of the load round instead of behind it (profiles/r05_pop_floor_table.md).
+                const int obx = rx + eox, oby = ry + eoy;
+                const uint32_t away = opq(nbm & ~m_pos(ddx * eox + ddy * eoy));                     // :296 (one of ddx, ddy is 0)
+                const int qx = x - obx, qy = y - oby;
+                const uint32_t new_sq = pin((uint32_t)(qx * qx + qy * qy));
+                const uint32_t my_obs = pin(pack_obs(obx - x, oby - y));                           // what I would store: my obstacle seen from the neighbour
+                const uint64_t entry_raw = q_entry(new_sq, x, y, obx - x, oby - y);
+                const uint64_t entry_spec = ((uint64_t)pin((uint32_t)(entry_raw >> 32)) << 32) | pin((uint32_t)entry_raw);
+                const uint32_t nsv_new = pin((uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK));
+                const uint32_t mask_off = pin(((slotw << 4) + (ci >> 6)) * 8u);
+                const uint32_t mask_bit_lo = pin((ci & 32u) ? 0u : (1u << (ci & 31u))), mask_bit_hi = pin((ci & 32u) ? (1u << (ci & 31u)) : 0u);
+                const uint64_t mask_bit = ((uint64_t)mask_bit_hi << 32) | mask_bit_lo;
                 BFT(0); BFF(0);
                 // the popped cell, and the obstacle cell it pointed to when it was queued
                 const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)s, 4);
@@ -1769,18 +1792,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #endif
                 if (__builtin_expect(!general, 1) && fire0 && (cos_ & SV_SQMASK) == 0u) {   // :191 (valid NOT tested)
                     floor_sq = cs & SV_SQMASK;                                           // lower() :303: candidates of cells further from the obstacle
-                    const int obx = rx + cox, oby = ry + coy;
-                    const uint32_t away = opq(nbm & ~m_pos(ddx * cox + ddy * coy));                     // :296 (one of ddx, ddy is 0)
-                    const uint32_t nbok = away & ~absent;
-                    const int qx = x - obx, qy = y - oby;
-                    const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
+                    const uint32_t nbok = away & ~absent;                                // (cox == eox, coy == eoy here: not stale)
                     const uint32_t ssq = s & SV_SQMASK;
                     const uint32_t svalid = opq((uint32_t)((int32_t)(s << 16) >> 31));                // bit 15
                     const uint32_t cmp = m_sel(svalid, ssq, prm.max_sqdist);
                     const uint32_t lt = opq(nbok & m_lt(new_sq, cmp));
                     const uint32_t tie = opq(nbok & ~lt & ~m_nz(new_sq ^ ssq));                       // :311-317
                     // the neighbour points at another obstacle than mine (lane 5 holds mine): a second load round, one pop in six
-                    const uint32_t my_obs = pack_obs(obx - x, oby - y);                                // what I would store: my obstacle seen from the neighbour
                     const uint32_t other = m_nz(ob ^ my_obs);
                     const uint32_t tie_other = opq(tie & other);
                     const uint32_t alloc = away & absent;                                            // a patch to allocate: general code
@@ -1810,14 +1828,14 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         over = overm != 0u;
                         // get() of the examined neighbours: the Container mask bit of a flag-less cell (raise() has the argument)
                         const uint32_t need_bit = nbok & ~m_nz(s & (uint32_t)(SV_VALID | SV_QUEUED));
-                        buf_or_u64(rmask, m_sel(need_bit, ((slotw << 4) + (ci >> 6)) * 8u, BUF_OOB), 1ull << (ci & 63u));
+                        buf_or_u64(rmask, m_sel(need_bit, mask_off, BUF_OOB), mask_bit);
                         // neighbours that are lowered, and the popped cell's is_queued (:329): one store instruction
-                        const uint32_t nsv = m_sel(curm, cs & ~(uint32_t)SV_QUEUED, (uint32_t)(SV_VALID | SV_QUEUED) | (new_sq & SV_SQMASK));
+                        const uint32_t nsv = m_sel(curm, cs & ~(uint32_t)SV_QUEUED, nsv_new);
                         buf_store_u16(rsv, m_sel(overm | curm, coff * 2u, BUF_OOB), nsv);
                         buf_store_u32(robs, m_sel(overm, coff * 4u, BUF_OOB), my_obs);
                         BFF(4);
                         const unsigned long long om = __ballot(overm != 0u);
-                        entry = q_entry(new_sq, x, y, obx - x, oby - y);
+                        entry = entry_spec;
                         const uint32_t rank = opq(lane_rank(om, lane) & 3u);                         // (opaque: computed for every lane, no exec-masked region)
                         uint64_t* dst = overm ? &sh.pl_e[tw_it & 1u][rank] : dmy;
                         *dst = entry;
