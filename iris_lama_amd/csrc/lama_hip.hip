@@ -91,6 +91,7 @@ struct PinVec {
     void reserve(size_t m)
     {
         if (m <= cap) return;
+        m = std::max(m, 2 * cap);                                   // geometric: a list built element by element re-pins O(log n) times
         T* q = nullptr;
         bool pin = hipHostMalloc((void**)&q, m * sizeof(T), hipHostMallocDefault) == hipSuccess && q;
         if (!pin) { (void)hipGetLastError(); q = (T*)std::malloc(m * sizeof(T)); }       // pageable memory still works, only slower
