@@ -31,6 +31,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstddef>
 
 #include "lama_heap.h"
 
@@ -126,29 +127,47 @@ struct PV {
     int32_t* counts; int32_t* rev;
     uint32_t dm_cap, occ_cap;
 };
-// The table is written by the host between launches and never by a kernel: read through the constant address space, so that a
-// wave-uniform particle index gives scalar loads (s_load_dwordx8) and the regions' base addresses / capacities stay in SGPRs --
-// a global load of a uniform address lands in VGPRs whenever the kernel also stores to global memory (the buffer resources of the
-// brushfire's straight-line pop are built from these values).
+// The table is written by the host between launches and never by a kernel.  It is read with agent-scope atomic loads (coherent at
+// the L2: no non-coherent cache can serve a record the host has rewritten since -- a move of the particle's region, a resample) and,
+// the particle index being wave-uniform, broadcast into SGPRs with v_readfirstlane: the regions' base addresses and capacities feed
+// scalar address arithmetic and the buffer resources of the brushfire's straight-line pop.  (Round 5 first read it through the
+// constant address space -- s_load through the scalar data cache.  With eight contexts on one device, 8 % of the runs then gave a
+// few particles a distance map that differed from the other runs': a record served from a stale scalar-cache line sends a
+// kernel to the region the particle has left.  tools: the run-to-run determinism loop of DESIGN.md section 2.)
 #ifdef LAMA_WAVE_SIM
-typedef const PartRec* PartTablePtr;
+__device__ inline uint32_t part_u32(const uint32_t* q) { return *q; }
+__device__ inline uint64_t part_u64(const uint64_t* q) { return *q; }
 #else
-typedef const __attribute__((address_space(4))) PartRec* PartTablePtr;
+__device__ inline uint32_t part_u32(const uint32_t* q)
+{
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ inline uint64_t part_u64(const uint64_t* q)
+{
+    const uint64_t v = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
 #endif
+// (p must be wave-uniform: every caller takes it from blockIdx or from a list entry all lanes read)
 __device__ inline PV pview(const DevParams& prm, int p)
 {
-    PartTablePtr t = (PartTablePtr)prm.part + p;
+    const PartRec* t = prm.part + p;
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(t);       // 10 quadwords: {home, dm_cap} {occ_cap, r0} 7 addresses, r1
     const size_t WW = (size_t)prm.W * prm.W;
-    const uint32_t home = t->home;
+    const uint64_t w0 = part_u64(q), w1 = part_u64(q + 1);
+    const uint32_t home = (uint32_t)w0;
     PV v;
     v.dm_dir = prm.dm_dir + (size_t)home * WW;
     v.occ_dir = prm.occ_dir + (size_t)home * WW;
-    v.dm_sv = t->dm_sv; v.dm_obs = t->dm_obs; v.dm_mask = t->dm_mask;
-    v.occ = t->occ; v.occ_mask = t->occ_mask; v.occ_hit = t->occ_hit; v.rev = t->rev;
+    v.dm_sv = (uint16_t*)part_u64(q + 2); v.dm_obs = (uint32_t*)part_u64(q + 3); v.dm_mask = (uint64_t*)part_u64(q + 4);
+    v.occ = (uint32_t*)part_u64(q + 5); v.occ_mask = (uint64_t*)part_u64(q + 6); v.occ_hit = (uint64_t*)part_u64(q + 7);
+    v.rev = (int32_t*)part_u64(q + 8);
     v.counts = prm.counts + 2 * (size_t)p;
-    v.dm_cap = t->dm_cap; v.occ_cap = t->occ_cap;
+    v.dm_cap = (uint32_t)(w0 >> 32); v.occ_cap = (uint32_t)w1;
     return v;
 }
+static_assert(sizeof(PartRec) == 80 && offsetof(PartRec, dm_sv) == 16 && offsetof(PartRec, rev) == 64, "pview reads PartRec as ten quadwords");
 
 // the particle of workgroup `bx` of a per-particle launch: early-lane launches walk their list, main-lane launches skip the early
 // lane's particles; -1: nothing to do

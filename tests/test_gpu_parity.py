@@ -682,6 +682,36 @@ def test_multi_gpu_object_is_bit_identical_to_one_shard(F, gpus, P, gain):
     _multi_gpu_object_vs_one_shard(F, gpus, P, gain)
 
 
+def test_runs_of_the_multi_gpu_object_are_bit_identical_to_each_other(F):
+    """Run-to-run determinism under concurrency: eight contexts on one device, driven by eight host threads, 3000 particles, the
+    first scans of the log (regions move after the first scan: the allocation guard's bound asks for head room) and a resample --
+    thirty times; every run must give every particle the map checksums, poses and weights of the first run after every update.
+    (Round 5: with the particle table read through the scalar data cache, 8 % of such runs gave one to three particles a distance
+    map of their own -- a stale cache line sends a kernel to the region the particle has left; the table is read with agent-scope
+    loads since.  One context alone never showed it.)"""
+    P, gpus, gain, steps, runs = 3000, 8, 1e-4, 3, 30
+    pts, odom, _ = F.corridor_log(steps, 1080)
+    base = None
+    for run in range(runs):
+        a = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, gpus=gpus))
+        a.set_prior(*odom[0])
+        rec = []
+        for k in range(steps + 1):
+            a.update(pts[k], odom[k], float(k))
+            dm = np.concatenate([a.shard_context(r).map_checksums(F.MAP_DISTANCE) for r in range(gpus)])
+            oc = np.concatenate([a.shard_context(r).map_checksums(F.MAP_OCCUPANCY) for r in range(gpus)])
+            rec.append((a.poses().copy(), a.weights()[1].copy(), dm, oc))
+        n_res = a.num_resamples()
+        a.close()
+        if base is None:
+            base = rec
+            assert n_res > 0
+            continue
+        for k in range(steps + 1):
+            for name, x, y in zip(("poses", "weights", "distance maps", "occupancy maps"), rec[k], base[k]):
+                assert np.array_equal(x, y), f"run {run}, update {k}: {name} of particles {np.nonzero(np.atleast_2d(x.T != y.T).any(axis=0))[0][:8]} differ from the first run's"
+
+
 def test_multi_gpu_object_on_distinct_devices(F):
     """The same object with one shard per REAL device (auto-skipped on a one-GPU box): Options::gpus = min(8, visible devices),
     3000 particles -- the clones that cross a shard border travel with hipMemcpyPeerAsync between different GPUs."""
