@@ -169,6 +169,54 @@ __device__ inline PV pview(const DevParams& prm, int p)
 }
 static_assert(sizeof(PartRec) == 80 && offsetof(PartRec, dm_sv) == 16 && offsetof(PartRec, rev) == 64, "pview reads PartRec as ten quadwords");
 
+// The same for callers whose wave is COMPLETE at the call (kernel prologues, behind wave-uniform returns only): lane k < 10 fetches
+// quadword k, ten v_readlane pairs distribute them -- one load instruction and two VGPRs instead of ten loads and twenty (which cost
+// k_ray_patches its sixth wave per SIMD).  Not for code behind a per-lane return: a lane that is gone leaves stale register contents.
+__device__ inline PV pview_w(const DevParams& prm, int p)
+{
+#ifdef LAMA_WAVE_SIM
+    return pview(prm, p);
+#else
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p);
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint64_t w = __hip_atomic_load(q + (lane < 10u ? lane : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lo = (int)(uint32_t)w, hi = (int)(uint32_t)(w >> 32);
+#define LAMA_PART_Q(k) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, k))
+    const size_t WW = (size_t)prm.W * prm.W;
+    const uint64_t w0 = LAMA_PART_Q(0), w1 = LAMA_PART_Q(1);
+    const uint32_t home = (uint32_t)w0;
+    PV v;
+    v.dm_dir = prm.dm_dir + (size_t)home * WW;
+    v.occ_dir = prm.occ_dir + (size_t)home * WW;
+    v.dm_sv = (uint16_t*)LAMA_PART_Q(2); v.dm_obs = (uint32_t*)LAMA_PART_Q(3); v.dm_mask = (uint64_t*)LAMA_PART_Q(4);
+    v.occ = (uint32_t*)LAMA_PART_Q(5); v.occ_mask = (uint64_t*)LAMA_PART_Q(6); v.occ_hit = (uint64_t*)LAMA_PART_Q(7);
+    v.rev = (int32_t*)LAMA_PART_Q(8);
+#undef LAMA_PART_Q
+    v.counts = prm.counts + 2 * (size_t)p;
+    v.dm_cap = (uint32_t)(w0 >> 32); v.occ_cap = (uint32_t)w1;
+    return v;
+#endif
+}
+// Only the occupancy side (k_ray_patches keeps a patch, its hit bits and a list of beams in registers: every scalar it does not hold
+// is a VGPR it does not lose to spilled SGPRs).  Complete waves only, like pview_w.
+struct PVOcc { uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit; int32_t* rev; };
+__device__ inline PVOcc pview_occ_w(const DevParams& prm, int p)
+{
+#ifdef LAMA_WAVE_SIM
+    const PV v = pview(prm, p);
+    return PVOcc{v.occ, v.occ_mask, v.occ_hit, v.rev};
+#else
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p) + 5;
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint64_t w = __hip_atomic_load(q + (lane < 4u ? lane : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lo = (int)(uint32_t)w, hi = (int)(uint32_t)(w >> 32);
+#define LAMA_PART_Q(k) (((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, k))
+    PVOcc v{(uint32_t*)LAMA_PART_Q(0), (uint64_t*)LAMA_PART_Q(1), (uint64_t*)LAMA_PART_Q(2), (int32_t*)LAMA_PART_Q(3)};
+#undef LAMA_PART_Q
+    return v;
+#endif
+}
+
 // the particle of workgroup `bx` of a per-particle launch: early-lane launches walk their list, main-lane launches skip the early
 // lane's particles; -1: nothing to do
 __device__ inline int lane_particle(const DevParams& prm, int first_particle, int bx)

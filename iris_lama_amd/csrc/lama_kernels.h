@@ -396,7 +396,7 @@ __global__ __launch_bounds__(SM_BLOCK) __attribute__((amdgpu_num_vgpr(128))) voi
 {
     __shared__ SMShared sh;
     const int p = blockIdx.x;
-    const PV pv_ = pview(prm, p);
+    const PV pv_ = pview_w(prm, p);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
                                                            int do_solve)
 {
     __shared__ SMShared sh;
-    const PV pv_ = pview(prm, particle);
+    const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_match_eval(DevParams prm, int particle,
                                                      int cell_mode /* 1: DynamicDistanceMap::distance(w2m(hit)), no interpolation (MatchSurface2D::error) */)
 {
     __shared__ Affine tfs;
-    const PV pv_ = pview(prm, particle);
+    const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) tfs = scan_tf(SE2{pose[0], pose[1], pose[2], pose[3]}, mtf);
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
     __shared__ double lut[SM_LUT];
     __shared__ Affine tfs;
     const int b = blockIdx.x;
-    const PV pv_ = pview(prm, particle);
+    const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_eval_batch(DevParams prm, int part
     __shared__ double tot[2];
     __shared__ Affine tfs;
     const int b = blockIdx.x;
-    const PV pv_ = pview(prm, particle);
+    const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int par
 {
     __shared__ double terms[SL_MAX_TERMS];
     const int k = blockIdx.x;
-    const PV pv_ = pview(prm, particle);
+    const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     const double tx = base.t[0] + xy[2 * k], ty = base.t[1] + xy[2 * k + 1];
@@ -1254,7 +1254,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
     const size_t WW = (size_t)prm.W * prm.W;
-    const PV pv = pview(prm, p);                               // (p is wave-uniform: scalar loads)
+    const PV pv = pview_w(prm, p);                             // (p is wave-uniform, both waves are complete here)
     int16_t* dir = pv.dm_dir;
     uint16_t* sv = pv.dm_sv;
     uint32_t* obs = pv.dm_obs;

@@ -342,7 +342,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         return;
     }
     const size_t WW = (size_t)prm.W * prm.W;
-    const PV pv = pview(prm, p);
+    const PV pv = pview_w(prm, p);
     int16_t* occ_dir = pv.occ_dir;
     int16_t* dm_dir = pv.dm_dir;
     uint32_t* occ = pv.occ;

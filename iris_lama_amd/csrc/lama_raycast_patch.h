@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int firs
     const int p = first_particle + blockIdx.x;
     const uint32_t W = prm.W, WW = W * W;
     const int tid = threadIdx.x, r = (int)prm.guard_r;
-    const PV pv = pview(prm, p);
+    const PV pv = pview_w(prm, p);
     const int16_t* occ_dir = pv.occ_dir;
     const int16_t* dm_dir = pv.dm_dir;
     // the patches the scan can touch: sensor origin (tf.translation(), src/pf_slam2d.cpp:452) +- reach, window-relative patch units
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int firs
 constexpr int RPT_CHUNK = 256;        // candidate beams tested per round: the records of those that cross the patch wait in LDS
 constexpr int RPT_WALK = 4;           // lanes that share the cells of one (beam, patch) crossing
 
-__global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec* __restrict__ recs, const uint64_t* __restrict__ bbox,
+__global__ __launch_bounds__(256, 6) void k_ray_patches(DevParams prm, const RayRec* __restrict__ recs, const uint64_t* __restrict__ bbox,
                                                       const RayChunk* __restrict__ chunks, int n, int first_particle)
 {
     static_assert(RPT_CHUNK == 256, "one candidate beam per thread and round");
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
     if (p < 0) return;                                             // (another lane's particle)
     const int count = prm.counts[2 * p + 1];
     const size_t WW = (size_t)prm.W * prm.W;
-    const PV pv = pview(prm, p);
+    const PVOcc pv = pview_occ_w(prm, p);
     uint32_t* occ = pv.occ;
     const RayRec* prec = recs + (size_t)p * n;
     const uint64_t* pbb = bbox + (size_t)p * n;
@@ -453,8 +453,9 @@ __global__ __launch_bounds__(256) void k_ray_patches(DevParams prm, const RayRec
             const uint64_t nm = (uint64_t)newm[2 * tid] | ((uint64_t)newm[2 * tid + 1] << 32);
             const uint64_t wm = (uint64_t)wrapm[2 * tid] | ((uint64_t)wrapm[2 * tid + 1] << 32);
             if (nm) {   // removeObstacle on a cell that cannot be an obstacle = get(): patch allocation + mask bit (:228-234)
-                const int ds = dir_get_or_alloc(pv.dm_dir, pidx, prm.counts + 2 * p, (int)pv.dm_cap, ERR_DM_CAP, prm.err);
-                if (ds >= 0) atomicOr((unsigned long long*)(pv.dm_mask + (size_t)ds * 16 + tid), (unsigned long long)nm);
+                const PV dv = pview(prm, p);                        // (the distance-map side only where it is needed: rare)
+                const int ds = dir_get_or_alloc(dv.dm_dir, pidx, prm.counts + 2 * p, (int)dv.dm_cap, ERR_DM_CAP, prm.err);
+                if (ds >= 0) atomicOr((unsigned long long*)(dv.dm_mask + (size_t)ds * 16 + tid), (unsigned long long)nm);
             }
             if (wm) atomicOr((unsigned long long*)(pv.occ_mask + (size_t)slot * 16 + tid), (unsigned long long)wm);
         }
