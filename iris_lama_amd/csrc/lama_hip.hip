@@ -1009,6 +1009,16 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
     c->h_jobs.resize(0); c->h_zjobs.resize(0);
     c->clone_bytes = 0;
     const size_t WW = (size_t)c->W * c->W;
+    // the directory rows that can hold a patch at all: the mapped box of the context (a superset of every particle's map, ensure_window);
+    // W is a multiple of 8, so a row is a whole number of 16-byte units
+    uint32_t dir_off16 = 0, dir_n16 = (uint32_t)(WW * 2 / 16);
+    {
+        const int64_t oy = c->wy0 >> 5, W = c->W;                   // (the rows of mapped_box_rel(c, 1))
+        if (c->mb_valid) {
+            const int64_t lo = std::min(std::max(c->mby0 - oy, (int64_t)0), W - 1), hi = std::min(std::max(c->mby1 - oy, (int64_t)0), W - 1);
+            if (hi >= lo) { dir_off16 = (uint32_t)(lo * W * 2 / 16); dir_n16 = (uint32_t)((hi - lo + 1) * W * 2 / 16); }
+        }
+    }
     // first pass: dead particles whose regions cannot be reused as they are go back to the allocator (so that the clones can have them)
     // -- a dead particle is matched with the clone of the same rank; capacities are mostly equal (particles of one filter map the
     // same world), so the common case is a plain overwrite
@@ -1043,9 +1053,10 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
         void* sp[5]; void* dp[5];
         region_ptrs(c, sr, sp); region_ptrs(c, r, dp);
         for (int q = 0; q < 5; ++q) { job.s[q] = sp[q]; job.d[q] = dp[q]; }
+        job.dir_off16 = dir_off16; job.dir_n16 = dir_n16;
         np[i] = r;
         c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = job;
-        c->clone_bytes += 2 * (uint64_t)WW * 2 + (uint64_t)job.sdm * (2048 + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
+        c->clone_bytes += 2 * (uint64_t)dir_n16 * 16 + (uint64_t)job.sdm * (2048 + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
     }
     c->h_part = np;
     std::memcpy(c->h_poses.data(), npose.data(), npose.size() * sizeof(double));

@@ -2508,6 +2508,8 @@ struct CloneJob {
     uint32_t src_home, dst_home;
     int32_t sdm, socc;             // used slots of the source
     int32_t odm, oocc;             // slots the destination region's previous owner had used (0: a region fresh from the allocator)
+    uint32_t dir_off16, dir_n16;   // the rows of the window directories that can hold a patch (the context's mapped box), 16-byte units
+    uint32_t pad0, pad1;
     const void* s[5];              // source region: dm_sv, dm_obs, dm_mask, occ, occ_mask
     void* d[5];                    // destination region, same order
 };
@@ -2534,7 +2536,9 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
         const uint32_t sh = J->src_home, dh = J->dst_home;
         if (sh == dh) return;
         int16_t* dir = plane == 0 ? prm.dm_dir : prm.occ_dir;
-        s = (const g_uint4*)(uintptr_t)(dir + sh * WW); d = (g_uint4*)(uintptr_t)(dir + dh * WW); ncopy = WW * 2 / 16;
+        // only the rows inside the mapped box: outside it every directory of the context is -1 (at W = 128 the two directories are a
+        // tenth of a corridor particle's bytes, at W = 432 more than its maps)
+        s = (const g_uint4*)(uintptr_t)(dir + sh * WW) + J->dir_off16; d = (g_uint4*)(uintptr_t)(dir + dh * WW) + J->dir_off16; ncopy = J->dir_n16;
     } else {
         const int k = plane - 2;
         const bool dm = k < 3;
