@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -2155,7 +2156,12 @@ int32_t lama_hip_blob_free(lama_hip_ctx* c, void* buf)
 // staged through host memory by the runtime instead of going GPU to GPU over xGMI.  Returns 1 when BOTH directions are enabled.
 static int peer_access_between(int a, int b)
 {
-    static std::map<std::pair<int, int>, int> state;              // calls on the contexts involved are serialised by the caller (one exchange at a time)
+    // (the shards of a multi-GPU object copy concurrently, a host thread each: the table is shared by all of them)
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, int> state;
+    std::lock_guard<std::mutex> lock(mu);
+    int prev_dev = -1;
+    (void)hipGetDevice(&prev_dev);
     auto one_way = [&](int from, int to) -> int {
         const auto key = std::make_pair(from, to);
         auto it = state.find(key);
@@ -2172,6 +2178,7 @@ static int peer_access_between(int a, int b)
         return ok;
     };
     const int ab = one_way(a, b), ba = one_way(b, a);
+    if (prev_dev >= 0) (void)hipSetDevice(prev_dev);              // enabling access switches the calling thread's device
     return ab && ba;
 }
 

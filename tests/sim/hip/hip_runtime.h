@@ -76,6 +76,7 @@ inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "h
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = std::getenv("LAMA_SIM_NO_DEVICE") ? 0 : 1; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 template <class T> inline hipError_t hipMalloc(T** p, size_t n) { *p = (T*)std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <class T> inline hipError_t hipHostMalloc(T** p, size_t n, unsigned = 0) { *p = (T*)std::malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
