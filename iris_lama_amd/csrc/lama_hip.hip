@@ -120,6 +120,7 @@ struct lama_hip_ctx {
     std::vector<PendingTimer> pending;
     size_t ev_used = 0;
     bool initialised = false;   // first scan done
+    bool poisoned = false;      // a resample ran out of device memory half-way: every later call fails (LAMA_HIP_E_STATE)
 
     uint32_t P = 0, W = 0, WC = 0, wx0 = 0, wy0 = 0;
     uint32_t max_sqdist = 0;
@@ -512,7 +513,9 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
     constexpr size_t GROUP = 64;
     struct Old { bool dm; uint32_t chunk, off, cap; };
     bool any = false;
-    for (size_t g0 = 0; g0 < reqs.size(); g0 += GROUP) {
+    int32_t err = LAMA_HIP_OK;                                     // a failed allocation: what was planned so far is still carried out (the table,
+                                                                   // the regions and their contents stay consistent), then the error is returned
+    for (size_t g0 = 0; g0 < reqs.size() && err == LAMA_HIP_OK; g0 += GROUP) {
         std::vector<Old> released;
         c->h_jobs.resize(0); c->h_zjobs.resize(0);
         for (size_t q = g0; q < std::min(reqs.size(), g0 + GROUP); ++q) {
@@ -520,21 +523,18 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
             HostPart& hp = c->h_part[r.p];
             const bool gd = r.dm_cap > hp.dm_cap, go = r.occ_cap > hp.occ_cap;
             if (!gd && !go) continue;
-            if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
+            if (r.dm_cap > MAX_PATCHES || r.occ_cap > MAX_PATCHES) { err = fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches"); break; }
             const HostPart before = hp;
+            uint32_t dch = 0, doff = 0, och = 0, ooff = 0;
+            if (gd) { err = region_alloc(c, true, r.dm_cap, dch, doff); if (err) break; }
+            if (go) { err = region_alloc(c, false, r.occ_cap, och, ooff); if (err) { if (gd) region_release(c, true, dch, doff, r.dm_cap); break; } }
             if (gd) {
-                uint32_t ch = 0, off = 0;
-                const int32_t rc = region_alloc(c, true, r.dm_cap, ch, off);
-                if (rc) return rc;
                 released.push_back(Old{true, hp.dm_chunk, hp.dm_off, hp.dm_cap});
-                hp.dm_chunk = ch; hp.dm_off = off; hp.dm_cap = r.dm_cap;
+                hp.dm_chunk = dch; hp.dm_off = doff; hp.dm_cap = r.dm_cap;
             }
             if (go) {
-                uint32_t ch = 0, off = 0;
-                const int32_t rc = region_alloc(c, false, r.occ_cap, ch, off);
-                if (rc) return rc;
                 released.push_back(Old{false, hp.occ_chunk, hp.occ_off, hp.occ_cap});
-                hp.occ_chunk = ch; hp.occ_off = off; hp.occ_cap = r.occ_cap;
+                hp.occ_chunk = och; hp.occ_off = ooff; hp.occ_cap = r.occ_cap;
             }
             CloneJob j{};
             j.src_home = j.dst_home = hp.home;
@@ -554,12 +554,14 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
         HIPCHK(c, hipStreamSynchronize(c->stream));
         for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of the group may land in a region another one still reads)
     }
-    if (!any) return LAMA_HIP_OK;
+    if (!any) return err;
+    const std::string msg = c->error;
     const int32_t rc = upload_part(c);
     if (rc) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->ctr.arena_growths += 1;
-    return LAMA_HIP_OK;
+    if (err) c->error = msg;
+    return err;
 }
 
 // after a map update (counts on the host, stream idle): every particle keeps head room for the next one
@@ -651,7 +653,7 @@ int32_t finish_pending(lama_hip_ctx* c)
     if (rc) c->error = "deferred from lama_hip_pf_update_maps_begin: " + c->error;
     return rc;
 }
-#define ENTER(c) do { const int32_t rc_enter_ = finish_pending(c); if (rc_enter_) return rc_enter_; } while (0)
+#define ENTER(c) do { if ((c)->poisoned) return fail((c), LAMA_HIP_E_STATE, "the context ran out of device memory in the middle of a resample and cannot continue"); const int32_t rc_enter_ = finish_pending(c); if (rc_enter_) return rc_enter_; } while (0)
 
 // hipEvent bracket around a kernel group; resolved (elapsed time read) by resolve_timers() after the API call's final
 // stream synchronisation, so profiling adds no host round trips.
@@ -1047,10 +1049,12 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
         CloneJob job{};
         job.src_home = sr.home; job.dst_home = r.home;
         job.sdm = c->h_counts[2 * j]; job.socc = c->h_counts[2 * j + 1];
+        // (a region of the capacity a dead particle of another size has just given back: this can only fail when the device is out of
+        // memory for another chunk.  The particle table is then half permuted: the context refuses further work.)
         if (sl.keep_dm) job.odm = sl.odm;
-        else { const int32_t rc = region_alloc(c, true, sr.dm_cap, r.dm_chunk, r.dm_off); if (rc) return rc; job.odm = 0; }
+        else { const int32_t rc = region_alloc(c, true, sr.dm_cap, r.dm_chunk, r.dm_off); if (rc) { c->poisoned = true; return rc; } job.odm = 0; }
         if (sl.keep_occ) job.oocc = sl.oocc;
-        else { const int32_t rc = region_alloc(c, false, sr.occ_cap, r.occ_chunk, r.occ_off); if (rc) return rc; job.oocc = 0; }
+        else { const int32_t rc = region_alloc(c, false, sr.occ_cap, r.occ_chunk, r.occ_off); if (rc) { c->poisoned = true; return rc; } job.oocc = 0; }
         void* sp[5]; void* dp[5];
         region_ptrs(c, sr, sp); region_ptrs(c, r, dp);
         for (int q = 0; q < 5; ++q) { job.s[q] = sp[q]; job.d[q] = dp[q]; }
