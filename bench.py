@@ -503,7 +503,7 @@ def main():
         try:      # peer access and the achieved GPU-to-GPU rate of lama_hip_blob_copy, from the shards' counters
             cs = [pf.shard_context(r).counters() for r in range(gpus)]
             b, ms = sum(x["peer_copy_bytes"] for x in cs), sum(x["peer_copy_ms"] for x in cs)
-            out["peer"] = {"peer_access": bool(all(x["peer_access"] for x in cs)) if b else None, "bytes": int(b), "ms": ms,
+            out["peer"] = {"peer_access": bool(all(x["peer_access"] for x in cs if x["peer_copy_bytes"] > 0)) if b else None, "bytes": int(b), "ms": ms,
                            "GBps": (b / (ms * 1e-3) / 1e9) if ms > 0 else None,
                            "note": "peer_access None: no copy crossed a device boundary (all shards on one device)" if not b else "hipEvents on the destination's stream"}
         except Exception as e:

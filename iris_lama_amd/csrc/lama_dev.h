@@ -149,9 +149,103 @@ __device__ inline uint64_t part_u64(const uint64_t* q)
     return ((uint64_t)hi << 32) | lo;
 }
 #endif
+#if defined(LAMA_KC_PROBE) && !defined(LAMA_WAVE_SIM)
+// Experiment build (tools/kc_probe.py, DESIGN.md section 8 "scalar-cache hazard"): every reader of the particle table ALSO fetches its
+// record the way round 5 first did -- through the constant address space, s_load through the scalar data cache -- and with a plain
+// vector load, compares both with the agent-scope load the product uses, and logs what differs.  LAMA_KC_PROBE=2: an s_dcache_inv
+// precedes the scalar loads (is the stale copy in the scalar cache, or behind it?).
+__device__ uint32_t g_kc_n;
+__device__ uint64_t g_kc_ev[64][8];
+__device__ __noinline__ void kc_probe(const DevParams& prm, int p)
+{
+    const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p);
+#if LAMA_KC_PROBE == 2
+    __builtin_amdgcn_s_dcache_inv();
+#endif
+    const unsigned long long act = __ballot(1);
+    const bool rec = (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1;
+    for (int k = 0; k < 9; ++k) {
+        const uint64_t* qa = q + k;
+        const uint64_t ua = (uint64_t)qa;
+        const uint64_t sa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ua >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ua);
+        uint64_t s, v;
+        asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(s) : "s"(sa) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(qa) : "memory");
+        const uint64_t a = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((s != a || v != a) && rec) {
+            const uint32_t i = atomicAdd(&g_kc_n, 1u);
+            if (i < 64u) {
+                g_kc_ev[i][0] = (uint64_t)(uint32_t)p | ((uint64_t)k << 32) | ((uint64_t)(s != a) << 40) | ((uint64_t)(v != a) << 41);
+                g_kc_ev[i][1] = s; g_kc_ev[i][2] = v; g_kc_ev[i][3] = a;
+                g_kc_ev[i][4] = (uint64_t)gridDim.x | ((uint64_t)gridDim.y << 24) | ((uint64_t)blockDim.x << 48);
+                g_kc_ev[i][5] = (uint64_t)blockIdx.x | ((uint64_t)blockIdx.y << 32);
+                g_kc_ev[i][6] = (uint64_t)prm.part; g_kc_ev[i][7] = __builtin_readcyclecounter();
+            }
+        }
+    }
+}
+#define LAMA_KC_PROBE_CALL(prm, p) kc_probe(prm, p)
+#else
+#define LAMA_KC_PROBE_CALL(prm, p) do {} while (0)
+#endif
 // (p must be wave-uniform: every caller takes it from blockIdx or from a list entry all lanes read)
+#if defined(LAMA_KC_OLD) && !defined(LAMA_WAVE_SIM)
+#if LAMA_KC_OLD == 4
+__device__ uint32_t g_kc_n;
+__device__ uint64_t g_kc_ev[64][8];
+#endif
+// Experiment build (tools/determinism_sweep.py with this library in place): the table read as round 5 first read it.  1: through the
+// constant address space (s_load, scalar data cache); 2: the same behind an s_dcache_inv; 3: a plain const pointer (the compiler's choice).
 __device__ inline PV pview(const DevParams& prm, int p)
 {
+#if LAMA_KC_OLD == 3
+    const PartRec* t = prm.part + p;      // (does not build: the brushfire's buffer resources need SGPRs)
+#else
+    typedef const __attribute__((address_space(4))) PartRec* PartTablePtr;
+    PartTablePtr t = (PartTablePtr)prm.part + p;
+#endif
+#if LAMA_KC_OLD == 2
+    asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+    const size_t WW = (size_t)prm.W * prm.W;
+    const uint32_t home = t->home;
+    PV v;
+    v.dm_dir = prm.dm_dir + (size_t)home * WW;
+    v.occ_dir = prm.occ_dir + (size_t)home * WW;
+    v.dm_sv = t->dm_sv; v.dm_obs = t->dm_obs; v.dm_mask = t->dm_mask;
+    v.occ = t->occ; v.occ_mask = t->occ_mask; v.occ_hit = t->occ_hit; v.rev = t->rev;
+    v.counts = prm.counts + 2 * (size_t)p;
+    v.dm_cap = t->dm_cap; v.occ_cap = t->occ_cap;
+#if LAMA_KC_OLD == 4
+    {   // the values the kernel goes on to USE (the scalar loads above) against agent-scope loads of the same words, logged when they differ
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p);
+        const uint64_t used[9] = {(uint64_t)home | ((uint64_t)v.dm_cap << 32), (uint64_t)v.occ_cap, (uint64_t)v.dm_sv, (uint64_t)v.dm_obs, (uint64_t)v.dm_mask,
+                                  (uint64_t)v.occ, (uint64_t)v.occ_mask, (uint64_t)v.occ_hit, (uint64_t)v.rev};
+        const unsigned long long act = __ballot(1);
+        const bool rec = (int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1;
+        for (int k = 0; k < 9; ++k) {
+            uint64_t a = __hip_atomic_load(q + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == 1) a &= 0xFFFFFFFFull;
+            if (used[k] != a && rec) {
+                const uint32_t i = atomicAdd(&g_kc_n, 1u);
+                if (i < 64u) {
+                    g_kc_ev[i][0] = (uint64_t)(uint32_t)p | ((uint64_t)k << 32) | (1ull << 40);
+                    g_kc_ev[i][1] = used[k]; g_kc_ev[i][2] = 0; g_kc_ev[i][3] = a;
+                    g_kc_ev[i][4] = (uint64_t)gridDim.x | ((uint64_t)gridDim.y << 24) | ((uint64_t)blockDim.x << 48);
+                    g_kc_ev[i][5] = (uint64_t)blockIdx.x | ((uint64_t)blockIdx.y << 32);
+                    g_kc_ev[i][6] = (uint64_t)prm.part; g_kc_ev[i][7] = __builtin_readcyclecounter();
+                }
+            }
+        }
+    }
+#endif
+    return v;
+}
+#define LAMA_PVIEW_OLD 1
+#else
+__device__ inline PV pview(const DevParams& prm, int p)
+{
+    LAMA_KC_PROBE_CALL(prm, p);
     const PartRec* t = prm.part + p;
     const uint64_t* q = reinterpret_cast<const uint64_t*>(t);       // 10 quadwords: {home, dm_cap} {occ_cap, r0} 7 addresses, r1
     const size_t WW = (size_t)prm.W * prm.W;
@@ -167,6 +261,7 @@ __device__ inline PV pview(const DevParams& prm, int p)
     v.dm_cap = (uint32_t)(w0 >> 32); v.occ_cap = (uint32_t)w1;
     return v;
 }
+#endif
 static_assert(sizeof(PartRec) == 80 && offsetof(PartRec, dm_sv) == 16 && offsetof(PartRec, rev) == 64, "pview reads PartRec as ten quadwords");
 
 // The same for callers whose wave is COMPLETE at the call (kernel prologues, behind wave-uniform returns only): lane k < 10 fetches
@@ -174,9 +269,10 @@ static_assert(sizeof(PartRec) == 80 && offsetof(PartRec, dm_sv) == 16 && offseto
 // k_ray_patches its sixth wave per SIMD).  Not for code behind a per-lane return: a lane that is gone leaves stale register contents.
 __device__ inline PV pview_w(const DevParams& prm, int p)
 {
-#ifdef LAMA_WAVE_SIM
+#if defined(LAMA_WAVE_SIM) || defined(LAMA_PVIEW_OLD)
     return pview(prm, p);
 #else
+    LAMA_KC_PROBE_CALL(prm, p);
     const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p);
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint64_t w = __hip_atomic_load(q + (lane < 10u ? lane : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -202,10 +298,11 @@ __device__ inline PV pview_w(const DevParams& prm, int p)
 struct PVOcc { uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit; int32_t* rev; };
 __device__ inline PVOcc pview_occ_w(const DevParams& prm, int p)
 {
-#ifdef LAMA_WAVE_SIM
+#if defined(LAMA_WAVE_SIM) || defined(LAMA_PVIEW_OLD)
     const PV v = pview(prm, p);
     return PVOcc{v.occ, v.occ_mask, v.occ_hit, v.rev};
 #else
+    LAMA_KC_PROBE_CALL(prm, p);
     const uint64_t* q = reinterpret_cast<const uint64_t*>(prm.part + p) + 5;
     const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     const uint64_t w = __hip_atomic_load(q + (lane < 4u ? lane : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -217,11 +314,61 @@ __device__ inline PVOcc pview_occ_w(const DevParams& prm, int p)
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// Wave-uniform reads of device data that the HOST rewrites between launches (job lists, shipping descriptors, the scan transforms,
+// poses, candidate lists) or that a kernel of ANOTHER stream of the context produced (the early / routed lists and their counts).
+// The rule of this library ("scalar-cache hazard"; enforced on the ISA by tools/check_scalar_loads.py): such data
+// is not read with s_load through the scalar data cache but with agent-scope loads -- coherent at the L2 -- and, the address being
+// wave-uniform, broadcast into SGPRs with v_readfirstlane.  A uniform plain load of `const __restrict__` memory becomes an s_load.
+// ------------------------------------------------------------------------------------------------
+#ifdef LAMA_WAVE_SIM
+__device__ inline uint32_t uload_u32(const void* q) { return *reinterpret_cast<const uint32_t*>(q); }
+__device__ inline uint64_t uload_u64(const void* q) { return *reinterpret_cast<const uint64_t*>(q); }
+#else
+__device__ inline uint32_t uload_u32(const void* q) { return part_u32(reinterpret_cast<const uint32_t*>(q)); }
+__device__ inline uint64_t uload_u64(const void* q) { return part_u64(reinterpret_cast<const uint64_t*>(q)); }
+#endif
+__device__ inline int32_t uload_i32(const void* q) { return (int32_t)uload_u32(q); }
+__device__ inline double uload_f64(const void* q) { return __longlong_as_double((long long)uload_u64(q)); }
+template <class T> __device__ inline T* uload_ptr(const void* q) { return reinterpret_cast<T*>(uload_u64(q)); }
+// the same without the broadcast, for a read that one lane does (thread 0 fetching a pose): coherent at the L2, never an s_load
+#ifdef LAMA_WAVE_SIM
+__device__ inline double cload_f64(const double* q) { return *q; }
+#else
+__device__ inline double cload_f64(const double* q)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+#endif
+// N <= 64 consecutive doubles for a COMPLETE wave (kernel prologues): lane k fetches element k, v_readlane distributes them -- one
+// load instruction instead of N (the scan transform of a particle: 12 doubles the host rewrites before every map update)
+template <int N> __device__ inline void uload_f64_w(const double* q, double (&out)[N])
+{
+#ifdef LAMA_WAVE_SIM
+    for (int k = 0; k < N; ++k) out[k] = q[k];
+#else
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint64_t w = __hip_atomic_load(reinterpret_cast<const uint64_t*>(q) + (lane < (uint32_t)N ? lane : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int lo = (int)(uint32_t)w, hi = (int)(uint32_t)(w >> 32);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        out[k] = __longlong_as_double((long long)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(hi, k) << 32) | (uint32_t)__builtin_amdgcn_readlane(lo, k)));
+#endif
+}
+// a record of N quadwords (8-byte aligned) into a by-value struct
+template <class T> __device__ inline T uload_rec(const T* q)
+{
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) <= 8, "uload_rec: whole quadwords");
+    union { T v; uint64_t w[sizeof(T) / 8]; } u;
+    for (unsigned k = 0; k < sizeof(T) / 8; ++k) u.w[k] = uload_u64(reinterpret_cast<const uint64_t*>(q) + k);
+    return u.v;
+}
+
 // the particle of workgroup `bx` of a per-particle launch: early-lane launches walk their list, main-lane launches skip the early
 // lane's particles; -1: nothing to do
 __device__ inline int lane_particle(const DevParams& prm, int first_particle, int bx)
 {
-    if (prm.elist) return bx < (int)*prm.elist_n ? (int)prm.elist[bx] : -1;
+    if (prm.elist) return bx < (int)uload_u32(prm.elist_n) ? (int)uload_u32(prm.elist + bx) : -1;     // (bx is the workgroup's index; the list is another stream's kernel's)
     const int p = first_particle + bx;
     return (prm.early && prm.early[p]) ? -1 : p;
 }

@@ -134,7 +134,6 @@ struct lama_hip_ctx {
     PinVec<CloneJob> h_jobs; CloneJob* d_jobs = nullptr; uint32_t jobs_cap = 0;
     PinVec<ZeroJob> h_zjobs; ZeroJob* d_zjobs = nullptr; uint32_t zjobs_cap = 0;
     uint32_t floor_dm = 256, floor_occ = 256;      // smallest region a particle gets (cfg.dm_patch_capacity / occ_patch_capacity)
-    uint32_t guard_head = 0;          // distance-map head room the allocation guard asked for lately (max over particles, decays)
     PinVec<uint32_t> h_guard;         // the guard's per-particle bound of the last map update
     uint64_t clone_bytes = 0;         // bytes the particle copies of the last resample moved (counters)
     double* d_poses = nullptr;
@@ -329,6 +328,23 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             const int32_t rr = recover_update(c, e);
             if (rr != LAMA_HIP_E_CAPACITY) return rr;      // done (or another error); E_CAPACITY: the arenas are at their limit
         }
+        if (e & (ERR_DM_CAP | ERR_OCC_CAP)) {
+            // A failed allocation keeps counting (dir_alloc_one: the counts then say what a particle WANTED, which the clean-abort path
+            // uses).  When the error is final, the counts go back into the regions: every later copy (resample, export, a region move)
+            // is sized from them and must not run into a neighbour's region.
+            if (!stats) HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            bool clamped = false;
+            for (uint32_t p = 0; p < c->P; ++p) {
+                const HostPart& hp = c->h_part[p];
+                if ((uint32_t)c->h_counts[2 * p] > hp.dm_cap) { c->h_counts[2 * p] = (int32_t)hp.dm_cap; clamped = true; }
+                if ((uint32_t)c->h_counts[2 * p + 1] > hp.occ_cap) { c->h_counts[2 * p + 1] = (int32_t)hp.occ_cap; clamped = true; }
+            }
+            if (clamped) {
+                HIPCHK(c, hipMemcpyAsync(c->ms.counts, c->h_counts.data(), sizeof(int32_t) * 2 * c->P, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipStreamSynchronize(c->stream));
+            }
+        }
         if (e & ERR_WINDOW) return fail(c, LAMA_HIP_E_WINDOW, "a map cell fell outside the device window (the mapped area is wider than 1016 patches)");
         if (e & ERR_DM_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's distance map exceeds 32767 patches (or the device is out of memory)");
         if (e & ERR_OCC_CAP) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's occupancy map exceeds 32767 patches (or the device is out of memory)");
@@ -484,15 +500,17 @@ static int32_t ensure_job_buffers(lama_hip_ctx* c, uint32_t nj, uint32_t nz)
 
 // run the jobs in c->h_jobs / c->h_zjobs: `zero_first` = the zero jobs free regions no job reads (resample); else they free the jobs'
 // own sources (growth) and run behind the copies
-static int32_t run_jobs(lama_hip_ctx* c, bool zero_first)
+// (j0 / z0: the jobs from these positions of the staging lists on -- set_capacities queues group after group without a host round
+// trip in between, so a group's slice of the page-locked lists must stay untouched until the stream has consumed it)
+static int32_t run_jobs(lama_hip_ctx* c, bool zero_first, size_t j0 = 0, size_t z0 = 0)
 {
-    const uint32_t nj = (uint32_t)c->h_jobs.size(), nz = (uint32_t)c->h_zjobs.size();
+    const uint32_t nj = (uint32_t)(c->h_jobs.size() - j0), nz = (uint32_t)(c->h_zjobs.size() - z0);
     if (nj == 0 && nz == 0) return LAMA_HIP_OK;
     const int32_t rb = ensure_job_buffers(c, nj, nz);
     if (rb) return rb;
     const DevParams prm = make_params(c);
-    if (nj) HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data(), sizeof(CloneJob) * nj, hipMemcpyHostToDevice, c->stream));
-    if (nz) HIPCHK(c, hipMemcpyAsync(c->d_zjobs, c->h_zjobs.data(), sizeof(ZeroJob) * nz, hipMemcpyHostToDevice, c->stream));
+    if (nj) HIPCHK(c, hipMemcpyAsync(c->d_jobs, c->h_jobs.data() + j0, sizeof(CloneJob) * nj, hipMemcpyHostToDevice, c->stream));
+    if (nz) HIPCHK(c, hipMemcpyAsync(c->d_zjobs, c->h_zjobs.data() + z0, sizeof(ZeroJob) * nz, hipMemcpyHostToDevice, c->stream));
     if (nz && zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, (const ZeroJob*)c->d_zjobs);
     if (nj) hipLaunchKernelGGL(k_clone_particles, dim3(nj, 7, CLONE_SPLIT), dim3(256), 0, c->stream, prm, (const CloneJob*)c->d_jobs);
     if (nz && !zero_first) hipLaunchKernelGGL(k_zero_regions, dim3(nz, 5, CLONE_SPLIT), dim3(256), 0, c->stream, (const ZeroJob*)c->d_zjobs);
@@ -510,14 +528,21 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
     // regions are all smaller than the next request).  So the movers go in groups: a group's old regions are zeroed and released
     // before the next group allocates -- first fit from the lowest address then places the next new regions into the space the
     // previous groups left (neighbouring free regions coalesce), and the pool stays at live data + head room + one group.
+    // The groups are ordered by the STREAM, not by the host (one host round trip per group was ~48 of them for one growth
+    // event at 3000 particles): group g+1's copies run behind group g's copies and zero jobs, so a region released on the host right
+    // after group g was queued may be handed to group g+1.  Every group has its own slice of the page-locked job lists (reserved up
+    // front: the lists must not be re-allocated while a transfer is pending) and of nothing else -- the device-side lists are read by
+    // a group's kernels before the next group's upload overwrites them, in stream order.
     constexpr size_t GROUP = 64;
     struct Old { bool dm; uint32_t chunk, off, cap; };
     bool any = false;
     int32_t err = LAMA_HIP_OK;                                     // a failed allocation: what was planned so far is still carried out (the table,
                                                                    // the regions and their contents stay consistent), then the error is returned
+    c->h_jobs.resize(0); c->h_zjobs.resize(0);
+    c->h_jobs.reserve(reqs.size()); c->h_zjobs.reserve(reqs.size());
     for (size_t g0 = 0; g0 < reqs.size() && err == LAMA_HIP_OK; g0 += GROUP) {
         std::vector<Old> released;
-        c->h_jobs.resize(0); c->h_zjobs.resize(0);
+        const size_t j0 = c->h_jobs.size(), z0 = c->h_zjobs.size();
         for (size_t q = g0; q < std::min(reqs.size(), g0 + GROUP); ++q) {
             const CapRequest& r = reqs[q];
             HostPart& hp = c->h_part[r.p];
@@ -549,10 +574,9 @@ int32_t set_capacities(lama_hip_ctx* c, const std::vector<CapRequest>& reqs)
         }
         if (released.empty()) continue;
         any = true;
-        const int32_t rc = run_jobs(c, false);
+        const int32_t rc = run_jobs(c, false, j0, z0);
         if (rc) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of the group may land in a region another one still reads)
+        for (const Old& o : released) region_release(c, o.dm, o.chunk, o.off, o.cap);     // (only now: no job of THIS group may land in a region another one of it still reads)
     }
     if (!any) return err;
     const std::string msg = c->error;
@@ -569,10 +593,7 @@ int32_t grow_arenas(lama_hip_ctx* c, uint32_t /*need_dm*/, uint32_t /*need_occ*/
 {
     std::vector<CapRequest> reqs;
     // the guard's bound of the last update says what the next one will ask for (open space: many occupancy patches without a
-    // distance-map patch nearby); decays so that one wide view does not pin the head room for ever
-    uint32_t gmax = 0;
-    for (uint32_t p = 0; p < c->P && p < c->h_guard.size(); ++p) gmax = std::max(gmax, c->h_guard[p]);
-    c->guard_head = std::max(gmax, c->guard_head - c->guard_head / 8u);
+    // distance-map patch nearby)
     for (uint32_t p = 0; p < c->P; ++p) {
         const HostPart& pr = c->h_part[p];
         const uint32_t dmc = (uint32_t)c->h_counts[2 * p], occ = (uint32_t)c->h_counts[2 * p + 1];
@@ -774,7 +795,11 @@ int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t 
     // beyond it must not push mapped patches out of the window
     double far = c->scan_reach;
     if (c->cfg.ray_rule == 0 && c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
-    const double reach = far + std::sqrt(mtf.t[0] * mtf.t[0] + mtf.t[1] * mtf.t[1]) + 2.0 * 32.0 * c->cfg.resolution;
+    // padding: the brushfire allocates distance-map patches up to guard_r patches beyond a hit (make_params: ceil(l2_max / resolution)
+    // + 1 cells), plus one patch for the rounding of the box.  permute_particles copies only the directory rows inside this box, so a
+    // patch outside it would be lost by a clone (a fixed 2 patches were too few for l2_max above 64 cells).
+    const uint32_t guard_r = ((uint32_t)std::ceil(std::sqrt((double)c->max_sqdist)) + 1u + 31u) / 32u;
+    const double reach = far + std::sqrt(mtf.t[0] * mtf.t[0] + mtf.t[1] * mtf.t[1]) + (double)(guard_r + 1u) * 32.0 * c->cfg.resolution;
     double xlo = 1e300, xhi = -1e300, ylo = 1e300, yhi = -1e300;
     for (uint32_t p = first; p < first + count; ++p) {
         const double x = c->h_poses[4 * p + 2], y = c->h_poses[4 * p + 3];
@@ -1560,6 +1585,26 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
     if (n > MAX_PATCHES) return fail(c, LAMA_HIP_E_CAPACITY, "a particle's map exceeds 32767 patches");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
+    // Convert and validate everything FIRST: a rejected upload must leave the particle's previous map as it was (the old
+    // slots were zeroed and the window / region possibly moved before a squared distance beyond the plane's 14 bits was noticed).
+    std::vector<uint16_t> hsv; std::vector<uint32_t> hobs;
+    if (n && dm) {     // distance_t (10 B: int16 obstacle[3], uint16 sqdist, bool valid_obstacle, bool is_queued) -> the two planes
+        hsv.resize((size_t)n * 1024); hobs.resize((size_t)n * 1024);
+        for (size_t k = 0; k < n; ++k)
+            for (int ci = 0; ci < 1024; ++ci) {
+                const uint8_t* o = cells + k * 10240 + 10 * (size_t)ci;
+                int16_t ox, oy; uint16_t sq;
+                std::memcpy(&ox, o, 2); std::memcpy(&oy, o + 2, 2); std::memcpy(&sq, o + 6, 2);
+                if (sq > SV_SQMASK) return fail(c, LAMA_HIP_E_INVALID, "the uploaded distance map holds a squared distance beyond 16383 cells^2 (l2_max above 127 cells)");
+                hsv[k * 1024 + ci] = (uint16_t)(sq | (o[8] ? SV_VALID : 0) | (o[9] ? SV_QUEUED : 0));
+                hobs[k * 1024 + ci] = ((uint32_t)(uint16_t)ox) | (((uint32_t)(uint16_t)oy) << 16);      // (pack_obs)
+            }
+    }
+    if (n) {           // a patch given twice is an error (checked on the ids: the window may still move below)
+        std::vector<uint64_t> ids(patch_ids, patch_ids + n);
+        std::sort(ids.begin(), ids.end());
+        if (std::adjacent_find(ids.begin(), ids.end()) != ids.end()) return fail(c, LAMA_HIP_E_INVALID, "a patch index appears twice in the uploaded map");
+    }
     if (n) {   // the window must hold the patches (it is centred / moved / grown for them)
         int64_t x0 = INT64_MAX, x1 = INT64_MIN, y0 = INT64_MAX, y1 = INT64_MIN;
         for (uint32_t k = 0; k < n; ++k) {
@@ -1611,17 +1656,7 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
         }
     }
     if (n) {
-        if (dm) {      // distance_t (10 B: int16 obstacle[3], uint16 sqdist, bool valid_obstacle, bool is_queued) -> the two planes
-            std::vector<uint16_t> hsv((size_t)n * 1024); std::vector<uint32_t> hobs((size_t)n * 1024);
-            for (size_t k = 0; k < n; ++k)
-                for (int ci = 0; ci < 1024; ++ci) {
-                    const uint8_t* o = cells + k * 10240 + 10 * (size_t)ci;
-                    int16_t ox, oy; uint16_t sq;
-                    std::memcpy(&ox, o, 2); std::memcpy(&oy, o + 2, 2); std::memcpy(&sq, o + 6, 2);
-                    if (sq > SV_SQMASK) return fail(c, LAMA_HIP_E_INVALID, "the uploaded distance map holds a squared distance beyond 16383 cells^2 (l2_max above 127 cells)");
-                    hsv[k * 1024 + ci] = (uint16_t)(sq | (o[8] ? SV_VALID : 0) | (o[9] ? SV_QUEUED : 0));
-                    hobs[k * 1024 + ci] = ((uint32_t)(uint16_t)ox) | (((uint32_t)(uint16_t)oy) << 16);      // (pack_obs)
-                }
+        if (dm) {
             HIPCHK(c, hipMemcpy(pr.dm_sv, hsv.data(), hsv.size() * 2, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(pr.dm_obs, hobs.data(), hobs.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(pr.dm_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
@@ -2199,7 +2234,7 @@ int32_t lama_hip_blob_copy(lama_hip_ctx* dc, void* dst, lama_hip_ctx* sc, const 
     // two devices: peer access first (queried and enabled once per pair), then the copy on the destination's stream; without peer
     // access the same call still works -- the runtime stages it -- and the counters say so (peer_access = 0)
     const int peer = peer_access_between(dc->cfg.device, sc->cfg.device);
-    dc->ctr.peer_access = sc->ctr.peer_access = (uint32_t)peer;
+    dc->ctr.peer_access = (uint32_t)peer;      // (the destination's own counter only: its thread is the caller; the source learns the value when it is a destination)
     HIPCHK(dc, hipSetDevice(dc->cfg.device));
     hipEvent_t e0 = dc->ev0, e1 = dc->ev1;
     HIPCHK(dc, hipEventRecord(e0, dc->stream));
@@ -2237,6 +2272,20 @@ int32_t lama_hip_debug_log(lama_hip_ctx* c, uint64_t* out /* 131072 words */)
     HIPCHK(c, hipMemcpy(out, c->d_dbg + 16 * (size_t)c->P, 1u << 20, hipMemcpyDeviceToHost));
     return LAMA_HIP_OK;
 }
+
+#if defined(LAMA_KC_PROBE) || (defined(LAMA_KC_OLD) && LAMA_KC_OLD == 4)
+// experiment build only (tools/kc_probe.py): out[0] = number of mismatches logged by kc_probe (lama_dev.h), then 64 x 8 words; clears the log
+int32_t lama_hip_debug_kc_probe(uint64_t* out /* 1 + 512 words */)
+{
+    uint32_t n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(lama_dev::g_kc_n), sizeof(n)) != hipSuccess) return LAMA_HIP_E_HIP;
+    out[0] = n;
+    if (hipMemcpyFromSymbol(out + 1, HIP_SYMBOL(lama_dev::g_kc_ev), sizeof(uint64_t) * 512) != hipSuccess) return LAMA_HIP_E_HIP;
+    n = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(lama_dev::g_kc_n), &n, sizeof(n)) != hipSuccess) return LAMA_HIP_E_HIP;
+    return LAMA_HIP_OK;
+}
+#endif
 
 // device memory the context holds: the maps (pools + directories), of which used, and everything
 static void memory_figures(const lama_hip_ctx* c, lama_hip_counters* o)

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(SM_BLOCK) __attribute__((amdgpu_num_vgpr(128))) voi
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = prm.poses + 4 * p;
-        sh.state = SE2{q[0], q[1], q[2], q[3]};
+        sh.state = SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)};
         sh.tf = scan_tf(sh.state, mtf);
         sh.ctl = 0;
     }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
-        sh.state = SE2{pose_io[0], pose_io[1], pose_io[2], pose_io[3]};
+        sh.state = SE2{cload_f64(pose_io), cload_f64(pose_io + 1), cload_f64(pose_io + 2), cload_f64(pose_io + 3)};
         sh.tf = scan_tf(sh.state, mtf);
         sh.ctl = 0;
     }
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void k_match_eval(DevParams prm, int particle,
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
-    if (threadIdx.x == 0) tfs = scan_tf(SE2{pose[0], pose[1], pose[2], pose[3]}, mtf);
+    if (threadIdx.x == 0) tfs = scan_tf(SE2{cload_f64(pose), cload_f64(pose + 1), cload_f64(pose + 2), cload_f64(pose + 3)}, mtf);     // (a pose the host uploaded)
     __syncthreads();
     const Affine tf = tfs;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
-        tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
+        tfs = scan_tf(SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)}, mtf);
     }
     sm_build_lut(prm, lut);
     __syncthreads();
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_eval_batch(DevParams prm, int part
     const uint16_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
-        tfs = scan_tf(SE2{q[0], q[1], q[2], q[3]}, mtf);
+        tfs = scan_tf(SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)}, mtf);
     }
     __syncthreads();
     const Affine tf = tfs;
@@ -699,8 +699,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
     // tf = fixed_tf * moving_tf of this particle (12 doubles, computed on the host with libm exactly
     // like the reference does on the CPU, so the integer cell coordinates below are reproducible)
     double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
+    uload_f64_w<12>(tfs + 12 * (size_t)p, T);            // (rewritten by the host before every update: coherent uniform loads, lama_dev.h)
     const double wsx = T[9], wsy = T[10], wsz = T[11];   // wso = tf.translation()
 
     for (int i = 0; i < n; ++i) {
@@ -1262,8 +1261,11 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     const uint32_t dm_cap = pv.dm_cap;
     uint64_t* g_lower = prm.q_lower + (size_t)p * prm.qcap;
     uint64_t* g_raise = prm.q_raise + (size_t)p * prm.qcap;
-    int count = prm.counts[2 * p];
-    uint32_t nl = prm.qsizes[2 * p], nr = prm.qsizes[2 * p + 1];
+    // (the counts and queue sizes are the ray-cast kernels' -- of another stream of the context when this stage was routed or belongs to
+    // the early lane: coherent uniform loads, lama_dev.h)
+    int count = uload_i32(prm.counts + 2 * p);
+    const uint64_t nlr = uload_u64(prm.qsizes + 2 * p);
+    uint32_t nl = (uint32_t)nlr, nr = (uint32_t)(nlr >> 32);
     // BOTH waves must have read the hand-over flag before thread 0 clears it (the helper wave may start later than the main wave)
     if (RESUME && TW) __syncthreads(); else LAMA_LOCKSTEP();
     if (RESUME && handed == 0) return;
@@ -2131,7 +2133,7 @@ __global__ __launch_bounds__(256) void k_early_list(const uint8_t* __restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t n = 0;
-        for (uint32_t i = 0; i < host_n && n < cap; ++i) { const uint32_t p = host_list[i]; if (p < (uint32_t)P && !early[p]) { early[p] = 1; elist[n++] = p; } }
+        for (uint32_t i = 0; i < host_n && n < cap; ++i) { const uint32_t p = __hip_atomic_load(host_list + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p < (uint32_t)P && !early[p]) { early[p] = 1; elist[n++] = p; } }
         *elist_n = n;
     }
     __syncthreads();
@@ -2146,7 +2148,7 @@ __global__ __launch_bounds__(256) void k_early_list(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(64) void k_mark_early(DevParams prm)
 {
     if (map_update_aborted(prm)) return;                      // nothing was queued for them: the host grows the arenas and repeats the update
-    const uint32_t n = *prm.elist_n;
+    const uint32_t n = uload_u32(prm.elist_n);
     for (uint32_t i = threadIdx.x; i < n; i += 64) prm.slow[prm.elist[i]] = 1;
 }
 
@@ -2173,10 +2175,11 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
         return;
     }
     if (routed == 2 && map_update_aborted(prm)) return;      // (the other lists are empty after an aborted allocation phase; this one is not)
-    const uint32_t n = routed == 2 ? *prm.elist_n : (routed ? prm.slow_n[2] : prm.slow_n[0]);
+    // (lists and counts of kernels that may have run on another stream of the context: coherent uniform loads, lama_dev.h)
+    const uint32_t n = uload_u32(routed == 2 ? prm.elist_n : (routed ? prm.slow_n + 2 : prm.slow_n));
     const uint32_t* list = routed == 2 ? prm.elist : prm.slow_list + (routed ? 2 * (size_t)prm.P : 0);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)list[i], sh);
+        bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)uload_u32(list + i), sh);
         __syncthreads();                                 // every wave is done with this particle's LDS before the next one is loaded
     }
 }
@@ -2528,23 +2531,25 @@ __device__ inline vec16 vec16_zero() { return vec16{0u, 0u, 0u, 0u}; }
 #endif
 __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const CloneJob* __restrict__ jobs)
 {
-    const CloneJob* __restrict__ J = jobs + blockIdx.x;            // (fields are read where they are needed: no by-value copy, no scratch)
+    // (the job list is rewritten by the host before every launch: coherent uniform loads, field by field -- no by-value copy, no scratch)
+    const CloneJob* J = jobs + blockIdx.x;
     const int plane = blockIdx.y;
     const size_t WW = (size_t)prm.W * prm.W;
     const g_uint4* s; g_uint4* d; size_t ncopy, nzero = 0;         // in 16-byte units
     if (plane < 2) {
-        const uint32_t sh = J->src_home, dh = J->dst_home;
+        const uint32_t sh = uload_u32(&J->src_home), dh = uload_u32(&J->dst_home);
         if (sh == dh) return;
         int16_t* dir = plane == 0 ? prm.dm_dir : prm.occ_dir;
         // only the rows inside the mapped box: outside it every directory of the context is -1 (at W = 128 the two directories are a
         // tenth of a corridor particle's bytes, at W = 432 more than its maps)
-        s = (const g_uint4*)(uintptr_t)(dir + sh * WW) + J->dir_off16; d = (g_uint4*)(uintptr_t)(dir + dh * WW) + J->dir_off16; ncopy = J->dir_n16;
+        const uint32_t off16 = uload_u32(&J->dir_off16);
+        s = (const g_uint4*)(uintptr_t)(dir + sh * WW) + off16; d = (g_uint4*)(uintptr_t)(dir + dh * WW) + off16; ncopy = uload_u32(&J->dir_n16);
     } else {
         const int k = plane - 2;
         const bool dm = k < 3;
         const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
-        const int32_t used = dm ? J->sdm : J->socc, old = dm ? J->odm : J->oocc;
-        s = (const g_uint4*)(uintptr_t)J->s[k]; d = (g_uint4*)(uintptr_t)J->d[k];
+        const int32_t used = uload_i32(dm ? &J->sdm : &J->socc), old = uload_i32(dm ? &J->odm : &J->oocc);
+        s = (const g_uint4*)(uintptr_t)uload_u64(&J->s[k]); d = (g_uint4*)(uintptr_t)uload_u64(&J->d[k]);
         ncopy = (size_t)used * bytes / 16; nzero = old > used ? (size_t)(old - used) * bytes / 16 : 0;
     }
     if (s == d) return;                                             // (this plane of the particle stays where it is)
@@ -2561,11 +2566,11 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
 struct ZeroJob { void* d[5]; int32_t ndm, nocc; };
 __global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob* __restrict__ jobs)
 {
-    const ZeroJob* __restrict__ J = jobs + blockIdx.x;
+    const ZeroJob* J = jobs + blockIdx.x;                          // (host-rewritten list: coherent uniform loads)
     const int k = blockIdx.y;
     const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
-    g_uint4* d = (g_uint4*)(uintptr_t)J->d[k];
-    const size_t n = (size_t)(k < 3 ? J->ndm : J->nocc) * bytes / 16;
+    g_uint4* d = (g_uint4*)(uintptr_t)uload_u64(&J->d[k]);
+    const size_t n = (size_t)uload_i32(k < 3 ? &J->ndm : &J->nocc) * bytes / 16;
     if (!d) return;
     const vec16 z = vec16_zero();
     for (size_t i = (size_t)blockIdx.z * 256 + threadIdx.x; i < n; i += 256 * (size_t)gridDim.z) d[i] = z;
@@ -2600,11 +2605,11 @@ __global__ __launch_bounds__(256) void k_export_particles(DevParams prm, const S
                                                            int32_t wx_patch, int32_t wy_patch, int32_t visit_bound,
                                                            int32_t bbox_x, int32_t bbox_y)
 {
-    const ShipDesc d = desc[blockIdx.x];
+    const ShipDesc d = uload_rec(desc + blockIdx.x);               // (host-rewritten descriptors: coherent uniform loads, lama_dev.h)
     const int j = (int)d.particle, plane = blockIdx.y;
     const uint32_t W = prm.W;
     const PV src = pview(prm, j);
-    const int dmc = src.counts[0], occ = src.counts[1];
+    const int dmc = uload_i32(src.counts), occ = uload_i32(src.counts + 1);
     const size_t WW = (size_t)W * W;
     size_t n16;
     uint4* out = const_cast<uint4*>(blob_plane(d.blob, plane, WW, dmc, occ, n16));
@@ -2621,7 +2626,7 @@ __global__ __launch_bounds__(256) void k_export_particles(DevParams prm, const S
     for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
     if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
         double* hp = reinterpret_cast<double*>(d.blob);
-        for (int k = 0; k < 4; ++k) hp[k] = poses[4 * j + k];
+        for (int k = 0; k < 4; ++k) hp[k] = uload_f64(poses + 4 * j + k);
         int32_t* hh = reinterpret_cast<int32_t*>(d.blob + 32);
         // [5] the sender's window side, [6] / [7] the extent of its mapped area inside that window (lo | hi << 16, patches)
         hh[0] = dmc; hh[1] = occ; hh[2] = wx_patch; hh[3] = wy_patch; hh[4] = visit_bound; hh[5] = (int32_t)W; hh[6] = bbox_x; hh[7] = bbox_y;
@@ -2633,7 +2638,9 @@ __global__ __launch_bounds__(64) void k_gather_blob_heads(const ShipDesc* __rest
 {
     const uint32_t j = blockIdx.x;
     if (j >= n || threadIdx.x >= 16) return;
-    reinterpret_cast<uint32_t*>(heads + (size_t)j * BLOB_HEAD)[threadIdx.x] = reinterpret_cast<const uint32_t*>(desc[j].blob)[threadIdx.x];
+    const uint8_t* blob = uload_ptr<const uint8_t>(&desc[j].blob);
+    reinterpret_cast<uint32_t*>(heads + (size_t)j * BLOB_HEAD)[threadIdx.x] =
+        __hip_atomic_load(reinterpret_cast<const uint32_t*>(blob) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the blob came in by a copy the host queued)
 }
 
 // grid (n, 7 planes, SHIP_SPLIT).  The directories are translated when the sender's window sits elsewhere (see k_shift_window); slots the
@@ -2642,14 +2649,14 @@ __global__ __launch_bounds__(64) void k_gather_blob_heads(const ShipDesc* __rest
 __global__ __launch_bounds__(256) void k_import_particles(DevParams prm, const ShipDesc* __restrict__ desc, const int32_t* __restrict__ old_counts, double* __restrict__ poses,
                                                            int32_t* err)
 {
-    const ShipDesc d = desc[blockIdx.x];
-    const int i = (int)d.particle, plane = blockIdx.y;
+    const ShipDesc d = uload_rec(desc + blockIdx.x);              // (host-rewritten descriptors, a blob and counts that copies queued by the
+    const int i = (int)d.particle, plane = blockIdx.y;           //  host brought in: coherent uniform loads, lama_dev.h)
     const uint32_t W = prm.W;
     const PV dst = pview(prm, i);                                // (the host has made the regions large enough for what is coming)
     const int32_t* hh = reinterpret_cast<const int32_t*>(d.blob + 32);
-    const int dmc = hh[0], occ = hh[1];
-    const int odm = old_counts[2 * i], oocc = old_counts[2 * i + 1];
-    const uint32_t Ws = (uint32_t)hh[5];                         // the sender's window side (windows grow independently)
+    const int dmc = uload_i32(hh), occ = uload_i32(hh + 1);
+    const int odm = uload_i32(old_counts + 2 * i), oocc = uload_i32(old_counts + 2 * i + 1);
+    const uint32_t Ws = uload_u32(hh + 5);                       // the sender's window side (windows grow independently)
     const size_t WW = (size_t)W * W, WWs = (size_t)Ws * Ws;
     size_t n16;
     const uint4* in = blob_plane(d.blob, plane, WWs, dmc, occ, n16);
@@ -2686,7 +2693,7 @@ __global__ __launch_bounds__(256) void k_import_particles(DevParams prm, const S
     if (plane == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
         dst.counts[0] = dmc; dst.counts[1] = occ;
         const double* hp = reinterpret_cast<const double*>(d.blob);
-        for (int k = 0; k < 4; ++k) poses[4 * i + k] = hp[k];
+        for (int k = 0; k < 4; ++k) poses[4 * i + k] = uload_f64(hp + k);
     }
 }
 

@@ -193,8 +193,7 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     const int ic = live ? i : n - 1;
     const size_t WW = (size_t)prm.W * prm.W;
     double T[12];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) T[k] = tfs[12 * (size_t)p + k];
+    uload_f64_w<12>(tfs + 12 * (size_t)p, T);                 // (rewritten by the host before every update: coherent uniform loads, lama_dev.h)
     const BeamGeom g = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
     uint64_t bb = RAY_BBOX_EMPTY;
     if (rec_out && live) bb = ray_hits_record(prm, g, p, i, n, rec_out, bbox_out);
@@ -467,9 +466,9 @@ __global__ __launch_bounds__(RP_BLOCK) void k_ray_replay(DevParams prm, int firs
         return;
     }
     const uint32_t seg = prm.lane ? 3u : 1u;                  // the lane's own hand-over segment
-    const uint32_t n = prm.slow_n[seg];
+    const uint32_t n = uload_u32(prm.slow_n + seg);           // (zeroed by the host's memset at the start of the update: coherent uniform loads)
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
-        ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, (int)prm.slow_list[(size_t)seg * prm.P + i], sh);
+        ray_replay_particle<SORT_CAP, EV_CAP, RESUME, RP_BLOCK>(prm, (int)uload_u32(prm.slow_list + (size_t)seg * prm.P + i), sh);
         __syncthreads();
     }
 }

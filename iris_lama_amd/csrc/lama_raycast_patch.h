@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int firs
     const int16_t* occ_dir = pv.occ_dir;
     const int16_t* dm_dir = pv.dm_dir;
     // the patches the scan can touch: sensor origin (tf.translation(), src/pf_slam2d.cpp:452) +- reach, window-relative patch units
-    const int scx = (int)(w2m(prm, tfs[12 * (size_t)p + 9]) - prm.wx0), scy = (int)(w2m(prm, tfs[12 * (size_t)p + 10]) - prm.wy0);
+    const int scx = (int)(w2m(prm, uload_f64(tfs + 12 * (size_t)p + 9)) - prm.wx0), scy = (int)(w2m(prm, uload_f64(tfs + 12 * (size_t)p + 10)) - prm.wy0);
     const int bx0 = imax((scx - reach_cells) >> 5, 0), bx1 = imin((scx + reach_cells) >> 5, (int)W - 1);
     const int by0 = imax((scy - reach_cells) >> 5, 0), by1 = imin((scy + reach_cells) >> 5, (int)W - 1);
     // the marked region: that box grown by guard_r, clipped to the window; too large for the bitmap -> no bound (as guard_off)

@@ -174,16 +174,16 @@ def test_early_lane_and_routing_at_1536_particles_against_the_oracle(F, monkeypa
     assert c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
 
 
-def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0):
+def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0, **map_opts):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
-    opts = O.default_options(particles=P, seed=7)
+    opts = O.default_options(particles=P, seed=7, **map_opts)
     pf = O.PF(opts)
     pose0 = O.se2(*odom[0])
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
 
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves, brushfire_mode=bf_mode))
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves, brushfire_mode=bf_mode, **map_opts))
     ctx.init(pts[0], pose0)
     for i in (0, P - 1):
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"init occ p{i}")
@@ -231,6 +231,46 @@ def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drif
     print("counters", c, "GN flips", flips)
     ctx.close()
     return c
+
+
+def test_clones_keep_distance_patches_far_beyond_the_hits(F):
+    """with l2_max above 64 cells (3.2 m at 0.05 m) the brushfire allocates distance-map patches more than two patches
+    beyond the scan's reach; a resample copies only the directory rows of the mapped box, which therefore has to include them.
+    A round room of 6 m radius (hits in every direction, also along y: the rows are what the copy cuts), l2_max = 4.2 m (84 cells,
+    guard radius 3 patches), a resample between two updates, every map of every clone against the oracle."""
+    n, radius, P = 1080, 6.0, 4
+    ang = np.deg2rad(-135.0 + 0.25 * np.arange(n))
+    rng = np.random.default_rng(11)
+
+    def scan():
+        r = radius + rng.normal(0, 0.01, n)
+        return np.stack([r * np.cos(ang), r * np.sin(ang), np.zeros(n)], axis=1)
+
+    pose0 = O.se2(0.3, -0.2, 0.1)
+    pf = O.PF(O.default_options(particles=P, seed=1, l2_max=4.2))
+    pf.set_prior(pose0)
+    pts = scan()
+    pf.update(pts, pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, l2_max=4.2))
+    ctx.init(pts, pose0)
+    for k, idx in ((1, None), (2, np.array([0, 0, 2, 2], dtype=np.int32)), (3, np.array([1, 1, 1, 3], dtype=np.int32))):
+        pts = scan()
+        poses = np.stack([O.se2_mul(pose0, O.se2(0.04 * i + 0.01 * k, -0.03 * i, 0.01 * i)) for i in range(P)])
+        pf.set_poses(poses)
+        ctx.set_poses(poses)
+        if idx is not None:
+            pf.stage_resample_with(idx)
+            ctx.resample(idx)
+            assert np.array_equal(ctx.get_poses(), pf.poses())
+        pf.stage_set_scan(pts)
+        pf.stage_update_maps()
+        ctx.update_maps(pts)
+        for i in range(P):
+            assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"scan {k} occ p{i}")
+            assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"scan {k} dm p{i}")
+    c = ctx.counters()
+    assert c["resample_clones"] >= 4
+    ctx.close()
 
 
 def test_parallel_raycast_with_truncation_and_mounted_sensor(F, monkeypatch):

@@ -4,8 +4,9 @@
 The same filter is run again and again -- one context, and 2 / 3 / 4 / 8 contexts on one device driven by as many host threads
 (lama::PFSlam2D, Options::gpus) -- and after EVERY update every particle's pose, weight and the device-side checksums of its two
 maps must equal the first run's.  Timing is the only thing that differs between runs, so any divergence is a race.  This loop found
-round 5's stale-scalar-cache bug (21 of 250 eight-context runs diverged, none with one context); at the fix 0 of 250,
-and 0 of 134 over the six configurations below (routing, early lane, resampling, cross-shard shipping all active)."""
+round 5's stale-scalar-cache bug (21 of 250 eight-context runs diverged, none with one context); at the fix 0 of 250.
+Round 6: the eight-context configurations (forced resampling, clones shipped between contexts in nearly every update) run 550 times at
+scale 1; the result file of the round is profiles/r06_determinism_sweep.txt."""
 import os
 import sys
 
@@ -47,14 +48,32 @@ def sweep(P, gpus, gain, steps, trials):
     return bad
 
 
+def sweep_env(env, *args):
+    """the same with environment overrides of the library's scheduling knobs (read when a context is created)"""
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return sweep(*args)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 if __name__ == "__main__":
     scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
     n = lambda t: max(2, int(round(t * scale)))
     total = 0
     total += sweep(3000, 1, 3.0, 25, n(12))      # default gain: drifting particles, routed stage, early lane
     total += sweep(3000, 1, 1e-4, 25, n(12))     # a resample in nearly every update
-    total += sweep(3000, 8, 1e-4, 12, n(40))     # BASELINE configs[2]'s split on one device, clones shipped between contexts
+    total += sweep(3000, 8, 1e-4, 12, n(300))    # BASELINE configs[2]'s split on one device, clones shipped between contexts in nearly every update
+    # the same with every brushfire stage on the context's main stream: the configuration in which the scalar-cache experiment of
+    # round 6 diverged most often (18 % of the runs with the table behind s_load; DESIGN.md section 8)
+    total += sweep_env({"LAMA_HIP_BF_ROUTE": "1000000,0,150,64"}, 3000, 8, 1e-4, 12, n(250))
     total += sweep(3000, 4, 3.0, 25, n(10))
     total += sweep(301, 3, 1e-3, 20, n(30))
     total += sweep(30, 2, 0.01, 30, n(30))
+    print("runs with a divergence:", total, flush=True)
     sys.exit(1 if total else 0)

@@ -1,10 +1,12 @@
 #!/bin/bash
-# One gpurun call of round 5: the -m gpu suite, then the driver's bench command; logs under gpurun_out/r05_<tag>/
+# One gpurun call of round 6: the -m gpu suite, then the driver's bench command; logs under gpurun_out/r06_<tag>/
+# usage: bash tools/round_call.sh <tag> [sweep scale (0 = no determinism sweep)]
 TAG=${1:-a}
+SWEEP=${2:-0}
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=gpurun_out/r05_$TAG
+OUT=gpurun_out/r06_$TAG
 mkdir -p "$OUT"
-timeout 1500 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests.log" 2>&1
+timeout 2400 python -m pytest tests -m gpu -x -q > "$OUT/gpu_tests.log" 2>&1
 echo "rc=$?" >> "$OUT/gpu_tests.log"
 tail -4 "$OUT/gpu_tests.log"
 timeout 900 python bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
@@ -27,3 +29,7 @@ except Exception as e:
     print("parse error", e)
     print(open("$OUT/bench.err").read()[-3000:])
 PY
+if [ "$SWEEP" != "0" ]; then
+  timeout 2400 python tools/determinism_sweep.py $SWEEP > "$OUT/determinism_sweep.txt" 2>&1
+  echo "sweep rc=$?"; grep -v "amdgpu.ids" "$OUT/determinism_sweep.txt" | tail -12
+fi
