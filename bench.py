@@ -230,36 +230,60 @@ def floor_plan_cells(width_m, height_m, room_m=4.0, wall_cells=2, res=0.05):
     return np.stack([xs + off, ys + off], axis=1).astype(np.uint32)
 
 
-def loc2d_map_load(F, with_cpu, budget_s=45.0):
-    """Loc2D::Init's distance-map build (src/loc2d.cpp:61-108: addObstacle for every occupied cell, then dm->update()) for a generated
-    floor plan, on the device (lama_hip_map_add_obstacles: k_dm_add_obstacles + ONE exact brushfire = one serial chain of pops) with
-    the CPU beside it.  A quarter-size plan first; the 100 m x 60 m plan only when the measured pace says it fits `budget_s`."""
+def loc2d_map_load(F, with_cpu, budget_s=20.0):
+    """Loc2D::Init's distance-map build (src/loc2d.cpp:61-108 with the caller's loop: addObstacle for every occupied cell, then
+    dm->update()) for a generated floor plan.
+
+    `gpu_seconds` is the PRODUCT path: lama::Loc2D through the host class -- the first build of the map is one serial chain of pops
+    with nothing to parallelise over, so the host facade replays it on one host core (iris_lama_amd/host/dm_builder.cpp, from-scratch
+    code, not the checker) and uploads the patches to the device (lama_hip_pf_upload_map); the map is then downloaded from the
+    DEVICE and compared with the CPU port's, record by record.  `device_chain` is the same build as ONE exact brushfire on the device
+    (lama_hip_map_add_obstacles, what round 5 measured: the queue starts beyond the LDS stages, so the one-lane kernel runs it), on
+    the quarter-size plan and on the full plan only when the measured pace fits `budget_s`."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     out = {}
+    off = (2642244 >> 1) * 32
     for label, (w, h) in (("plan_50x30m", (50.0, 30.0)), ("plan_100x60m", (100.0, 60.0))):
         cells = floor_plan_cells(w, h)
         row = {"occupied_cells": int(len(cells)), "l2_max_m": 1.0, "resolution_m": 0.05}
-        if label != "plan_50x30m":
-            prev = out["plan_50x30m"]
-            predicted = prev["gpu_seconds"] * len(cells) / max(prev["occupied_cells"], 1)
-            row["predicted_gpu_seconds"] = predicted
-            if predicted > budget_s:
-                row["skipped"] = "predicted device time beyond the bench's budget"
-                out[label] = row
-                continue
-        cfg = F.default_cfg(particles=1, l2_max=1.0, queue_capacity=1 << 20, window_patches=128, profile=1)
-        ctx = F.HipContext(cfg)
+        world = (cells.astype(np.float64) - off) * 0.05
+        loc = F.Loc2D(l2_max=1.0)
         t0 = time.perf_counter()
-        ctx.add_obstacles(0, cells)
+        loc.set_obstacles_world(world)                 # occupancy_map->setOccupied + distance_map->addObstacle per cell, one update()
         row["gpu_seconds"] = time.perf_counter() - t0
+        row["gpu_seconds_is"] = "lama::Loc2D host class: host replay of the first build (one core) + upload of the patches to the device"
+        ctx = loc.hip_context()
+        dev_map = ctx.download_map(0, F.MAP_DISTANCE)
         c = ctx.counters()
-        row["pops"] = int(c["bf_cells"]); row["dm_patches"] = int(c["dm_patches"])
-        row["gpu_us_per_pop"] = 1e6 * row["gpu_seconds"] / max(row["pops"], 1)
+        row["dm_patches"] = int(c["dm_patches"]) if c["dm_patches"] else len(dev_map)
         row["hbm_bytes_allocated"] = int(c["hbm_bytes_allocated"]); row["hbm_bytes_used"] = int(c["hbm_bytes_used"])
-        ctx.close()
+        loc.close()
+        # the same build as one chain on the device (C-ABI), when it fits the budget
+        chain = {}
+        prev = out.get("plan_50x30m", {}).get("device_chain", {})
+        predicted = prev["seconds"] * len(cells) / max(out["plan_50x30m"]["occupied_cells"], 1) if prev.get("seconds") else 0.0
+        if predicted > budget_s:
+            chain = {"skipped": "predicted device time beyond the bench's budget", "predicted_seconds": predicted}
+        else:
+            cfg = F.default_cfg(particles=1, l2_max=1.0, queue_capacity=1 << 20, window_patches=128, profile=1)
+            ctx = F.HipContext(cfg)
+            t0 = time.perf_counter()
+            ctx.add_obstacles(0, cells)
+            chain["seconds"] = time.perf_counter() - t0
+            c = ctx.counters()
+            chain["pops"] = int(c["bf_cells"])
+            chain["us_per_pop"] = 1e6 * chain["seconds"] / max(chain["pops"], 1)
+            chain_map = ctx.download_map(0, F.MAP_DISTANCE)
+            ctx.close()
+            from _cmp import DM_FIELDS, diff_maps
+            chain["identical_to_host_build"] = all(v == 0 for v in diff_maps(chain_map, dev_map, DM_FIELDS).values())
+            assert chain["identical_to_host_build"], "device chain and host build of the same map differ"
+            row["pops"] = chain["pops"]
+        row["device_chain"] = chain
         if with_cpu:
             import _oracle as O
+            from _cmp import DM_FIELDS, diff_maps
             dm = O.DM.new(l2_max=1.0)
             t0 = time.perf_counter()
             for x, y in cells: dm.add(int(x), int(y))
@@ -267,7 +291,11 @@ def loc2d_map_load(F, with_cpu, budget_s=45.0):
             n = dm.update()
             t2 = time.perf_counter()
             row["cpu_oracle_port"] = {"add_seconds_incl_ctypes": t1 - t0, "update_seconds": t2 - t1, "pops": int(n), "us_per_pop": 1e6 * (t2 - t1) / max(int(n), 1)}
+            row.setdefault("pops", int(n))
             assert int(n) == row["pops"], (n, row["pops"])      # the same chain, pop for pop
+            d = diff_maps(dev_map, dm.dump(), DM_FIELDS)
+            row["device_map_identical_to_cpu_port"] = all(v == 0 for v in d.values())
+            assert row["device_map_identical_to_cpu_port"], d
             del dm
             try:
                 import _reference as R
@@ -505,6 +533,9 @@ def main():
             b, ms = sum(x["peer_copy_bytes"] for x in cs), sum(x["peer_copy_ms"] for x in cs)
             out["peer"] = {"peer_access": bool(all(x["peer_access"] for x in cs if x["peer_copy_bytes"] > 0)) if b else None, "bytes": int(b), "ms": ms,
                            "GBps": (b / (ms * 1e-3) / 1e9) if ms > 0 else None,
+                           # every destination shard pulls its incoming clones from at most two neighbours (systematic resampling keeps
+                           # the order): its own rate is the rate of those one or two links
+                           "GBps_per_destination_shard": [round(x["peer_copy_bytes"] / (x["peer_copy_ms"] * 1e-3) / 1e9, 2) if x["peer_copy_ms"] > 0 else None for x in cs],
                            "note": "peer_access None: no copy crossed a device boundary (all shards on one device)" if not b else "hipEvents on the destination's stream"}
         except Exception as e:
             out["peer"] = {"error": str(e)}
@@ -599,7 +630,19 @@ def main():
         result["value_source"] = f"lama::PFSlam2D, Options::gpus = {world} (one process, {cpp_multi['devices']} device(s)), run by rank 0; rounds 1-3 reported torch_distributed_ranks here"
         if torch.cuda.device_count() < world:
             result["devices_short"] = f"{torch.cuda.device_count()} device(s) for {world} shards: the shards SHARE devices, this is not a scaling measurement"
-        result["peer_access"] = cpp_multi.get("peer")
+        result["peer_access"] = cpp_multi_forced.get("peer") if (cpp_multi_forced.get("peer") or {}).get("bytes") else cpp_multi.get("peer")
+        result["rccl_ranks"] = world if (torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl") else 0
+        # what the first real curve can be read against: the clones of a resample cross at most one xGMI link per (source, destination)
+        # pair, 153 GB/s per link and direction (MI355X_MICROARCH.md); a destination's incoming bytes over its one or two links
+        f = cpp_multi_forced
+        if f and f.get("resamples"):
+            per_res = f["shipped_bytes"] / f["resamples"]
+            result["xgmi_shipping_estimate"] = {"shipped_bytes_per_resample": int(per_res), "shipped_particles_per_resample": f["shipped_particles"] / f["resamples"],
+                                                "bytes_per_destination_shard": int(per_res / world),
+                                                "ms_per_resample_at_153_GBps_per_link": 1e3 * (per_res / world) / 153e9,
+                                                "measured_ship_ms_per_resample": f["exchange_ms"]["ship_per_resample"],
+                                                "note": "forced-resample variant (nearly every step resamples); the default-gain pool resamples rarely. "
+                                                        "Estimate = one destination's incoming clones over ONE link; the shards copy concurrently"}
         result["strong_scaling_ceiling"] = {"particles_per_gpu": max(P_total // world, 1), "ms_per_step_of_one_share_alone": share["ms_per_step"],
                                             "ceiling_speedup": single["ms_per_step"] / share["ms_per_step"],
                                             "note": "step time of the unsharded pool / step time of ONE GPU's share alone on one GPU: no exchange, "

@@ -60,6 +60,8 @@ public:
     const std::vector<double>& lastGlocErrors() const { return gloc_errors_; }
     const std::vector<double>& lastSamplingLikelihoods() const { return sampling_l_; }
     uint32_t getLastIterations() const { return last_iterations_; }
+    // true when the first build of the distance map was replayed on the host and uploaded (iris_lama_amd/host/dm_builder.hpp)
+    bool distanceMapBuiltOnHost() const { return host_built_; }
     lama_hip_ctx* deviceContext() const { return ctx_; }
     const HipEngine* engine() const { return eng_.get(); }
 
@@ -78,6 +80,7 @@ private:
     double rmse_ = 0.0;
     bool has_first_scan = false;
     uint32_t last_iterations_ = 0;
+    bool host_built_ = false;
     bool do_global_localization_ = false;
     uint32_t gloc_cur_iter_ = 0;
     double cov_blend_ = 0.0;

@@ -203,6 +203,14 @@ int lama_sdm_image(int kind, double resolution, uint32_t max_sqdist, uint32_t n,
                    const uint64_t* masks, uint32_t* width, uint32_t* height, uint8_t* out, uint64_t cap);
 int lama_sdm_export_png(int kind, double resolution, uint32_t max_sqdist, uint32_t n, const uint64_t* ids, const uint8_t* cells,
                         const uint64_t* masks, const char* file);
+/* The FIRST build of lama::Loc2D's distance map on the host (iris_lama_amd/host/dm_builder.hpp: addObstacle for n cells of an empty
+ * map in the given order + one update(), /root/reference/src/loc2d.cpp:61-108, src/sdm/dynamic_distance_map.cpp:160-226,281-330) --
+ * what lama::DynamicDistanceMap::update() of a Loc2D runs before it uploads the result to the device.  Exposed so that the harness can
+ * compare it with the checker and time it.  lama_dm_build returns the number of patches (kept until the next call on this thread;
+ * -1: not buildable on the host, e.g. max_sqdist beyond the device's 14 bits) and update()'s return value in *processed;
+ * lama_dm_build_fetch copies the records out (ids n, cells n x 10240 B, masks n x 16 words). */
+int64_t lama_dm_build(const uint32_t* cells_xy, uint64_t n, uint32_t max_sqdist, uint32_t* processed);
+int lama_dm_build_fetch(uint64_t* ids, uint8_t* cells, uint64_t* masks);
 /* lama::random (include/lama/random.h) */
 void lama_random_set_seed(uint32_t seed);
 double lama_random_uniform(void);

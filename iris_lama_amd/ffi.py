@@ -449,7 +449,7 @@ HOST_SYMBOLS = [
     "lama_loc_create2", "lama_loc_occ_set_cells", "lama_loc_occ_bounds", "lama_loc_trigger_global_localization",
     "lama_loc_global_localization_active", "lama_loc_gloc_candidates", "lama_loc_sampling_likelihoods",
     "lama_random_set_seed", "lama_random_uniform",
-    "lama_sdm_write", "lama_sdm_read", "lama_sdm_image", "lama_sdm_export_png",
+    "lama_sdm_write", "lama_sdm_read", "lama_sdm_image", "lama_sdm_export_png", "lama_dm_build", "lama_dm_build_fetch",
     "lama_lo_create", "lama_lo_destroy", "lama_lo_last_error", "lama_lo_engine_origin", "lama_lo_update", "lama_lo_get_odom",
     "lama_lo_iterations", "lama_lo_deleted_patches", "lama_lo_device_context",
 ]
@@ -504,6 +504,7 @@ def _bind_host(L):
         "lama_sdm_read": (i32, [C.c_char_p, vp, vp, vp, u32, vp, vp, vp, vp]),
         "lama_sdm_image": (i32, [i32, d, u32, u32, vp, vp, vp, vp, vp, vp, C.c_uint64]),
         "lama_sdm_export_png": (i32, [i32, d, u32, u32, vp, vp, vp, C.c_char_p]),
+        "lama_dm_build": (C.c_int64, [vp, C.c_uint64, u32, vp]), "lama_dm_build_fetch": (i32, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)
@@ -995,6 +996,25 @@ def sdm_read(filename):
     masks = np.zeros((n.value, 16), dtype=np.uint64)
     L.lama_sdm_read(filename.encode(), None, None, None, n.value, _p(ids), _p(cells), _p(masks), None)
     return kind.value, res.value, msq.value, {int(ids[k]): (cells[k], masks[k]) for k in range(n.value)}
+
+
+def dm_build(cells_xy, max_sqdist):
+    """The first build of Loc2D's distance map as the host facade does it (iris_lama_amd/host/dm_builder.hpp): addObstacle for the
+    cells in order on an empty map + one update().  -> (cells processed, {patch id: (distance_t[1024] structured, mask[16])}),
+    or None when the host does not build it (the facade then uses the device chain)."""
+    L = _hostlib()
+    cells_xy = np.ascontiguousarray(cells_xy, dtype=np.uint32)
+    done = C.c_uint32(0)
+    n = L.lama_dm_build(_p(cells_xy), len(cells_xy), int(max_sqdist), C.byref(done))
+    if n < 0:
+        return None
+    ids = np.zeros(n, dtype=np.uint64)
+    cells = np.zeros((n, 10240), dtype=np.uint8)
+    masks = np.zeros((n, 16), dtype=np.uint64)
+    if n:
+        L.lama_dm_build_fetch(_p(ids), _p(cells), _p(masks))
+    dist_t = np.dtype([("obstacle", "<i2", (3,)), ("sqdist", "<u2"), ("valid", "u1"), ("queued", "u1")])
+    return done.value, {int(ids[k]): (cells[k].view(dist_t), masks[k]) for k in range(n)}
 
 
 def sdm_image(patches, kind, resolution=0.05, max_sqdist=100):

@@ -14,6 +14,7 @@
 #include "lama/loc2d.h"
 #include "lama/random.h"
 #include "lama/sdm_io.h"
+#include "dm_builder.hpp"
 #include "lama/slam2d.h"
 
 using namespace lama;
@@ -675,6 +676,26 @@ int lama_sdm_export_png(int kind, double resolution, uint32_t max_sqdist, uint32
                         const uint64_t* masks, const char* file)
 {
     return lama::sdm::export_to_png(host_map(kind, resolution, max_sqdist, n, ids, cells, masks), file) ? 0 : -1;
+}
+static thread_local lama::sdm::HostMap g_dm_build;
+int64_t lama_dm_build(const uint32_t* cells_xy, uint64_t n, uint32_t max_sqdist, uint32_t* processed)
+{
+    uint32_t done = 0;
+    g_dm_build = lama::sdm::HostMap();
+    g_dm_build.kind = lama::sdm::kDistanceMap; g_dm_build.max_sqdist = max_sqdist;
+    try {
+        if (!cells_xy || !lama::detail::build_distance_map(cells_xy, (size_t)n, max_sqdist, g_dm_build, done)) return -1;
+    } catch (...) { return -1; }
+    if (processed) *processed = done;
+    return (int64_t)g_dm_build.numPatches();
+}
+int lama_dm_build_fetch(uint64_t* ids, uint8_t* cells, uint64_t* masks)
+{
+    if (!ids || !cells || !masks) return -1;
+    std::memcpy(ids, g_dm_build.ids.data(), g_dm_build.ids.size() * 8);
+    std::memcpy(cells, g_dm_build.cells.data(), g_dm_build.cells.size());
+    std::memcpy(masks, g_dm_build.masks.data(), g_dm_build.masks.size() * 8);
+    return 0;
 }
 void lama_random_set_seed(uint32_t seed) { lama::random::setSeed(seed); }
 double lama_random_uniform(void) { return lama::random::uniform(); }

@@ -8,6 +8,7 @@
 #include <stdexcept>
 
 #include "covariance3.hpp"
+#include "dm_builder.hpp"
 #include "hip_engine.hpp"
 #include "lama/random.h"
 
@@ -33,6 +34,24 @@ void Loc2D::Init(const Options& o)
     w.apply = [this](std::vector<uint32_t>& cells_xy, double max_distance) -> uint32_t {
         (void)max_distance;                                 // part of the context's configuration (ensureContext)
         ensureContext();
+        {   // The FIRST build -- every occupied cell of a static map added to an empty distance map, one update(): src/loc2d.cpp:61-108
+            // with the caller's loop -- is one serial chain of pops with nothing to parallelise over; it is replayed on the host
+            // (dm_builder.hpp: from-scratch code, std::priority_queue for the reference's tie order) and uploaded like a map read
+            // from a file.  Later updates of the map that now exists run on the device.
+            uint32_t have = 0;
+            if (eng_->pf_map_patches(ctx_, 0, 0 /* distance map */, &have) == 0 && have == 0) {
+                sdm::HostMap m;
+                m.kind = sdm::kDistanceMap; m.resolution = distance_map->resolution; m.patch_length = distance_map->patch_length;
+                m.max_sqdist = distance_map->maxSqDist();
+                uint32_t processed = 0;
+                if (detail::build_distance_map(cells_xy.data(), cells_xy.size() / 2, m.max_sqdist, m, processed)) {
+                    const int32_t ru = eng_->pf_upload_map(ctx_, 0, 0, (uint32_t)m.ids.size(), m.ids.data(), m.cells.data(), m.masks.data());
+                    if (ru) fail(ru, "lama_hip_pf_upload_map (first build of the distance map)");
+                    host_built_ = true;
+                    return processed;
+                }
+            }
+        }
         lama_hip_counters c0, c1;
         const bool have0 = eng_->get_counters(ctx_, &c0) == 0;
         const int32_t rc = eng_->map_add_obstacles(ctx_, 0, cells_xy.data(), (uint32_t)(cells_xy.size() / 2));
@@ -55,6 +74,7 @@ void Loc2D::Init(const Options& o)
     };
     distance_map->bindWriter(std::move(w));
     rmse_ = 0.0;
+    host_built_ = false;
     cov_ = Matrix3d::Identity();
     has_first_scan = false;
     do_global_localization_ = false;                                   // :80-90

@@ -196,6 +196,7 @@ int32_t lama_hip_ctx_device(const lama_hip_ctx* c) { return c ? 0 : -1; }
 
 int32_t lama_hip_pf_map_patches(lama_hip_ctx* c, uint32_t particle, int32_t kind, uint32_t* num)
 {
+    if (!c->init) { *num = 0; return LAMA_HIP_OK; }      // (no map yet, like the device library before its first scan / upload)
     *num = (uint32_t)(kind == LAMA_HIP_MAP_DISTANCE ? c->dm[particle]->patches.size()
                       : (c->cfg.occupancy_policy == 1 ? c->pocc[particle]->patches.size() : c->occ[particle]->patches.size()));
     return LAMA_HIP_OK;

@@ -575,6 +575,39 @@ def test_free_running_3000_particles_tracks_oracle(F):
         h.close()
 
 
+def test_long_free_running_3000_particles_every_map_every_scan(F):
+    """BASELINE's largest pool compared DIRECTLY, not transitively -- 3000 particles free running (no teacher
+    forcing) over 27 scans next to the oracle, with a gain that makes the filter resample on its own (scans 17 and 24) and with the
+    routed stage and the early lane at their default thresholds; after EVERY scan the device-side checksums of both maps of ALL 3000
+    particles equal the oracle's (patch set, every cell, every mask bit), poses within 1e-6, same resampling decisions, same best
+    particle.  (Free-running poses differ from the oracle's by ~1e-11 m; a hit within that distance of a cell border would
+    legitimately change a map -- expected 0.03 times in this run.)"""
+    import os
+    P, steps, gain = 3000, 26, 0.0012
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=9, meas_sigma_gain=gain))
+    o = O.PF(O.default_options(particles=P, seed=9, meas_sigma_gain=gain, threads=min(64, os.cpu_count() or 1)))
+    h.set_prior(*odom[0])
+    o.set_prior(O.se2(*odom[0]))
+    worst = 0.0
+    for k in range(steps + 1):
+        assert h.update(pts[k], odom[k], float(k)) == o.update(pts[k], O.se2(*odom[k]), float(k))
+        worst = max(worst, float(np.abs(h.poses() - o.poses()).max()))
+        assert worst < 1e-6, k
+        assert h.num_resamples() == o.num_resamples(), k
+        assert h.best() == o.best(), k
+        ctx = h.hip_context()
+        assert np.array_equal(ctx.map_checksums(F.MAP_DISTANCE), o.map_checksums(0)), f"distance maps after scan {k}"
+        assert np.array_equal(ctx.map_checksums(F.MAP_OCCUPANCY), o.map_checksums(1)), f"occupancy maps after scan {k}"
+    c = h.hip_context().counters()
+    assert o.num_resamples() >= 2                                  # the filter resampled by itself
+    assert c["brushfire_routed"] > 0 and c["brushfire_early"] > 0, c      # long chains went through the routed stage / the early lane
+    assert c["resample_clones"] > 0
+    print("largest pose difference to the oracle over the run", worst, "resamples", o.num_resamples(),
+          "routed / early", c["brushfire_routed"], c["brushfire_early"])
+    h.close()
+
+
 def test_sharded_two_ranks_one_gpu_gloo(F):
     """G = 2 logical shards on ONE device (two processes, gloo collectives, blobs staged through the GPU):
     exercises export/import of particles in HBM and the sharded driver against the real HIP library."""
@@ -836,6 +869,8 @@ def test_loc2d_gpu_vs_oracle(F):
     h = F.Loc2D()
     h.set_obstacles_world(obst)
     assert h.engine_origin().endswith("liblama_hip.so")
+    # round 6: the FIRST build of the map is replayed by the host facade and uploaded; what the DEVICE then holds is the oracle's map
+    assert_maps_equal(h.hip_context().download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "Loc2D distance map after Init")
     start = truth[0] + np.array([0.05, -0.04, 0.01])
     o.set_pose(O.se2(*start))
     h.set_pose(*start)
@@ -845,7 +880,42 @@ def test_loc2d_gpu_vs_oracle(F):
         assert o.iterations() == h.iterations()
         assert abs(o.rmse() - h.rmse()) < 1e-9
         assert np.allclose(o.covar(), h.covar(), rtol=1e-6, atol=1e-12)
+    # a LATER update of the map that now exists -- a box of new obstacles in the corridor -- runs on the device (lama_hip_map_add_obstacles
+    # on top of the uploaded map): still the oracle's map, and the localisation goes on identically
+    box = np.array([(9.0 + 0.05 * i, 1.6 + 0.05 * j) for i in range(8) for j in range(8) if i in (0, 7) or j in (0, 7)])
+    for x, y in box:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    h.set_obstacles_world(box)
+    assert_maps_equal(h.hip_context().download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "Loc2D distance map after a later update")
+    assert o.update(pts[steps], O.se2(*odom[steps]), 99.0, force=True) == h.update(pts[steps], odom[steps], 99.0, force=True)
+    assert np.abs(o.pose() - h.pose()).max() < 1e-7
     h.close()
+
+
+def test_first_map_build_device_chain_equals_host_build(F):
+    """The same first build -- every occupied cell of a floor plan added to an empty map, one update() -- through the C-ABI as ONE exact
+    brushfire on the device (lama_hip_map_add_obstacles) and through lama::Loc2D (host replay + upload): the same distance map, which
+    is the oracle's, and the same number of processed cells."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import floor_plan_cells
+    cells = floor_plan_cells(24.0, 16.0)
+    dm = O.DM.new(l2_max=1.0)
+    for x, y in cells:
+        dm.add(int(x), int(y))
+    n = dm.update()
+    ctx = F.HipContext(F.default_cfg(particles=1, l2_max=1.0, queue_capacity=1 << 20))
+    ctx.add_obstacles(0, cells)
+    assert ctx.counters()["bf_cells"] == n
+    chain = ctx.download_map(0, F.MAP_DISTANCE)
+    ctx.close()
+    assert_maps_equal(chain, dm.dump(), DM_FIELDS, "device chain")
+    loc = F.Loc2D(l2_max=1.0)
+    loc.set_obstacles_world((cells.astype(np.float64) - (2642244 >> 1) * 32) * 0.05)
+    assert_maps_equal(loc.hip_context().download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "host build, uploaded")
+    loc.close()
 
 
 def test_loc2d_loads_a_prebuilt_distance_map(F, tmp_path):
