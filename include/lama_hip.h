@@ -69,14 +69,14 @@ typedef struct lama_hip_cfg {
     uint32_t window_patches;     /* INITIAL side of the square map window in patches (default 128 = 204.8 m; a multiple of 8).  The window
                                     follows the robot and GROWS (re-allocated at least half as large again) when the mapped area
                                     outgrows it, up to 1016 patches = 1.6 km at 0.05 m; only a wider map is LAMA_HIP_E_WINDOW */
-    uint32_t dm_patch_capacity;  /* smallest DM region a particle gets, in patches (default 256).  The reference's maps are unbounded; here
+    uint32_t dm_patch_capacity;  /* smallest DM region a particle gets, in patches (default 128: 10 m x 10 m of map; regions grow on demand).  The reference's maps are unbounded; here
                                     every particle owns one contiguous region per map kind inside pooled planes: the region grows with
                                     ITS particle's map (moved to a larger one, that particle alone, when it runs short), the pools grow
                                     chunk by chunk.  A map update that needs more patches than are free reports that BEFORE it modifies
                                     any cell (its allocation phase comes first), upon which the particles that ran short get what they
                                     asked for and the update is run again.  LAMA_HIP_E_CAPACITY remains for the hard limit of 32767
                                     patches per particle and map, and for a device that has no memory left for another pool chunk */
-    uint32_t occ_patch_capacity; /* smallest occupancy region a particle gets (default 256)      */
+    uint32_t occ_patch_capacity; /* smallest occupancy region a particle gets (default 128)      */
     uint32_t queue_capacity;     /* brushfire queue entries per particle (default 32768)          */
     uint32_t profile;            /* !=0: bracket every kernel with hipEvents (lama_hip_get_counters) */
     uint32_t active_capacity;    /* parallel ray-cast: max. order-sensitive cell visits per particle and scan (default 8192) */

@@ -133,7 +133,7 @@ struct lama_hip_ctx {
     PinVec<PartRec> h_part_stage;     // (page-locked staging of the upload)
     PinVec<CloneJob> h_jobs; CloneJob* d_jobs = nullptr; uint32_t jobs_cap = 0;
     PinVec<ZeroJob> h_zjobs; ZeroJob* d_zjobs = nullptr; uint32_t zjobs_cap = 0;
-    uint32_t floor_dm = 256, floor_occ = 256;      // smallest region a particle gets (cfg.dm_patch_capacity / occ_patch_capacity)
+    uint32_t floor_dm = 128, floor_occ = 128;      // smallest region a particle gets (cfg.dm_patch_capacity / occ_patch_capacity)
     PinVec<uint32_t> h_guard;         // the guard's per-particle bound of the last map update
     uint64_t clone_bytes = 0;         // bytes the particle copies of the last resample moved (counters)
     double* d_poses = nullptr;
@@ -1123,8 +1123,8 @@ void lama_hip_default_cfg(lama_hip_cfg* cfg)
     cfg->max_iter = 100;
     cfg->device = 0;
     cfg->window_patches = 128;
-    cfg->dm_patch_capacity = 256;
-    cfg->occ_patch_capacity = 256;
+    cfg->dm_patch_capacity = 128;
+    cfg->occ_patch_capacity = 128;
     cfg->queue_capacity = 32768;
     cfg->active_capacity = 8192;
 }
@@ -1145,8 +1145,8 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     *out = nullptr;
     lama_hip_cfg cfg = *cfg_in;
     if (cfg.window_patches == 0) cfg.window_patches = 128;
-    if (cfg.dm_patch_capacity == 0) cfg.dm_patch_capacity = 256;
-    if (cfg.occ_patch_capacity == 0) cfg.occ_patch_capacity = 256;
+    if (cfg.dm_patch_capacity == 0) cfg.dm_patch_capacity = 128;
+    if (cfg.occ_patch_capacity == 0) cfg.occ_patch_capacity = 128;
     if (cfg.queue_capacity == 0) cfg.queue_capacity = 32768;
     if (cfg.active_capacity == 0) cfg.active_capacity = 8192;
     if (cfg.active_capacity > 8192) cfg.active_capacity = 8192;      // largest k_ray_replay stage

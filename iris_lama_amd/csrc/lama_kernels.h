@@ -1235,6 +1235,16 @@ __device__ __forceinline__ void lds_barrier() { __syncthreads(); }
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #endif
 
+// a 64-bit value that is the same in every lane, said so to the compiler (two v_readfirstlane; folded away when it already knows)
+#ifdef LAMA_WAVE_SIM
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) { return v; }
+#else
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
+{
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+#endif
+
 // hand particle p to the next stage: the first stage lists it for the resume stage, the resume stage flags it for k_brushfire_slow
 __device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool from_resume)
 {
@@ -1385,7 +1395,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
         tw_running = tw_go = !spill && (nr > 0 || nl > 0);
         if (lane == 0) { sh.cmd = tw_go ? nl : BF_CMD_EXIT; sh.cmd_r = nr; }
-        if (tw_go) e_next = nr > 0 ? sh.raise[0] : sh.lower[0];
+        if (tw_go) e_next = uniform_u64(nr > 0 ? sh.raise[0] : sh.lower[0]);
         __syncthreads();                                       // S0
     }
     // end of a TW iteration: deliver the push lists, meet the helper (its pop is done), derive the next top from the root it
@@ -1579,7 +1589,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 spill = nl + 4 > (uint32_t)LQ_LDS || (nr > 0 && nr + 4 > (uint32_t)RQ_LDS);
                 tw_running = !spill && (nr > 0 || nl > 0);
                 if (tw_running) {
-                    if (nr == 0) { lds_barrier(); /* X: the helper has applied the pushes */ e_next = sh.lower[0]; }
+                    if (nr == 0) { lds_barrier(); /* X: the helper has applied the pushes */ e_next = uniform_u64(sh.lower[0]); }
                     else e_next = cand_;
                 }
                 ++tw_it;
@@ -1733,7 +1743,11 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         };
 
         if (tw_running && nl > 0) for (;;) {
-            const uint64_t e = e_next;                                     // the same value in every lane
+            // the same value in every lane -- SAID so (round 6): as a vector value the entry makes `stale`, hence `general`, hence every
+            // branch of the pop divergent to the compiler, and everything defined under them (the push count, the queue length, the
+            // next-top test, the loop test) a vector phi with exec-mask control flow: ~12 VALU instructions and half a dozen
+            // vector -> scalar hand-overs behind the barrier, on the chain of every pop
+            const uint64_t e = uniform_u64(e_next);
             ++processed;
             --nl;                                                          // the helper wave pops
             uint32_t cnt = 0;
@@ -1851,6 +1865,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             prof[0] += 1; prof[1] += general ? 1 : 0;
 #endif
             if (__builtin_expect(general, 0)) cnt = general_pop(e, over, entry);
+#ifndef LAMA_WAVE_SIM
+            // (wave-uniform by construction -- ballots and lane-4 / lane-5 values --, but the general code reaches them through per-lane
+            // loads: said here, the queue length, the next-top test and the loop test stay on the scalar unit)
+            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+            floor_sq = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_sq);
+#endif
             BFT(3);
             // ---- hand-over: the push list is in the mailbox; meet the helper (its pop is done) and derive the next top from the root
             // it saw after pop() and my own pushes: push_heap lifts an entry above its parent only if the parent's priority is
@@ -1870,7 +1890,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)root_), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(root_ >> 32));
                 const bool have_root = nl > 0;
                 e_next = ((uint64_t)rhi << 32) | rlo;
-                if (__builtin_expect(cnt > 0 && (!have_root || (rhi >> 16) > floor_sq + 1u), 0)) {
+                // (integer arithmetic on wave-uniform words: as a `&&` / `||` of bools the compiler builds the condition with v_cndmask)
+                const uint32_t own_may_win = (cnt != 0u ? 1u : 0u) & ((have_root ? 0u : 1u) | ((rhi >> 16) > floor_sq + 1u ? 1u : 0u));
+                if (__builtin_expect(own_may_win != 0u, 0)) {
                     uint32_t key = over ? ((heap_prio(entry) << 2) | (uint32_t)(lane & 3)) : 0xFFFFFFFFu;
                     uint32_t blo = (uint32_t)entry, bhi = (uint32_t)(entry >> 32);
 #define BF_QUAD_MIN(CTRL)                                                                                              \

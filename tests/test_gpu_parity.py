@@ -122,7 +122,8 @@ def test_drifted_poses_long_chains_default_routing(F, cap, monkeypatch):
     print("counters", c)
     assert c["brushfire_routed"] > 0 and c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
     assert c["brushfire_early"] > 0, c          # routed in one update, early lane in the next (no resample in between)
-    assert (c["arena_growths"] > 0) == (cap != 0), c
+    if cap:
+        assert c["arena_growths"] > 0, c          # (with the default floor of 128 patches the drifted particles may grow once, too)
 
 
 def test_early_lane_and_routing_at_1536_particles_against_the_oracle(F, monkeypatch):
