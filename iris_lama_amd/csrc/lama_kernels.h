@@ -1481,7 +1481,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         };
 
         while (tw_running && nr > 0) {
-            const uint64_t e = e_next;
+            const uint64_t e = uniform_u64(e_next);                       // (see the lower wave)
             ++processed;
 #ifdef LAMA_PROFILE_BF_COUNT
             prof[7] += 1;
@@ -1554,6 +1554,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 }
             }
             if (__builtin_expect(general, 0)) general_raise(e, cnt_r, cnt_l, entry, rm);
+#ifndef LAMA_WAVE_SIM
+            cnt_r = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_r); cnt_l = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_l);
+            rm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rm);
+#endif
             // ---- hand-over (see the lower wave): both counts in one LDS store, meet the helper, next top = the raise heap's root after
             // pop() unless one of my own raise pushes beats it -- push_heap lifts an entry above its parent only if the parent's
             // priority is strictly greater, so the first of my smallest pushes becomes the root iff its priority is smaller than the
