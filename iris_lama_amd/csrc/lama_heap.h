@@ -26,7 +26,7 @@
 
 namespace lama_dev {
 
-LAMA_HD uint32_t heap_prio(uint64_t e) { return (uint32_t)(e >> 48); }
+LAMA_HD uint32_t heap_prio(uint64_t e) { return (uint32_t)(e >> 32) >> 16; }      // (of the high word: a 32-bit shift and 32-bit compares on the device)
 // compare_prio(left, right): left.first > right.first
 LAMA_HD bool heap_comp(uint64_t l, uint64_t r) { return heap_prio(l) > heap_prio(r); }
 

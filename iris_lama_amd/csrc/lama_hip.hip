@@ -932,7 +932,10 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 hipLaunchKernelGGL(k_early_list, dim3(1), dim3(256), 0, c->stream, prev_ok ? (const uint8_t*)c->d_heavy : (const uint8_t*)nullptr,
                                    (const uint32_t*)c->d_hlist, host_n, c->d_early, c->d_elist, c->d_slow_n + 4, (int)c->P, route_places(c, count));
             { const int32_t ra = launch_allocation_phase(c, prm, n, first, count, 0); if (ra) return ra; }
-            const unsigned gy = count <= 64 ? 128u : 32u;        // patches of a particle in flight at once
+            // workgroups per particle = patches of a particle in flight at once.  A chip full of particles needs no more parallelism
+            // inside one: 8 instead of 32 workgroups per particle (each then walks ~8 of its ~65 patches behind ONE prologue) took the
+            // ray-cast of the 3000-particle pool from 1.31 to 1.24 ms (round 6); 4 and 16 are within noise of it, 64 is slower
+            const unsigned gy = count <= 64 ? 128u : (count >= 1024 ? 8u : 32u);
             if (early_lane) {
                 // The early lane's own ray-cast kernels run HERE, on an otherwise idle chip (~0.1 ms for a few particles); its
                 // brushfire goes to a stream of its own.  The main lane's 96 k-workgroup launches must not reach the dispatcher before

@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
         const uint32_t cand = opq(innerm & go & m_lt(parent, lim));  // my parent has both children
         const uint32_t la = 1u + (lm1 & cand);
         const uint64_t vl = h[la], vr = h[la + 1];
-        const uint32_t pl = opq((uint32_t)(vl >> 32)) >> 16, pr = opq((uint32_t)(vr >> 32)) >> 16;
+        const uint32_t pl = (uint32_t)(vl >> 32) >> 16, pr = (uint32_t)(vr >> 32) >> 16;
         const uint32_t take_left = m_lt(pl, pr);                     // __adjust_heap: right unless prio(right) > prio(left)
         const uint32_t step = opq(cand & ~(take_left ^ leftm));      // it steps to me
         const unsigned long long okm = __ballot(step != 0u);
@@ -1802,9 +1802,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)s, 4);
                 const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
                 const uint32_t cos_ = (uint32_t)__builtin_amdgcn_readlane((int)s, 5);
-                const int cox = obs_x(cob), coy = obs_y(cob);
-                const bool stale = (cox != eox) | (coy != eoy);
-                const bool fire0 = ((cs & SV_VALID) != 0u) & ((cs & SV_QUEUED) != 0u);      // :183, lower() :283
+                // (one compare of the packed offsets, one of both flags: this test is scalar code on the chain of every pop)
+                const bool stale = cob != pack_obs(eox, eoy);
+                const bool fire0 = (cs & (uint32_t)(SV_VALID | SV_QUEUED)) == (uint32_t)(SV_VALID | SV_QUEUED);      // :183, lower() :283
                 general = (unk != 0ull) | (fire0 & stale);
                 BFT(1); BFF(1);
 #ifdef LAMA_PROFILE_BF_COUNT
@@ -1868,12 +1868,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #ifdef LAMA_PROFILE_BF_COUNT
             prof[0] += 1; prof[1] += general ? 1 : 0;
 #endif
-            if (__builtin_expect(general, 0)) cnt = general_pop(e, over, entry);
-#ifndef LAMA_WAVE_SIM
-            // (wave-uniform by construction -- ballots and lane-4 / lane-5 values --, but the general code reaches them through per-lane
-            // loads: said here, the queue length, the next-top test and the loop test stay on the scalar unit)
-            cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
-            floor_sq = (uint32_t)__builtin_amdgcn_readfirstlane((int)floor_sq);
+            // (the count is wave-uniform by construction -- a ballot's population --, but the general code reaches it through per-lane
+            // loads: said where it happens, so that the queue length, the next-top test and the loop test stay on the scalar unit)
+#ifdef LAMA_WAVE_SIM
+            if (general) cnt = general_pop(e, over, entry);
+#else
+            if (__builtin_expect(general, 0)) cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)general_pop(e, over, entry));
 #endif
             BFT(3);
             // ---- hand-over: the push list is in the mailbox; meet the helper (its pop is done) and derive the next top from the root
