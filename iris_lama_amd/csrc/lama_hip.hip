@@ -157,6 +157,7 @@ struct lama_hip_ctx {
     hipStream_t stream2 = nullptr; hipEvent_t ev_route = nullptr, ev_heavy = nullptr;
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     bool route_forced = false; uint32_t num_cus = 256;
+    bool debug_tail = false, debug_window = false;      // LAMA_HIP_DEBUG_TAIL / LAMA_HIP_DEBUG_WINDOW, read at creation
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
@@ -364,7 +365,7 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             uint64_t mx = 0, sum = 0; uint32_t arg = 0;
             for (uint32_t p = 0; p < c->P; ++p) { sum += st[4 * p + 3]; if (st[4 * p + 3] > mx) { mx = st[4 * p + 3]; arg = p; } }
             c->ctr.bf_longest_chain_sum += mx; c->ctr.bf_longest_chain_last = mx;
-            if (std::getenv("LAMA_HIP_DEBUG_TAIL")) {
+            if (c->debug_tail) {
                 // (how well would the scan match's log-likelihood have predicted the longest chain? its rank among the pool, 0 = lowest)
                 uint32_t rank = 0; double ll = 0, mean_ll = 0;
                 if (c->h_results.size() >= c->results_bytes && c->P > 1) {
@@ -769,7 +770,7 @@ int32_t ensure_window(lama_hip_ctx* c, int64_t x0, int64_t x1, int64_t y0, int64
     if (!c->mb_valid) { c->mbx0 = x0; c->mbx1 = x1; c->mby0 = y0; c->mby1 = y1; c->mb_valid = true; }
     else { c->mbx0 = std::min(c->mbx0, x0); c->mbx1 = std::max(c->mbx1, x1); c->mby0 = std::min(c->mby0, y0); c->mby1 = std::max(c->mby1, y1); }
     const int64_t ox = c->wx0 >> 5, oy = c->wy0 >> 5, W = c->W;
-    if (std::getenv("LAMA_HIP_DEBUG_WINDOW")) std::fprintf(stderr, "ensure_window: box x [%ld, %ld] y [%ld, %ld] mapped x [%ld, %ld] y [%ld, %ld] window x [%ld, %ld) y [%ld, %ld)\n", (long)x0, (long)x1, (long)y0, (long)y1, (long)c->mbx0, (long)c->mbx1, (long)c->mby0, (long)c->mby1, (long)ox, (long)(ox + W), (long)oy, (long)(oy + W));
+    if (c->debug_window) std::fprintf(stderr, "ensure_window: box x [%ld, %ld] y [%ld, %ld] mapped x [%ld, %ld] y [%ld, %ld] window x [%ld, %ld) y [%ld, %ld)\n", (long)x0, (long)x1, (long)y0, (long)y1, (long)c->mbx0, (long)c->mbx1, (long)c->mby0, (long)c->mby1, (long)ox, (long)(ox + W), (long)oy, (long)(oy + W));
     if (c->mbx0 >= ox && c->mbx1 < ox + W && c->mby0 >= oy && c->mby1 < oy + W) return LAMA_HIP_OK;
     const int64_t span = std::max(c->mbx1 - c->mbx0 + 1, c->mby1 - c->mby0 + 1);
     int64_t newW = W;
@@ -1169,6 +1170,10 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     std::memset(&c->ctr, 0, sizeof(c->ctr));
     c->P = cfg.particles; c->W = cfg.window_patches; c->WC = c->W * 32;
     c->ctr.window_patches = c->W;
+    // developer switches, read ONCE here (never on the path of an update): LAMA_HIP_DEBUG_TAIL / LAMA_HIP_DEBUG_WINDOW print what the
+    // longest chain / the window did; LAMA_HIP_BF_ROUTE overrides the routing thresholds (tests, experiments)
+    c->debug_tail = std::getenv("LAMA_HIP_DEBUG_TAIL") != nullptr;
+    c->debug_window = std::getenv("LAMA_HIP_DEBUG_WINDOW") != nullptr;
     if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
         unsigned a = 0, b = 0, pc = 0, d = 0, e = 1;
         if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; c->early_min_count = 0; c->route_forced = true; }
