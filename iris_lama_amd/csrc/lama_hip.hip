@@ -936,7 +936,11 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             // workgroups per particle = patches of a particle in flight at once.  A chip full of particles needs no more parallelism
             // inside one: 8 instead of 32 workgroups per particle (each then walks ~8 of its ~65 patches behind ONE prologue) took the
             // ray-cast of the 3000-particle pool from 1.31 to 1.24 ms (round 6); 4 and 16 are within noise of it, 64 is slower
+#ifdef LAMA_WAVE_SIM
+            const unsigned gy = 4u;                              // (tests/sim runs every thread as a fiber: 128 mostly idle workgroups per particle cost it minutes)
+#else
             const unsigned gy = count <= 64 ? 128u : (count >= 1024 ? 8u : 32u);
+#endif
             if (early_lane) {
                 // The early lane's own ray-cast kernels run HERE, on an otherwise idle chip (~0.1 ms for a few particles); its
                 // brushfire goes to a stream of its own.  The main lane's 96 k-workgroup launches must not reach the dispatcher before

@@ -35,7 +35,11 @@ inline wsim_tidx wsim_thread_idx() { const wsim::Block* b = wsim::blk(); const u
 #define __builtin_amdgcn_readlane(v, l) wsim::readlane((int)(v), (int)(l), __LINE__)
 #define __builtin_amdgcn_readfirstlane(v) wsim::readfirstlane((int)(v), __LINE__)
 #define __builtin_amdgcn_update_dpp(old, src, ctrl, rm, bm, bc) wsim::dpp((int)(old), (int)(src), (ctrl), (rm), (bm), (bc), __LINE__)
-#define __builtin_amdgcn_fence(...) ((void)0)
+// A wavefront-scope fence says "this wave's earlier stores are visible to its later loads" -- on the device that holds between LANES
+// too, because a wave issues its memory instructions in program order; for cooperative fibers it has to be a rendezvous (round 6:
+// the one-wave brushfire loops have nothing else between the stores of one pop and the loads of the next, and a fiber that ran
+// ahead read cells its neighbours had not written yet -- found by the randomised small-room cases, never on the device)
+#define __builtin_amdgcn_fence(...) ((void)__ballot(true))
 #define __builtin_amdgcn_s_sleep(n) wsim::yield()
 #define __builtin_readcyclecounter() wsim::clock()
 #define __syncthreads() wsim::syncthreads()
@@ -111,7 +115,7 @@ inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms =
 
 // kernel launch: every argument is copied once (as the device would receive it), every thread calls the kernel with the copies
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
-    wsim::launch(wsim::dim3s(grid), wsim::dim3s(block), [=]() { (kernel)(__VA_ARGS__); })
+    wsim::launch_named(#kernel, wsim::dim3s(grid), wsim::dim3s(block), [=]() { (kernel)(__VA_ARGS__); })
 
 // ---- small vector types / bit casts / scoped atomic loads ----------------------------------------------------------------------
 struct alignas(16) uint4 { unsigned x, y, z, w; };
