@@ -158,6 +158,7 @@ struct lama_hip_ctx {
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     bool route_forced = false; uint32_t num_cus = 256;
     bool debug_tail = false, debug_window = false;      // LAMA_HIP_DEBUG_TAIL / LAMA_HIP_DEBUG_WINDOW, read at creation
+    uint32_t big_stage_pad = 0;                         // dynamic LDS added to the early lane's big-queue workgroups (a FULL chip) so that a long chain has its CU to itself
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
     lama_dev::RayRec* d_rrec = nullptr; uint64_t* d_rbbox = nullptr; lama_dev::RayChunk* d_rchunk = nullptr; size_t rrec_cap = 0;
@@ -958,7 +959,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 HIPCHK(c, hipStreamWaitEvent(c->stream3, c->ev_alloc, 0));
                 hipLaunchKernelGGL(k_mark_early, dim3(1), dim3(64), 0, c->stream3, pe);
                 HIPCHK(c, hipEventRecord(c->ev_go, c->stream3));
-                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(eg), dim3(2 * UM_BLOCK), 0, c->stream3, pe, 0, 2);
+                hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(eg), dim3(2 * UM_BLOCK), c->big_stage_pad, c->stream3, pe, 0, 2);
                 HIPCHK(c, hipEventRecord(c->ev_early, c->stream3));
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_go, 0));
                 prm.early = c->d_early;                          // everybody else: the main lane skips them
@@ -1178,6 +1179,17 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // longest chain / the window did; LAMA_HIP_BF_ROUTE overrides the routing thresholds (tests, experiments)
     c->debug_tail = std::getenv("LAMA_HIP_DEBUG_TAIL") != nullptr;
     c->debug_window = std::getenv("LAMA_HIP_DEBUG_WINDOW") != nullptr;
+    {   // A long chain that shares its CU with six first-stage workgroups runs at 0.79 us per pop, alone at 0.75 (and 0.65 on an idle
+        // chip): the routed / early big-queue workgroups of a full chip ask for the REST of the CU's LDS as dynamic shared memory, so
+        // nothing else is placed beside them (workgroups of that launch without a list entry exit at once and free their CU).
+        // 3000 particles: brushfire 4.31 -> 4.10 ms, step 6.36 -> 6.17 ms (round 6); 120 KB instead of the whole CU: no gain.  Only the
+        // EARLY lane's launch is padded -- the chains predicted to be the longest; padding the routed launch as well (up to 64 places
+        // when many particles re-draw their walls, e.g. after every resample) takes more LDS than the first stage can spare and
+        // measured 0.5 - 1 % slower.
+        constexpr uint32_t CU_LDS = 160u * 1024u, GRAN = 1280u;
+        const uint32_t used = (uint32_t)((sizeof(lama_dev::BfLds<LQ_BIG, RQ_BIG>) + GRAN - 1) / GRAN * GRAN);
+        c->big_stage_pad = CU_LDS > used + 2u * GRAN ? CU_LDS - used - 2u * GRAN : 0u;
+    }
     if (const char* rr = std::getenv("LAMA_HIP_BF_ROUTE")) {      // "min particles,min events,percent of the mean,places" (tests, experiments; places 0: off)
         unsigned a = 0, b = 0, pc = 0, d = 0, e = 1;
         if (std::sscanf(rr, "%u,%u,%u,%u,%u", &a, &b, &pc, &d, &e) >= 4) { c->route_min_count = a; c->route_min_events = b; c->route_percent = pc; c->route_cap = std::min(d, 256u); c->early_on = e; c->early_min_count = 0; c->route_forced = true; }
