@@ -255,3 +255,33 @@ def test_randomized_rooms_on_the_simulator(Fsim, seed):
     rendezvous of the fibers, tests/sim/hip/hip_runtime.h; 40 of 40 such cases are exact on the device.)"""
     from _stress import random_rooms_case
     random_rooms_case(Fsim, seed, small=True)
+
+
+def test_seventy_particles_outgrow_their_regions_together(Fsim):
+    """set_capacities moves the particles that outgrow their regions in groups of 64, ordered by the stream, and a region
+    released by one group may be handed to the next.  70 particles with regions of 8 patches, a resample with many clones, then an
+    update that makes all of them grow (two groups, regions recycled through the allocator) -- the device-side checksums of both maps
+    of every particle equal the oracle's, a sample is compared cell by cell."""
+    F, P = Fsim, 70
+    pts, odom, truth = F.corridor_log(1, 36)                     # (sparse scans: the simulator pays ~0.3 ms per brushfire pop)
+    pose0 = O.se2(*odom[0])
+    pf = O.PF(O.default_options(particles=P, seed=3))
+    pf.set_prior(pose0)
+    pf.update(pts[0], pose0)
+    ctx = F.HipContext(F.default_cfg(particles=P, device=0, dm_patch_capacity=8, occ_patch_capacity=8))
+    ctx.init(pts[0], pose0)
+    rng = np.random.default_rng(2)
+    poses = np.stack([O.se2_mul(O.se2(*truth[1]), O.se2(*rng.normal(0, [0.3, 0.05, 0.03]))) for _ in range(P)])
+    pf.set_poses(poses); ctx.set_poses(poses)
+    idx = np.sort(rng.integers(0, P, size=P)).astype(np.int32)
+    pf.stage_resample_with(idx); ctx.resample(idx)
+    pf.stage_set_scan(pts[1]); pf.stage_update_maps()
+    ctx.update_maps(pts[1])
+    assert np.array_equal(ctx.map_checksums(F.MAP_DISTANCE), pf.map_checksums(0)), "distance maps"
+    assert np.array_equal(ctx.map_checksums(F.MAP_OCCUPANCY), pf.map_checksums(1)), "occupancy maps"
+    for i in (0, 33, 64, 69):
+        assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"occ p{i}")
+        assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"dm p{i}")
+    c = ctx.counters()
+    assert c["arena_growths"] >= 1 and c["resample_clones"] > P - 1, c
+    ctx.close()
