@@ -677,7 +677,6 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
     __shared__ uint32_t lds_dc[2 * DC_SIZE];
     const int p = first_particle + blockIdx.x;
     const int lane = threadIdx.x;
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview(prm, p);
     int16_t* dm_dir = pv.dm_dir;
     int16_t* occ_dir = pv.occ_dir;
@@ -1262,7 +1261,6 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     const uint32_t handed = RESUME ? prm.slow[p] : 1u;   // resume stage: only particles an earlier stage handed over
     const int lane = threadIdx.x & 63;
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview_w(prm, p);                             // (p is wave-uniform, both waves are complete here)
     int16_t* dir = pv.dm_dir;
     uint16_t* sv = pv.dm_sv;

@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
     const int lane = threadIdx.x & 63;
     const bool live = i < n;
     const int ic = live ? i : n - 1;
-    const size_t WW = (size_t)prm.W * prm.W;
     double T[12];
     uload_f64_w<12>(tfs + 12 * (size_t)p, T);                 // (rewritten by the host before every update: coherent uniform loads, lama_dev.h)
     const BeamGeom g = beam_geometry(prm, T, pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);

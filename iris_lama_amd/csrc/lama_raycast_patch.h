@@ -156,7 +156,6 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
     if (!(r.nnf & (1u << 18))) return;
     const uint32_t steps = (r.nnf & 0xFFFFu) - 1u;
     const uint32_t t0 = 1u + (uint32_t)(((uint64_t)steps * (uint32_t)seg) / RW_SEG), t1 = (uint32_t)(((uint64_t)steps * (uint32_t)(seg + 1)) / RW_SEG);
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview(prm, p);
     int16_t* occ_dir = pv.occ_dir;
     if (t0 > t1) return;
