@@ -370,6 +370,7 @@ __device__ inline int lane_particle(const DevParams& prm, int first_particle, in
 {
     if (prm.elist) return bx < (int)uload_u32(prm.elist_n) ? (int)uload_u32(prm.elist + bx) : -1;     // (bx is the workgroup's index; the list is another stream's kernel's)
     const int p = first_particle + bx;
+    if (p >= (int)prm.P) return -1;                 // (two-dimensional launches round their particle dimension up to a multiple of 8: see xcd_grid)
     return (prm.early && prm.early[p]) ? -1 : p;
 }
 

@@ -812,6 +812,16 @@ int32_t fit_window(lama_hip_ctx* c, const Affine& mtf, uint32_t first, uint32_t 
     return ensure_window(c, patch(xlo), patch(xhi), patch(ylo), patch(yhi));
 }
 
+// The dispatcher hands workgroup number b of a launch to XCD b mod 8, and every XCD has its own L2.  A one-dimensional launch with a
+// workgroup per particle therefore keeps particle p on XCD p mod 8 in every kernel of an update; a two-dimensional one (particle,
+// something) does so only when its particle dimension is a multiple of 8 -- else the workgroups of one particle are spread over all
+// XCDs and the brushfire finds none of its cells in the L2 its ray-cast wrote them through.  Launches over the whole pool round the
+// particle dimension up (the kernels skip particles >= P).
+static unsigned xcd_grid(const lama_hip_ctx* c, uint32_t first, uint32_t count)
+{
+    return (first == 0 && count == c->P) ? (count + 7u) / 8u * 8u : count;
+}
+
 // allocation phase of a map update (ray records, hit cells' patches, the patches the rays cross, the bound on the distance-map patches
 // still to come): afterwards either every patch the update needs exists or an error bit is set and no map cell has been modified
 int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t n, uint32_t first, uint32_t count, int alloc_only)
@@ -824,10 +834,10 @@ int32_t launch_allocation_phase(lama_hip_ctx* c, const DevParams& prm, uint32_t 
         HIPCHK(c, hipMalloc(&c->d_rchunk, (size_t)c->P * ((n + 63) / 64) * sizeof(lama_dev::RayChunk)));     // per 64 beams of a particle
         c->rrec_cap = need;
     }
-    hipLaunchKernelGGL(k_ray_hits, dim3(count, (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
+    hipLaunchKernelGGL(k_ray_hits, dim3(xcd_grid(c, first, count), (n + 255) / 256), dim3(256), 0, c->stream, prm, c->d_pts, (int)n, c->d_tfs, (int)first,
                        c->d_rrec, c->d_rbbox, alloc_only, c->d_rchunk);
     const int rw_seg = count <= 64 ? 4 : 1;
-    hipLaunchKernelGGL(k_ray_alloc_walk, dim3(count, (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
+    hipLaunchKernelGGL(k_ray_alloc_walk, dim3(xcd_grid(c, first, count), (n * rw_seg + 255) / 256), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec, (int)n, (int)first, rw_seg);
     double far = c->scan_reach;                                   // no cell further than truncated_range from the sensor is touched
     if (c->cfg.truncated_range > 0.0) far = std::min(far, c->cfg.truncated_range);
     const int reach_cells = (int)std::ceil(far * c->scale) + 2;
@@ -964,7 +974,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
                 HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_go, 0));
                 prm.early = c->d_early;                          // everybody else: the main lane skips them
             }
-            hipLaunchKernelGGL(k_ray_patches, dim3(count, gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
+            hipLaunchKernelGGL(k_ray_patches, dim3(xcd_grid(c, first, count), gy), dim3(256), 0, c->stream, prm, (const lama_dev::RayRec*)c->d_rrec,
                                (const uint64_t*)c->d_rbbox, (const lama_dev::RayChunk*)c->d_rchunk, (int)n, (int)first);
             const unsigned resume_grid = std::min<unsigned>(count, 256u);       // walks the (usually empty) hand-over list
             if (count <= 512) {

@@ -2371,7 +2371,6 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
 {
     const int p = first_particle + blockIdx.x;
     if (prm.slow[p] == 0 || threadIdx.x != 0) return;
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview(prm, p);
     BfCtx c{prm, pv.dm_dir, pv.dm_sv, pv.dm_obs, pv.dm_mask, prm.counts[2 * p], (int)pv.dm_cap,
             GlobalStore{prm.q_lower + (size_t)p * prm.qcap}, GlobalStore{prm.q_raise + (size_t)p * prm.qcap},
@@ -2418,7 +2417,6 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
 {
     __shared__ uint32_t lds_dc[DC_SIZE];
     const int lane = threadIdx.x;
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview(prm, p);
     int16_t* dm_dir = pv.dm_dir;
     uint16_t* dm_sv = pv.dm_sv;

@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256) void k_ray_hits(DevParams prm, const double* _
                                                    RayChunk* __restrict__ chunk_out = nullptr)
 {
     const int p = first_particle + blockIdx.x;
+    if (p >= (int)prm.P) return;                    // (the particle dimension of the grid is rounded up to a multiple of 8: xcd_grid)
     const int i = blockIdx.y * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const bool live = i < n;
@@ -339,7 +340,6 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         }
         return;
     }
-    const size_t WW = (size_t)prm.W * prm.W;
     const PV pv = pview_w(prm, p);
     int16_t* occ_dir = pv.occ_dir;
     int16_t* dm_dir = pv.dm_dir;

@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_ray_alloc_walk(DevParams prm, const Ray
     const int p = first_particle + blockIdx.x;
     const int g = blockIdx.y * 256 + threadIdx.x;
     const int i = g / RW_SEG, seg = g % RW_SEG;
-    if (i >= n) return;
+    if (i >= n || p >= (int)prm.P) return;          // (the particle dimension of the grid is rounded up to a multiple of 8: xcd_grid)
     const RayRec r = recs[(size_t)p * n + i];
     if (!(r.nnf & (1u << 18))) return;
     const uint32_t steps = (r.nnf & 0xFFFFu) - 1u;
@@ -291,7 +291,6 @@ __global__ __launch_bounds__(256, 6) void k_ray_patches(DevParams prm, const Ray
     if (map_update_aborted(prm)) { if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) atomicOr(prm.err, ERR_CLEAN_ABORT); return; }
     if (p < 0) return;                                             // (another lane's particle)
     const int count = prm.counts[2 * p + 1];
-    const size_t WW = (size_t)prm.W * prm.W;
     const PVOcc pv = pview_occ_w(prm, p);
     uint32_t* occ = pv.occ;
     const RayRec* prec = recs + (size_t)p * n;
