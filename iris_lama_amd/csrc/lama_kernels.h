@@ -1175,6 +1175,29 @@ __device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const
     for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
 }
 
+// the same when the caller holds the (wave-uniform) count in a register: the one-wave form of the straight-line pop pushes its own
+// mailbox without the round trip through the count word
+__device__ __forceinline__ void lds_push_flat_n(uint64_t* heap, uint32_t& n, const uint64_t* ent, const uint32_t cnt, const int lane, uint64_t* dummy)
+{
+    if (cnt == 0) return;
+    const uint32_t l4 = (uint32_t)lane & 3u;
+    const uint64_t entry = ent[l4];
+    const uint32_t pos = n + l4;
+    const uint32_t pprio = heap_prio(heap[n >= 4 ? (pos - 1) / 2 : 0]);
+    const bool mine = (uint32_t)lane < cnt;
+    const bool up = mine && pprio > heap_prio(entry);
+    const unsigned long long upm = __ballot(up);
+    if (n >= 4 && upm == 0ull) {
+        uint64_t* dst = mine ? heap + pos : dummy;
+        *dst = entry;
+        n += cnt;
+        LAMA_LOCKSTEP();
+        return;
+    }
+    #pragma unroll 1
+    for (uint32_t i = 0; i < cnt; ++i) lds_push(heap, n, ent[i], lane == 0);
+}
+
 // push_heap of `cnt` (<= 4) entries ent[0 .. cnt), in order.  Fast path: one gather of all would-be parents; if none of the new
 // entries has to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply appended, exactly
 // what the sequential push_heap calls would have done.  Returns true if the entries were appended unmoved.
@@ -1664,7 +1687,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     }
 
     // ---- lower wave of the wave pair (round 4: speculative straight-line pop, general code for the rare cases) ---- :175-194
-    if (TW) {
+    // Round 6: the same straight-line pop as a ONE-WAVE form (TW == false): the wave pops its heap itself (lds_pop_flat, issued under
+    // the cell loads) and pushes its own mailbox -- no helper wave, no barrier, no second copy of the loop control.  Fewer
+    // instructions per pop in total than the pair, a longer chain per pop: the form for a chip that is full of particles, where the
+    // instruction streams of the pairs compete for the same issue slots (section 8 of DESIGN.md).
+    constexpr bool PAIR = TW;
+    if (TW || !spill) {
+        if (!TW) { tw_running = nl > 0; if (tw_running) e_next = uniform_u64(sh.lower[0]); }
         BFT(7);                                                    // (profiling build: everything before the lower wave)
         uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
         const BufRsrc rsv = buf_make(sv, dm_cap * 2048u), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
@@ -1751,7 +1780,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             // vector -> scalar hand-overs behind the barrier, on the chain of every pop
             const uint64_t e = uniform_u64(e_next);
             ++processed;
-            --nl;                                                          // the helper wave pops
+            if (PAIR) --nl;                                                // the helper wave pops
             uint32_t cnt = 0;
             bool general;
             uint32_t floor_sq = 0;                                         // every push of this pop has a priority above this
@@ -1796,6 +1825,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t mask_bit_lo = pin((ci & 32u) ? 0u : (1u << (ci & 31u))), mask_bit_hi = pin((ci & 32u) ? (1u << (ci & 31u)) : 0u);
                 const uint64_t mask_bit = ((uint64_t)mask_bit_hi << 32) | mask_bit_lo;
                 BFT(0); BFF(0);
+                if (!PAIR) {                                               // one-wave form: pop() of the heap while the cell loads are in flight
+                    if (LQ_LDS > 2047 && nl > 2047u) lds_pop_flat<3>(sh.lower, nl, lane, anc, &sh.topq[tw_it & 1u], dmy);
+                    else lds_pop_flat<2>(sh.lower, nl, lane, anc, &sh.topq[tw_it & 1u], dmy);
+                }
                 // the popped cell, and the obstacle cell it pointed to when it was queued
                 const uint32_t cs = (uint32_t)__builtin_amdgcn_readlane((int)s, 4);
                 const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
@@ -1883,10 +1916,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             // the quad of neighbour lanes, DPP) is compared with it.
             {
                 const uint32_t b_ = tw_it & 1u;
-                uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)dmy;
-                *np = cnt;
+                if (PAIR) {
+                    uint32_t* np = lane == 0 ? &sh.pl_n[b_] : (uint32_t*)dmy;
+                    *np = cnt;
+                }
                 BFT_MAIN(5); BFF(6);
-                lds_barrier();                                     // D
+                if (PAIR) lds_barrier();                           // D
+                else LAMA_LOCKSTEP();                              // (one wave: its LDS accesses are in order; the fibers of the simulator meet here)
                 BFT_MAIN(6);
                 const uint64_t root_ = sh.topq[b_];
                 const uint32_t rlo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)root_), rhi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(root_ >> 32));
@@ -1912,7 +1948,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     const uint32_t olo = (uint32_t)__builtin_amdgcn_readfirstlane((int)blo), ohi = (uint32_t)__builtin_amdgcn_readfirstlane((int)bhi);
                     if (!have_root || (okey >> 2) < (rhi >> 16)) e_next = ((uint64_t)ohi << 32) | olo;
                 }
-                nl += cnt;
+                if (PAIR) nl += cnt;
+                else lds_push_flat_n(sh.lower, nl, sh.pl_e[b_], cnt, lane, dmy);      // (the next top was derived above, as in the pair)
                 ++tw_it;
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
