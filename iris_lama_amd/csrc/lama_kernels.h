@@ -1132,7 +1132,7 @@ __device__ __forceinline__ void lds_pop_flat(uint64_t* h, uint32_t& size, const 
     }
     // the hole has a lone left child, the array's last entry (rare: only when the descent ran to the very end of the array)
     const bool up = go != 0u && (len & 1u) == 0u && H == (len - 2) / 2 && heap_prio(tailc) <= vprio;
-    if (up) {
+    if (__builtin_expect(up, 0)) {                                   // (rare: laid out of line, the common path falls through)
         if (lane == 0) { h[H] = tailc; if (H == 0) *root_out = tailc; }
         root_value = root_value && H != 0;
         H = len - 1;
@@ -1164,7 +1164,7 @@ __device__ __forceinline__ void lds_push_flat(uint64_t* heap, uint32_t& n, const
     const unsigned long long upm = __ballot(up);
     const uint32_t cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt_v);
     if (cnt == 0) return;
-    if (n >= 4 && upm == 0ull) {
+    if (__builtin_expect(n >= 4 && upm == 0ull, 1)) {
         uint64_t* dst = mine ? heap + pos : dummy;
         *dst = entry;
         n += cnt;
@@ -1841,7 +1841,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
 #ifdef LAMA_PROFILE_BF_COUNT
                 prof[2] += unk != 0ull ? 1 : 0; prof[3] += (fire0 & stale) ? 1 : 0; prof[6] += (fire0 & ((cos_ & SV_SQMASK) == 0u)) ? 1 : 0;
 #endif
-                if (__builtin_expect(!general, 1) && fire0 && (cos_ & SV_SQMASK) == 0u) {   // :191 (valid NOT tested)
+                if (__builtin_expect(!general && fire0 && (cos_ & SV_SQMASK) == 0u, 1)) {   // :191 (valid NOT tested); the likely path, so that it is laid out in line: two taken branches less per firing pop
                     floor_sq = cs & SV_SQMASK;                                           // lower() :303: candidates of cells further from the obstacle
                     const uint32_t nbok = away & ~absent;                                // (cox == eox, coy == eoy here: not stale)
                     const uint32_t ssq = s & SV_SQMASK;
