@@ -581,7 +581,8 @@ __global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int par
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
     const uint16_t* sv = pv_.dm_sv;
-    const double tx = base.t[0] + xy[2 * k], ty = base.t[1] + xy[2 * k + 1];
+    // (xy is rewritten by the host before every call: a coherent load, not the s_load a uniform read of it would become)
+    const double tx = base.t[0] + cload_f64(xy + 2 * k), ty = base.t[1] + cload_f64(xy + 2 * k + 1);
     const int nterms = (n + step - 1) / step;
     for (int j = threadIdx.x; j < nterms; j += 64) {
         const int i = j * step;

@@ -51,44 +51,86 @@ def demangle(names):
 
 
 def scan(lines):
-    """-> {kernel: [(line number, instruction, 'kernarg' | 'device')]}"""
+    """-> {kernel: [(line number, instruction, 'kernarg' | 'device')]}
+
+    Provenance of scalar registers: a register holds ('k', id, half) when it is half `half` of kernarg-derived pointer number `id`
+    (the kernarg segment pointer s[0:1] itself, a copy of it, or kernarg + constant: the hidden arguments); copies by s_mov, the
+    add / addc pair that forms kernarg + constant, and spills to VGPR lanes (v_writelane / v_readlane) carry it along; every other
+    write to a register clears it.  A scalar load is a kernel-argument load iff both halves of its base pair carry the same id."""
     res = collections.OrderedDict()
-    kern, kernarg = None, set()
+    kern, prov, spill, next_id, pending = None, {}, {}, 1, None
+
+    def is_karg(lo, hi):
+        a, b = prov.get(lo), prov.get(hi)
+        return a is not None and b is not None and a[1] == b[1] and a[2] == 0 and b[2] == 1
+
     for i, l in enumerate(lines):
         m = re.match(r"^(_Z\w+):", l)
         if m:
-            kern, kernarg = m.group(1), {(0, 1)}
+            kern, prov, spill, next_id, pending = m.group(1), {0: ("k", 0, 0), 1: ("k", 0, 1)}, {}, 1, None
             res[kern] = []
             continue
         if kern is None:
             continue
         t = l.strip()
-        m = re.match(r"s_mov_b64\s+s\[(\d+):(\d+)\],\s*s\[(\d+):(\d+)\]", t)
-        if m:
-            dst, src = (int(m.group(1)), int(m.group(2))), (int(m.group(3)), int(m.group(4)))
-            if src in kernarg:
-                kernarg.add(dst)
-            else:
-                kernarg.discard(dst)
+        if not t or t.startswith((";", ".")):
             continue
         m = re.match(r"(s_load_dword\w*|s_buffer_load_dword\w*)\s+(s\d+|s\[\d+:\d+\]),\s*s\[(\d+):(\d+)\]", t)
         if m:
-            base = (int(m.group(3)), int(m.group(4)))
-            res[kern].append((i + 1, t, "kernarg" if base in kernarg else "device"))
-            # the destination overwrites whatever the registers held
+            res[kern].append((i + 1, t, "kernarg" if is_karg(int(m.group(3)), int(m.group(4))) else "device"))
             d = re.match(r"s\[(\d+):(\d+)\]", m.group(2))
             lo, hi = (int(d.group(1)), int(d.group(2))) if d else (int(m.group(2)[1:]),) * 2
-            for k in list(kernarg):
-                if k != (0, 1) and not (k[1] < lo or k[0] > hi):
-                    kernarg.discard(k)
+            for r in range(lo, hi + 1):
+                prov.pop(r, None)
             continue
-        # any other write to a tracked pair ends its life as a kernarg copy
-        m = re.match(r"s_\w+\s+s\[(\d+):(\d+)\],", t) or re.match(r"s_\w+\s+s(\d+)(),", t)
-        if m and not t.startswith(("s_cmp", "s_cbranch", "s_waitcnt", "s_bitcmp")):
-            lo = int(m.group(1)); hi = int(m.group(2)) if m.group(2) else lo
-            for k in list(kernarg):
-                if k != (0, 1) and not (k[1] < lo or k[0] > hi):
-                    kernarg.discard(k)
+        m = re.match(r"s_mov_b64\s+s\[(\d+):(\d+)\],\s*s\[(\d+):(\d+)\]$", t)
+        if m:
+            d0, s0 = int(m.group(1)), int(m.group(3))
+            a, b = prov.get(s0), prov.get(s0 + 1)
+            prov.pop(d0, None); prov.pop(d0 + 1, None)
+            if a: prov[d0] = a
+            if b: prov[d0 + 1] = b
+            continue
+        m = re.match(r"s_mov_b32\s+s(\d+),\s*s(\d+)$", t)
+        if m:
+            a = prov.get(int(m.group(2)))
+            prov.pop(int(m.group(1)), None)
+            if a: prov[int(m.group(1))] = a
+            continue
+        m = re.match(r"s_add_u32\s+s(\d+),\s*s(\d+),\s*(0x[0-9a-f]+|\d+)$", t)
+        if m and prov.get(int(m.group(2)), (0, 0, 1))[2] == 0:
+            src = prov[int(m.group(2))]
+            prov.pop(int(m.group(1)), None)
+            pending = (int(m.group(1)), src[1], next_id)            # low half formed; the high half follows with s_addc_u32
+            prov[int(m.group(1))] = ("k", next_id, 0)
+            next_id += 1
+            continue
+        m = re.match(r"s_addc_u32\s+s(\d+),\s*s(\d+),\s*0$", t)
+        if m and pending and prov.get(int(m.group(2))) == ("k", pending[1], 1):
+            prov.pop(int(m.group(1)), None)
+            prov[int(m.group(1))] = ("k", pending[2], 1)
+            pending = None
+            continue
+        m = re.match(r"v_writelane_b32\s+v(\d+),\s*s(\d+),\s*(\d+)$", t)
+        if m:
+            a = prov.get(int(m.group(2)))
+            key = (int(m.group(1)), int(m.group(3)))
+            if a: spill[key] = a
+            else: spill.pop(key, None)
+            continue
+        m = re.match(r"v_readlane_b32\s+s(\d+),\s*v(\d+),\s*(\d+)$", t)
+        if m:
+            prov.pop(int(m.group(1)), None)
+            a = spill.get((int(m.group(2)), int(m.group(3))))
+            if a: prov[int(m.group(1))] = a
+            continue
+        # any other instruction that writes scalar registers ends their provenance
+        m = re.match(r"(?:s_|v_readfirstlane|v_readlane|v_cmp|v_cmpx)\S*\s+(s\[(\d+):(\d+)\]|s(\d+))\b", t)
+        if m and not t.startswith(("s_cmp", "s_cmpk", "s_cbranch", "s_branch", "s_waitcnt", "s_bitcmp", "s_barrier", "s_nop", "s_endpgm", "s_setprio", "s_sleep", "s_dcache")):
+            lo = int(m.group(2)) if m.group(2) else int(m.group(4))
+            hi = int(m.group(3)) if m.group(3) else lo
+            for r in range(lo, hi + 1):
+                prov.pop(r, None)
     return res
 
 
