@@ -62,7 +62,7 @@ __device__ inline int cn_slot(CanonLds& sh, uint32_t key)
 struct CnMap {
     const DevParams& prm;
     int p;
-    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask; int cap;
+    int16_t* dir; sv_t* sv; uint32_t* obs; uint64_t* mask; int cap;
     // side-effect free cell index (slot*1024 + ci) or -1 when the patch does not exist / outside the window
     __device__ inline int peek(int x, int y) const
     {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
                 const int nx = rx + DX[i], ny = ry + DY[i];
                 const int nc = M.get(nx, ny);
                 if (nc >= 0) {
-                    const uint16_t s = M.sv[nc];
+                    const sv_t s = M.sv[nc];
                     if (!(s & SV_QUEUED) && (s & SV_VALID)) {
                         const uint32_t o = M.obs[nc];
                         const int oc = M.peek(nx + obs_x(o), ny + obs_y(o));
@@ -156,13 +156,13 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
                 if (ts < 0) { sh.fail = 1; continue; }
                 if (atomicExch(&sh.tval[ts], 0u) != CN_EMPTY) continue;          // another frontier cell owns it
                 const int nc = M.peek(nx, ny);
-                const uint16_t s = M.sv[nc];
+                const sv_t s = M.sv[nc];
                 if (d == 1) {                                                    // its obstacle is gone: clear, raise further
                     M.sv[nc] = SV_QUEUED; M.obs[nc] = 0;
                     const uint32_t k = atomicAdd(&sh.n_b, 1u);
                     if (k < FCAP) fb[k] = nloc; else sh.fail = 1;
                 } else {                                                         // still has a live obstacle: re-lower from it
-                    M.sv[nc] = (uint16_t)(s | SV_QUEUED);
+                    M.sv[nc] = (sv_t)(s | SV_QUEUED);
                     const uint32_t k = atomicAdd(&sh.n_list, 1u);
                     const uint32_t o = M.obs[nc];
                     if (k < prm.qcap) list[k] = q_entry(s & SV_SQMASK, nx, ny, obs_x(o), obs_y(o)); else sh.fail = 1;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
                 }
             }
             const int cc = M.peek(rx, ry);
-            if (cc >= 0) M.sv[cc] = (uint16_t)(M.sv[cc] & ~SV_QUEUED);            // :278
+            if (cc >= 0) M.sv[cc] = (sv_t)(M.sv[cc] & ~SV_QUEUED);            // :278
         }
         __syncthreads();
         const uint32_t nn = sh.n_b < FCAP ? sh.n_b : FCAP;
@@ -200,14 +200,14 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
             ++processed;
             const int cc = M.peek(rx, ry);
             if (cc < 0) continue;
-            const uint16_t s = M.sv[cc];
+            const sv_t s = M.sv[cc];
             if (!(s & SV_VALID) || !(s & SV_QUEUED)) continue;
             const uint32_t o = M.obs[cc];
             const int oc = M.peek(rx + obs_x(o), ry + obs_y(o));
             if (oc < 0 || (M.sv[oc] & SV_SQMASK) != 0) continue;                 // :191 (valid NOT tested)
             const uint32_t k = atomicAdd(&sh.n_a, 1u);
             if (k < FCAP) fa[k] = (uint64_t)loc | ((uint64_t)o << 32); else sh.fail = 1;
-            M.sv[cc] = (uint16_t)(s & ~SV_QUEUED);                               // :329 (nothing reads it inside this level)
+            M.sv[cc] = (sv_t)(s & ~SV_QUEUED);                               // :329 (nothing reads it inside this level)
         }
         __syncthreads();
         if (tid == 0) sh.hist[lev] = 0;
@@ -250,17 +250,17 @@ __global__ __launch_bounds__(CN_BLOCK) void k_brushfire_canon(DevParams prm, int
                     const uint32_t cand = (uint32_t)(qx * qx + qy * qy);
                     const int ts = cn_slot(sh, ((uint32_t)ny << 16) | (uint32_t)nx);
                     if (ts < 0 || sh.tval[ts] != ((cand << 2) | (uint32_t)i)) continue;
-                    const uint16_t ns = M.sv[nc];
+                    const sv_t ns = M.sv[nc];
                     const uint32_t cmp = (ns & SV_VALID) ? (uint32_t)(ns & SV_SQMASK) : prm.max_sqdist;
                     bool over = cand < cmp;
                     if (!over && cand == (uint32_t)(ns & SV_SQMASK)) {
                         const uint32_t no = M.obs[nc];
                         const int oc = M.get(nx + obs_x(no), ny + obs_y(no));
-                        const uint16_t os = oc >= 0 ? M.sv[oc] : (uint16_t)0;
+                        const sv_t os = oc >= 0 ? M.sv[oc] : (sv_t)0;
                         if (!(ns & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
                     }
                     if (!over) continue;
-                    M.sv[nc] = (uint16_t)(SV_VALID | SV_QUEUED | (cand & SV_SQMASK));
+                    M.sv[nc] = (sv_t)(SV_VALID | SV_QUEUED | (cand & SV_SQMASK));
                     M.obs[nc] = pack_obs(obx - nx, oby - ny);
                     const uint32_t k = atomicAdd(&sh.n_list, 1u);
                     if (k < prm.qcap) list[k] = q_entry(cand, nx, ny, obx - nx, oby - ny); else sh.fail = 1;

@@ -33,6 +33,17 @@
 #include <stdint.h>
 #include <cstddef>
 
+// Two instantiations of the library (iris_lama_amd/Makefile): the default one, and -- compiled with -DLAMA_WIDE_DM into
+// liblama_hip_wide.so -- the one for a distance map whose l2_max lies beyond 127 cells, up to the 255 cells that the reference's own
+// records can hold (distance_t::sqdist is a uint16_t, include/lama/sdm/dynamic_distance_map.h:74-88: 255^2 = 65,025).  What differs:
+//   * plane A of the distance map is 4 bytes per cell instead of 2 (sv_t: flags in bits 31 / 30, the squared distance below);
+//   * a brushfire queue entry carries the obstacle offset in 9 + 9 bits and the cell in 15 + 15 (q_entry below).
+// Everything else -- kernels, queues, the heap (16-bit priorities), the host side -- is the same source; the kernels of the wide
+// build live in a namespace of their own so that both libraries can be loaded into one process.
+#ifdef LAMA_WIDE_DM
+#define lama_dev lama_dev_wide
+#endif
+
 #include "lama_heap.h"
 
 // The lanes of a wave execute in lock step on the device: "every lane reads X, then lane 0 overwrites X" needs no synchronisation
@@ -46,9 +57,23 @@
 
 namespace lama_dev {
 
+#ifdef LAMA_WIDE_DM
+typedef uint32_t sv_t;
+constexpr uint32_t SV_VALID = 0x80000000u;
+constexpr uint32_t SV_QUEUED = 0x40000000u;
+constexpr uint32_t SV_SQMASK = 0x3FFFFFFFu;
+constexpr int SV_VALID_BIT = 31;
+constexpr uint32_t MAX_OFFSET_CELLS = 255;        // |obstacle offset| a queue entry can carry
+#else
+typedef uint16_t sv_t;
 constexpr uint16_t SV_VALID = 0x8000;
 constexpr uint16_t SV_QUEUED = 0x4000;
 constexpr uint16_t SV_SQMASK = 0x3FFF;
+constexpr int SV_VALID_BIT = 15;
+constexpr uint32_t MAX_OFFSET_CELLS = 127;
+#endif
+constexpr uint32_t SV_BYTES = (uint32_t)sizeof(sv_t);         // per cell of plane A ...
+constexpr uint32_t SV_PATCH_BYTES = 1024u * SV_BYTES;         // ... and per patch
 
 constexpr int ERR_WINDOW = 1;
 constexpr int ERR_DM_CAP = 2;
@@ -69,7 +94,7 @@ struct Affine {            // rows 0..2 of [R | t]
 // where each plane of them starts (the host's region allocator places a region inside one chunk of the pool)
 struct PartRec {
     uint32_t home, dm_cap, occ_cap, r0;
-    uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
+    sv_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
     uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit;
     int32_t* rev;          // [occ_cap] region slot -> directory position, rebuilt per scan (k_occ_reverse_dir)
     uint64_t r1;
@@ -122,7 +147,7 @@ struct DevParams {
 // Particle p's view of the maps: its directories, its regions of the pooled planes (slot-relative addressing inside), capacities.
 struct PV {
     int16_t* dm_dir; int16_t* occ_dir;
-    uint16_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
+    sv_t* dm_sv; uint32_t* dm_obs; uint64_t* dm_mask;
     uint32_t* occ; uint64_t* occ_mask; uint64_t* occ_hit;
     int32_t* counts; int32_t* rev;
     uint32_t dm_cap, occ_cap;
@@ -254,7 +279,7 @@ __device__ inline PV pview(const DevParams& prm, int p)
     PV v;
     v.dm_dir = prm.dm_dir + (size_t)home * WW;
     v.occ_dir = prm.occ_dir + (size_t)home * WW;
-    v.dm_sv = (uint16_t*)part_u64(q + 2); v.dm_obs = (uint32_t*)part_u64(q + 3); v.dm_mask = (uint64_t*)part_u64(q + 4);
+    v.dm_sv = (sv_t*)part_u64(q + 2); v.dm_obs = (uint32_t*)part_u64(q + 3); v.dm_mask = (uint64_t*)part_u64(q + 4);
     v.occ = (uint32_t*)part_u64(q + 5); v.occ_mask = (uint64_t*)part_u64(q + 6); v.occ_hit = (uint64_t*)part_u64(q + 7);
     v.rev = (int32_t*)part_u64(q + 8);
     v.counts = prm.counts + 2 * (size_t)p;
@@ -284,7 +309,7 @@ __device__ inline PV pview_w(const DevParams& prm, int p)
     PV v;
     v.dm_dir = prm.dm_dir + (size_t)home * WW;
     v.occ_dir = prm.occ_dir + (size_t)home * WW;
-    v.dm_sv = (uint16_t*)LAMA_PART_Q(2); v.dm_obs = (uint32_t*)LAMA_PART_Q(3); v.dm_mask = (uint64_t*)LAMA_PART_Q(4);
+    v.dm_sv = (sv_t*)LAMA_PART_Q(2); v.dm_obs = (uint32_t*)LAMA_PART_Q(3); v.dm_mask = (uint64_t*)LAMA_PART_Q(4);
     v.occ = (uint32_t*)LAMA_PART_Q(5); v.occ_mask = (uint64_t*)LAMA_PART_Q(6); v.occ_hit = (uint64_t*)LAMA_PART_Q(7);
     v.rev = (int32_t*)LAMA_PART_Q(8);
 #undef LAMA_PART_Q
@@ -520,20 +545,20 @@ __device__ inline uint32_t w2m(const DevParams& prm, double v) { return (uint32_
 // Map::get (src/sdm/map.cpp:414-455): absent patch / mask bit off / !valid_obstacle -> max distance.
 // An off-bit cell is still all-zero, hence reads as !valid: the mask needs no separate test.
 __device__ inline double dm_distance_cell(const DevParams& prm, const int16_t* __restrict__ dir,
-                                          const uint16_t* __restrict__ sv, uint32_t x, uint32_t y)
+                                          const sv_t* __restrict__ sv, uint32_t x, uint32_t y)
 {
     const uint32_t rx = x - prm.wx0, ry = y - prm.wy0;
     if (rx >= prm.WC || ry >= prm.WC) return prm.maxdist;
     const int slot = dir[(ry >> 5) * prm.W + (rx >> 5)];
     if (slot < 0) return prm.maxdist;
-    const uint16_t v = sv[(uint32_t)slot * 1024u + ((rx & 31u) | ((ry & 31u) << 5))];
+    const sv_t v = sv[(uint32_t)slot * 1024u + ((rx & 31u) | ((ry & 31u) << 5))];
     if (!(v & SV_VALID)) return prm.maxdist;
     return sqrt((double)(v & SV_SQMASK)) * prm.resolution;
 }
 
 // DynamicDistanceMap::distance(Vector3d, Vector3d*) 2-D branch (src/sdm/dynamic_distance_map.cpp:66-91)
 __device__ inline double dm_distance(const DevParams& prm, const int16_t* __restrict__ dir,
-                                     const uint16_t* __restrict__ sv, double wx, double wy, double* gx, double* gy)
+                                     const sv_t* __restrict__ sv, double wx, double wy, double* gx, double* gy)
 {
     const double mx = w2m_nocast(prm, wx), my = w2m_nocast(prm, wy);
     const uint32_t dx = (uint32_t)mx, dy = (uint32_t)my;
@@ -571,6 +596,19 @@ struct HybridStore {
 
 // queue entry: [63:48] priority | [47:40] oy+128 | [39:32] ox+128 | [31:16] ry | [15:0] rx.  (ox, oy) = the obstacle
 // offset the cell had when it was queued: lets a pop fetch the obstacle cell in the same round as the cell itself.
+// Wide build: [63:48] priority | [47:39] oy+256 | [38:30] ox+256 | [29:15] ry | [14:0] rx (a window is at most 1016 patches =
+// 32,512 cells a side: 15 bits).
+#ifdef LAMA_WIDE_DM
+__device__ inline uint64_t q_entry(uint32_t prio, int rx, int ry, int ox = 0, int oy = 0)
+{
+    return ((uint64_t)prio << 48) | ((uint64_t)(uint32_t)((oy + 256) & 0x1FF) << 39) | ((uint64_t)(uint32_t)((ox + 256) & 0x1FF) << 30) |
+           ((uint64_t)(uint32_t)ry << 15) | (uint32_t)rx;
+}
+__device__ inline int q_ox(uint64_t e) { return (int)((e >> 30) & 0x1FFu) - 256; }
+__device__ inline int q_oy(uint64_t e) { return (int)((e >> 39) & 0x1FFu) - 256; }
+__device__ inline int q_rx(uint64_t e) { return (int)(e & 0x7FFFu); }
+__device__ inline int q_ry(uint64_t e) { return (int)((e >> 15) & 0x7FFFu); }
+#else
 __device__ inline uint64_t q_entry(uint32_t prio, int rx, int ry, int ox = 0, int oy = 0)
 {
     return ((uint64_t)prio << 48) | ((uint64_t)(uint32_t)((oy + 128) & 0xFF) << 40) | ((uint64_t)(uint32_t)((ox + 128) & 0xFF) << 32) |
@@ -580,6 +618,7 @@ __device__ inline int q_ox(uint64_t e) { return (int)((e >> 32) & 0xFFu) - 128; 
 __device__ inline int q_oy(uint64_t e) { return (int)((e >> 40) & 0xFFu) - 128; }
 __device__ inline int q_rx(uint64_t e) { return (int)(e & 0xFFFFu); }
 __device__ inline int q_ry(uint64_t e) { return (int)((e >> 16) & 0xFFFFu); }
+#endif
 
 // True when the allocation phase of this map update failed (see ERR_CLEAN_ABORT): the calling kernel must not touch the maps.
 __device__ inline bool map_update_aborted(const DevParams& prm)

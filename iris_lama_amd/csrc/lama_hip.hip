@@ -35,7 +35,7 @@ struct MapStore {
     int32_t* counts = nullptr;                                      // [P][2] logical particle
     std::vector<PoolChunk> dm_chunks, occ_chunks;
 };
-constexpr size_t DM_PLANE_B[3] = {2048, 4096, 128};                 // dm_sv, dm_obs, dm_mask bytes per patch
+constexpr size_t DM_PLANE_B[3] = {SV_PATCH_BYTES, 4096, 128};                 // dm_sv, dm_obs, dm_mask bytes per patch
 constexpr size_t OCC_PLANE_B[4] = {4096, 128, 128, 4};              // occ, occ_mask, occ_hit, rev
 // the host's record of a particle: home + region (chunk, offset, capacity) per map kind; the device gets PartRec (addresses)
 struct HostPart { uint32_t home, dm_chunk, dm_off, dm_cap, occ_chunk, occ_off, occ_cap; };
@@ -407,7 +407,7 @@ static PartRec dev_part(const lama_hip_ctx* c, const HostPart& h)
     r.home = h.home; r.dm_cap = h.dm_cap; r.occ_cap = h.occ_cap;
     const PoolChunk& d = c->ms.dm_chunks[h.dm_chunk];
     const PoolChunk& o = c->ms.occ_chunks[h.occ_chunk];
-    r.dm_sv = (uint16_t*)(d.plane[0] + (size_t)h.dm_off * DM_PLANE_B[0]);
+    r.dm_sv = (sv_t*)(d.plane[0] + (size_t)h.dm_off * DM_PLANE_B[0]);
     r.dm_obs = (uint32_t*)(d.plane[1] + (size_t)h.dm_off * DM_PLANE_B[1]);
     r.dm_mask = (uint64_t*)(d.plane[2] + (size_t)h.dm_off * DM_PLANE_B[2]);
     r.occ = (uint32_t*)(o.plane[0] + (size_t)h.occ_off * OCC_PLANE_B[0]);
@@ -434,7 +434,7 @@ int32_t add_chunk(lama_hip_ctx* c, bool dm, uint32_t min_patches)
     for (const PoolChunk& k : chunks) total += k.patches;
     uint64_t want = std::max<uint64_t>(std::max<uint64_t>(min_patches, total / 4u), 1024u);      // geometric: the number of chunks stays small, the last one mostly used
     want = (want + 1023u) / 1024u * 1024u;
-    const uint64_t per_patch = dm ? (2048 + 4096 + 128) : (4096 + 128 + 128 + 4);
+    const uint64_t per_patch = dm ? (SV_PATCH_BYTES + 4096 + 128) : (4096 + 128 + 128 + 4);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
         const uint64_t room = free_b > (1ull << 30) ? free_b - (1ull << 30) : 0;       // leave 1 GB for everything else
@@ -1108,7 +1108,7 @@ int32_t permute_particles(lama_hip_ctx* c, const int32_t* idx)
         job.dir_off16 = dir_off16; job.dir_n16 = dir_n16;
         np[i] = r;
         c->h_jobs.resize(c->h_jobs.size() + 1); c->h_jobs[c->h_jobs.size() - 1] = job;
-        c->clone_bytes += 2 * (uint64_t)dir_n16 * 16 + (uint64_t)job.sdm * (2048 + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
+        c->clone_bytes += 2 * (uint64_t)dir_n16 * 16 + (uint64_t)job.sdm * (SV_PATCH_BYTES + 4096 + 128) + (uint64_t)job.socc * (4096 + 128);
     }
     c->h_part = np;
     std::memcpy(c->h_poses.data(), npose.data(), npose.size() * sizeof(double));
@@ -1212,7 +1212,9 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153)
     uint32_t md = (uint32_t)std::ceil(cfg.l2_max * c->scale);
     c->max_sqdist = md * md;
-    if (c->max_sqdist == 0 || md > 127) { delete c; return LAMA_HIP_E_INVALID; }   // offsets are carried as int8, sqdist in 14 bits
+    // this build's queue entries carry obstacle offsets up to MAX_OFFSET_CELLS and its distance plane that range squared: 127 cells
+    // in liblama_hip.so, 255 -- all that the reference's uint16_t sqdist can hold -- in liblama_hip_wide.so (lama_dev.h)
+    if (c->max_sqdist == 0 || md > MAX_OFFSET_CELLS) { delete c; return LAMA_HIP_E_INVALID; }
 
 #define CHK(call) do { if ((call) != hipSuccess) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; } } while (0)
     CHK(hipSetDevice(cfg.device));
@@ -1523,7 +1525,7 @@ int32_t lama_hip_pf_delete_patches(lama_hip_ctx* c, uint32_t particle, const uin
                 return hipMemsetAsync(b + (size_t)last * bytes_per_slot, 0, bytes_per_slot, c->stream);
             };
             if (dm) {
-                HIPCHK(c, plane_move(pr.dm_sv, 2048)); HIPCHK(c, plane_move(pr.dm_obs, 4096)); HIPCHK(c, plane_move(pr.dm_mask, 128));
+                HIPCHK(c, plane_move(pr.dm_sv, SV_PATCH_BYTES)); HIPCHK(c, plane_move(pr.dm_obs, 4096)); HIPCHK(c, plane_move(pr.dm_mask, 128));
             } else {
                 HIPCHK(c, plane_move(pr.occ, 4096)); HIPCHK(c, plane_move(pr.occ_mask, 128));
                 HIPCHK(c, plane_move(pr.occ_hit, 128));
@@ -1575,10 +1577,10 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
     std::vector<uint64_t> hmask((size_t)count * 16);
     HIPCHK(c, hipMemcpy(hmask.data(), dm ? pr.dm_mask : pr.occ_mask,
                         hmask.size() * 8, hipMemcpyDeviceToHost));
-    std::vector<uint16_t> hsv; std::vector<uint32_t> hobs, hocc;
+    std::vector<sv_t> hsv; std::vector<uint32_t> hobs, hocc;
     if (dm) {
         hsv.resize((size_t)count * 1024); hobs.resize((size_t)count * 1024);
-        HIPCHK(c, hipMemcpy(hsv.data(), pr.dm_sv, hsv.size() * 2, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(hsv.data(), pr.dm_sv, hsv.size() * SV_BYTES, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(hobs.data(), pr.dm_obs, hobs.size() * 4, hipMemcpyDeviceToHost));
     } else {
         hocc.resize((size_t)count * 1024);
@@ -1593,10 +1595,10 @@ int32_t lama_hip_pf_download_map(lama_hip_ctx* c, uint32_t particle, int32_t kin
         if (dm) {
             uint8_t* o = cells + (size_t)k * 10240;
             for (int ci = 0; ci < 1024; ++ci) {
-                const uint16_t sv = hsv[(size_t)slot * 1024 + ci];
+                const sv_t sv = hsv[(size_t)slot * 1024 + ci];
                 const uint32_t ob = hobs[(size_t)slot * 1024 + ci];
                 const int16_t ox = (int16_t)(ob & 0xFFFF), oy = (int16_t)(ob >> 16), oz = 0;
-                const uint16_t sq = sv & SV_SQMASK;
+                const uint16_t sq = (uint16_t)(sv & SV_SQMASK);
                 std::memcpy(o + 10 * ci + 0, &ox, 2); std::memcpy(o + 10 * ci + 2, &oy, 2); std::memcpy(o + 10 * ci + 4, &oz, 2);
                 std::memcpy(o + 10 * ci + 6, &sq, 2);
                 o[10 * ci + 8] = (sv & SV_VALID) ? 1 : 0;
@@ -1624,7 +1626,7 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
     const bool dm = kind == LAMA_HIP_MAP_DISTANCE;
     // Convert and validate everything FIRST: a rejected upload must leave the particle's previous map as it was (the old
     // slots were zeroed and the window / region possibly moved before a squared distance beyond the plane's 14 bits was noticed).
-    std::vector<uint16_t> hsv; std::vector<uint32_t> hobs;
+    std::vector<sv_t> hsv; std::vector<uint32_t> hobs;
     if (n && dm) {     // distance_t (10 B: int16 obstacle[3], uint16 sqdist, bool valid_obstacle, bool is_queued) -> the two planes
         hsv.resize((size_t)n * 1024); hobs.resize((size_t)n * 1024);
         for (size_t k = 0; k < n; ++k)
@@ -1632,8 +1634,8 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
                 const uint8_t* o = cells + k * 10240 + 10 * (size_t)ci;
                 int16_t ox, oy; uint16_t sq;
                 std::memcpy(&ox, o, 2); std::memcpy(&oy, o + 2, 2); std::memcpy(&sq, o + 6, 2);
-                if (sq > SV_SQMASK) return fail(c, LAMA_HIP_E_INVALID, "the uploaded distance map holds a squared distance beyond 16383 cells^2 (l2_max above 127 cells)");
-                hsv[k * 1024 + ci] = (uint16_t)(sq | (o[8] ? SV_VALID : 0) | (o[9] ? SV_QUEUED : 0));
+                if ((uint32_t)sq > (uint32_t)SV_SQMASK) return fail(c, LAMA_HIP_E_INVALID, "the uploaded distance map holds a squared distance beyond 16383 cells^2 (l2_max above 127 cells)");
+                hsv[k * 1024 + ci] = (sv_t)((sv_t)sq | (o[8] ? SV_VALID : (sv_t)0) | (o[9] ? SV_QUEUED : (sv_t)0));
                 hobs[k * 1024 + ci] = ((uint32_t)(uint16_t)ox) | (((uint32_t)(uint16_t)oy) << 16);      // (pack_obs)
             }
     }
@@ -1684,7 +1686,7 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
     if (old > (int32_t)n) {
         const size_t keep = n, gone = (size_t)old - n;
         if (dm) {
-            HIPCHK(c, hipMemsetAsync((char*)pr.dm_sv + keep * 2048, 0, gone * 2048, c->stream));
+            HIPCHK(c, hipMemsetAsync((char*)pr.dm_sv + keep * SV_PATCH_BYTES, 0, gone * SV_PATCH_BYTES, c->stream));
             HIPCHK(c, hipMemsetAsync((char*)pr.dm_obs + keep * 4096, 0, gone * 4096, c->stream));
             HIPCHK(c, hipMemsetAsync((char*)pr.dm_mask + keep * 128, 0, gone * 128, c->stream));
         } else {
@@ -1694,7 +1696,7 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
     }
     if (n) {
         if (dm) {
-            HIPCHK(c, hipMemcpy(pr.dm_sv, hsv.data(), hsv.size() * 2, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pr.dm_sv, hsv.data(), hsv.size() * SV_BYTES, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(pr.dm_obs, hobs.data(), hobs.size() * 4, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemcpy(pr.dm_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
         } else {       // frequency {u16 occupied, u16 visited} / float log-odds: 4 B cells as they are
@@ -2069,7 +2071,7 @@ static int32_t match_solve_impl(lama_hip_ctx* c, uint32_t particle, const double
 // (the directories in the SENDER's window side W: windows grow independently, the header carries the side)
 static uint64_t blob_bytes_w(uint64_t W, int dmc, int occ)
 {
-    return 32 + 32 + 2 * W * W * 2 + (uint64_t)dmc * (2048 + 4096 + 128) + (uint64_t)occ * (4096 + 128);
+    return 32 + 32 + 2 * W * W * 2 + (uint64_t)dmc * (SV_PATCH_BYTES + 4096 + 128) + (uint64_t)occ * (4096 + 128);
 }
 static uint64_t blob_bytes(const lama_hip_ctx* c, int dmc, int occ) { return blob_bytes_w(c->W, dmc, occ); }
 
@@ -2335,8 +2337,8 @@ static void memory_figures(const lama_hip_ctx* c, lama_hip_counters* o)
     uint64_t dm_pool = 0, occ_pool = 0;
     for (const PoolChunk& k : m.dm_chunks) dm_pool += k.patches;
     for (const PoolChunk& k : m.occ_chunks) occ_pool += k.patches;
-    o->hbm_bytes_allocated = dirs + dm_pool * (2048 + 4096 + 128) + occ_pool * (4096 + 128 + 128 + 4);
-    o->hbm_bytes_used = dirs + dm_used * (2048 + 4096 + 128) + occ_used * (4096 + 128 + 128 + 4);
+    o->hbm_bytes_allocated = dirs + dm_pool * (SV_PATCH_BYTES + 4096 + 128) + occ_pool * (4096 + 128 + 128 + 4);
+    o->hbm_bytes_used = dirs + dm_used * (SV_PATCH_BYTES + 4096 + 128) + occ_used * (4096 + 128 + 128 + 4);
     const uint64_t other = 2 * P * (uint64_t)c->cfg.queue_capacity * 8 + P * (uint64_t)c->cfg.active_capacity * 8 + (uint64_t)c->rrec_cap * (sizeof(lama_dev::RayRec) + 8) +
                            P * (16 * 8 + 12 * 8 + 4 * 8 + 64) + (1u << 20) + (uint64_t)c->pts_cap * 24;
     o->hbm_bytes_total = o->hbm_bytes_allocated + other;

@@ -127,7 +127,7 @@ __device__ inline void sm_corners_begin(const DevParams& prm, const Affine& tf, 
 // value + gradient of DynamicDistanceMap::distance(Vector3d, Vector3d*) (src/sdm/dynamic_distance_map.cpp:66-91) from the
 // four fetched cells
 template <bool BIGSQ>
-__device__ inline double sm_corners_finish(const DevParams& prm, const double* lut, const BeamCorners& b, const uint16_t (&v)[4],
+__device__ inline double sm_corners_finish(const DevParams& prm, const double* lut, const BeamCorners& b, const sv_t (&v)[4],
                                            double* gx, double* gy)
 {
     double d[4];
@@ -148,9 +148,9 @@ __device__ inline double sm_corners_finish(const DevParams& prm, const double* l
 }
 
 // stages 1 + 2 for the thread's beams of the batch starting at `base`; returns the number of beams it owns there
-__device__ inline int sm_gather(const DevParams& prm, const int16_t* __restrict__ dir, const uint16_t* __restrict__ sv,
+__device__ inline int sm_gather(const DevParams& prm, const int16_t* __restrict__ dir, const sv_t* __restrict__ sv,
                                 const double* __restrict__ pts, int n, int base, const Affine& tf, BeamCorners (&bc)[SM_NB],
-                                uint16_t (&cv)[SM_NB][4])
+                                sv_t (&cv)[SM_NB][4])
 {
     int nb = 0;
 #pragma unroll
@@ -181,14 +181,14 @@ __device__ inline int sm_gather(const DevParams& prm, const int16_t* __restrict_
 }
 
 template <bool BIGSQ>
-__device__ inline void eval_beams_jac(const DevParams& prm, const int16_t* dir, const uint16_t* sv,
+__device__ inline void eval_beams_jac(const DevParams& prm, const int16_t* dir, const sv_t* sv,
                                       const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[NJ], const double* lut)
 {
 #pragma unroll
     for (int k = 0; k < NJ; ++k) acc[k] = 0.0;
     for (int base = 0; base < n; base += SM_NB * SM_BLOCK) {
         BeamCorners bc[SM_NB];
-        uint16_t cv[SM_NB][4];
+        sv_t cv[SM_NB][4];
         const int nb = sm_gather(prm, dir, sv, pts, n, base, tf, bc, cv);
 #pragma unroll
         for (int b = 0; b < SM_NB; ++b) {
@@ -215,13 +215,13 @@ __device__ inline void eval_beams_jac(const DevParams& prm, const int16_t* dir, 
 // residual-only evaluation: acc[0] = sum (w r)^2 (validation, solver.cpp:90-96),
 //                           acc[1] = sum -(d*d)/meas_sigma (calculateLikelihood, pf_slam2d.cpp:393-414)
 template <bool BIGSQ>
-__device__ inline void eval_beams_res(const DevParams& prm, const int16_t* dir, const uint16_t* sv,
+__device__ inline void eval_beams_res(const DevParams& prm, const int16_t* dir, const sv_t* sv,
                                       const double* __restrict__ pts, int n, const Affine& tf, double (&acc)[2], const double* lut)
 {
     acc[0] = 0.0; acc[1] = 0.0;
     for (int base = 0; base < n; base += SM_NB * SM_BLOCK) {
         BeamCorners bc[SM_NB];
-        uint16_t cv[SM_NB][4];
+        sv_t cv[SM_NB][4];
         const int nb = sm_gather(prm, dir, sv, pts, n, base, tf, bc, cv);
 #pragma unroll
         for (int b = 0; b < SM_NB; ++b) {
@@ -261,7 +261,7 @@ struct SMShared {
 #define SMT(k) do {} while (0)
 #endif
 template <bool BIGSQ>
-__device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, const uint16_t* sv, const double* __restrict__ pts, int n,
+__device__ inline uint32_t gn_solve(const DevParams& prm, const int16_t* dir, const sv_t* sv, const double* __restrict__ pts, int n,
                                     const Affine& mtf, SMShared& sh, uint32_t& evals)
 {
 #ifdef LAMA_PROFILE_SM
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(SM_BLOCK) __attribute__((amdgpu_num_vgpr(128))) voi
     const int p = blockIdx.x;
     const PV pv_ = pview_w(prm, p);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = prm.poses + 4 * p;
         sh.state = SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)};
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_match_solve(DevParams prm, int par
     __shared__ SMShared sh;
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         sh.state = SE2{cload_f64(pose_io), cload_f64(pose_io + 1), cload_f64(pose_io + 2), cload_f64(pose_io + 3)};
         sh.tf = scan_tf(sh.state, mtf);
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_match_eval(DevParams prm, int particle,
     __shared__ Affine tfs;
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) tfs = scan_tf(SE2{cload_f64(pose), cload_f64(pose + 1), cload_f64(pose + 2), cload_f64(pose + 3)}, mtf);     // (a pose the host uploaded)
     __syncthreads();
     const Affine tf = tfs;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_loglik_batch(DevParams prm, int pa
     const int b = blockIdx.x;
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
         tfs = scan_tf(SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)}, mtf);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(SM_BLOCK) void k_eval_batch(DevParams prm, int part
     const int b = blockIdx.x;
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     if (threadIdx.x == 0) {
         const double* q = poses + 4 * b;
         tfs = scan_tf(SE2{cload_f64(q), cload_f64(q + 1), cload_f64(q + 2), cload_f64(q + 3)}, mtf);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) void k_sample_likelihood(DevParams prm, int par
     const int k = blockIdx.x;
     const PV pv_ = pview_w(prm, particle);
     const int16_t* dir = pv_.dm_dir;
-    const uint16_t* sv = pv_.dm_sv;
+    const sv_t* sv = pv_.dm_sv;
     // (xy is rewritten by the host before every call: a coherent load, not the s_load a uniform read of it would become)
     const double tx = base.t[0] + cload_f64(xy + 2 * k), ty = base.t[1] + cload_f64(xy + 2 * k + 1);
     const int nterms = (n + step - 1) / step;
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
     const PV pv = pview(prm, p);
     int16_t* dm_dir = pv.dm_dir;
     int16_t* occ_dir = pv.occ_dir;
-    uint16_t* dm_sv = pv.dm_sv;
+    sv_t* dm_sv = pv.dm_sv;
     uint32_t* dm_obs = pv.dm_obs;
     uint64_t* dm_mask = pv.dm_mask;
     uint32_t* occ = pv.occ;
@@ -812,10 +812,10 @@ __global__ __launch_bounds__(UM_BLOCK) void k_raycast(DevParams prm, const doubl
                 uint64_t* w = dm_mask + (size_t)dslot * 16 + (ci >> 6);
                 if (!(*w & bit)) atomicOr((unsigned long long*)w, (unsigned long long)bit);
                 const uint32_t di = (uint32_t)dslot * 1024u + ci;
-                const uint16_t s = dm_sv[di];
+                const sv_t s = dm_sv[di];
                 const bool is_obstacle = (s & SV_VALID) && (s & SV_SQMASK) == 0;
                 if (is_hit) {                                               // addObstacle (dynamic_distance_map.cpp:212-226)
-                    if (!is_obstacle) { dm_sv[di] = (uint16_t)(SV_VALID | SV_QUEUED); dm_obs[di] = 0; push = true; }
+                    if (!is_obstacle) { dm_sv[di] = (sv_t)(SV_VALID | SV_QUEUED); dm_obs[di] = 0; push = true; }
                 } else {                                                    // removeObstacle (:228-242)
                     if (is_obstacle) { dm_sv[di] = SV_QUEUED; dm_obs[di] = 0; push = true; }
                 }
@@ -1047,6 +1047,14 @@ __device__ __forceinline__ void buf_store_u32(BufRsrc r, uint32_t off, uint32_t 
 // v_readlane right in front of this instruction -- found on the device: the atomic went elsewhere, mask words were lost)
 __device__ __forceinline__ void buf_or_u64(BufRsrc r, uint32_t off, uint64_t v) { asm volatile("s_nop 4\n\tbuffer_atomic_or_x2 %0, %1, %2, 0 offen" :: "v"(v), "v"(off), "s"(r) : "memory"); }
 __device__ __forceinline__ uint32_t lane_rank(unsigned long long m, int) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+#endif
+// a cell of plane A of the distance map (sv_t: 2 bytes, 4 in the wide build)
+#ifdef LAMA_WIDE_DM
+#define buf_load_sv buf_load_u32
+#define buf_store_sv buf_store_u32
+#else
+#define buf_load_sv buf_load_u16
+#define buf_store_sv buf_store_u16
 #endif
 // A value the optimiser must take as it is, in a vector register: lane predicates kept as 0 / ~0 words stay on the VALU (v_and /
 // v_or) instead of becoming wave masks that are combined on the scalar unit -- a vector -> scalar hand-over per operation.
@@ -1287,7 +1295,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     const int tid = threadIdx.x, nthreads = TW ? 2 * UM_BLOCK : UM_BLOCK;
     const PV pv = pview_w(prm, p);                             // (p is wave-uniform, both waves are complete here)
     int16_t* dir = pv.dm_dir;
-    uint16_t* sv = pv.dm_sv;
+    sv_t* sv = pv.dm_sv;
     uint32_t* obs = pv.dm_obs;
     uint64_t* mask = pv.dm_mask;
     const uint32_t dm_cap = pv.dm_cap;
@@ -1389,12 +1397,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);                              \
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);                               \
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;                                                  \
-        uint16_t s = 0; uint32_t ob = 0;                                                                    \
+        sv_t s = 0; uint32_t ob = 0;                                                                    \
         if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; ob = obs[slot * 1024 + (int)ci]; }
     // round B: the cell my offset points to (obstacle cell); offset 0 -> myself
     #define BF_LOAD_B()                                                                                     \
         const int ox = x + obs_x(ob), oy = y + obs_y(ob);                                                   \
-        uint16_t os = 0;                                                                                    \
+        sv_t os = 0;                                                                                    \
         {                                                                                                   \
             const bool oin = role && slot >= 0 && (uint32_t)ox < prm.WC && (uint32_t)oy < prm.WC;           \
             const uint32_t opidx = ((uint32_t)oy >> 5) * prm.W + ((uint32_t)ox >> 5);                       \
@@ -1463,7 +1471,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     // patch to allocate, a neighbour whose obstacle cell is another neighbour (raise() handles them in order) -- take the general code.
     if (TW) {
         uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
-        const BufRsrc rsv = buf_make(sv, dm_cap * 2048u), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
+        const BufRsrc rsv = buf_make(sv, dm_cap * SV_PATCH_BYTES), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
         const bool is_oc = lane == 5;
         const uint32_t rolem = lane < 6 ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
 
@@ -1498,8 +1506,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             if (to_lower) sh.pl_e[tw_it & 1u][__popc(lm & below)] = entry_r;
             cnt_r = (uint32_t)__popc(rm); cnt_l = (uint32_t)__popc(lm); rm_out = rm;
             if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0u; }
-            if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
-            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
+            if (to_lower) sv[slot * 1024 + (int)ci] = (sv_t)(s | SV_QUEUED);
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (sv_t)(s & ~SV_QUEUED);      // :278
         };
 
         while (tw_running && nr > 0) {
@@ -1513,9 +1521,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             uint64_t entry = 0;
             bool general;
             {
+#ifdef LAMA_WIDE_DM
+                const int rx = q_rx(e), ry = q_ry(e), eox = q_ox(e), eoy = q_oy(e);
+#else
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
                 const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
+#endif
                 const int obx = rx + eox, oby = ry + eoy;                  // the obstacle cell the popped cell pointed to
                 const int x = is_oc ? obx : rx + ddx, y = is_oc ? oby : ry + ddy;
                 const uint32_t mxy = (uint32_t)x > (uint32_t)y ? (uint32_t)x : (uint32_t)y;
@@ -1528,12 +1540,12 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t absent = opq((uint32_t)((int32_t)slotw >> 31));
                 const uint32_t have = opq(rolem & hit & ~absent);
                 const uint32_t coff = (slotw << 10) | ci;
-                const uint32_t s = buf_load_u16(rsv, m_sel(have, coff * 2u, BUF_OOB));
+                const uint32_t s = buf_load_sv(rsv, m_sel(have, coff * SV_BYTES, BUF_OOB));
                 const uint32_t ob = buf_load_u32(robs, m_sel(have, coff * 4u, BUF_OOB));
                 // general code: a role cell that is not cached or outside the window, a neighbour (or the popped cell) without a patch
                 const uint32_t rare0 = (rolem & ~hit) | ((nbm | curm) & hit & absent);
                 // :253  neighbours that are valid and not queued
-                const uint32_t svalid = opq((uint32_t)((int32_t)(s << 16) >> 31)), squeued = opq((uint32_t)((int32_t)(s << 17) >> 31));
+                const uint32_t svalid = opq((uint32_t)((int32_t)(s << (31 - SV_VALID_BIT)) >> 31)), squeued = opq((uint32_t)((int32_t)(s << (32 - SV_VALID_BIT)) >> 31));
                 const uint32_t cand = opq(nbm & svalid & ~squeued);
                 // the neighbour's obstacle cell: the one lane 5 holds, or another one (second round)
                 const int ox = x + obs_x(ob), oy = y + obs_y(ob);
@@ -1553,9 +1565,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     const uint32_t odv = sh.dc[dc.index(opidx & oin)];
                     const uint32_t ohit = opq((odv >> 15) == (opidx >> 3) ? oin : 0u);
                     const uint32_t oslot = (odv & 0x7FFFu) - 1u;
-                    const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
-                    const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
-                    ovalid = m_sel(other, (uint32_t)((int32_t)(os2 << 16) >> 31), ovalid);
+                    const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * SV_BYTES;
+                    const uint32_t os2 = buf_load_sv(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
+                    ovalid = m_sel(other, (uint32_t)((int32_t)(os2 << (31 - SV_VALID_BIT)) >> 31), ovalid);
                     general = __ballot((oin & ~ohit) != 0u) != 0ull;       // its directory entry is not cached
                 }
                 if (__builtin_expect(!general, 1)) {
@@ -1565,7 +1577,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     buf_or_u64(rmask, m_sel(need_bit, ((slotw << 4) + (ci >> 6)) * 8u, BUF_OOB), 1ull << (ci & 63u));
                     // raised: is_queued only, obstacle cleared; lowered: is_queued added; the popped cell: is_queued removed (:278)
                     const uint32_t nsv = m_sel(to_raise, (uint32_t)SV_QUEUED, m_sel(curm, s & ~(uint32_t)SV_QUEUED, s | (uint32_t)SV_QUEUED));
-                    buf_store_u16(rsv, m_sel(to_raise | to_lower | curm, coff * 2u, BUF_OOB), nsv);
+                    buf_store_sv(rsv, m_sel(to_raise | to_lower | curm, coff * SV_BYTES, BUF_OOB), nsv);
                     buf_store_u32(robs, m_sel(to_raise, coff * 4u, BUF_OOB), 0u);
                     const unsigned long long rmm = __ballot(to_raise != 0u), lmm = __ballot(to_lower != 0u);
                     entry = q_entry(s & SV_SQMASK, x, y, obs_x(ob), obs_y(ob));
@@ -1681,8 +1693,8 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             }
         }
         if (to_raise) { sv[slot * 1024 + (int)ci] = SV_QUEUED; obs[slot * 1024 + (int)ci] = 0u; }
-        if (to_lower) sv[slot * 1024 + (int)ci] = (uint16_t)(s | SV_QUEUED);
-        if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(s & ~SV_QUEUED);      // :278
+        if (to_lower) sv[slot * 1024 + (int)ci] = (sv_t)(s | SV_QUEUED);
+        if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (sv_t)(s & ~SV_QUEUED);      // :278
         if (TW) BF_TW_TAIL(true, nr, rw_cnt_r, rw_cnt_l, rw_entry_r, rw_rm)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
@@ -1697,7 +1709,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         if (!TW) { tw_running = nl > 0; if (tw_running) e_next = uniform_u64(sh.lower[0]); }
         BFT(7);                                                    // (profiling build: everything before the lower wave)
         uint64_t* const dmy = sh.dummy[0] + (lane & (BF_DUMMY - 1));
-        const BufRsrc rsv = buf_make(sv, dm_cap * 2048u), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
+        const BufRsrc rsv = buf_make(sv, dm_cap * SV_PATCH_BYTES), robs = buf_make(obs, dm_cap * 4096u), rmask = buf_make(mask, dm_cap * 128u);
         const bool is_oc = lane == 5, role = lane < 6;
         const uint32_t rolem = role ? 0xFFFFFFFFu : 0u, nbm = is_nb ? 0xFFFFFFFFu : 0u, curm = is_cur ? 0xFFFFFFFFu : 0u;
 
@@ -1712,15 +1724,15 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
             const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
             int slot = (role && inwin) ? dc.lookup(pidx) : -1;
-            uint16_t s = 0; uint32_t ob = 0;
+            sv_t s = 0; uint32_t ob = 0;
             if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) ob = obs[slot * 1024 + (int)ci]; }
-            const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
+            const sv_t cs = (sv_t)__builtin_amdgcn_readlane((int)s, 4);
             const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
-            uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)s, 5);
+            sv_t cos_ = (sv_t)__builtin_amdgcn_readlane((int)s, 5);
             if (obs_x(cob) != q_ox(e) || obs_y(cob) != q_oy(e)) {
                 // stale entry (the cell was overwritten after it was queued): fetch the obstacle cell it points to now
                 const int ox2 = rx + obs_x(cob), oy2 = ry + obs_y(cob);
-                uint16_t t = 0;
+                sv_t t = 0;
                 if ((uint32_t)ox2 < prm.WC && (uint32_t)oy2 < prm.WC) {
                     const int os2 = dc.lookup(((uint32_t)oy2 >> 5) * prm.W + ((uint32_t)ox2 >> 5));
                     if (os2 >= 0) t = sv[os2 * 1024 + (int)(((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5))];
@@ -1751,7 +1763,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 // the neighbour's own obstacle cell: usually the very cell the popped cell points to, whose state lane 5 holds
                 const int ox = x + obs_x(ob), oy = y + obs_y(ob);
                 const bool same = ox == obx && oy == oby;
-                uint16_t os = cos_;
+                sv_t os = cos_;
                 if (__ballot(tie && !same)) {
                     if (tie && !same) {
                         os = 0;
@@ -1764,10 +1776,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 if (tie && (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0))) over = true;
             }
             if (over) {
-                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                sv[slot * 1024 + (int)ci] = (sv_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
                 obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
             }
-            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (sv_t)(cs & ~SV_QUEUED);   // :329
             const unsigned long long om = __ballot(over);
             over_out = over; entry_out = q_entry(new_sq, x, y, obx - x, oby - y);
             if (over) sh.pl_e[tw_it & 1u][__popcll(om & ((1ull << lane) - 1ull))] = entry_out;
@@ -1790,9 +1802,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             {
                 // ---- speculative loads: every lane its role's cell through the directory cache, absent / foreign lanes out of range.
                 // Lane predicates are 0 / ~0 words (see lds_pop_flat); what is wave-uniform stays in scalar registers.
+#ifdef LAMA_WIDE_DM
+                const int rx = q_rx(e), ry = q_ry(e), eox = q_ox(e), eoy = q_oy(e);
+#else
                 const uint32_t elo = (uint32_t)e, ehi = (uint32_t)(e >> 32);
                 const int rx = (int)(elo & 0xFFFFu), ry = (int)(elo >> 16);
                 const int eox = (int)(ehi & 0xFFu) - 128, eoy = (int)((ehi >> 8) & 0xFFu) - 128;
+#endif
                 const int x = rx + (is_oc ? eox : ddx), y = ry + (is_oc ? eoy : ddy);
                 const uint32_t mxy = (uint32_t)x > (uint32_t)y ? (uint32_t)x : (uint32_t)y;
                 const uint32_t inwin = opq(mxy < prm.WC ? 0xFFFFFFFFu : 0u);
@@ -1806,7 +1822,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 const uint32_t have = opq(rolem & hit & ~absent);
                 const uint32_t unknown = opq(rolem & ~hit);                                   // not cached / outside the window: general code
                 const uint32_t coff = (slotw << 10) | ci;
-                const uint32_t s = buf_load_u16(rsv, m_sel(have, coff * 2u, BUF_OOB));
+                const uint32_t s = buf_load_sv(rsv, m_sel(have, coff * SV_BYTES, BUF_OOB));
                 const uint32_t ob = buf_load_u32(robs, m_sel(have, coff * 4u, BUF_OOB));
                 const unsigned long long unk = __ballot(unknown != 0u);
                 // Round 5: what lower() computes from the popped cell's obstacle offset alone -- the "away" test, every neighbour's new
@@ -1846,7 +1862,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                     floor_sq = cs & SV_SQMASK;                                           // lower() :303: candidates of cells further from the obstacle
                     const uint32_t nbok = away & ~absent;                                // (cox == eox, coy == eoy here: not stale)
                     const uint32_t ssq = s & SV_SQMASK;
-                    const uint32_t svalid = opq((uint32_t)((int32_t)(s << 16) >> 31));                // bit 15
+                    const uint32_t svalid = opq((uint32_t)((int32_t)(s << (31 - SV_VALID_BIT)) >> 31));   // the valid bit
                     const uint32_t cmp = m_sel(svalid, ssq, prm.max_sqdist);
                     const uint32_t lt = opq(nbok & m_lt(new_sq, cmp));
                     const uint32_t tie = opq(nbok & ~lt & ~m_nz(new_sq ^ ssq));                       // :311-317
@@ -1864,9 +1880,9 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         const uint32_t odv = sh.dc[dc.index(opidx & oin)];
                         const uint32_t ohit = opq((odv >> 15) == (opidx >> 3) ? oin : 0u);
                         const uint32_t oslot = (odv & 0x7FFFu) - 1u;
-                        const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * 2u;
-                        const uint32_t os2 = buf_load_u16(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
-                        const uint32_t olive = opq((uint32_t)((int32_t)(os2 << 16) >> 31) & ~m_nz(os2 & SV_SQMASK));
+                        const uint32_t ooff = ((oslot << 10) | ((uint32_t)ox & 31u) | (((uint32_t)oy & 31u) << 5)) * SV_BYTES;
+                        const uint32_t os2 = buf_load_sv(rsv, m_sel(ohit & ~(uint32_t)((int32_t)oslot >> 31), ooff, BUF_OOB));   // outside the window / absent: reads as 0
+                        const uint32_t olive = opq((uint32_t)((int32_t)(os2 << (31 - SV_VALID_BIT)) >> 31) & ~m_nz(os2 & SV_SQMASK));
                         dead = m_sel(tie_other, ~olive, dead);
                         // rare among the rare: a directory entry that is not cached, or a patch to allocate: general code
                         general = __ballot(((oin & ~ohit) | alloc) != 0u) != 0ull;
@@ -1883,7 +1899,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                         buf_or_u64(rmask, m_sel(need_bit, mask_off, BUF_OOB), mask_bit);
                         // neighbours that are lowered, and the popped cell's is_queued (:329): one store instruction
                         const uint32_t nsv = m_sel(curm, cs & ~(uint32_t)SV_QUEUED, nsv_new);
-                        buf_store_u16(rsv, m_sel(overm | curm, coff * 2u, BUF_OOB), nsv);
+                        buf_store_sv(rsv, m_sel(overm | curm, coff * SV_BYTES, BUF_OOB), nsv);
                         buf_store_u32(robs, m_sel(overm, coff * 4u, BUF_OOB), my_obs);
                         BFF(4);
                         const unsigned long long om = __ballot(overm != 0u);
@@ -1979,7 +1995,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
         const uint32_t pidx = ((uint32_t)y >> 5) * prm.W + ((uint32_t)x >> 5);
         const uint32_t ci = ((uint32_t)x & 31u) | (((uint32_t)y & 31u) << 5);
         int slot = (role && inwin) ? dc.lookup(pidx) : -1;
-        uint16_t s = 0; uint32_t ob = 0;
+        sv_t s = 0; uint32_t ob = 0;
         if (slot >= 0) { s = sv[slot * 1024 + (int)ci]; if (!is_oc) ob = obs[slot * 1024 + (int)ci]; }
         BFT(1);
         uint32_t tw_cnt = 0, tw_om = 0;
@@ -1990,13 +2006,13 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
             (void)lds_pop_topdown(sh.lower, nl, lane, anc);
         }
         BFT(2);
-        const uint16_t cs = (uint16_t)__builtin_amdgcn_readlane((int)s, 4);
+        const sv_t cs = (sv_t)__builtin_amdgcn_readlane((int)s, 4);
         const uint32_t cob = (uint32_t)__builtin_amdgcn_readlane((int)ob, 4);
-        uint16_t cos_ = (uint16_t)__builtin_amdgcn_readlane((int)s, 5);
+        sv_t cos_ = (sv_t)__builtin_amdgcn_readlane((int)s, 5);
         if (obs_x(cob) != q_ox(e) || obs_y(cob) != q_oy(e)) {
             // stale entry (the cell was overwritten after it was queued): fetch the obstacle cell it points to now
             const int ox2 = rx + obs_x(cob), oy2 = ry + obs_y(cob);
-            uint16_t t = 0;
+            sv_t t = 0;
             if ((uint32_t)ox2 < prm.WC && (uint32_t)oy2 < prm.WC) {
                 const int os2 = dc.lookup(((uint32_t)oy2 >> 5) * prm.W + ((uint32_t)ox2 >> 5));
                 if (os2 >= 0) t = sv[os2 * 1024 + (int)(((uint32_t)ox2 & 31u) | (((uint32_t)oy2 & 31u) << 5))];
@@ -2035,7 +2051,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 // reached from the same obstacle), whose state lane 5 already holds -- no second load round then
                 const int ox = x + obs_x(ob), oy = y + obs_y(ob);
                 const bool same = ox == obx && oy == oby;
-                uint16_t os = cos_;
+                sv_t os = cos_;
 #ifdef LAMA_PROFILE_BF_COUNT
                 prof[4] += __ballot(tie && !same) ? 1 : 0;
 #endif
@@ -2051,10 +2067,10 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
                 if (tie && (!(s & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0))) over = true;
             }
             if (over) {
-                sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+                sv[slot * 1024 + (int)ci] = (sv_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
                 obs[slot * 1024 + (int)ci] = pack_obs(obx - x, oby - y);
             }
-            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (uint16_t)(cs & ~SV_QUEUED);   // :329
+            if (is_cur && slot >= 0) sv[slot * 1024 + (int)ci] = (sv_t)(cs & ~SV_QUEUED);   // :329
             BFT(4);
             // pushes in neighbour order.  Fast path: one gather of all parents; if none of the new entries has
             // to move up (parent priority <= new priority: the normal case in a Dijkstra wave) they are simply
@@ -2280,7 +2296,13 @@ __global__ __launch_bounds__(256) void k_map_checksum(DevParams prm, int kind /*
             uint64_t f;
             if (kind == 0) {
                 const uint64_t m = (pv.dm_mask[(size_t)slot * 16 + (c >> 6)] >> (c & 63)) & 1ull;
+#ifdef LAMA_WIDE_DM          // the squared distance takes all 16 low bits: the two flags move above the mask bit
+                const uint32_t w = pv.dm_sv[(size_t)slot * 1024 + c];
+                f = (uint64_t)(w & 0xFFFFu) | ((uint64_t)pv.dm_obs[(size_t)slot * 1024 + c] << 16) | (m << 48) |
+                    ((w & SV_VALID) ? 1ull << 49 : 0ull) | ((w & SV_QUEUED) ? 1ull << 50 : 0ull);
+#else
                 f = (uint64_t)pv.dm_sv[(size_t)slot * 1024 + c] | ((uint64_t)pv.dm_obs[(size_t)slot * 1024 + c] << 16) | (m << 48);
+#endif
             } else {
                 // Container mask of a frequency cell = "visited != 0", plus the plane bits kept for uint16 wraps (as in the download)
                 const uint32_t ov = pv.occ[(size_t)slot * 1024 + c];
@@ -2312,7 +2334,7 @@ struct GlobalStore {
 
 struct BfCtx {
     const DevParams& prm;
-    int16_t* dir; uint16_t* sv; uint32_t* obs; uint64_t* mask;
+    int16_t* dir; sv_t* sv; uint32_t* obs; uint64_t* mask;
     int count; int cap;
     GlobalStore lower, raise;
     uint32_t nl, nr;
@@ -2353,7 +2375,7 @@ __device__ __noinline__ void bf_raise(BfCtx& c, int rx, int ry, int cur)        
         const int nx = rx + DX[i], ny = ry + DY[i];
         const int nc = bf_get(c, nx, ny);
         if (nc < 0) continue;
-        const uint16_t s = c.sv[nc];
+        const sv_t s = c.sv[nc];
         if ((s & SV_QUEUED) || !(s & SV_VALID)) continue;
         const uint32_t no = c.obs[nc];
         const int oc = bf_get(c, nx + obs_x(no), ny + obs_y(no));
@@ -2367,12 +2389,12 @@ __device__ __noinline__ void bf_raise(BfCtx& c, int rx, int ry, int cur)        
             c.sv[nc] = s | SV_QUEUED;
         }
     }
-    c.sv[cur] &= (uint16_t)~SV_QUEUED;
+    c.sv[cur] &= (sv_t)~SV_QUEUED;
 }
 
 __device__ __noinline__ void bf_lower(BfCtx& c, int rx, int ry, int cur)            // :281-330
 {
-    const uint16_t s = c.sv[cur];
+    const sv_t s = c.sv[cur];
     if (!(s & SV_QUEUED)) return;
     const uint32_t co = c.obs[cur];
     const int cox = obs_x(co), coy = obs_y(co);
@@ -2383,7 +2405,7 @@ __device__ __noinline__ void bf_lower(BfCtx& c, int rx, int ry, int cur)        
         const int nx = rx + DX[i], ny = ry + DY[i];
         const int nc = bf_get(c, nx, ny);
         if (nc < 0) continue;
-        const uint16_t ns = c.sv[nc];
+        const sv_t ns = c.sv[nc];
         const int qx = nx - obx, qy = ny - oby;
         const uint32_t new_sq = (uint32_t)(qx * qx + qy * qy);
         const uint32_t cmp = (ns & SV_VALID) ? (uint32_t)(ns & SV_SQMASK) : c.prm.max_sqdist;
@@ -2392,17 +2414,17 @@ __device__ __noinline__ void bf_lower(BfCtx& c, int rx, int ry, int cur)        
             const uint32_t nobs = c.obs[nc];
             const int oc = bf_get(c, nx + obs_x(nobs), ny + obs_y(nobs));
             if (oc >= 0) {
-                const uint16_t os = c.sv[oc];
+                const sv_t os = c.sv[oc];
                 if (!(ns & SV_VALID) || !((os & SV_VALID) && (os & SV_SQMASK) == 0)) over = true;
             }
         }
         if (over) {
             bf_push(c, true, new_sq, nx, ny);
-            c.sv[nc] = (uint16_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
+            c.sv[nc] = (sv_t)(SV_VALID | SV_QUEUED | (new_sq & SV_SQMASK));
             c.obs[nc] = pack_obs(obx - nx, oby - ny);
         }
     }
-    c.sv[cur] &= (uint16_t)~SV_QUEUED;
+    c.sv[cur] &= (sv_t)~SV_QUEUED;
 }
 
 __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int first_particle)
@@ -2427,7 +2449,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_brushfire_slow(DevParams prm, int 
         const int cur = bf_get(c, rx, ry);
         ++c.processed;
         if (cur < 0) continue;
-        const uint16_t s = c.sv[cur];
+        const sv_t s = c.sv[cur];
         if (s & SV_VALID) {
             const uint32_t o = c.obs[cur];
             const int oc = bf_get(c, rx + obs_x(o), ry + obs_y(o));
@@ -2457,7 +2479,7 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
     const int lane = threadIdx.x;
     const PV pv = pview(prm, p);
     int16_t* dm_dir = pv.dm_dir;
-    uint16_t* dm_sv = pv.dm_sv;
+    sv_t* dm_sv = pv.dm_sv;
     uint32_t* dm_obs = pv.dm_obs;
     uint64_t* dm_mask = pv.dm_mask;
     uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
@@ -2485,9 +2507,9 @@ __global__ __launch_bounds__(UM_BLOCK) void k_dm_add_obstacles(DevParams prm, in
         bool push = false;
         if (want && slot >= 0) {
             atomicOr((unsigned long long*)(dm_mask + (size_t)slot * 16 + (ci >> 6)), 1ull << (ci & 63));
-            const uint16_t s = dm_sv[slot * 1024 + (int)ci];
+            const sv_t s = dm_sv[slot * 1024 + (int)ci];
             if (first && !((s & SV_VALID) && (s & SV_SQMASK) == 0)) {
-                dm_sv[slot * 1024 + (int)ci] = (uint16_t)(SV_VALID | SV_QUEUED);
+                dm_sv[slot * 1024 + (int)ci] = (sv_t)(SV_VALID | SV_QUEUED);
                 dm_obs[slot * 1024 + (int)ci] = 0;
                 push = true;
             }
@@ -2607,7 +2629,7 @@ __global__ __launch_bounds__(256) void k_clone_particles(DevParams prm, const Cl
     } else {
         const int k = plane - 2;
         const bool dm = k < 3;
-        const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
+        const size_t bytes = k == 0 ? SV_PATCH_BYTES : (k == 1 || k == 3) ? 4096 : 128;
         const int32_t used = uload_i32(dm ? &J->sdm : &J->socc), old = uload_i32(dm ? &J->odm : &J->oocc);
         s = (const g_uint4*)(uintptr_t)uload_u64(&J->s[k]); d = (g_uint4*)(uintptr_t)uload_u64(&J->d[k]);
         ncopy = (size_t)used * bytes / 16; nzero = old > used ? (size_t)(old - used) * bytes / 16 : 0;
@@ -2628,7 +2650,7 @@ __global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob* __restrict_
 {
     const ZeroJob* J = jobs + blockIdx.x;                          // (host-rewritten list: coherent uniform loads)
     const int k = blockIdx.y;
-    const size_t bytes = k == 0 ? 2048 : (k == 1 || k == 3) ? 4096 : 128;
+    const size_t bytes = k == 0 ? SV_PATCH_BYTES : (k == 1 || k == 3) ? 4096 : 128;
     g_uint4* d = (g_uint4*)(uintptr_t)uload_u64(&J->d[k]);
     const size_t n = (size_t)uload_i32(k < 3 ? &J->ndm : &J->nocc) * bytes / 16;
     if (!d) return;
@@ -2640,7 +2662,7 @@ __global__ __launch_bounds__(256) void k_zero_regions(const ZeroJob* __restrict_
 // ------------------------------------------------------------------------------------------------
 // Particle shipping (multi-GPU resampling): ALL outgoing / incoming particles of a resample in one launch each.
 // Blob layout (16-byte aligned): [pose 4 f64][header 8 i32: dm patches, occ patches, window origin x / y in patches, visited bound, 0, 0, 0]
-// [dm_dir W*W i16][occ_dir W*W i16][dm_sv n_dm x 2048 B][dm_obs n_dm x 4096 B][dm_mask n_dm x 128 B][occ n_occ x 4096 B][occ_mask n_occ x 128 B]
+// [dm_dir W*W i16][occ_dir W*W i16][dm_sv n_dm x 2048 B (wide build: 4096)][dm_obs n_dm x 4096 B][dm_mask n_dm x 128 B][occ n_occ x 4096 B][occ_mask n_occ x 128 B]
 // ------------------------------------------------------------------------------------------------
 constexpr int BLOB_HEAD = 64;
 struct ShipDesc {
@@ -2653,7 +2675,7 @@ struct ShipDesc {
 __device__ inline const uint4* blob_plane(const uint8_t* blob, int plane, size_t WW, int dmc, int occ, size_t& n16)
 {
     size_t off = BLOB_HEAD;
-    const size_t sz[7] = {WW * 2, WW * 2, (size_t)dmc * 2048, (size_t)dmc * 4096, (size_t)dmc * 128, (size_t)occ * 4096, (size_t)occ * 128};
+    const size_t sz[7] = {WW * 2, WW * 2, (size_t)dmc * SV_PATCH_BYTES, (size_t)dmc * 4096, (size_t)dmc * 128, (size_t)occ * 4096, (size_t)occ * 128};
     for (int k = 0; k < plane; ++k) off += sz[k];
     n16 = sz[plane] / 16;
     return reinterpret_cast<const uint4*>(blob + off);
@@ -2724,7 +2746,7 @@ __global__ __launch_bounds__(256) void k_import_particles(DevParams prm, const S
     switch (plane) {
     case 0: out = (uint4*)dst.dm_dir; break;
     case 1: out = (uint4*)dst.occ_dir; break;
-    case 2: out = (uint4*)dst.dm_sv; nzero = odm > dmc ? (size_t)(odm - dmc) * 2048 / 16 : 0; break;
+    case 2: out = (uint4*)dst.dm_sv; nzero = odm > dmc ? (size_t)(odm - dmc) * SV_PATCH_BYTES / 16 : 0; break;
     case 3: out = (uint4*)dst.dm_obs; nzero = odm > dmc ? (size_t)(odm - dmc) * 4096 / 16 : 0; break;
     case 4: out = (uint4*)dst.dm_mask; nzero = odm > dmc ? (size_t)(odm - dmc) * 128 / 16 : 0; break;
     case 5: out = (uint4*)dst.occ; nzero = oocc > occ ? (size_t)(oocc - occ) * 4096 / 16 : 0; break;

@@ -344,7 +344,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
     int16_t* occ_dir = pv.occ_dir;
     int16_t* dm_dir = pv.dm_dir;
     uint32_t* occ = pv.occ;
-    uint16_t* dm_sv = pv.dm_sv;
+    sv_t* dm_sv = pv.dm_sv;
     uint32_t* dm_obs = pv.dm_obs;
     uint64_t* q_lower = prm.q_lower + (size_t)p * prm.qcap;
     uint64_t* q_raise = prm.q_raise + (size_t)p * prm.qcap;
@@ -372,7 +372,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
         uint32_t o = v & 0xFFFFu, vis = v >> 16;
         bool dm_loaded = false, dirty = false, had_hit = false;
         int dslot = -1;
-        uint16_t s = 0;
+        sv_t s = 0;
         for (uint32_t j = i; j < n; ++j) {
             const uint64_t kj = sh.keys[j];
             if ((uint32_t)(kj >> ACT_SEQ_BITS) != ck) break;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void ray_replay_particle(const DevParams& prm, const 
             if (dslot < 0) continue;
             const bool is_obstacle = (s & SV_VALID) && (s & SV_SQMASK) == 0;
             bool emit = false;
-            if (is_hit && !is_obstacle) { s = (uint16_t)(SV_VALID | SV_QUEUED); emit = true; }     // addObstacle :212-226
+            if (is_hit && !is_obstacle) { s = (sv_t)(SV_VALID | SV_QUEUED); emit = true; }     // addObstacle :212-226
             if (!is_hit && is_obstacle) { s = SV_QUEUED; emit = true; }                            // removeObstacle :228-242
             if (emit) {
                 dirty = true;

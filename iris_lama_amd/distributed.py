@@ -56,7 +56,7 @@ class ShardedPF:
             device = torch.device("cuda", opts.gpu_device) if self.backend == "nccl" else torch.device("cpu")
         self.device = device                      # where the collective's tensors live (cuda for RCCL, cpu for gloo)
         # particle blobs are written by the engine: device memory for liblama_hip.so, host memory for the test double
-        on_gpu = self.pf.engine_origin().endswith("liblama_hip.so")
+        on_gpu = F.is_device_library(self.pf.engine_origin())
         self.blob_device = torch.device("cuda", opts.gpu_device) if on_gpu else torch.device("cpu")
         self.blocks = [((r * self.P + self.world - 1) // self.world, ((r + 1) * self.P + self.world - 1) // self.world)
                        for r in range(self.world)]

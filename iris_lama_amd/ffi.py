@@ -1,5 +1,6 @@
 """ctypes bindings of include/lama_hip.h and include/lama_host.h."""
 import ctypes as C
+import math
 import os
 import sys
 
@@ -7,6 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB = os.path.join(_HERE, "lib", "liblama_hip.so")
+HIP_LIB_WIDE = os.path.join(_HERE, "lib", "liblama_hip_wide.so")
 HOST_LIB = os.path.join(_HERE, "lib", "liblama_host.so")
 _PRODUCT_HOST_LIB = HOST_LIB
 
@@ -68,6 +70,7 @@ HIP_SYMBOLS = [
 ]
 
 _hip = None
+_hip_wide = None
 
 
 def _torch_runtime_first():
@@ -84,9 +87,19 @@ def _torch_runtime_first():
             pass               # to skip the import altogether, e.g. for pure-ctypes users who never touch torch)
 
 
-def hip_lib():
-    """Load liblama_hip.so (raises if it has not been built: there is no fallback path)."""
-    global _hip
+def hip_lib(wide=False):
+    """Load liblama_hip.so -- or, with wide=True, liblama_hip_wide.so, the build of the same sources for distance maps with an
+    l2_max of 128 .. 255 cells (csrc/lama_dev.h).  Raises if it has not been built: there is no fallback path."""
+    global _hip, _hip_wide
+    if wide:
+        if _hip_wide is None:
+            if not os.path.exists(HIP_LIB_WIDE):
+                raise LamaError(f"{HIP_LIB_WIDE} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback.")
+            _torch_runtime_first()
+            L = C.CDLL(HIP_LIB_WIDE)
+            _bind_hip(L)
+            _hip_wide = L
+        return _hip_wide
     if _hip is None:
         if not os.path.exists(HIP_LIB):
             raise LamaError(f"{HIP_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -96,6 +109,27 @@ def hip_lib():
         _bind_hip(L)
         _hip = L
     return _hip
+
+
+def needs_wide(l2_max, resolution):
+    """True when a distance map of this reach needs liblama_hip_wide.so: ceil(l2_max / resolution) > 127 cells (as
+    lama_hip_ctx_create and the host classes compute it, DynamicDistanceMap::setMaxDistance)."""
+    return resolution > 0.0 and math.ceil(l2_max * (1.0 / resolution)) > 127
+
+
+def is_device_library(path):
+    """Is this engine origin one of the two device libraries (and not the test double of tests/cpu_engine)?"""
+    return path.endswith("liblama_hip.so") or path.endswith("liblama_hip_wide.so")
+
+
+def _lib_of_origin(path):
+    if path.endswith("liblama_hip.so"):
+        return hip_lib()
+    if path.endswith("liblama_hip_wide.so"):
+        return hip_lib(wide=True)
+    L = C.CDLL(path)                   # test double bound through set_engine_library()
+    _bind_hip(L)
+    return L
 
 
 def hip_lib_or_none():
@@ -192,7 +226,7 @@ class HipContext:
     """One device context = one shard of the particle pool (include/lama_hip.h)."""
 
     def __init__(self, cfg):
-        self.L = hip_lib()
+        self.L = hip_lib(wide=needs_wide(cfg.l2_max, cfg.resolution))
         self.cfg = cfg
         self.P = cfg.particles
         h = C.c_void_p()
@@ -704,11 +738,7 @@ class PFSlam2D:
     def hip_context(self):
         """Borrowed HipContext view of the local shard's device context (export/import, counters, maps)."""
         ctx = HipContext.__new__(HipContext)
-        if self.engine_origin().endswith("liblama_hip.so"):
-            ctx.L = hip_lib()
-        else:                      # test double bound through set_engine_library()
-            ctx.L = C.CDLL(self.engine_origin())
-            _bind_hip(ctx.L)
+        ctx.L = _lib_of_origin(self.engine_origin())
         ctx.cfg = None
         ctx.P = self.hi - self.lo
         ctx.h = C.c_void_p(self.device_context())
@@ -835,11 +865,7 @@ class Slam2D:
 
     def hip_context(self):
         ctx = HipContext.__new__(HipContext)
-        if self.engine_origin().endswith("liblama_hip.so"):
-            ctx.L = hip_lib()
-        else:
-            ctx.L = C.CDLL(self.engine_origin())
-            _bind_hip(ctx.L)
+        ctx.L = _lib_of_origin(self.engine_origin())
         ctx.cfg = None
         ctx.P = 1
         ctx.h = C.c_void_p(self.L.lama_slam_device_context(self.h))
@@ -886,9 +912,7 @@ class Loc2D:
     def hip_context(self):
         """Borrowed HipContext view of the device context (map downloads in tests)."""
         ctx = HipContext.__new__(HipContext)
-        ctx.L = hip_lib() if self.engine_origin().endswith("liblama_hip.so") else C.CDLL(self.engine_origin())
-        if ctx.L is not hip_lib_or_none():
-            _bind_hip(ctx.L)
+        ctx.L = _lib_of_origin(self.engine_origin())
         ctx.cfg = None
         ctx.P = 1
         ctx.h = C.c_void_p(self.L.lama_loc_device_context(self.h))
@@ -1117,11 +1141,7 @@ class LidarOdometry2D:
     def hip_context(self):
         """Borrowed HipContext view of the device context (map downloads in tests)."""
         ctx = HipContext.__new__(HipContext)
-        if self.engine_origin().endswith("liblama_hip.so"):
-            ctx.L = hip_lib()
-        else:
-            ctx.L = C.CDLL(self.engine_origin())
-            _bind_hip(ctx.L)
+        ctx.L = _lib_of_origin(self.engine_origin())
         ctx.cfg = None
         ctx.P = 1
         ctx.h = C.c_void_p(self.L.lama_lo_device_context(self.h))

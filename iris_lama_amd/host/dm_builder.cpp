@@ -46,7 +46,7 @@ bool build_distance_map(const uint32_t* cells_xy, size_t n, uint32_t max_sqdist,
                         uint64_t max_store_cells)
 {
     processed = 0;
-    if (n == 0 || max_sqdist > 16383u) return false;      // (the device's distance plane holds 14 bits: lama_hip_pf_upload_map would refuse)
+    if (n == 0 || max_sqdist > 65025u) return false;      // (255 cells: what the reference's uint16_t sqdist and the wide device library hold)
     uint32_t xlo = UINT32_MAX, xhi = 0, ylo = UINT32_MAX, yhi = 0;
     for (size_t i = 0; i < n; ++i) {
         xlo = std::min(xlo, cells_xy[2 * i]); xhi = std::max(xhi, cells_xy[2 * i]);

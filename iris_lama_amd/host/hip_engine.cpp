@@ -2,6 +2,7 @@
 
 #include <dlfcn.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <stdexcept>
 
@@ -12,28 +13,43 @@ HipEngine::~HipEngine()
     // the library stays loaded for the life of the process (HIP runtimes do not like dlclose)
 }
 
+static std::string siblingPath(const char* name)
+{
+    Dl_info info;
+    if (dladdr((void*)&loadHipEngine, &info) && info.dli_fname) {
+        std::string p(info.dli_fname);
+        size_t k = p.find_last_of('/');
+        if (k != std::string::npos) return p.substr(0, k + 1) + name;
+    }
+    return name;
+}
+
+static bool needs_wide(double l2_max, double resolution)
+{
+    // DynamicDistanceMap::setMaxDistance (src/sdm/dynamic_distance_map.cpp:149-153), as lama_hip_ctx_create computes it
+    return resolution > 0.0 && std::ceil(l2_max * (1.0 / resolution)) > 127.0;
+}
+
 #ifdef LAMA_TESTING      // the test-suite's host library only (tests/cpu_engine/Makefile): the shipped liblama_host.so has no such hook
 static std::shared_ptr<HipEngine> g_override;
 void setEngineOverride(std::shared_ptr<HipEngine> e) { g_override = std::move(e); }
 std::shared_ptr<HipEngine> defaultEngine() { return g_override ? g_override : loadHipEngine(); }
+std::shared_ptr<HipEngine> defaultEngine(double l2_max, double resolution)
+{
+    if (g_override) return g_override;
+    return needs_wide(l2_max, resolution) ? loadHipEngine(siblingPath("liblama_hip_wide.so")) : loadHipEngine();
+}
 #else
 std::shared_ptr<HipEngine> defaultEngine() { return loadHipEngine(); }
-#endif
-
-static std::string siblingPath()
+std::shared_ptr<HipEngine> defaultEngine(double l2_max, double resolution)
 {
-    Dl_info info;
-    if (dladdr((void*)&siblingPath, &info) && info.dli_fname) {
-        std::string p(info.dli_fname);
-        size_t k = p.find_last_of('/');
-        if (k != std::string::npos) return p.substr(0, k + 1) + "liblama_hip.so";
-    }
-    return "liblama_hip.so";
+    return needs_wide(l2_max, resolution) ? loadHipEngine(siblingPath("liblama_hip_wide.so")) : loadHipEngine();
 }
+#endif
 
 std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path)
 {
-    const std::string path = explicit_path.empty() ? siblingPath() : explicit_path;
+    const std::string path = explicit_path.empty() ? siblingPath("liblama_hip.so") : explicit_path;
     void* dl = dlopen(path.c_str(), RTLD_NOW | RTLD_GLOBAL);
     if (!dl) throw std::runtime_error(std::string("lama: cannot load the device library ") + path + ": " + dlerror() +
                                       " (build it with hipcc --offload-arch=gfx950; there is no CPU fallback)");

@@ -58,6 +58,10 @@ std::shared_ptr<HipEngine> loadHipEngine(const std::string& explicit_path = std:
 
 // The engine a newly constructed host object binds: liblama_hip.so through loadHipEngine().
 std::shared_ptr<HipEngine> defaultEngine();
+// The same for a distance map of the given reach: ceil(l2_max / resolution) <= 127 cells binds liblama_hip.so; beyond that, up to the
+// 255 cells the reference's uint16_t sqdist can hold, liblama_hip_wide.so (the same sources compiled with -DLAMA_WIDE_DM: a 4-byte
+// distance plane, 9-bit obstacle offsets in the queue entries; csrc/lama_dev.h).  More than 255 cells is refused by ctx_create.
+std::shared_ptr<HipEngine> defaultEngine(double l2_max, double resolution);
 #ifdef LAMA_TESTING
 // Test builds of the host library only (-DLAMA_TESTING, tests/cpu_engine/Makefile): an engine that the objects constructed
 // afterwards bind instead (nullptr = default loader).  The shipped liblama_host.so is compiled without it.

@@ -109,7 +109,7 @@ void Loc2D::ensureContext()
 {
     if (ctx_) return;
     if (!distance_map) throw std::runtime_error("lama::Loc2D: Init() must be called first");
-    eng_ = defaultEngine();
+    eng_ = defaultEngine(distance_map->maxDistanceOption(), opt_.resolution);
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = 1;

@@ -116,7 +116,7 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
         if ((uint32_t)options_.gpus > options_.particles) throw std::runtime_error("lama::PFSlam2D: more GPUs than particles");
         // all shards replay the same host random stream: settle the seed first (0 = random_device, src/pf_slam2d.cpp:131-134)
         if (options_.seed == 0) options_.seed = std::random_device()() | 1u;
-        eng_ = defaultEngine();
+        eng_ = defaultEngine(options_.l2_max, options_.resolution);
         int32_t ndev = 0;
         if (eng_->device_count(&ndev) != 0 || ndev <= 0)
             throw std::runtime_error("lama::PFSlam2D: no usable MI355X / HIP device; there is no CPU fallback");
@@ -140,7 +140,7 @@ PFSlam2D::PFSlam2D(const Options& options) : options_(options)
     hi_ = (uint32_t)(((r + 1) * P + G - 1) / G);
     if (hi_ <= lo_) throw std::runtime_error("lama::PFSlam2D: more shards than particles");
 
-    eng_ = defaultEngine();
+    eng_ = defaultEngine(options_.l2_max, options_.resolution);
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = hi_ - lo_;

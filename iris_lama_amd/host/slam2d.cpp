@@ -27,7 +27,7 @@ Slam2D::Slam2D(const Options& o) : trans_thresh_(o.trans_thresh), rot_thresh_(o.
     if (o.use_compression) throw std::runtime_error("lama::Slam2D: use_compression is not supported on the device path");
     transient_map_ = o.transient_map; truncated_range_ = o.truncated_range;
     if (o.create_summary) summary = new Summary;                 // src/slam2d.cpp:117-118
-    eng_ = defaultEngine();
+    eng_ = defaultEngine(o.l2_max, o.resolution);
     lama_hip_cfg cfg;
     eng_->default_cfg(&cfg);
     cfg.particles = 1;

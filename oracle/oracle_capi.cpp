@@ -366,7 +366,7 @@ static uint64_t map_checksum(const Map* m, FIELDS fields)
     return acc;
 }
 extern "C" {
-void orc_pf_map_checksums(void* h, int kind /*0 distance, 1 occupancy*/, uint64_t* out)
+void orc_pf_map_checksums(void* h, int kind /*0 distance, 1 occupancy, 2 distance in the wide library's packing*/, uint64_t* out)
 {
     auto& ps = ((PFBox*)h)->pf->particles();
     for (size_t i = 0; i < ps.size(); ++i) {
@@ -377,6 +377,14 @@ void orc_pf_map_checksums(void* h, int kind /*0 distance, 1 occupancy*/, uint64_
                 const uint64_t sv = (uint64_t)(d.sqdist & 0x3FFFu) | (d.valid_obstacle ? 0x8000ull : 0ull) | (d.is_queued ? 0x4000ull : 0ull);
                 const uint64_t ob = (uint64_t)(uint16_t)d.obstacle[0] | ((uint64_t)(uint16_t)d.obstacle[1] << 16);
                 return sv | (ob << 16);
+            });
+        else if (kind == 2)     // distance map as liblama_hip_wide.so packs it (l2_max beyond 127 cells: sqdist takes all 16 low bits,
+                                // the two flags sit above the mask bit)
+            out[i] = map_checksum(ps[i].dm.get(), [](const Container& c, uint32_t cell) {
+                distance_t d;
+                std::memcpy(&d, c.data.data() + (size_t)cell * sizeof(distance_t), sizeof(d));
+                const uint64_t ob = (uint64_t)(uint16_t)d.obstacle[0] | ((uint64_t)(uint16_t)d.obstacle[1] << 16);
+                return (uint64_t)d.sqdist | (ob << 16) | (d.valid_obstacle ? 1ull << 49 : 0ull) | (d.is_queued ? 1ull << 50 : 0ull);
             });
         else
             out[i] = map_checksum(ps[i].occ.get(), [](const Container& c, uint32_t cell) {

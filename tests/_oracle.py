@@ -454,7 +454,8 @@ class PF:
         return dict(zip(["iterations", "evals", "ray_cells", "occ_events", "bf_processed", "n_match", "n_occ", "n_bf", "n_match_or_bf"], c.tolist()))
 
     def map_checksums(self, kind):
-        """Per-particle map checksums, the function lama_hip_pf_map_checksums computes on the device (kind: 0 distance, 1 occupancy)."""
+        """Per-particle map checksums, the function lama_hip_pf_map_checksums computes on the device (kind: 0 distance, 1 occupancy,
+        2 distance as liblama_hip_wide.so packs it: l2_max beyond 127 cells)."""
         L = lib()
         L.orc_pf_map_checksums.restype = None
         L.orc_pf_map_checksums.argtypes = [C.c_void_p, C.c_int, C.c_void_p]

@@ -23,10 +23,11 @@ def random_room_scan(rng, pose_xyr, n_beams, kind):
     return np.stack([r * np.cos(ang), r * np.sin(ang), np.zeros(n_beams)], axis=1)
 
 
-def random_rooms_case(F, seed, small=False):
+def random_rooms_case(F, seed, small=False, l2_max=None):
     """Random star-shaped room, random beam count, ray truncation options and particle count; 4 scans from perturbed poses (walls are
     re-drawn a cell off: raise waves as well as lower waves) with a resample in between: occupancy and distance maps bit-identical to
-    the oracle.  small: rooms of 2.5 - 4.5 m, at most 360 beams and 3 particles (the lane simulator)."""
+    the oracle.  small: rooms of 2.5 - 4.5 m, at most 360 beams and 3 particles (the lane simulator).  l2_max: the reach of the distance
+    map in metres (default: the option's default, 0.5 m = 10 cells; beyond 6.35 m = 127 cells the wide device library runs)."""
     rng = np.random.default_rng(1000 + seed)
     kind = {"R": rng.uniform(2.5, 4.5 if small else 14.0), "coef": [(m, rng.uniform(0.02, 0.12), rng.uniform(0, 2 * np.pi)) for m in (2, 3, 5, 7)]}
     n_beams = int(rng.choice([90, 180, 360] if small else [90, 360, 720, 1080]))
@@ -37,14 +38,15 @@ def random_rooms_case(F, seed, small=False):
     bf_waves = int(rng.choice([1, 2]))
     bf_mode = 0
     base = np.array([rng.uniform(-0.3, 0.3) * kind["R"], rng.uniform(-0.3, 0.3) * kind["R"], rng.uniform(-np.pi, np.pi)])
-    opts = O.default_options(particles=P, seed=seed + 1, truncated_ray=trunc_ray, truncated_range=trunc_range)
+    more = {} if l2_max is None else {"l2_max": float(l2_max)}
+    opts = O.default_options(particles=P, seed=seed + 1, truncated_ray=trunc_ray, truncated_range=trunc_range, **more)
     pf = O.PF(opts)
     scan0 = random_room_scan(rng, base, n_beams, kind)
     pose0 = O.se2(*base)
     pf.set_prior(pose0)
     assert pf.update(scan0, pose0)
     ctx = F.HipContext(F.default_cfg(particles=P, truncated_ray=trunc_ray, truncated_range=trunc_range, sequential_raycast=seq_ray,
-                                     brushfire_waves=bf_waves, brushfire_mode=bf_mode, dm_patch_capacity=1024, occ_patch_capacity=1024))
+                                     brushfire_waves=bf_waves, brushfire_mode=bf_mode, dm_patch_capacity=1024, occ_patch_capacity=1024, **more))
     ctx.init(scan0, pose0)
     for k in range(4):
         truth = base + np.array([rng.uniform(-0.4, 0.4), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3)])

@@ -28,6 +28,26 @@ def test_hip_library_exports_header_symbols():
         assert hasattr(L, n), n
 
 
+def test_wide_hip_library_exports_the_same_symbols():
+    """liblama_hip_wide.so (the build for distance maps of 128 .. 255 cells, csrc/lama_dev.h) is a second instantiation of the same
+    C-ABI: every symbol of include/lama_hip.h, the kernels in a namespace of their own, intra-library calls bound to itself."""
+    if not os.path.exists(F.HIP_LIB_WIDE):
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "iris_lama_amd"), "hip"], check=True)
+    L = C.CDLL(F.HIP_LIB_WIDE)
+    for n in _declared("lama_hip.h", "lama_hip_"):
+        assert hasattr(L, n), n
+    dyn = subprocess.run(["readelf", "-d", F.HIP_LIB_WIDE], check=True, capture_output=True, text=True).stdout
+    assert "SYMBOLIC" in dyn, dyn
+    dyn = subprocess.run(["readelf", "-d", F.HIP_LIB], check=True, capture_output=True, text=True).stdout
+    assert "SYMBOLIC" in dyn, dyn
+    syms = subprocess.run(["nm", "-D", "--defined-only", F.HIP_LIB_WIDE], check=True, capture_output=True, text=True).stdout
+    assert "lama_dev_wide" in syms and "8lama_dev1" not in syms            # kernel stubs of the wide build: their own namespace
+    assert F.needs_wide(6.4, 0.05) and not F.needs_wide(6.35, 0.05) and F.needs_wide(0.5, 0.003)
+    if F.device_count() == 0:
+        with pytest.raises(F.LamaError):
+            F.HipContext(F.default_cfg(particles=2, l2_max=8.0))
+
+
 def test_counters_struct_matches_the_ctypes_mirror():
     """lama_hip_counters grows at its end; the Python mirror must be the library's struct, byte for byte in size, and a
     caller built against an older (shorter) header is served by lama_hip_get_counters_sized without being written past."""

@@ -6,6 +6,7 @@
     order of the 1080-row normal equations), identical Gauss-Newton iteration counts;
   * log-likelihood: relative 1e-9.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -175,7 +176,7 @@ def test_early_lane_and_routing_at_1536_particles_against_the_oracle(F, monkeypa
     assert c["bf_longest_chain_sum"] > 2 * c["bf_cells"] / P, c
 
 
-def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0, **map_opts):
+def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drifted=0, cfg_extra=None, **map_opts):
     pts, odom, truth = F.corridor_log(steps, 1080)
     rng = np.random.default_rng(5)
     opts = O.default_options(particles=P, seed=7, **map_opts)
@@ -184,7 +185,7 @@ def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drif
     pf.set_prior(pose0)
     assert pf.update(pts[0], pose0)
 
-    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves, brushfire_mode=bf_mode, **map_opts))
+    ctx = F.HipContext(F.default_cfg(particles=P, profile=1, sequential_raycast=seq_ray, brushfire_waves=bf_waves, brushfire_mode=bf_mode, **map_opts, **(cfg_extra or {})))
     ctx.init(pts[0], pose0)
     for i in (0, P - 1):
         assert_maps_equal(ctx.download_map(i, F.MAP_OCCUPANCY), pf.occ(i).dump(), OCC_FIELDS, f"init occ p{i}")
@@ -232,6 +233,97 @@ def _stagewise(F, P, steps, seq_ray, bf_waves, bf_mode, sxy=0.03, sth=0.01, drif
     print("counters", c, "GN flips", flips)
     ctx.close()
     return c
+
+
+@pytest.mark.parametrize("l2_max,bf_waves", [(8.0, 2), (12.75, 2), (6.6, 1)])
+def test_stagewise_parity_l2_max_beyond_127_cells(F, l2_max, bf_waves):
+    """VERDICT r05 item 7 -- an option limit lifted: l2_max of 160, 255 and 132 cells (the reference's uint16_t sqdist ends at 255^2).
+    Such a context runs liblama_hip_wide.so: the same sources with a 4-byte distance plane and 9-bit obstacle offsets in the queue
+    entries (csrc/lama_dev.h), picked by the reach of the map when the context is created.  The three stages -- scan match, resampling
+    (clones of 4-byte planes), map update with an exact brushfire that now floods the whole corridor and 8 - 13 m around it -- against
+    the oracle, bit for bit, and the device-side checksum in the wide packing."""
+    assert F.needs_wide(l2_max, 0.05) and not F.needs_wide(6.35, 0.05)
+    P, steps = 3, 3
+    c = _stagewise(F, P, steps, 2, bf_waves, 0, l2_max=l2_max, cfg_extra=dict(queue_capacity=1 << 20))
+    assert c["launches_update_maps"] == steps + 1
+    # the default library refuses the same configuration when it is called directly
+    h = C.c_void_p()
+    cfg = F.default_cfg(particles=2, l2_max=l2_max)
+    assert F.hip_lib().lama_hip_ctx_create(C.byref(cfg), C.byref(h)) == -1 and not h
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_randomized_rooms_maps_bit_exact_wide_library(F, seed):
+    """The randomised rooms (2.5 - 14 m, 90 - 1080 beams, truncation options, both ray-casts, one- and two-wave brushfire, a resample
+    in between) with a distance map that reaches 6.4 - 12.75 m: every scan floods the whole room; raise waves too (walls are re-drawn
+    a cell off)."""
+    l2 = [6.4, 7.0, 9.0, 10.0, 12.0, 12.75][seed]
+    from _stress import random_rooms_case
+    random_rooms_case(F, 50 + seed, l2_max=l2)
+
+
+def test_host_classes_pick_the_wide_library(F):
+    """lama::Slam2D and lama::PFSlam2D with l2_max = 7 m (140 cells) bind liblama_hip_wide.so by themselves and run free next to the
+    oracle; particle blobs (4-byte distance plane) travel between two wide contexts; Loc2D builds its 7 m map on the host and
+    uploads it to a wide context."""
+    steps = 6
+    pts, odom, truth = F.corridor_log(steps, 1080)
+    h = F.Slam2D(l2_max=7.0)
+    assert h.engine_origin().endswith("liblama_hip_wide.so")
+    o = O.Slam(l2_max=7.0)
+    h.set_pose(*odom[0])
+    o.set_pose(O.se2(*odom[0]))
+    for k in range(steps + 1):
+        assert h.update(pts[k], odom[k], float(k)) == o.update(pts[k], O.se2(*odom[k]), float(k))
+        assert np.abs(h.pose() - o.pose()).max() < 1e-7, k
+    ctx = h.hip_context()
+    assert_maps_equal(ctx.download_map(0, F.MAP_OCCUPANCY), o.occ().dump(), OCC_FIELDS, "slam occ (wide)")
+    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), o.dm().dump(), DM_FIELDS, "slam dm (wide)")
+    h.close()
+
+    P = 6
+    hp = F.PFSlam2D(F.pf_options(particles=P, seed=11, l2_max=7.0))
+    assert hp.engine_origin().endswith("liblama_hip_wide.so")
+    op = O.PF(O.default_options(particles=P, seed=11, l2_max=7.0))
+    hp.set_prior(*odom[0])
+    op.set_prior(O.se2(*odom[0]))
+    for k in range(4):
+        assert hp.update(pts[k], odom[k], float(k)) == op.update(pts[k], O.se2(*odom[k]), float(k))
+    ctx = hp.hip_context()
+    assert np.array_equal(ctx.map_checksums(F.MAP_OCCUPANCY), op.map_checksums(1))
+    assert np.array_equal(ctx.map_checksums(F.MAP_DISTANCE), op.map_checksums(2))          # (2: the wide library's packing)
+    # a particle's blob into a second wide context and back out: identical maps
+    other = F.HipContext(F.default_cfg(particles=2, l2_max=7.0))
+    other.init(pts[0], O.se2(*odom[0]))
+    import torch
+    n = ctx.export_bytes(3)
+    buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+    ctx.export_particle(3, buf.data_ptr(), n)
+    other.import_particle(1, buf.data_ptr(), n)
+    assert other.map_checksums(F.MAP_DISTANCE)[1] == ctx.map_checksums(F.MAP_DISTANCE)[3]
+    assert_maps_equal(other.download_map(1, F.MAP_DISTANCE), ctx.download_map(3, F.MAP_DISTANCE), DM_FIELDS, "imported particle (wide)")
+    other.close()
+    hp.close()
+
+    from _worlds import corridor_obstacles
+    obst = corridor_obstacles()
+    ol = O.Loc(l2_max=7.0)
+    dm = ol.dm()
+    for x, y in obst:
+        c = O.w2m([x, y, 0.0])
+        dm.add(int(c[0]), int(c[1]))
+    dm.update()
+    hl = F.Loc2D(l2_max=7.0)
+    hl.set_obstacles_world(obst)
+    assert hl.engine_origin().endswith("liblama_hip_wide.so")
+    assert_maps_equal(hl.hip_context().download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "Loc2D 7 m distance map after Init")
+    start = truth[0] + np.array([0.05, -0.04, 0.01])
+    ol.set_pose(O.se2(*start))
+    hl.set_pose(*start)
+    for k in range(4):
+        assert ol.update(pts[k], O.se2(*odom[k]), float(k), force=(k == 0)) == hl.update(pts[k], odom[k], float(k), force=(k == 0))
+        assert np.abs(ol.pose() - hl.pose()).max() < 1e-7, k
+    hl.close()
 
 
 def test_clones_keep_distance_patches_far_beyond_the_hits(F):
@@ -1512,7 +1604,7 @@ def test_limits_fail_loudly_with_status_codes(F):
     ctx = F.HipContext(F.default_cfg(particles=2, active_capacity=64, sequential_raycast=2))
     ctx.init(pts[0], pose0)
     ctx.close()
-    for bad in (dict(patch_size=16), dict(window_patches=252), dict(window_patches=1024), dict(resolution=0.0), dict(l2_max=10.0)):
+    for bad in (dict(patch_size=16), dict(window_patches=252), dict(window_patches=1024), dict(resolution=0.0), dict(l2_max=13.0)):      # (13 m = 260 cells: beyond the 255 of the wide library)
         with pytest.raises(F.LamaError, match="lama_hip_ctx_create failed"):
             F.HipContext(F.default_cfg(particles=2, **bad))
     # calls before init / with bad arguments

@@ -14,6 +14,7 @@ from _cmp import DM_FIELDS, OCC_FIELDS, assert_maps_equal
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SIM_LIB = os.path.join(HERE, "sim", "_build", "liblama_hip_sim.so")
+SIM_LIB_WIDE = os.path.join(HERE, "sim", "_build", "liblama_hip_sim_wide.so")
 SIM_LIB_SMALLQ = os.path.join(HERE, "sim", "_build", "liblama_hip_sim_smallq.so")      # first-stage brushfire queues of 320 / 80 entries
 
 
@@ -35,6 +36,16 @@ def Fsim():
 @pytest.fixture()
 def Fsim_smallq():
     yield from _with_lib(SIM_LIB_SMALLQ)
+
+
+@pytest.fixture()
+def Fsim_wide():
+    """the sources compiled with -DLAMA_WIDE_DM (liblama_hip_wide.so on the device): l2_max of 128 .. 255 cells"""
+    for F in _with_lib(SIM_LIB):
+        saved, saved_lib = F.HIP_LIB_WIDE, F._hip_wide
+        F.HIP_LIB_WIDE, F._hip_wide = SIM_LIB_WIDE, None
+        yield F
+        F.HIP_LIB_WIDE, F._hip_wide = saved, saved_lib
 
 
 def _run(F, P, steps, **cfg):
@@ -285,3 +296,14 @@ def test_seventy_particles_outgrow_their_regions_together(Fsim):
     c = ctx.counters()
     assert c["arena_growths"] >= 1 and c["resample_clones"] > P - 1, c
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,l2_max", [(0, 6.6), (3, 12.75)])
+def test_wide_build_randomized_small_rooms(Fsim_wide, seed, l2_max):
+    """The wide build of the kernels (4-byte distance plane, 9-bit obstacle offsets in the queue entries) on the lane simulator: a
+    distance map that reaches 132 / 255 cells floods the whole small room on every scan; occupancy and distance maps of every
+    particle after every scan against the oracle, bit for bit (the oracle itself is pinned against the reference's build in this
+    range by tests/test_oracle_vs_reference.py::test_dynamic_brushfire_beyond_127_cells)."""
+    from _stress import random_rooms_case
+    assert Fsim_wide.needs_wide(l2_max, 0.05)
+    random_rooms_case(Fsim_wide, seed, small=True, l2_max=l2_max)

@@ -80,6 +80,27 @@ def test_dynamic_brushfire_with_removals_and_ties(seed):
         assert da == db and np.array_equal(ga, gb)
 
 
+@pytest.mark.parametrize("l2_max", [6.6, 12.75])
+def test_dynamic_brushfire_beyond_127_cells(l2_max):
+    """The same with a reach of 132 and of 255 cells -- the whole range of the reference's uint16_t sqdist (255^2 = 65,025), and the
+    range that the wide device library (liblama_hip_wide.so) covers: the oracle is pinned there too."""
+    rng = np.random.default_rng(int(l2_max * 10))
+    a, b = R.DM.new(l2_max=l2_max), O.DM.new(l2_max=l2_max)
+    base = 42275904 + 40
+    live = set()
+    for rnd in range(6):
+        for _ in range(int(rng.integers(2, 12))):
+            c = (base + int(rng.integers(0, 300)), base + int(rng.integers(0, 300)))
+            if c in live and rng.random() < 0.5:
+                live.discard(c); a.remove(*c); b.remove(*c)
+            else:
+                live.add(c); a.add(*c); b.add(*c)
+        if rnd == 3 and live:
+            c = next(iter(live)); live.discard(c); a.remove(*c); b.remove(*c)
+        assert a.update() == b.update()
+        same_maps(a, b)
+
+
 def test_frequency_occupancy_counters():
     rng = np.random.default_rng(5)
     a, b = R.Occ.new(), O.Occ.new()
