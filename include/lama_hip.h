@@ -60,7 +60,11 @@ typedef struct lama_hip_cfg {
     uint32_t particles;          /* particles owned by THIS context (one shard of the pool)       */
     double resolution;           /* Options::resolution (0.05)                                    */
     uint32_t patch_size;         /* Options::patch_size; only 32 is supported on the device       */
-    double l2_max;               /* Options::l2_max -> DynamicDistanceMap::setMaxDistance          */
+    double l2_max;               /* Options::l2_max -> DynamicDistanceMap::setMaxDistance.  ceil(l2_max / resolution) <= 127 cells in
+                                    liblama_hip.so; liblama_hip_wide.so -- the same sources and the same C-ABI, built with a 4-byte
+                                    distance plane -- takes up to 255 cells, which is all the reference's own record can hold
+                                    (distance_t::sqdist is a uint16_t).  The host classes and iris_lama_amd.ffi bind the library
+                                    that the reach of the map asks for; a C caller links the one it needs.               */
     double meas_sigma;           /* Options::meas_sigma (likelihood divisor, pf_slam2d.cpp:411)   */
     uint32_t max_iter;           /* Options::max_iter                                             */
     double truncated_ray;        /* Options::truncated_ray                                        */
