@@ -31,7 +31,7 @@ def _check(cells, l2_max):
     return n, len(got[1])
 
 
-@pytest.mark.parametrize("l2_max", [0.5, 1.0, 2.0])
+@pytest.mark.parametrize("l2_max", [0.5, 1.0, 2.0, 7.0])
 def test_first_build_of_the_corridor_map_equals_the_oracle(l2_max):
     """the corridor world of the Loc2D tests: walls and pillars, in the order Loc2D's caller adds them"""
     pts = _worlds.corridor_obstacles()
@@ -84,5 +84,6 @@ def test_first_build_of_a_floor_plan_with_many_equal_priorities():
 
 
 def test_the_host_does_not_build_what_the_device_plane_cannot_hold():
-    assert F.dm_build(np.array([[OFF, OFF]], dtype=np.uint32), 16384) is None           # beyond 14 bits of squared distance
+    assert F.dm_build(np.array([[OFF, OFF]], dtype=np.uint32), 65026) is None           # beyond 255 cells: the end of the reference's uint16_t sqdist and of the wide device library
+    assert F.dm_build(np.array([[OFF, OFF]], dtype=np.uint32), 65025) is not None
     assert F.dm_build(np.zeros((0, 2), dtype=np.uint32), 100) is None
