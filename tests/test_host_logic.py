@@ -422,15 +422,16 @@ def test_lm_strategy_host_matches_oracle():
         assert ol.iterations() == hl.iterations()
 
 
-def test_no_scalar_loads_of_host_rewritten_tables():
-    """tools/check_scalar_loads.py on the assembly of the device library: no s_load of device data beyond the justified allow-list
-    (tables the host rewrites between launches and lists of other streams' kernels go through the coherent uniform loads of
-    lama_dev.h -- DESIGN.md section 8, "scalar-cache hazard")."""
+@pytest.mark.parametrize("wide", [False, True])
+def test_no_scalar_loads_of_host_rewritten_tables(wide):
+    """tools/check_scalar_loads.py on the assembly of the device library (and of its wide instantiation): no s_load of device data
+    beyond the justified allow-list (tables the host rewrites between launches and lists of other streams' kernels go through the
+    coherent uniform loads of lama_dev.h -- DESIGN.md section 8, "scalar-cache hazard")."""
     import shutil
     import subprocess
     import sys
     if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
         pytest.skip("no hipcc on this box")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_scalar_loads.py")], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_scalar_loads.py")] + (["--wide"] if wide else []), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

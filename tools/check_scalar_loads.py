@@ -2,6 +2,7 @@
 """ISA check of the library's rule for data that is rewritten between kernel launches ("scalar-cache hazard").
 
     python tools/check_scalar_loads.py            # compiles iris_lama_amd/csrc/lama_hip.hip to gfx950 assembly and checks it
+    python tools/check_scalar_loads.py --wide     # the same for the -DLAMA_WIDE_DM instantiation (liblama_hip_wide.so)
 
 Every scalar memory load (s_load_*, s_buffer_load_*) of every kernel is classified by where its base address comes from:
 
@@ -35,12 +36,12 @@ ALLOWED = {
 }
 
 
-def assembly():
+def assembly(wide=False):
     out = os.path.join(ROOT, "tools", "_tmp")
     os.makedirs(out, exist_ok=True)
-    path = os.path.join(out, "check_scalar_loads.s")
+    path = os.path.join(out, "check_scalar_loads_wide.s" if wide else "check_scalar_loads.s")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
-           "-S", "--cuda-device-only", "-o", path, SRC]
+           "-S", "--cuda-device-only", "-o", path, SRC] + (["-DLAMA_WIDE_DM"] if wide else [])
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return open(path).read().split("\n")
 
@@ -135,7 +136,7 @@ def scan(lines):
 
 
 def main():
-    lines = assembly()
+    lines = assembly(wide="--wide" in sys.argv)          # --wide: the -DLAMA_WIDE_DM instantiation (liblama_hip_wide.so)
     res = scan(lines)
     names = demangle(list(res))
     bad = 0
@@ -147,7 +148,7 @@ def main():
         total_dev += len(dev)
         name = names[k]
         name = name[5:] if name.startswith("void ") else name
-        allow = next((v for pre, v in ALLOWED.items() if name.startswith(pre)), None)
+        allow = next((v for pre, v in ALLOWED.items() if name.replace("lama_dev_wide::", "lama_dev::").startswith(pre)), None)
         limit = allow[0] if allow else 0
         status = "ok" if len(dev) <= limit else "FAIL"
         print(f"{status:4s} {len(dev)} device-data scalar load(s), {limit} allowed: {name[:110]}")
