@@ -2,7 +2,7 @@
 # `target_link_libraries(node iris_lama::iris_lama)`, reference CMakeLists.txt:25-55 and
 # cmake/iris_lamaConfig.cmake.in:7-11) pick up the MI355X path instead, in-tree:
 #     cmake -Diris_lama_DIR=<this repo>/cmake ...
-# The imported target is the host library liblama_host.so (it dlopen()s its sibling liblama_hip.so at run time);
+# The imported target is the host library liblama_host.so (it dlopen()s its sibling liblama_hip.so -- liblama_hip_wide.so for an l2_max beyond 127 cells -- at run time);
 # build both first with `make -C iris_lama_amd` (or python -c "import __graft_entry__ as g; g.build()").
 # Eigen3 is optional here: when it is found the public vector types are Eigen's (include/lama/types.h), otherwise the
 # POD stand-ins are used.
