@@ -396,7 +396,7 @@ class PF:
         self._keep = None
 
     def __del__(self):
-        if self.h:
+        if self.h and lib is not None:          # (at interpreter shutdown the module's globals may be gone already)
             lib().orc_pf_free(self.h)
             self.h = None
 
