@@ -273,7 +273,10 @@ __global__ __launch_bounds__(256) void k_occ_reverse_dir(DevParams prm, int firs
 #define RPT_T(k) do {} while (0)
 #endif
 constexpr int RPT_CHUNK = 256;        // candidate beams tested per round: the records of those that cross the patch wait in LDS
-constexpr int RPT_WALK = 4;           // lanes that share the cells of one (beam, patch) crossing
+#ifndef LAMA_RPT_WALK
+#define LAMA_RPT_WALK 4
+#endif
+constexpr int RPT_WALK = LAMA_RPT_WALK;   // lanes that share the cells of one (beam, patch) crossing
 
 __global__ __launch_bounds__(256, 6) void k_ray_patches(DevParams prm, const RayRec* __restrict__ recs, const uint64_t* __restrict__ bbox,
                                                       const RayChunk* __restrict__ chunks, int n, int first_particle)

@@ -16,7 +16,7 @@ import iris_lama_amd.ffi as F      # noqa: E402
 P, WARM, STEPS = 30, 3, 12
 pts, odom, truth = F.corridor_log(WARM + STEPS, 1080)
 for l2 in (0.5, 3.0, 7.0, 12.75):
-    pf = F.PFSlam2D(F.pf_options(particles=P, seed=42, l2_max=l2, create_summary=0, queue_capacity=1 << 20))
+    pf = F.PFSlam2D(F.pf_options(particles=P, seed=42, l2_max=l2, create_summary=0, **({} if "--default-queue" in sys.argv else {"queue_capacity": 1 << 20})))
     pf.set_prior(*odom[0])
     t0 = None
     for k in range(WARM + STEPS + 1):
