@@ -173,7 +173,8 @@ struct lama_hip_ctx {
     // d_poses | d_loglik | d_iters | d_err are carved out of ONE allocation so that a scan match brings all of its results
     // (and the error word) back with a single device-to-host copy
     uint8_t* d_results = nullptr;
-    size_t results_bytes = 0;
+    size_t results_bytes = 0, status_off = 0, status_bytes = 0;
+    PinVec<uint8_t> h_status;
     PinVec<uint8_t> h_results;
     int32_t* d_oldcounts = nullptr;
     double* d_bposes = nullptr; double* d_bout = nullptr; uint32_t b_cap = 0;
@@ -311,15 +312,30 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
     int32_t& e = c->h_err[0];
     e = 0;
     const bool stats = maps || match;
-    if (stats) {
-        c->h_stats.resize((size_t)c->P * 4);
-        HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
-        if (maps) { c->h_guard.resize(c->P); HIPCHK(c, hipMemcpyAsync(c->h_guard.data(), c->d_guard, sizeof(uint32_t) * c->P, hipMemcpyDeviceToHost, c->stream)); }
-        HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
+    const bool packed = maps && !err_in_results;      // a map update: error word, hand-over counts, statistics, guard and patch counts in ONE copy
+    if (stats) c->h_stats.resize((size_t)c->P * 4);
+    if (packed) {
+        c->h_status.resize(c->status_bytes); c->h_guard.resize(c->P); c->h_slow_n.resize(5);
+        HIPCHK(c, hipMemcpyAsync(c->h_status.data(), c->d_results + c->status_off, c->status_bytes, hipMemcpyDeviceToHost, c->stream));
+    } else {
+        if (stats) {
+            HIPCHK(c, hipMemcpyAsync(c->h_counts.data(), c->ms.counts, sizeof(int32_t) * 2 * c->P, hipMemcpyDeviceToHost, c->stream));
+            if (maps) { c->h_guard.resize(c->P); HIPCHK(c, hipMemcpyAsync(c->h_guard.data(), c->d_guard, sizeof(uint32_t) * c->P, hipMemcpyDeviceToHost, c->stream)); }
+            HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
+        }
+        if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
+        if (maps) { c->h_slow_n.resize(5); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     }
-    if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-    if (maps) { c->h_slow_n.resize(5); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (packed) {
+        const uint8_t* b = c->h_status.data();
+        const size_t o_slow = (const uint8_t*)c->d_slow_n - (c->d_results + c->status_off);
+        std::memcpy(&e, b, sizeof(e));
+        std::memcpy(c->h_slow_n.data(), b + o_slow, 5 * sizeof(uint32_t));
+        std::memcpy(c->h_stats.data(), b + o_slow + 32, sizeof(uint64_t) * 4 * c->P);
+        std::memcpy(c->h_guard.data(), b + o_slow + 32 + sizeof(uint64_t) * 4 * c->P, sizeof(uint32_t) * c->P);
+        std::memcpy(c->h_counts.data(), b + o_slow + 32 + sizeof(uint64_t) * 4 * c->P + sizeof(uint32_t) * 2 * c->P, sizeof(int32_t) * 2 * c->P);
+    }
     if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1] + c->h_slow_n[3]; c->ctr.brushfire_routed += c->h_slow_n[2] + c->h_slow_n[4]; c->ctr.brushfire_early += c->h_slow_n[4]; c->early_candidates = c->h_slow_n[2] + c->h_slow_n[4]; }
     if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
@@ -872,8 +888,7 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
     {
         Timer t(c, &c->ctr.ms_raycast, &c->ctr.launches_raycast);
         // both ray-casts are bit-exact; the parallel one wins while the chip is not yet full of particles
-        (void)hipMemsetAsync(c->d_stats, 0, sizeof(uint64_t) * 4 * c->P, c->stream);
-        (void)hipMemsetAsync(c->d_slow_n, 0, 5 * sizeof(uint32_t), c->stream);
+        (void)hipMemsetAsync(c->d_slow_n, 0, 32 + sizeof(uint64_t) * 4 * c->P, c->stream);      // hand-over counts and statistics: adjacent (ctx_create)
         bool sequential = c->cfg.sequential_raycast == 1 || c->cfg.occupancy_policy == 1 ||
                           c->cfg.ray_rule == 1;      // the parallel kernels implement the frequency counters and the PF ray rule only
         // every hit is an order-sensitive visit (the list holds active_capacity of them) and the visit key carries the beam index
@@ -1231,7 +1246,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
         if (P * dc > 0xFFFFFFF0ull || P * oc > 0xFFFFFFF0ull) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_INVALID; }
         CHK(hipMalloc(&m.dm_dir, P * WW * 2));                 CHK(hipMemset(m.dm_dir, 0xFF, P * WW * 2));
         CHK(hipMalloc(&m.occ_dir, P * WW * 2));                CHK(hipMemset(m.occ_dir, 0xFF, P * WW * 2));
-        CHK(hipMalloc(&m.counts, P * 2 * 4));                  CHK(hipMemset(m.counts, 0, P * 2 * 4));
+        // (m.counts lives in the results / status block below: one copy brings a map update's counters back)
         // first chunk of each pool: P regions of the configured capacity
         if (add_chunk(c, true, (uint32_t)(P * dc)) != LAMA_HIP_OK || add_chunk(c, false, (uint32_t)(P * oc)) != LAMA_HIP_OK) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; }
         c->ctr.pool_growths = 0;
@@ -1246,15 +1261,25 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
         if (upload_part(c) != LAMA_HIP_OK) { lama_hip_ctx_destroy(c); return LAMA_HIP_E_HIP; }
         CHK(hipStreamSynchronize(c->stream));
     }
+    // ONE allocation: [poses | loglik | iters | err]   what a scan match brings back (results_bytes, one copy) ...
+    //                 [err | slow_n | stats | guard | counts]   ... and what a map update brings back (status_bytes from status_off, one
+    // copy: round 6 -- the five copies it used to take were 23 us at the end of every 1.8 ms update); slow_n and stats are adjacent:
+    // one memset clears both when an update starts.
     c->results_bytes = P * 4 * 8 + P * 8 + P * 4 + 8;
-    CHK(hipMalloc(&c->d_results, c->results_bytes));   CHK(hipMemset(c->d_results, 0, c->results_bytes));
+    c->status_off = P * 4 * 8 + P * 8 + P * 4;                                  // the error word: last of the results, first of the status
+    const size_t slow_off = (c->results_bytes + 7) / 8 * 8;
+    c->status_bytes = (slow_off - c->status_off) + 32 + P * 4 * 8 + P * 2 * 4 + P * 2 * 4;
+    CHK(hipMalloc(&c->d_results, c->status_off + c->status_bytes));   CHK(hipMemset(c->d_results, 0, c->status_off + c->status_bytes));
     c->d_poses = reinterpret_cast<double*>(c->d_results);
     c->d_loglik = c->d_poses + P * 4;
     c->d_iters = reinterpret_cast<int32_t*>(c->d_loglik + P);
     c->d_err = c->d_iters + P;
+    c->d_slow_n = reinterpret_cast<uint32_t*>(c->d_results + slow_off);
+    c->d_stats = reinterpret_cast<uint64_t*>(c->d_results + slow_off + 32);
+    c->d_guard = reinterpret_cast<uint32_t*>(c->d_stats + P * 4);
+    c->ms.counts = reinterpret_cast<int32_t*>(c->d_guard + P * 2);
     CHK(hipMalloc(&c->d_qlower, P * (size_t)cfg.queue_capacity * 8));
     CHK(hipMalloc(&c->d_qraise, P * (size_t)cfg.queue_capacity * 8));
-    CHK(hipMalloc(&c->d_stats, P * 4 * 8));          CHK(hipMemset(c->d_stats, 0, P * 4 * 8));
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
@@ -1268,9 +1293,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipEventCreateWithFlags(&c->ev_alloc, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_early, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&c->ev_go, hipEventDisableTiming));
     CHK(hipEventCreateWithFlags(&c->ev_route, hipEventDisableTiming)); CHK(hipEventCreateWithFlags(&c->ev_heavy, hipEventDisableTiming));
-    CHK(hipMalloc(&c->d_slow_n, 32));                CHK(hipMemset(c->d_slow_n, 0, 32));
     CHK(hipMalloc(&c->d_scalar, 16));                CHK(hipMemset(c->d_scalar, 0, 16));
-    CHK(hipMalloc(&c->d_guard, P * 2 * 4));          CHK(hipMemset(c->d_guard, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_act, P * (size_t)cfg.active_capacity * 8));
     CHK(hipMalloc(&c->d_act_count, P * 4));          CHK(hipMemset(c->d_act_count, 0, P * 4));
     CHK(hipMalloc(&c->d_tfs, P * 12 * 8));
@@ -1290,12 +1313,12 @@ void lama_hip_ctx_destroy(lama_hip_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     {
         MapStore& m = c->ms;
-        (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir); (void)hipFree(m.counts);
+        (void)hipFree(m.dm_dir); (void)hipFree(m.occ_dir);
         for (PoolChunk& k : m.dm_chunks) for (int i = 0; i < 4; ++i) (void)hipFree(k.plane[i]);
         for (PoolChunk& k : m.occ_chunks) for (int i = 0; i < 4; ++i) (void)hipFree(k.plane[i]);
         (void)hipFree(c->d_part); (void)hipFree(c->d_jobs); (void)hipFree(c->d_zjobs);
     }
-    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_stats); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_slow_n); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar); (void)hipFree(c->d_guard); (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk);
+    (void)hipFree(c->d_results); (void)hipFree(c->d_qlower); (void)hipFree(c->d_qraise); (void)hipFree(c->d_qsizes); (void)hipFree(c->d_dbg); (void)hipFree(c->d_slow); (void)hipFree(c->d_slow_list); (void)hipFree(c->d_heavy); (void)hipFree(c->d_early); (void)hipFree(c->d_elist); (void)hipFree(c->d_hlist); (void)hipFree(c->d_scalar);  (void)hipFree(c->d_ship_desc); (void)hipFree(c->d_ship_heads); (void)hipFree(c->d_act); (void)hipFree(c->d_act_count); (void)hipFree(c->d_rrec); (void)hipFree(c->d_rbbox); (void)hipFree(c->d_rchunk);
     (void)hipFree(c->d_pts); (void)hipFree(c->d_tfs);
     (void)hipFree(c->d_oldcounts);
     (void)hipFree(c->d_bposes); (void)hipFree(c->d_bout);
