@@ -327,8 +327,6 @@ typedef struct lama_hip_counters {
     uint32_t struct_bytes;              /* sizeof(lama_hip_counters) of the library that filled the struct (see lama_hip_get_counters_sized) */
     double peer_copy_ms;                /* device time (hipEvents on the destination's stream) of the cross-device lama_hip_blob_copy calls ... */
     uint64_t peer_copy_bytes;           /* ... and the bytes they moved INTO this context: bytes / ms = the achieved xGMI rate               */
-    uint64_t brushfire_big_handovers;   /* round 6: particle updates whose queue outgrew the big-queue stage too (8,192 entries): they continue in the
-                                           third LDS stage (16,384 entries) when the previous update had any, else in the one-lane kernel    */
 } lama_hip_counters;
 int32_t lama_hip_get_counters(lama_hip_ctx* ctx, lama_hip_counters* out);
 /* The same for a caller compiled against another version of this header: at most `bytes` bytes are written (the struct

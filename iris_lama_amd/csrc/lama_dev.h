@@ -121,8 +121,8 @@ struct DevParams {
     uint64_t* q_raise;     // [P][qcap]
     uint32_t* qsizes;      // [P][2] entries handed from k_raycast to k_brushfire (lower, raise)
     uint32_t* slow;        // [P] 1 = a stage handed this particle to the next (bigger / slower) stage
-    uint32_t* slow_list;   // [5][P] ([4]: particles a big-queue brushfire stage handed on to the third LDS stage; [2]: the routed particles, [3]: replay hand-overs of the early lane) particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
-    uint32_t* slow_n;      // [6]    ... and how many ([5]: of list 4); [2]: particles routed to the big-queue stage before the brushfire started (k_bf_route); [3]: early lane's replay hand-overs; [4]: early-lane particles
+    uint32_t* slow_list;   // [4][P] ([2]: the routed particles, [3]: replay hand-overs of the early lane) particles the first stage of the brushfire ([0]) / of the ordered replay ([1]) handed to its resume stage ...
+    uint32_t* slow_n;      // [5]    ... and how many; [2]: particles routed to the big-queue stage before the brushfire started (k_bf_route); [3]: early lane's replay hand-overs; [4]: early-lane particles
     uint8_t* heavy;        // [P]    1 = routed: the first brushfire stage skips the particle (nullptr: routing is off)
     // early lane (k_early_list): the particles that were routed in the PREVIOUS update are usually the long chains again; their
     // modifying ray-cast kernels and their brushfire run on a stream of their own, ahead of everybody else's

@@ -158,8 +158,6 @@ struct lama_hip_ctx {
     uint32_t route_min_count = 64, route_min_events = 48, route_percent = 150, route_cap = 64;     // LAMA_HIP_BF_ROUTE overrides (tests)
     bool route_forced = false; uint32_t num_cus = 256;
     bool debug_tail = false, debug_window = false;      // LAMA_HIP_DEBUG_TAIL / LAMA_HIP_DEBUG_WINDOW, read at creation
-    bool xl_stage = false;                              // the previous map update handed particles on from a big-queue brushfire stage: launch the third LDS stage
-    int xl_forced = -1;                                 // LAMA_HIP_BF_XL = 1 / 0 (tests): always / never launch it
     uint32_t big_stage_pad = 0;                         // dynamic LDS added to the early lane's big-queue workgroups (a FULL chip) so that a long chain has its CU to itself
     uint64_t* d_act = nullptr; uint32_t* d_act_count = nullptr;
     // patch-centric ray-cast (lama_raycast_patch.h): ray records / bounding boxes of the scan's beams, arena slot -> directory position
@@ -317,7 +315,7 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
     const bool packed = maps && !err_in_results;      // a map update: error word, hand-over counts, statistics, guard and patch counts in ONE copy
     if (stats) c->h_stats.resize((size_t)c->P * 4);
     if (packed) {
-        c->h_status.resize(c->status_bytes); c->h_guard.resize(c->P); c->h_slow_n.resize(6);
+        c->h_status.resize(c->status_bytes); c->h_guard.resize(c->P); c->h_slow_n.resize(5);
         HIPCHK(c, hipMemcpyAsync(c->h_status.data(), c->d_results + c->status_off, c->status_bytes, hipMemcpyDeviceToHost, c->stream));
     } else {
         if (stats) {
@@ -326,20 +324,19 @@ int32_t check_device_errors(lama_hip_ctx* c, bool maps = false, bool match = fal
             HIPCHK(c, hipMemcpyAsync(c->h_stats.data(), c->d_stats, sizeof(uint64_t) * c->h_stats.size(), hipMemcpyDeviceToHost, c->stream));
         }
         if (!err_in_results) HIPCHK(c, hipMemcpyAsync(&e, c->d_err, sizeof(e), hipMemcpyDeviceToHost, c->stream));
-        if (maps) { c->h_slow_n.resize(6); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 6 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
+        if (maps) { c->h_slow_n.resize(5); HIPCHK(c, hipMemcpyAsync(c->h_slow_n.data(), c->d_slow_n, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream)); }
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (packed) {
         const uint8_t* b = c->h_status.data();
         const size_t o_slow = (const uint8_t*)c->d_slow_n - (c->d_results + c->status_off);
         std::memcpy(&e, b, sizeof(e));
-        std::memcpy(c->h_slow_n.data(), b + o_slow, 6 * sizeof(uint32_t));
+        std::memcpy(c->h_slow_n.data(), b + o_slow, 5 * sizeof(uint32_t));
         std::memcpy(c->h_stats.data(), b + o_slow + 32, sizeof(uint64_t) * 4 * c->P);
         std::memcpy(c->h_guard.data(), b + o_slow + 32 + sizeof(uint64_t) * 4 * c->P, sizeof(uint32_t) * c->P);
         std::memcpy(c->h_counts.data(), b + o_slow + 32 + sizeof(uint64_t) * 4 * c->P + sizeof(uint32_t) * 2 * c->P, sizeof(int32_t) * 2 * c->P);
     }
-    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1] + c->h_slow_n[3]; c->ctr.brushfire_routed += c->h_slow_n[2] + c->h_slow_n[4]; c->ctr.brushfire_early += c->h_slow_n[4]; c->early_candidates = c->h_slow_n[2] + c->h_slow_n[4];
-                 c->ctr.brushfire_big_handovers += c->h_slow_n[5]; c->xl_stage = c->xl_forced >= 0 ? c->xl_forced == 1 : c->h_slow_n[5] > 0; }
+    if (maps) { c->ctr.brushfire_handovers += c->h_slow_n[0]; c->ctr.replay_handovers += c->h_slow_n[1] + c->h_slow_n[3]; c->ctr.brushfire_routed += c->h_slow_n[2] + c->h_slow_n[4]; c->ctr.brushfire_early += c->h_slow_n[4]; c->early_candidates = c->h_slow_n[2] + c->h_slow_n[4]; }
     if (err_in_results) std::memcpy(&e, c->h_results.data() + ((const uint8_t*)c->d_err - c->d_results), sizeof(e));
     resolve_timers(c);
     if (e != 0) {
@@ -1045,13 +1042,6 @@ int32_t run_update_maps(lama_hip_ctx* c, uint32_t n, const Affine& mtf, uint32_t
             hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 0);
         }
         if (early_lane) HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev_early, 0));
-        // third LDS stage (queues of up to 16 k entries at the wave pair's pace instead of the one-lane kernel's): behind every big-queue
-        // stage of the update, and only when the previous update handed particles on from there -- floods come in runs (a reach of metres,
-        // a hall being entered), and an empty launch of a 148 KB workgroup per list walker is not free
-        if (c->xl_stage) {
-            if (two_waves) hipLaunchKernelGGL((k_brushfire<LQ_XL, RQ_XL, true, true>), dim3(resume_grid), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)first, 3);
-            else hipLaunchKernelGGL((k_brushfire<LQ_XL, RQ_XL, true, false>), dim3(resume_grid), dim3(UM_BLOCK), 0, c->stream, prm, (int)first, 3);
-        }
         hipLaunchKernelGGL(k_brushfire_slow, dim3(count), dim3(UM_BLOCK), 0, c->stream, prm, (int)first);
         c->early_ok = route && first == 0 && count == c->P;      // d_heavy now holds this update's routed particles (early lane included)
         t.stop();
@@ -1217,7 +1207,6 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     // longest chain / the window did; LAMA_HIP_BF_ROUTE overrides the routing thresholds (tests, experiments)
     c->debug_tail = std::getenv("LAMA_HIP_DEBUG_TAIL") != nullptr;
     c->debug_window = std::getenv("LAMA_HIP_DEBUG_WINDOW") != nullptr;
-    if (const char* xl = std::getenv("LAMA_HIP_BF_XL")) { c->xl_forced = xl[0] == '1' ? 1 : 0; c->xl_stage = c->xl_forced == 1; }
     {   // A long chain that shares its CU with six first-stage workgroups runs at 0.79 us per pop, alone at 0.75 (and 0.65 on an idle
         // chip): the routed / early big-queue workgroups of a full chip ask for the REST of the CU's LDS as dynamic shared memory, so
         // nothing else is placed beside them (workgroups of that launch without a list entry exit at once and free their CU).
@@ -1294,7 +1283,7 @@ int32_t lama_hip_ctx_create(const lama_hip_cfg* cfg_in, lama_hip_ctx** out)
     CHK(hipMalloc(&c->d_qsizes, P * 2 * 4));         CHK(hipMemset(c->d_qsizes, 0, P * 2 * 4));
     CHK(hipMalloc(&c->d_dbg, P * 16 * 8 + (1u << 20)));   CHK(hipMemset(c->d_dbg, 0, P * 16 * 8 + (1u << 20)));   // + 1 MiB developer event log
     CHK(hipMalloc(&c->d_slow, P * 4));               CHK(hipMemset(c->d_slow, 0, P * 4));
-    CHK(hipMalloc(&c->d_slow_list, 5 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 5 * P * 4));
+    CHK(hipMalloc(&c->d_slow_list, 4 * P * 4));      CHK(hipMemset(c->d_slow_list, 0, 4 * P * 4));
     CHK(hipMalloc(&c->d_heavy, P));                  CHK(hipMemset(c->d_heavy, 0, P));
     CHK(hipMalloc(&c->d_early, P));                  CHK(hipMemset(c->d_early, 0, P));
     CHK(hipMalloc(&c->d_elist, 256 * 4));            CHK(hipMemset(c->d_elist, 0, 256 * 4));
@@ -1995,11 +1984,10 @@ int32_t lama_hip_map_add_obstacles(lama_hip_ctx* c, uint32_t particle, const uin
     // obstacles then updating in slices yields the same distance map only if no slice boundary matters -- so a list
     // longer than the queue is rejected instead)
     if (n > c->cfg.queue_capacity) { (void)hipFree(d_cells); return fail(c, LAMA_HIP_E_CAPACITY, "more obstacle cells than cfg.queue_capacity"); }
-    HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, 8 * sizeof(uint32_t), c->stream));    // all of them: check_device_errors(maps) adds every word to the counters
+    HIPCHK(c, hipMemsetAsync(c->d_slow_n, 0, 5 * sizeof(uint32_t), c->stream));    // all five: check_device_errors(maps) adds every word to the counters
     hipLaunchKernelGGL(k_dm_add_obstacles, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle, d_cells, n);
     hipLaunchKernelGGL((k_brushfire<LQ_SMALL, RQ_SMALL, false, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
     hipLaunchKernelGGL((k_brushfire<LQ_BIG, RQ_BIG, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 0);
-    hipLaunchKernelGGL((k_brushfire<LQ_XL, RQ_XL, true, true>), dim3(1), dim3(2 * UM_BLOCK), 0, c->stream, prm, (int)particle, 3);
     hipLaunchKernelGGL(k_brushfire_slow, dim3(1), dim3(UM_BLOCK), 0, c->stream, prm, (int)particle);
     HIPCHK(c, hipGetLastError());
     int32_t rc = check_device_errors(c, true, false);

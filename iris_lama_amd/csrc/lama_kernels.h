@@ -22,15 +22,7 @@ constexpr int LQ_SMALL = LAMA_TEST_SMALL_QUEUES, RQ_SMALL = LAMA_TEST_SMALL_QUEU
 #else
 constexpr int LQ_SMALL = 1024, RQ_SMALL = 256;     // 8 + 2 KiB
 #endif
-#ifdef LAMA_TEST_SMALL_QUEUES
-constexpr int LQ_BIG = 2 * LAMA_TEST_SMALL_QUEUES, RQ_BIG = 2048;     // (tests/sim: the hand-over to the third stage happens too)
-#else
 constexpr int LQ_BIG = 8192, RQ_BIG = 2048;        // 64 + 16 KiB
-#endif
-// third LDS stage: a flood that outgrows the big stage -- a distance map with a reach of metres (the wide library), the first scan of a
-// hall -- used to fall to the one-lane kernel with its heap in HBM (7 us per pop); a workgroup with (nearly) all of a CU's LDS keeps
-// the wave pair's pace up to 16 k queue entries.  Launched only when the previous update needed it (lama_hip.hip).
-constexpr int LQ_XL = 16384, RQ_XL = 2048;         // 128 + 16 KiB
 constexpr uint32_t BF_TW_MAX_PARTICLES = 1u << 30;     // the helper-wave form wins at every measured particle count (30 .. 3000); cfg.brushfire_waves = 1 forces one wave
 
 // ------------------------------------------------------------------------------------------------
@@ -1284,13 +1276,11 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
 }
 #endif
 
-// hand particle p to the next stage: the first stage (0) lists it for the big-queue stage, the big-queue stage (1) for the third LDS
-// stage (list 4 / count 5); every resume stage flags it, which is what k_brushfire_slow looks at
-__device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, int stage)
+// hand particle p to the next stage: the first stage lists it for the resume stage, the resume stage flags it for k_brushfire_slow
+__device__ __forceinline__ void bf_hand_over(const DevParams& prm, int p, bool from_resume)
 {
     prm.slow[p] = 1;
-    if (stage == 0) prm.slow_list[atomicAdd(prm.slow_n, 1u)] = (uint32_t)p;
-    else if (stage == 1) prm.slow_list[4 * (size_t)prm.P + atomicAdd(prm.slow_n + 5, 1u)] = (uint32_t)p;
+    if (!from_resume) prm.slow_list[atomicAdd(prm.slow_n, 1u)] = (uint32_t)p;
 }
 
 // the brushfire of ONE particle by the calling workgroup (body of k_brushfire)
@@ -1321,7 +1311,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     if (RESUME && handed == 0) return;
     if (tid == 0) prm.slow[p] = 0;
     if (nl == 0 && nr == 0) return;
-    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) bf_hand_over(prm, p, RESUME ? (LQ_LDS >= LQ_XL ? 2 : 1) : 0); return; }
+    if (nl + 4 > (uint32_t)LQ_LDS || nr + 4 > (uint32_t)RQ_LDS) { if (tid == 0) bf_hand_over(prm, p, RESUME); return; }
 
     for (int k = tid; k < DC_SIZE; k += nthreads) sh.dc[k] = DC_EMPTY;
     for (uint32_t k = tid; k < nl; k += nthreads) sh.lower[k] = g_lower[k];
@@ -2138,7 +2128,7 @@ __device__ __forceinline__ void bf_particle(const DevParams& prm, const int p_an
     if (lane == 0) {
         prm.counts[2 * p] = count;
         prm.stats[4 * p + 3] += processed;
-        if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; bf_hand_over(prm, p, RESUME ? (LQ_LDS >= LQ_XL ? 2 : 1) : 0); }
+        if (spill) { prm.qsizes[2 * p] = nl; prm.qsizes[2 * p + 1] = nr; bf_hand_over(prm, p, RESUME); }
 #ifdef LAMA_PROFILE_BF
 #ifdef LAMA_PROFILE_BF_MAIN
         for (int k = 0; k < 8; ++k) prm.dbg[8 * p + k] = prof[k];
@@ -2241,7 +2231,7 @@ __global__ __launch_bounds__(64) void k_mark_early(DevParams prm)
 }
 
 // `routed` (resume stages only): 1 = walk the list of the routed particles (k_bf_route) instead of the first stage's hand-over list,
-// 2 = the early lane's list, 3 = the particles the big-queue stages handed on (the third LDS stage)
+// 2 = the early lane's list
 template <int LQ_LDS, int RQ_LDS, bool RESUME, bool TW>
 __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevParams prm, int first_particle, int routed = 0)
 {
@@ -2264,8 +2254,8 @@ __global__ __launch_bounds__(TW ? 2 * UM_BLOCK : UM_BLOCK) void k_brushfire(DevP
     }
     if (routed == 2 && map_update_aborted(prm)) return;      // (the other lists are empty after an aborted allocation phase; this one is not)
     // (lists and counts of kernels that may have run on another stream of the context: coherent uniform loads, lama_dev.h)
-    const uint32_t n = uload_u32(routed == 2 ? prm.elist_n : (routed == 3 ? prm.slow_n + 5 : (routed ? prm.slow_n + 2 : prm.slow_n)));
-    const uint32_t* list = routed == 2 ? prm.elist : prm.slow_list + (routed == 3 ? 4 * (size_t)prm.P : (routed ? 2 * (size_t)prm.P : 0));
+    const uint32_t n = uload_u32(routed == 2 ? prm.elist_n : (routed ? prm.slow_n + 2 : prm.slow_n));
+    const uint32_t* list = routed == 2 ? prm.elist : prm.slow_list + (routed ? 2 * (size_t)prm.P : 0);
     for (uint32_t i = blockIdx.x; i < n; i += gridDim.x) {
         bf_particle<LQ_LDS, RQ_LDS, RESUME, TW>(prm, (int)uload_u32(list + i), sh);
         __syncthreads();                                 // every wave is done with this particle's LDS before the next one is loaded

@@ -50,8 +50,7 @@ class HipCounters(C.Structure):
                 ("bf_longest_chain_sum", C.c_uint64), ("bf_longest_chain_last", C.c_uint64), ("brushfire_early", C.c_uint64), ("brushfire_routed", C.c_uint64),
                 ("pool_growths", C.c_uint64), ("resample_clones", C.c_uint64), ("resample_bytes", C.c_uint64),
                 ("hbm_bytes_allocated", C.c_uint64), ("hbm_bytes_used", C.c_uint64), ("hbm_bytes_total", C.c_uint64),
-                ("peer_access", C.c_uint32), ("struct_bytes", C.c_uint32), ("peer_copy_ms", C.c_double), ("peer_copy_bytes", C.c_uint64),
-                ("brushfire_big_handovers", C.c_uint64)]
+                ("peer_access", C.c_uint32), ("struct_bytes", C.c_uint32), ("peer_copy_ms", C.c_double), ("peer_copy_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

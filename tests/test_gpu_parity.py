@@ -326,47 +326,6 @@ def test_host_classes_pick_the_wide_library(F):
     hl.close()
 
 
-@pytest.mark.parametrize("xl", ["1", "0", None])
-def test_floods_beyond_the_big_queue_stage(F, monkeypatch, xl):
-    """A queue that outgrows the big-queue LDS stage (8,192 entries) continues in the third LDS stage (16,384 entries, one workgroup
-    per CU) when the previous update had such particles, else -- and beyond 16,384 -- in the one-lane kernel: the three ways (stage
-    forced on, forced off, the product's rule) give the oracle's maps.  A round room of 12 m with a reach of 6 m (default library)
-    and of 12.75 m (wide library), 4 particles, drifted poses so that walls are re-drawn."""
-    from _stress import random_room_scan
-    if xl is None:
-        monkeypatch.delenv("LAMA_HIP_BF_XL", raising=False)
-    else:
-        monkeypatch.setenv("LAMA_HIP_BF_XL", xl)
-    for l2 in (6.0, 12.75):
-        rng = np.random.default_rng(7)
-        kind = {"R": 12.0, "coef": [(2, 0.05, 0.3), (3, 0.04, 1.1), (5, 0.03, 2.0), (7, 0.02, 0.7)]}
-        P = 4
-        base = np.array([0.5, -0.4, 0.3])
-        pf = O.PF(O.default_options(particles=P, seed=5, l2_max=l2))
-        scan0 = random_room_scan(rng, base, 1080, kind)
-        pose0 = O.se2(*base)
-        pf.set_prior(pose0)
-        assert pf.update(scan0, pose0)
-        ctx = F.HipContext(F.default_cfg(particles=P, l2_max=l2, queue_capacity=1 << 20, dm_patch_capacity=2048, occ_patch_capacity=1024))
-        ctx.init(scan0, pose0)
-        for k in range(4):
-            truth = base + np.array([rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5), rng.uniform(-0.3, 0.3)])
-            scan = random_room_scan(rng, truth, 1080, kind)
-            poses = np.stack([O.se2(*(truth + rng.normal(0, [0.03, 0.03, 0.01]))) for _ in range(P)])
-            pf.set_poses(poses)
-            pf.stage_set_scan(scan)
-            pf.stage_update_maps()
-            ctx.set_poses(poses)
-            ctx.update_maps(scan)
-            for i in range(P):
-                assert_maps_equal(ctx.download_map(i, F.MAP_DISTANCE), pf.dm(i).dump(), DM_FIELDS, f"xl {xl} l2 {l2} scan {k} dm p{i}")
-            base = truth
-        c = ctx.counters()
-        print("xl", xl, "l2_max", l2, {k: c[k] for k in ("brushfire_handovers", "brushfire_big_handovers", "bf_cells")})
-        assert c["brushfire_handovers"] > 0
-        ctx.close()
-
-
 def test_clones_keep_distance_patches_far_beyond_the_hits(F):
     """with l2_max above 64 cells (3.2 m at 0.05 m) the brushfire allocates distance-map patches more than two patches
     beyond the scan's reach; a resample copies only the directory rows of the mapped box, which therefore has to include them.
@@ -826,13 +785,15 @@ def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.00
         for r in res:
             assert np.array_equal(r["hist"][k]["w"], w) and np.array_equal(r["hist"][k]["ws"], ws) and r["hist"][k]["best"] == h.best()
     c = h.hip_context()
-    assert np.array_equal(np.concatenate([r["sums"][0] for r in res]), c.map_checksums(F.MAP_DISTANCE))
-    assert np.array_equal(np.concatenate([r["sums"][1] for r in res]), c.map_checksums(F.MAP_OCCUPANCY))
+    for kind, name in ((0, "distance"), (1, "occupancy")):
+        got, want = np.concatenate([r["sums"][kind] for r in res]), c.map_checksums(F.MAP_DISTANCE if kind == 0 else F.MAP_OCCUPANCY)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, f"{name} maps of particles {bad[:20].tolist()} ({bad.size} of {P}) differ between the {world} shards and the single context"
     assert h.num_resamples() == res[0]["resamples"]
     h.close()
 
 
-@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("world", [4, 8] + [int(w) for w in os.environ.get("LAMA_TEST_EXTRA_WORLDS", "").split(",") if w])
 def test_config3_split_partition_invariance(F, world):
     """BASELINE configs[2]: 3000 particles in G = 4 / 8 contiguous shards (750 / 375 per shard -- the 8-GPU split), here as G
     processes on ONE device over gloo, with a small meas_sigma_gain so that the filter resamples and clones cross shard
@@ -1050,31 +1011,6 @@ def test_first_map_build_device_chain_equals_host_build(F):
     loc.set_obstacles_world((cells.astype(np.float64) - (2642244 >> 1) * 32) * 0.05)
     assert_maps_equal(loc.hip_context().download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "host build, uploaded")
     loc.close()
-
-
-@pytest.mark.parametrize("n_side,l2", [(100, 1.0), (110, 0.5), (70, 7.0)])
-def test_third_lds_stage_runs_a_queue_of_ten_thousand_entries(F, n_side, l2):
-    """lama_hip_map_add_obstacles with 4,900 - 12,100 obstacle cells at once (a lattice, every third cell: the lower queue starts with all
-    of them): more than the big-queue stage holds, so the chain runs in the third LDS stage (16,384 entries) -- the counter says it was
-    handed on, the processed cells and the map are the oracle's.  The 7 m case runs the wide library and grows the queue by flooding."""
-    off = 42275904 + 300
-    xs, ys = np.meshgrid(np.arange(n_side) * 3, np.arange(n_side) * 3)
-    cells = np.stack([xs.ravel() + off, ys.ravel() + off], axis=1).astype(np.uint32)
-    rng = np.random.default_rng(n_side)
-    cells = cells[rng.permutation(len(cells))]                      # addObstacle order is part of the result (ties)
-    dm = O.DM.new(l2_max=l2)
-    for x, y in cells:
-        dm.add(int(x), int(y))
-    n = dm.update()
-    ctx = F.HipContext(F.default_cfg(particles=1, l2_max=l2, queue_capacity=1 << 20))
-    ctx.add_obstacles(0, cells)
-    c = ctx.counters()
-    print("cells", len(cells), "l2_max", l2, "processed", n, {k: c[k] for k in ("brushfire_handovers", "brushfire_big_handovers", "bf_cells")})
-    assert c["bf_cells"] == n
-    if len(cells) > 8192:
-        assert c["brushfire_big_handovers"] == 1, c
-    assert_maps_equal(ctx.download_map(0, F.MAP_DISTANCE), dm.dump(), DM_FIELDS, "third LDS stage")
-    ctx.close()
 
 
 def test_loc2d_loads_a_prebuilt_distance_map(F, tmp_path):

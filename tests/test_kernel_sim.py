@@ -308,15 +308,3 @@ def test_wide_build_randomized_small_rooms(Fsim_wide, seed, l2_max):
     from _stress import random_rooms_case
     assert Fsim_wide.needs_wide(l2_max, 0.05)
     random_rooms_case(Fsim_wide, seed, small=True, l2_max=l2_max)
-
-
-@pytest.mark.parametrize("seed", [6, 7])
-def test_third_lds_stage_of_the_brushfire(Fsim_smallq, monkeypatch, seed):
-    """A flood whose queue outgrows the big-queue stage too goes on in the third LDS stage (k_brushfire<16384, 2048, RESUME>) instead of the
-    one-lane kernel.  The small-queue build (first stage 320 entries, big stage 640) with a reach of 6 m and the stage forced on
-    (LAMA_HIP_BF_XL=1; the product launches it when the previous update handed particles on): seed 6 runs the wave pair, seed 7 the
-    one-wave form; maps of every particle after every scan against the oracle."""
-    from _stress import random_rooms_case
-    monkeypatch.setenv("LAMA_HIP_BF_XL", "1")
-    c = random_rooms_case(Fsim_smallq, seed, small=True, l2_max=6.0)
-    assert c["brushfire_big_handovers"] > 0, c
