@@ -2725,6 +2725,28 @@ __global__ __launch_bounds__(64) void k_gather_blob_heads(const ShipDesc* __rest
         __hip_atomic_load(reinterpret_cast<const uint32_t*>(blob) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (the blob came in by a copy the host queued)
 }
 
+// The bytes of an incoming blob were written by a copy that somebody else queued -- another stream of this process (torch.distributed's
+// gloo backend stages a received message with its own copy stream), a peer device -- into a buffer whose address the caller's
+// allocator reuses from one resample to the next: lines of the PREVIOUS blob at that address may still sit in a cache on the way.
+// Read with agent-scope loads, as everything else that this library's own stream did not produce (lama_dev.h, uload_*).
+#ifdef LAMA_WAVE_SIM
+__device__ __forceinline__ uint4 blob_load16(const uint4* q) { return *q; }
+__device__ __forceinline__ int16_t blob_load_i16(const int16_t* q) { return *q; }
+#else
+__device__ __forceinline__ uint4 blob_load16(const uint4* q)
+{
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(q);
+    const uint64_t a = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b = __hip_atomic_load(w + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+__device__ __forceinline__ int16_t blob_load_i16(const int16_t* q)
+{
+    const uintptr_t u = reinterpret_cast<uintptr_t>(q);
+    const uint32_t w = __hip_atomic_load(reinterpret_cast<const uint32_t*>(u & ~(uintptr_t)3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (int16_t)((u & 2) ? (w >> 16) : (w & 0xFFFFu));
+}
+#endif
+
 // grid (n, 7 planes, SHIP_SPLIT).  The directories are translated when the sender's window sits elsewhere (see k_shift_window); slots the
 // destination used before and the incoming particle does not are zeroed ("unused slot == zero"); old_counts = the destination's counts
 // before the import.
@@ -2759,16 +2781,16 @@ __global__ __launch_bounds__(256) void k_import_particles(DevParams prm, const S
             const int wy = (int)(idx / W), wx = (int)(idx % W);
             const int sx = wx + d.wdx, sy = wy + d.wdy;
             const bool inw = sx >= 0 && sy >= 0 && sx < (int)Ws && sy < (int)Ws;
-            ddir[idx] = inw ? sdir[(size_t)sy * Ws + (size_t)sx] : (int16_t)-1;
+            ddir[idx] = inw ? blob_load_i16(sdir + (size_t)sy * Ws + (size_t)sx) : (int16_t)-1;
         }
         for (size_t idx = (size_t)blockIdx.z * 256 + threadIdx.x; idx < WWs; idx += 256 * SHIP_SPLIT) {
             const int wy = (int)(idx / Ws), wx = (int)(idx % Ws);
             const int tx = wx - d.wdx, ty = wy - d.wdy;          // where the sender's entry (wx, wy) ends up
-            if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && sdir[idx] >= 0) atomicOr(err, ERR_WINDOW);
+            if (!(tx >= 0 && ty >= 0 && tx < (int)W && ty < (int)W) && blob_load_i16(sdir + idx) >= 0) atomicOr(err, ERR_WINDOW);
         }
         n16 = WW * 2 / 16;                                       // (what this plane occupies in the DESTINATION: nothing is zeroed behind it)
     } else {
-        for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = in[k];
+        for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < n16; k += 256 * SHIP_SPLIT) out[k] = blob_load16(in + k);
     }
     const uint4 z = make_uint4(0, 0, 0, 0);
     for (size_t k = (size_t)blockIdx.z * 256 + threadIdx.x; k < nzero; k += 256 * SHIP_SPLIT) out[n16 + k] = z;
