@@ -793,12 +793,14 @@ def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.00
     h.close()
 
 
-@pytest.mark.parametrize("world", [4, 8] + [int(w) for w in os.environ.get("LAMA_TEST_EXTRA_WORLDS", "").split(",") if w])
+@pytest.mark.parametrize("world", sorted({4, 6, 8} | {int(w) for w in os.environ.get("LAMA_TEST_EXTRA_WORLDS", "").split(",") if w}))
 def test_config3_split_partition_invariance(F, world):
-    """BASELINE configs[2]: 3000 particles in G = 4 / 8 contiguous shards (750 / 375 per shard -- the 8-GPU split), here as G
+    """BASELINE configs[2]: 3000 particles in G = 4 / 6 / 8 contiguous shards (750 / 500 / 375 per shard -- the 8-GPU split), here as G
     processes on ONE device over gloo, with a small meas_sigma_gain so that the filter resamples and clones cross shard
     borders.  Every shard must agree with a single-shard run of the same library bit for bit: poses, weights, resampling
-    decisions, and a device-side checksum of every particle's maps."""
+    decisions, and a device-side checksum of every particle's maps.  (Round 6: this test is what caught the import kernel reading
+    blobs that a foreign copy stream had written with plain loads -- 10 - 27 % of its runs diverged at G >= 5 with one binary of the
+    round; tools/flake_partition.sh repeats it, LAMA_TEST_EXTRA_WORLDS adds process counts.)"""
     _partition_invariance(F, world, "gloo", [0] * world)
 
 
