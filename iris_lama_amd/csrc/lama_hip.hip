@@ -1717,20 +1717,23 @@ int32_t lama_hip_pf_upload_map(lama_hip_ctx* c, uint32_t particle, int32_t kind,
             HIPCHK(c, hipMemsetAsync((char*)pr.occ_mask + keep * 128, 0, gone * 128, c->stream));
         }
     }
+    // The copies go through the context's OWN stream, the one whose kernels read these planes afterwards with plain loads: a copy that
+    // another stream carries out (a synchronous hipMemcpy runs on the null stream) into memory this context's kernels have read before
+    // can leave them looking at cached lines of the old content -- the import of particle blobs taught that.
     if (n) {
         if (dm) {
-            HIPCHK(c, hipMemcpy(pr.dm_sv, hsv.data(), hsv.size() * SV_BYTES, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(pr.dm_obs, hobs.data(), hobs.size() * 4, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(pr.dm_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpyAsync(pr.dm_sv, hsv.data(), hsv.size() * SV_BYTES, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pr.dm_obs, hobs.data(), hobs.size() * 4, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pr.dm_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice, c->stream));
         } else {       // frequency {u16 occupied, u16 visited} / float log-odds: 4 B cells as they are
-            HIPCHK(c, hipMemcpy(pr.occ, cells, (size_t)n * 4096, hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(pr.occ_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpyAsync(pr.occ, cells, (size_t)n * 4096, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(pr.occ_mask, masks, (size_t)n * 128, hipMemcpyHostToDevice, c->stream));
         }
     }
-    HIPCHK(c, hipMemcpy((dm ? c->ms.dm_dir : c->ms.occ_dir) + hp.home * WW, dir.data(), WW * 2, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpyAsync((dm ? c->ms.dm_dir : c->ms.occ_dir) + hp.home * WW, dir.data(), WW * 2, hipMemcpyHostToDevice, c->stream));
     c->h_counts[2 * particle + (dm ? 0 : 1)] = (int32_t)n;
-    HIPCHK(c, hipMemcpy(c->ms.counts + 2 * particle + (dm ? 0 : 1), &c->h_counts[2 * particle + (dm ? 0 : 1)], sizeof(int32_t), hipMemcpyHostToDevice));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->ms.counts + 2 * particle + (dm ? 0 : 1), &c->h_counts[2 * particle + (dm ? 0 : 1)], sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));                   // (the caller's buffers and the staging vectors are free again)
     if (!dm) c->visit_bound = 65535u;                             // unknown counters: let the wrap guard look before the next parallel ray-cast
     c->early_ok = false;
     return LAMA_HIP_OK;
