@@ -533,6 +533,48 @@ def test_particle_blob_between_contexts_with_different_windows(F):
     a.close(); b.close()
 
 
+def test_import_reads_what_the_last_copy_wrote_into_a_reused_buffer(F):
+    """The bug of round 6: blobs arrive through copies that somebody else's stream carries out, into a buffer whose
+    address the caller's allocator reuses -- the import must see the bytes of the LAST copy, never cached lines of the blob that lay
+    there before.  Two different blobs of one particle (after scan 1 and after scan 3: the second one holds more map) alternate in
+    ONE device buffer, each written by torch's own copy (not the library's stream), 60 imports: the distance and occupancy maps of
+    the receiving slot must be the exporter's of that moment, every time.  (In ONE process the library of before the fix passes this
+    too -- the stale lines needed several processes sharing the device, tools/flake_partition.sh -- so this test states the contract;
+    the many-processes partition test is what guards it.)"""
+    import torch
+    pts, odom, truth = F.corridor_log(3, 1080)
+    a = F.HipContext(F.default_cfg(particles=2))
+    b = F.HipContext(F.default_cfg(particles=2))
+    a.init(pts[0], O.se2(*odom[0]))
+    b.init(pts[0], O.se2(*odom[0]))
+    blobs, want = [], []
+    for k in (1, 2, 3):
+        a.set_poses(np.tile(O.se2(*truth[k]), (2, 1)))
+        a.update_maps(pts[k])
+        if k in (1, 3):
+            n = a.export_bytes(0)
+            buf = torch.empty(n, dtype=torch.uint8, device="cuda")
+            a.export_particle(0, buf.data_ptr(), n)
+            blobs.append(buf.cpu().pin_memory())
+            want.append((a.map_checksums(F.MAP_DISTANCE)[0], a.map_checksums(F.MAP_OCCUPANCY)[0]))
+    assert want[0] != want[1]
+    dev = torch.empty(max(len(h) for h in blobs), dtype=torch.uint8, device="cuda")      # ONE buffer, reused for every import
+    side = torch.cuda.Stream()
+    for rep in range(30):
+        for j in (0, 1):
+            h = blobs[j]
+            if rep % 2:                                   # a copy stream of its own (what a communication library does) ...
+                with torch.cuda.stream(side):
+                    dev[:len(h)].copy_(h, non_blocking=True)
+            else:                                         # ... or the null stream
+                dev[:len(h)].copy_(h)
+            torch.cuda.synchronize()
+            b.import_particle(1, dev.data_ptr(), len(h))
+            got = (b.map_checksums(F.MAP_DISTANCE)[1], b.map_checksums(F.MAP_OCCUPANCY)[1])
+            assert got == want[j], (rep, j, got, want[j])
+    a.close(); b.close()
+
+
 def test_batched_import_grows_the_receiving_arenas(F):
     """A shard whose arenas are still small receives particles from a shard whose arenas have grown: the batched import enlarges
     the receiver first (all slots keep their maps), several slots take the same blob, and the receiver carries on updating."""
