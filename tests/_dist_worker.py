@@ -28,7 +28,8 @@ def run(rank, world, port, backend, engine_path, P, steps, beams, gain, out_dir,
         import _testhost                 # test double of the device C-ABI: needs the test-suite's own -DLAMA_TESTING host build
         _testhost.set_engine_library(engine_path)
     pts, odom, _ = F.corridor_log(steps, beams)
-    opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=gpu)
+    more = {"l2_max": float(os.environ["LAMA_TEST_L2_MAX"])} if os.environ.get("LAMA_TEST_L2_MAX") else {}     # (the wide device library)
+    opts = F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, shard_rank=rank, shard_world=world, gpu_device=gpu, **more)
     pf = ShardedPF(opts, device=torch.device("cpu") if backend == "gloo" else None)
     pf.set_prior(*odom[0])
     hist = []

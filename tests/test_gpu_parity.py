@@ -789,7 +789,7 @@ def _visible_gpus():
     return torch.cuda.device_count()
 
 
-def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.0001):
+def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.0001, l2_max=None):
     """`world` processes, one shard each (on the HIP devices `devices[r]`), against a single-shard run of the same library: poses,
     weights, resampling decisions and a device-side checksum of every particle's maps must agree bit for bit."""
     import os, pickle, tempfile
@@ -800,9 +800,14 @@ def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.00
     out = tempfile.mkdtemp()
     port = _free_port()
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=run, args=(r, world, port, backend, None, P, steps, beams, gain, out, devices[r], True)) for r in range(world)]
-    for p in procs:
-        p.start()
+    if l2_max is not None:
+        os.environ["LAMA_TEST_L2_MAX"] = str(l2_max)          # (inherited by the spawned ranks)
+    try:
+        procs = [ctx.Process(target=run, args=(r, world, port, backend, None, P, steps, beams, gain, out, devices[r], True)) for r in range(world)]
+        for p in procs:
+            p.start()
+    finally:
+        os.environ.pop("LAMA_TEST_L2_MAX", None)
     for p in procs:
         p.join(900)
     if any(p.exitcode != 0 for p in procs) and not all(os.path.exists(os.path.join(out, f"rank{r}.up")) for r in range(world)):
@@ -817,7 +822,8 @@ def _partition_invariance(F, world, backend, devices, P=3000, steps=5, gain=0.00
     assert len({r["resamples"] for r in res}) == 1 and res[0]["resamples"] > 0
     assert sum(r["shipped"] for r in res) > 0, "no clone crossed a shard border: the test would not exercise the shipping"
     pts, odom, _ = F.corridor_log(steps, beams)
-    h = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain))
+    h = F.PFSlam2D(F.pf_options(particles=P, seed=42, meas_sigma_gain=gain, **({} if l2_max is None else {"l2_max": l2_max})))
+    assert l2_max is None or h.engine_origin().endswith("liblama_hip_wide.so")
     h.set_prior(*odom[0])
     for k in range(steps + 1):
         h.update(pts[k], odom[k], float(k))
@@ -844,6 +850,12 @@ def test_config3_split_partition_invariance(F, world):
     blobs that a foreign copy stream had written with plain loads -- 10 - 27 % of its runs diverged at G >= 5 with one binary of the
     round; tools/flake_partition.sh repeats it, LAMA_TEST_EXTRA_WORLDS adds process counts.)"""
     _partition_invariance(F, world, "gloo", [0] * world)
+
+
+def test_partition_invariance_with_the_wide_library(F):
+    """The same with a distance map that reaches 7 m (140 cells): every rank binds liblama_hip_wide.so, the blobs that cross shard
+    borders carry 4-byte distance planes; 600 particles in 4 processes on one device against one context."""
+    _partition_invariance(F, 4, "gloo", [0] * 4, P=600, steps=4, l2_max=7.0)
 
 
 def test_config3_on_distinct_devices_over_rccl(F):
